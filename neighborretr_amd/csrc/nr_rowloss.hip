@@ -1,0 +1,257 @@
+// Row-wise fused losses of the NeighborRetr head, forward and backward.
+//
+// One wave owns one (row i, direction) of the B x B problem; direction 1 reads the transposed
+// matrices, i.e. it is the reference's "v2t" call on S.T / G.T.  Each lane keeps NE = ceil(B/64)
+// entries of every row vector in registers; all reductions are wave shuffles.  Per row:
+//   centrality  (until_module.py:303-328):  -w_i * log_softmax(S*logit_scale)[i,i]
+//   uniform CE  (until_module.py:285-289):  -sum_j tgt[i,j] * log_softmax(G*T)[i,j]
+//   KL          (until_module.py:351-357):   sum_j p_ij (log p_ij - log_softmax(G)[i,j]),  p = softmax(S)
+//   neighbour   (until_module.py:161-211):  top-K of the row without the diagonal (K rounds of wave
+//               arg-max, ties -> lowest column), min/max of S and of the bank centrality over the
+//               REST set (neither neighbour nor diagonal), p_j = softmax_N(T*(ns_j - nc_j)), p_i = 1,
+//               -sum_{E} p_j log_softmax_E(S)_j / sum p,   E = N u {i}.
+// rowloss[dir][term][i] is reduced by nr_loss_finalize (fixed order => deterministic).
+#include "nr_common.h"
+#include "../../include/nr_hip.h"
+
+struct NrRowArgs {
+    const float *S, *G, *tgt_rows, *tgt_cols, *bank_c0, *bank_c1, *wc_text, *wc_video, *logit_scale;
+    int B, K;
+    float T;
+};
+
+// wave arg-max with ties broken towards the lower index
+__device__ __forceinline__ void nr_wave_argmax(float& v, int& idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(v, o);
+        int oi = __shfl_xor(idx, o);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+// Everything the forward and the backward need about one row, recomputed identically in both.
+template <int NE>
+struct NrRowState {
+    float s[NE], g[NE], c[NE], tg[NE];
+    bool valid[NE], sel[NE], rest[NE];
+    float ls, wci, T;
+    float lse_c;             // LSE_j(ls * s_j)
+    float lse_s;             // LSE_j(s_j)
+    float lse_g;             // LSE_j(g_j)
+    float lse_u;             // LSE_j(T * g_j)
+    float min_s, max_s, min_c, max_c;
+    float lse_e;             // LSE over E of s
+    float amax, asum;        // softmax stats of T*adj over the neighbours
+    float psum;              // sum of positive weights (incl. the diagonal's 1)
+    float s_ii;
+    int i, B;
+
+    __device__ __forceinline__ void load(const NrRowArgs& a, int row, int dir, int lane) {
+        i = row; B = a.B; T = a.T;
+        ls = a.logit_scale[0];
+        wci = dir == 0 ? a.wc_text[row] : a.wc_video[row];
+        const float* cvec = dir == 0 ? a.bank_c0 : a.bank_c1;
+        const float* tgt = dir == 0 ? a.tgt_rows : a.tgt_cols;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            int j = e * 64 + lane;
+            valid[e] = j < B;
+            int jj = valid[e] ? j : 0;
+            size_t idx = dir == 0 ? (size_t)row * B + jj : (size_t)jj * B + row;
+            s[e] = a.S[idx];
+            g[e] = a.G[idx];
+            c[e] = cvec[jj];
+            tg[e] = tgt[(size_t)row * B + jj];
+        }
+    }
+
+    __device__ __forceinline__ float lse(const float (&x)[NE], float scale) const {
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) if (valid[e]) m = fmaxf(m, x[e] * scale);
+        m = nr_wave_max(m);
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) if (valid[e]) t += expf(x[e] * scale - m);
+        t = nr_wave_sum(t);
+        return m + logf(t);
+    }
+
+    __device__ __forceinline__ void stats(int K, int lane) {
+        lse_c = lse(s, ls);
+        lse_s = lse(s, 1.0f);
+        lse_g = lse(g, 1.0f);
+        lse_u = lse(g, T);
+        // diagonal value
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) if (e * 64 + lane == i) d = s[e];
+        s_ii = nr_wave_sum(d);
+        // ---- top-K neighbours (until_module.py:100-129) ----
+        float cand[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            int j = e * 64 + lane;
+            sel[e] = false;
+            cand[e] = (valid[e] && j != i) ? s[e] : -INFINITY;
+        }
+        for (int k = 0; k < K; ++k) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                if (cand[e] > bv) { bv = cand[e]; bi = e * 64 + lane; }
+            nr_wave_argmax(bv, bi);
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                if (e * 64 + lane == bi) { sel[e] = true; cand[e] = -INFINITY; }
+        }
+        // ---- min / max over the rest set (until_module.py:65-86) ----
+        float mns = NR_POS_BIG, mxs = NR_NEG_BIG, mnc = NR_POS_BIG, mxc = NR_NEG_BIG;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            int j = e * 64 + lane;
+            rest[e] = valid[e] && !sel[e] && j != i;
+            if (rest[e]) {
+                mns = fminf(mns, s[e]); mxs = fmaxf(mxs, s[e]);
+                mnc = fminf(mnc, c[e]); mxc = fmaxf(mxc, c[e]);
+            }
+        }
+        min_s = nr_wave_min(mns); max_s = nr_wave_max(mxs);
+        min_c = nr_wave_min(mnc); max_c = nr_wave_max(mxc);
+        // ---- positive weights: softmax over the neighbours of T*(ns - nc) ----
+        const float rs = 1.0f / (max_s - min_s), rc = 1.0f / (max_c - min_c);
+        float am = -INFINITY, em = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (sel[e]) {
+                float adj = (s[e] - min_s) * rs - (c[e] - min_c) * rc;
+                am = fmaxf(am, adj * T);
+            }
+            if (sel[e] || (valid[e] && e * 64 + lane == i)) em = fmaxf(em, s[e]);
+        }
+        amax = nr_wave_max(am);
+        em = nr_wave_max(em);
+        float as = 0.f, es = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (sel[e]) {
+                float adj = (s[e] - min_s) * rs - (c[e] - min_c) * rc;
+                as += expf(adj * T - amax);
+            }
+            if (sel[e] || (valid[e] && e * 64 + lane == i)) es += expf(s[e] - em);
+        }
+        asum = nr_wave_sum(as);
+        lse_e = em + logf(nr_wave_sum(es));
+    }
+
+    // positive weight of entry e (0 outside the neighbour set; the diagonal is handled separately)
+    __device__ __forceinline__ float posw(int e) const {
+        if (!sel[e]) return 0.f;
+        const float rs = 1.0f / (max_s - min_s), rc = 1.0f / (max_c - min_c);
+        float adj = (s[e] - min_s) * rs - (c[e] - min_c) * rc;
+        return expf(adj * T - amax) / asum;
+    }
+};
+
+template <int NE>
+__global__ __launch_bounds__(256) void nr_row_losses_fwd_kernel(NrRowArgs a, float* __restrict__ rowloss) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int dir = blockIdx.y;
+    if (row >= a.B) return;
+    NrRowState<NE> r;
+    r.load(a, row, dir, lane);
+    r.stats(a.K, lane);
+
+    float l_u = 0.f, l_kl = 0.f, num = 0.f, ps = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        if (!r.valid[e]) continue;
+        l_u -= r.tg[e] * (r.g[e] * r.T - r.lse_u);
+        float lp = r.s[e] - r.lse_s;
+        l_kl += expf(lp) * (lp - (r.g[e] - r.lse_g));
+        float p = r.posw(e);
+        num += p * (r.s[e] - r.lse_e);
+        ps += p;
+    }
+    l_u = nr_wave_sum(l_u);
+    l_kl = nr_wave_sum(l_kl);
+    num = nr_wave_sum(num) + (r.s_ii - r.lse_e);   // diagonal weight 1
+    ps = nr_wave_sum(ps) + 1.0f;
+    if (lane == 0) {
+        const int B = a.B;
+        float* o = rowloss + (size_t)dir * 4 * B;
+        o[0 * B + row] = -(r.s_ii * r.ls - r.lse_c) * r.wci;
+        o[1 * B + row] = l_u;
+        o[2 * B + row] = -num / ps;
+        o[3 * B + row] = l_kl;
+    }
+}
+
+// losses = (total, centrality, uniform, neighbour, kl)   (modeling.py:329-358)
+__global__ __launch_bounds__(256) void nr_loss_finalize_kernel(const float* __restrict__ rowloss, int B, float wu, float wn,
+                                                               float wkl, float* __restrict__ losses) {
+    __shared__ float red[8][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave w handles term w; both directions
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int j = lane; j < B; j += 64) {
+        acc0 += rowloss[(size_t)(0 * 4 + wave) * B + j];
+        acc1 += rowloss[(size_t)(1 * 4 + wave) * B + j];
+    }
+    acc0 = nr_wave_sum(acc0);
+    acc1 = nr_wave_sum(acc1);
+    if (lane == 0) { red[wave][0] = acc0; red[wave][1] = acc1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float invB = 1.0f / (float)B;
+        float c = (red[0][0] * invB + red[0][1] * invB) * 0.5f;
+        float u = (red[1][0] * invB + red[1][1] * invB) * 0.5f;
+        float n = (red[2][0] * invB + red[2][1] * invB) * 0.5f;
+        float k = (red[3][0] * invB * invB + red[3][1] * invB * invB) * 0.5f;   // kl_div 'mean' divides by B*B
+        losses[0] = c + u * wu + n * wn + k * wkl;
+        losses[1] = c; losses[2] = u; losses[3] = n; losses[4] = k;
+    }
+}
+
+static int nr_row_ne(int B) {
+    int ne = (B + 63) / 64;
+    if (ne <= 2) return 2;
+    if (ne <= 4) return 4;
+    if (ne <= 8) return 8;
+    if (ne <= 16) return 16;
+    if (ne <= 32) return 32;
+    return 0;
+}
+
+extern "C" int nr_row_losses_fwd(const float* S, const float* G, const float* tgt_rows, const float* tgt_cols,
+                                 const float* bank_c0, const float* bank_c1, const float* wc_text, const float* wc_video,
+                                 const float* logit_scale, int B, int K, float temperature, float* rowloss, void* stream) {
+    if (!S || !G || !tgt_rows || !tgt_cols || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale || !rowloss)
+        return NR_EINVAL;
+    if (B <= 0 || K < 0 || K > B) return NR_EINVAL;    // the reference raises IndexError for K > B
+    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature};
+    dim3 grid((B + 3) / 4, 2);
+    hipStream_t st = (hipStream_t)stream;
+    switch (nr_row_ne(B)) {
+        case 2: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<2>, grid, dim3(256), 0, st, a, rowloss); break;
+        case 4: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<4>, grid, dim3(256), 0, st, a, rowloss); break;
+        case 8: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<8>, grid, dim3(256), 0, st, a, rowloss); break;
+        case 16: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<16>, grid, dim3(256), 0, st, a, rowloss); break;
+        case 32: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<32>, grid, dim3(256), 0, st, a, rowloss); break;
+        default: return NR_EUNSUPPORTED;   // B > 2048
+    }
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+extern "C" int nr_loss_finalize(const float* rowloss, int B, float uniform_weight, float neighbor_weight, float kl_weight,
+                                float* losses, void* stream) {
+    if (!rowloss || !losses || B <= 0) return NR_EINVAL;
+    hipLaunchKernelGGL(nr_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rowloss, B, uniform_weight,
+                       neighbor_weight, kl_weight, losses);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}

@@ -1,0 +1,177 @@
+// Log-domain Sinkhorn targets for the uniform-regularisation loss.
+// Reference: UniformRegularizationLoss.sinkhorn_algorithm, until_module.py:235-266 --
+//   mu = nu = -log(2B); u = v = 0; 50 x { u = mu - LSE_j(G + v);  v = nu - LSE_i(G + u) };
+//   Q = exp(G + u + v - norm);  target = beta*Q + (1-beta)*I.
+// The reference runs it on G and, separately, on G^T (modeling.py:440-441); both problems are
+// solved in one launch (blockIdx.x = direction).
+//
+// B <= 128: ONE persistent workgroup of 1024 threads per direction.  The 100 dependent
+// reductions never leave the CU: 8 lanes share a row (or column), every thread keeps its <=16
+// matrix entries for the row pass AND its <=16 entries for the column pass in registers (G is
+// constant across iterations), only the dual vectors u, v travel through LDS.
+// B > 128: the matrix stays in L2/MALL; one launch per half-iteration (wave per row, coalesced),
+// the column pass running on a transposed copy held in the workspace.
+#include "nr_common.h"
+#include "../../include/nr_hip.h"
+
+#define SK_EPT 16
+
+__global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __restrict__ G, int B, float beta, int iters,
+                                                                 float* __restrict__ tgt_rows, float* __restrict__ tgt_cols) {
+    __shared__ float s_u[128], s_v[128];
+    const int dir = blockIdx.x;                 // 0: problem on G, 1: problem on G^T
+    float* tgt = dir == 0 ? tgt_rows : tgt_cols;
+    const int tid = threadIdx.x;
+    const int line = tid >> 3, sub = tid & 7;   // `line` = row in the u-pass, column in the v-pass
+    const float norm = -logf((float)(2 * B));
+    const bool live = line < B;
+
+    // X[i][j] = G[i][j] (dir 0) or G[j][i] (dir 1)
+    float gr[SK_EPT], gc[SK_EPT];
+#pragma unroll
+    for (int k = 0; k < SK_EPT; ++k) {
+        int o = sub + 8 * k;
+        bool ok = live && o < B;
+        size_t ir = dir == 0 ? (size_t)line * B + o : (size_t)o * B + line;   // X[line][o]
+        size_t ic = dir == 0 ? (size_t)o * B + line : (size_t)line * B + o;   // X[o][line]
+        gr[k] = ok ? G[ir] : -INFINITY;
+        gc[k] = ok ? G[ic] : -INFINITY;
+    }
+    if (tid < 128) { s_u[tid] = 0.f; s_v[tid] = 0.f; }
+    __syncthreads();
+
+    for (int it = 0; it < iters; ++it) {
+        // u_i = norm - LSE_j(X_ij + v_j)
+        {
+            float x[SK_EPT], m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < SK_EPT; ++k) {
+                int o = sub + 8 * k;
+                x[k] = gr[k] + s_v[o & 127];
+                m = fmaxf(m, x[k]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < SK_EPT; ++k) s += __expf(x[k] - m);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            if (live && sub == 0) s_u[line] = norm - (m + __logf(s));
+        }
+        __syncthreads();
+        // v_j = norm - LSE_i(X_ij + u_i)
+        {
+            float x[SK_EPT], m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < SK_EPT; ++k) {
+                int o = sub + 8 * k;
+                x[k] = gc[k] + s_u[o & 127];
+                m = fmaxf(m, x[k]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < SK_EPT; ++k) s += __expf(x[k] - m);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            if (live && sub == 0) s_v[line] = norm - (m + __logf(s));
+        }
+        __syncthreads();
+    }
+    if (live) {
+        const float ui = s_u[line];
+#pragma unroll
+        for (int k = 0; k < SK_EPT; ++k) {
+            int o = sub + 8 * k;
+            if (o < B) {
+                float q = __expf(gr[k] + ui + s_v[o] - norm);
+                tgt[(size_t)line * B + o] = beta * q + (o == line ? 1.0f - beta : 0.f);
+            }
+        }
+    }
+}
+
+// ---- large-B path ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nr_transpose_kernel(const float* __restrict__ in, int B, float* __restrict__ out) {
+    __shared__ float t[32][33];
+    int x = blockIdx.x * 32 + (threadIdx.x & 31), y0 = blockIdx.y * 32;
+    for (int r = threadIdx.x >> 5; r < 32; r += 8)
+        if (x < B && y0 + r < B) t[r][threadIdx.x & 31] = in[(size_t)(y0 + r) * B + x];
+    __syncthreads();
+    int ox = blockIdx.y * 32 + (threadIdx.x & 31), oy0 = blockIdx.x * 32;
+    for (int r = threadIdx.x >> 5; r < 32; r += 8)
+        if (ox < B && oy0 + r < B) out[(size_t)(oy0 + r) * B + ox] = t[threadIdx.x & 31][r];
+}
+
+// dual_out[dir][i] = norm - LSE_j(M_dir[i][j] + dual_in[dir][j]);  M_0 = X0, M_1 = X1.
+// blockIdx.y = direction; one wave per row.
+__global__ __launch_bounds__(256) void nr_sinkhorn_rowlse_kernel(const float* __restrict__ X0, const float* __restrict__ X1,
+                                                                 int B, float norm, const float* __restrict__ dual_in,
+                                                                 float* __restrict__ dual_out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int dir = blockIdx.y;
+    if (i >= B) return;
+    const float* row = (dir == 0 ? X0 : X1) + (size_t)i * B;
+    const float* din = dual_in + (size_t)dir * B;
+    float m = -INFINITY, s = 0.f;
+    for (int j = lane; j < B; j += 64) {
+        float x = row[j] + din[j];
+        float mn = fmaxf(m, x);
+        s = s * __expf(m - mn) + __expf(x - mn);
+        m = mn;
+    }
+    float mw = nr_wave_max(m);
+    s *= __expf(m - mw);
+    s = nr_wave_sum(s);
+    if (lane == 0) dual_out[(size_t)dir * B + i] = norm - (mw + __logf(s));
+}
+
+__global__ __launch_bounds__(256) void nr_sinkhorn_plan_kernel(const float* __restrict__ G, const float* __restrict__ GT,
+                                                               int B, float norm, float beta, const float* __restrict__ u,
+                                                               const float* __restrict__ v, float* __restrict__ tgt_rows,
+                                                               float* __restrict__ tgt_cols) {
+    const int dir = blockIdx.y;
+    const float* X = dir == 0 ? G : GT;
+    float* tgt = dir == 0 ? tgt_rows : tgt_cols;
+    size_t n = (size_t)B * B;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+        int i = (int)(idx / B), j = (int)(idx - (size_t)i * B);
+        float q = __expf(X[idx] + u[(size_t)dir * B + i] + v[(size_t)dir * B + j] - norm);
+        tgt[idx] = beta * q + (i == j ? 1.0f - beta : 0.f);
+    }
+}
+
+extern "C" size_t nr_sinkhorn_workspace_bytes(int B) {
+    if (B <= 128) return 16;
+    return ((size_t)B * B + 4 * (size_t)B) * sizeof(float) + 64;
+}
+
+extern "C" int nr_sinkhorn_targets(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols,
+                                   void* workspace, void* stream) {
+    if (!G || !tgt_rows || !tgt_cols || B <= 0 || iters < 0) return NR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B <= 128) {
+        hipLaunchKernelGGL(nr_sinkhorn_small_kernel, dim3(2), dim3(1024), 0, st, G, B, beta, iters, tgt_rows, tgt_cols);
+        NR_LAUNCH_CHECK();
+        return NR_OK;
+    }
+    if (!workspace) return NR_EINVAL;
+    float* GT = reinterpret_cast<float*>(workspace);
+    float* u = GT + (size_t)B * B;     // [2][B]
+    float* v = u + 2 * (size_t)B;      // [2][B]
+    const float norm = -logf((float)(2 * B));
+    dim3 tg((B + 31) / 32, (B + 31) / 32);
+    hipLaunchKernelGGL(nr_transpose_kernel, tg, dim3(256), 0, st, G, B, GT);
+    hipError_t e = hipMemsetAsync(u, 0, 4 * (size_t)B * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    dim3 rg((B + 3) / 4, 2);
+    for (int it = 0; it < iters; ++it) {
+        // dir 0: u from rows of G with v; dir 1: u from rows of G^T with v
+        hipLaunchKernelGGL(nr_sinkhorn_rowlse_kernel, rg, dim3(256), 0, st, G, GT, B, norm, v, u);
+        // dir 0: v from columns of G = rows of G^T with u; dir 1: rows of G
+        hipLaunchKernelGGL(nr_sinkhorn_rowlse_kernel, rg, dim3(256), 0, st, GT, G, B, norm, u, v);
+    }
+    hipLaunchKernelGGL(nr_sinkhorn_plan_kernel, dim3(1024, 2), dim3(256), 0, st, G, GT, B, norm, beta, u, v, tgt_rows,
+                       tgt_cols);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}

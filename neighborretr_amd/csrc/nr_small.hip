@@ -1,0 +1,159 @@
+// Small supporting kernels of the loss head: partial-sum reduction, the exact-fp32 global-logit
+// GEMM, centrality weights, memory-bank FIFO push, diagonal ranks for R@K.
+#include "nr_common.h"
+#include "../../include/nr_hip.h"
+
+extern "C" int nr_version(void) { return NR_ABI_VERSION; }
+
+// ---- out[i] = scale * sum_p part[p,i]  (until_module.py:181) -----------------------------------
+__global__ __launch_bounds__(256) void nr_reduce_parts_kernel(const float* __restrict__ part, int n_parts, int n,
+                                                              float scale, float* __restrict__ out) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < n_parts; ++p) s += part[(size_t)p * n + i];
+    out[i] = s * scale;
+}
+
+extern "C" int nr_reduce_parts(const float* part, int n_parts, int n, float scale, float* out, void* stream) {
+    if (!part || !out || n_parts <= 0 || n <= 0) return NR_EINVAL;
+    hipLaunchKernelGGL(nr_reduce_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, n_parts,
+                       n, scale, out);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// ---- C = A * B^T in exact fp32 on v_mfma_f32_16x16x4_f32 (modeling.py:526, one global token) ---
+// One wave per 16x16 output tile; operands straight from global/L2 as float4 along k.  Element s of
+// a lane's float4 feeds MFMA step s, i.e. step s multiplies k = k0 + 4*(lane>>4) + s on both
+// operands -- a permutation of the k order, identical for A and B, so the sum is unchanged.
+__global__ __launch_bounds__(256) void nr_gemm_nt_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             int M, int N, int K, float* __restrict__ c) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.y * 32 + (wave >> 1) * 16;
+    const int col0 = blockIdx.x * 32 + (wave & 1) * 16;
+    if (row0 >= M || col0 >= N) return;
+    const int ar = min(row0 + (lane & 15), M - 1);
+    const int br = min(col0 + (lane & 15), N - 1);
+    const float* pa = a + (size_t)ar * K + 4 * (lane >> 4);
+    const float* pb = b + (size_t)br * K + 4 * (lane >> 4);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        f32x4_t va = *reinterpret_cast<const f32x4_t*>(pa + k0);
+        f32x4_t vb = *reinterpret_cast<const f32x4_t*>(pb + k0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va[s], vb[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int r = row0 + (lane >> 4) * 4 + j, cc = col0 + (lane & 15);
+        if (r < M && cc < N) c[(size_t)r * N + cc] = acc[j];
+    }
+}
+
+extern "C" int nr_gemm_nt_f32(const float* a, const float* b, int M, int N, int K, float* c, void* stream) {
+    if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || (K % 16) != 0) return NR_EINVAL;
+    dim3 grid((N + 31) / 32, (M + 31) / 32);
+    hipLaunchKernelGGL(nr_gemm_nt_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, b, M, N, K, c);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// ---- centrality weights (modeling.py:403-430) ---------------------------------------------------
+// mean over ALL tokens of g_hat . x_hat  ==  g_hat . (mean of x_hat): a mat-vec instead of the
+// reference's [B,d] x [d,B*N] GEMM.  32 samples per workgroup; every workgroup rebuilds the mean
+// vector from the per-workgroup column sums written by nr_prepare_tokens (L2-resident).
+__global__ __launch_bounds__(256) void nr_centrality_kernel(const float* __restrict__ g, int B, int d,
+                                                            const float* __restrict__ colsum_part, int n_parts,
+                                                            float inv_tok, float scale, float* __restrict__ w,
+                                                            float* __restrict__ gnorm, float* __restrict__ mean_out) {
+    __shared__ float s_mean[1024];
+    for (int k = threadIdx.x; k < d; k += 256) {
+        float s = 0.f;
+        for (int p = 0; p < n_parts; ++p) s += colsum_part[(size_t)p * d + k];
+        s *= inv_tok;
+        s_mean[k] = s;
+        if (mean_out && blockIdx.x == 0) mean_out[k] = s;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = wave; q < 32; q += 4) {
+        int i = blockIdx.x * 32 + q;
+        if (i >= B) break;
+        const float* gi = g + (size_t)i * d;
+        float dot = 0.f, ss = 0.f;
+        for (int k = lane; k < d; k += 64) {
+            float x = gi[k];
+            dot += x * s_mean[k];
+            ss += x * x;
+        }
+        dot = nr_wave_sum(dot);
+        ss = nr_wave_sum(ss);
+        float nrm = fmaxf(sqrtf(ss), 1e-12f);
+        if (lane == 0) {
+            w[i] = expf(dot / nrm * scale);
+            if (gnorm) gnorm[i] = nrm;
+        }
+    }
+}
+
+extern "C" int nr_centrality_weights(const float* g, int B, int d, const float* colsum_part, int n_parts, int n_tok,
+                                     float scale, float* w, float* gnorm, float* mean_out, void* stream) {
+    if (!g || !colsum_part || !w || B <= 0 || d <= 0 || d > 1024 || n_parts <= 0 || n_tok <= 0) return NR_EINVAL;
+    hipLaunchKernelGGL(nr_centrality_kernel, dim3((B + 31) / 32), dim3(256), 0, (hipStream_t)stream, g, B, d,
+                       colsum_part, n_parts, 1.0f / (float)n_tok, scale, w, gnorm, mean_out);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// ---- memory-bank FIFO (modeling.py:237-249) -----------------------------------------------------
+extern "C" int nr_bank_push(void* bank, const void* batch, int capacity, int n_new, size_t row_bytes, void* scratch,
+                            void* stream) {
+    if (!bank || !batch || capacity <= 0 || n_new <= 0 || row_bytes == 0) return NR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    if (n_new >= capacity) {
+        e = hipMemcpyAsync(bank, batch, (size_t)capacity * row_bytes, hipMemcpyDeviceToDevice, st);
+        return e == hipSuccess ? NR_OK : (int)e;
+    }
+    if (!scratch) return NR_EINVAL;
+    size_t keep = (size_t)(capacity - n_new) * row_bytes;
+    e = hipMemcpyAsync(scratch, bank, keep, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync((char*)bank + (size_t)n_new * row_bytes, scratch, keep, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(bank, batch, (size_t)n_new * row_bytes, hipMemcpyDeviceToDevice, st);
+    return e == hipSuccess ? NR_OK : (int)e;
+}
+
+// ---- diagonal ranks (metrics.py:58-66) ----------------------------------------------------------
+__global__ __launch_bounds__(256) void nr_diag_ranks_kernel(const float* __restrict__ S, int N, int32_t* __restrict__ greater,
+                                                            int32_t* __restrict__ equal) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const float* row = S + (size_t)i * N;
+    const float dval = row[i];
+    int g = 0, e = 0;
+    for (int j = lane; j < N; j += 64) {
+        float x = row[j];
+        g += (x > dval);
+        e += (x == dval);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        g += __shfl_xor(g, o);
+        e += __shfl_xor(e, o);
+    }
+    if (lane == 0) {
+        greater[i] = g;
+        equal[i] = e;
+    }
+}
+
+extern "C" int nr_diag_ranks(const float* S, int N, int32_t* greater, int32_t* equal, void* stream) {
+    if (!S || !greater || !equal || N <= 0) return NR_EINVAL;
+    hipLaunchKernelGGL(nr_diag_ranks_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, N, greater, equal);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}

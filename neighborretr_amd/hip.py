@@ -1,0 +1,123 @@
+"""ctypes binding of libnr_hip.so (include/nr_hip.h) for torch tensors on ROCm.
+
+This is the only bridge between the Python host code and the HIP kernels.  There is no CPU or
+eager fallback behind it: if the shared library is missing or a tensor is not a contiguous
+device tensor of the right dtype, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnr_hip.so")
+
+PREC_BF16 = 0
+PREC_BF16X3 = 1
+OUT_FULL, OUT_ROWSUM, OUT_COLSUM = 0, 1, 2
+
+_lib = None
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_Z = ctypes.c_size_t
+
+_SIGNATURES = {
+    "nr_version": ([], _I),
+    "nr_prepare_parts": ([_I], _I),
+    "nr_prepare_tokens": ([_P, _P, _I, _I, _I, _P, _P, _P, _P, _P], _I),
+    "nr_split_bf16": ([_P, _Z, _P, _P, _P], _I),
+    "nr_token_logits_fwd": ([_P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P], _I),
+    "nr_token_softmax": ([_P, _I, _P, _P, _I, _I, _P, _P, _P], _I),
+    "nr_local_level_tiles": ([_I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)], _I),
+    "nr_local_level_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P], _I),
+    "nr_reduce_parts": ([_P, _I, _I, _F, _P, _P], _I),
+    "nr_gemm_nt_f32": ([_P, _P, _I, _I, _I, _P, _P], _I),
+    "nr_centrality_weights": ([_P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P], _I),
+    "nr_sinkhorn_workspace_bytes": ([_I], _Z),
+    "nr_sinkhorn_targets": ([_P, _I, _F, _I, _P, _P, _P, _P], _I),
+    "nr_row_losses_fwd": ([_P] * 9 + [_I, _I, _F, _P, _P], _I),
+    "nr_loss_finalize": ([_P, _I, _F, _F, _F, _P, _P], _I),
+    "nr_row_losses_bwd": ([_P] * 9 + [_I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P], _I),
+    "nr_local_level_bwd": ([_P] * 7 + [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P], _I),
+    "nr_bank_push": ([_P, _P, _I, _I, _Z, _P, _P], _I),
+    "nr_diag_ranks": ([_P, _I, _P, _P, _P], _I),
+}
+
+
+class NrHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises if it has not been built (python -m neighborretr_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NrHipError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -m neighborretr_amd.build` or __graft_entry__.build()). "
+                "There is no fallback path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            if not hasattr(handle, name):
+                continue          # declared in the header but not built yet -> call() raises
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def _check(name, rc):
+    if rc != 0:
+        kind = "invalid argument / unsupported shape" if rc < 0 else "hipError_t"
+        raise NrHipError(f"{name} failed with status {rc} ({kind})")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise NrHipError("required tensor argument is None")
+    if not t.is_cuda:
+        raise NrHipError("tensor is not on the GPU; the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise NrHipError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise NrHipError(f"expected dtype {dtype}, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def call(name, *args):
+    fn = getattr(lib(), name, None)
+    if fn is None:
+        raise NrHipError(f"{name} is not exported by {LIB_PATH}")
+    _check(name, fn(*args))
+
+
+def version():
+    return lib().nr_version()
+
+
+def prepare_parts(n_tok):
+    return lib().nr_prepare_parts(int(n_tok))
+
+
+def local_level_tiles(A, Nt, Bv, Nv):
+    r, c = _I(0), _I(0)
+    _check("nr_local_level_tiles", lib().nr_local_level_tiles(A, Nt, Bv, Nv, ctypes.byref(r), ctypes.byref(c)))
+    return r.value, c.value
+
+
+def sinkhorn_workspace_bytes(B):
+    return int(lib().nr_sinkhorn_workspace_bytes(int(B)))

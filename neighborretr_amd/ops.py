@@ -1,0 +1,163 @@
+"""Tensor-level wrappers, one per C entry point of libnr_hip.so (no autograd here).
+
+Each function allocates its outputs with torch (device memory plumbing only), enqueues the HIP
+kernel on torch's current stream and returns without synchronising.
+"""
+from collections import namedtuple
+
+import torch
+
+from . import hip
+
+Prepared = namedtuple("Prepared", "hi lo norm colsum n_tok d")
+
+
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+
+def prepare_tokens(x, mask=None, normalize=True, want_lo=True, want_norm=True, want_colsum=False):
+    """x [..., d] f32 -> bf16 hi/lo of normalize(x)*mask  (nr_prepare_tokens)."""
+    x = _f32(x).contiguous()
+    d = x.shape[-1]
+    n_tok = x.numel() // d
+    dev = x.device
+    hi = torch.empty((n_tok, d), dtype=torch.int16, device=dev)
+    lo = torch.empty((n_tok, d), dtype=torch.int16, device=dev) if want_lo else None
+    norm = torch.empty((n_tok,), dtype=torch.float32, device=dev) if want_norm else None
+    colsum = None
+    if want_colsum:
+        colsum = torch.empty((hip.prepare_parts(n_tok), d), dtype=torch.float32, device=dev)
+    m = None
+    if mask is not None:
+        m = _f32(mask).contiguous()
+        if m.numel() != n_tok:
+            raise ValueError("mask does not match the token count")
+    hip.call("nr_prepare_tokens", hip.ptr(x, torch.float32), hip.ptr(m, allow_none=True), n_tok, d,
+             1 if normalize else 0, hip.ptr(hi), hip.ptr(lo, allow_none=True), hip.ptr(norm, allow_none=True),
+             hip.ptr(colsum, allow_none=True), hip.stream_ptr())
+    return Prepared(hi, lo, norm, colsum, n_tok, d)
+
+
+def split_bf16(w, want_lo=True):
+    w = _f32(w).contiguous()
+    hi = torch.empty(w.shape, dtype=torch.int16, device=w.device)
+    lo = torch.empty(w.shape, dtype=torch.int16, device=w.device) if want_lo else None
+    hip.call("nr_split_bf16", hip.ptr(w, torch.float32), w.numel(), hip.ptr(hi), hip.ptr(lo, allow_none=True),
+             hip.stream_ptr())
+    return hi, lo
+
+
+def token_logit_parts(prep, w1_hi, w1_lo, b1, w2, prec):
+    """[H/128, n_tok] partial logits of the token scorer (nr_token_logits_fwd)."""
+    H = w1_hi.shape[0]
+    parts = torch.empty((H // 128, prep.n_tok), dtype=torch.float32, device=prep.hi.device)
+    hip.call("nr_token_logits_fwd", hip.ptr(prep.hi), hip.ptr(prep.lo, allow_none=True), hip.ptr(prep.norm), prep.n_tok,
+             prep.d, hip.ptr(w1_hi), hip.ptr(w1_lo, allow_none=True), hip.ptr(b1, torch.float32),
+             hip.ptr(w2, torch.float32), H, prec, hip.ptr(parts), hip.stream_ptr())
+    return parts
+
+
+def token_softmax(parts, b2, mask, n_samples, N, want_logits=False):
+    w = torch.empty((n_samples, N), dtype=torch.float32, device=parts.device)
+    logits = torch.empty((n_samples, N), dtype=torch.float32, device=parts.device) if want_logits else None
+    m = _f32(mask).contiguous() if mask is not None else None
+    hip.call("nr_token_softmax", hip.ptr(parts), parts.shape[0], hip.ptr(b2, torch.float32), hip.ptr(m, allow_none=True),
+             n_samples, N, hip.ptr(w), hip.ptr(logits, allow_none=True), hip.stream_ptr())
+    return w, logits
+
+
+def local_level(prep_t, prep_v, w_t, w_v, A, Nt, Bv, Nv, prec=hip.PREC_BF16, out_mode=hip.OUT_FULL, want_arg=False):
+    """Fused token-token similarity (nr_local_level_fwd).  Returns (out, arg_v, arg_t)."""
+    dev = prep_t.hi.device
+    if prep_t.n_tok != A * Nt or prep_v.n_tok != Bv * Nv:
+        raise ValueError("prepared token counts do not match A*Nt / Bv*Nv")
+    if out_mode == hip.OUT_FULL:
+        out = torch.empty((A, Bv), dtype=torch.float32, device=dev)
+    else:
+        nr, nc = hip.local_level_tiles(A, Nt, Bv, Nv)
+        out = torch.empty((nc, A) if out_mode == hip.OUT_ROWSUM else (nr, Bv), dtype=torch.float32, device=dev)
+    arg_v = torch.empty((A, Bv, Nt), dtype=torch.uint8, device=dev) if want_arg else None
+    arg_t = torch.empty((A, Bv, Nv), dtype=torch.uint8, device=dev) if want_arg else None
+    hip.call("nr_local_level_fwd", hip.ptr(prep_t.hi), hip.ptr(prep_t.lo, allow_none=True), hip.ptr(prep_v.hi),
+             hip.ptr(prep_v.lo, allow_none=True), hip.ptr(w_t, torch.float32), hip.ptr(w_v, torch.float32),
+             A, Nt, Bv, Nv, prep_t.d, prec, out_mode, hip.ptr(out), hip.ptr(arg_v, allow_none=True),
+             hip.ptr(arg_t, allow_none=True), hip.stream_ptr())
+    return out, arg_v, arg_t
+
+
+def reduce_parts(parts, scale):
+    out = torch.empty((parts.shape[1],), dtype=torch.float32, device=parts.device)
+    hip.call("nr_reduce_parts", hip.ptr(parts, torch.float32), parts.shape[0], parts.shape[1], float(scale), hip.ptr(out),
+             hip.stream_ptr())
+    return out
+
+
+def gemm_nt_f32(a, b):
+    a, b = _f32(a).contiguous(), _f32(b).contiguous()
+    M, K = a.shape
+    N = b.shape[0]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    hip.call("nr_gemm_nt_f32", hip.ptr(a), hip.ptr(b), M, N, K, hip.ptr(c), hip.stream_ptr())
+    return c
+
+
+def centrality_weights(g, colsum, n_tok, scale, want_aux=False):
+    g = _f32(g).contiguous()
+    B, d = g.shape
+    w = torch.empty((B,), dtype=torch.float32, device=g.device)
+    gnorm = torch.empty((B,), dtype=torch.float32, device=g.device) if want_aux else None
+    mean = torch.empty((d,), dtype=torch.float32, device=g.device) if want_aux else None
+    hip.call("nr_centrality_weights", hip.ptr(g), B, d, hip.ptr(colsum, torch.float32), colsum.shape[0], n_tok,
+             float(scale), hip.ptr(w), hip.ptr(gnorm, allow_none=True), hip.ptr(mean, allow_none=True), hip.stream_ptr())
+    return w, gnorm, mean
+
+
+def sinkhorn_targets(G, beta, iters=50):
+    G = _f32(G).contiguous()
+    B = G.shape[0]
+    tr = torch.empty_like(G)
+    tc = torch.empty_like(G)
+    ws = torch.empty((hip.sinkhorn_workspace_bytes(B),), dtype=torch.uint8, device=G.device)
+    hip.call("nr_sinkhorn_targets", hip.ptr(G), B, float(beta), int(iters), hip.ptr(tr), hip.ptr(tc), hip.ptr(ws),
+             hip.stream_ptr())
+    return tr, tc
+
+
+def row_losses(S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, K, T):
+    B = S.shape[0]
+    rowloss = torch.empty((2, 4, B), dtype=torch.float32, device=S.device)
+    hip.call("nr_row_losses_fwd", hip.ptr(S, torch.float32), hip.ptr(G, torch.float32), hip.ptr(tgt_rows), hip.ptr(tgt_cols),
+             hip.ptr(bank_c0, torch.float32), hip.ptr(bank_c1, torch.float32), hip.ptr(wc_text, torch.float32),
+             hip.ptr(wc_video, torch.float32), hip.ptr(logit_scale, torch.float32), B, int(K), float(T),
+             hip.ptr(rowloss), hip.stream_ptr())
+    return rowloss
+
+
+def loss_finalize(rowloss, wu, wn, wkl):
+    B = rowloss.shape[-1]
+    losses = torch.empty((5,), dtype=torch.float32, device=rowloss.device)
+    hip.call("nr_loss_finalize", hip.ptr(rowloss), B, float(wu), float(wn), float(wkl), hip.ptr(losses), hip.stream_ptr())
+    return losses
+
+
+def bank_push(bank, batch, scratch=None):
+    """In-place FIFO push: bank <- cat(batch, bank)[:capacity]  (nr_bank_push)."""
+    cap, n_new = bank.shape[0], batch.shape[0]
+    row_bytes = bank[0].numel() * bank.element_size()
+    if batch.dtype != bank.dtype or batch[0].numel() != bank[0].numel():
+        raise ValueError("bank / batch row layout mismatch")
+    if scratch is None and n_new < cap:
+        scratch = torch.empty_like(bank)
+    hip.call("nr_bank_push", hip.ptr(bank), hip.ptr(batch.contiguous()), cap, n_new, row_bytes,
+             hip.ptr(scratch, allow_none=True), hip.stream_ptr())
+    return bank
+
+
+def diag_ranks(S):
+    S = _f32(S).contiguous()
+    N = S.shape[0]
+    g = torch.empty((N,), dtype=torch.int32, device=S.device)
+    e = torch.empty((N,), dtype=torch.int32, device=S.device)
+    hip.call("nr_diag_ranks", hip.ptr(S), N, hip.ptr(g), hip.ptr(e), hip.stream_ptr())
+    return g, e

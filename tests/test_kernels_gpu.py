@@ -1,0 +1,237 @@
+"""GPU parity of every HIP entry point against the CPU oracle (same seeded inputs).
+
+Tolerances (floating point path; stated per SURVEY.md 8d / BASELINE.json north_star):
+  * split-bf16 (BF16X3) contractions: <= 2e-6 on cosine sims (|S| <= 1)
+  * single-pass bf16 contractions:    <= 1e-3 on sims ("logits within 1e-3")
+  * fp32 kernels (softmax, Sinkhorn, row losses): <= 1e-4 relative to the oracle's fp32
+"""
+import numpy as np
+import pytest
+import torch
+
+import nr_oracle as O
+from neighborretr_amd import hip, ops
+from util import maxdiff, params, problem
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _tw(prep, mask, P, prefix, n, N, prec):
+    w1h, w1l = ops.split_bf16(P[prefix + ".0.weight"])
+    parts = ops.token_logit_parts(prep, w1h, w1l, P[prefix + ".0.bias"], P[prefix + ".2.weight"].reshape(-1).contiguous(), prec)
+    return ops.token_softmax(parts, P[prefix + ".2.bias"], mask, n, N, want_logits=True)
+
+
+def test_library_loads_and_version():
+    assert hip.version() == 1
+
+
+@pytest.mark.parametrize("n,N,d", [(16, 24, 512), (5, 7, 256), (3, 64, 768)])
+def test_prepare_tokens(n, N, d):
+    g = torch.Generator().manual_seed(n * 100 + N)
+    x = torch.randn(n, N, d, generator=g) * 3
+    mask = (torch.rand(n, N, generator=g) > 0.3).long()
+    prep = ops.prepare_tokens(x.to(DEV), mask.to(DEV), want_colsum=True)
+    hi = prep.hi.view(torch.bfloat16).float().cpu()
+    lo = prep.lo.view(torch.bfloat16).float().cpu()
+    xn = torch.nn.functional.normalize(x.reshape(-1, d), dim=-1)
+    ref = xn * mask.reshape(-1, 1)
+    assert maxdiff(hi + lo, ref) < 2e-5                  # two bf16 terms carry ~16 mantissa bits
+    assert maxdiff(hi, ref) < 5e-3
+    assert maxdiff(prep.norm.cpu(), x.reshape(-1, d).norm(dim=-1)) < 1e-4 * float(x.norm(dim=-1).max())
+    assert maxdiff(prep.colsum.sum(0).cpu(), xn.sum(0)) < 1e-4
+    # masked rows are exact zero vectors
+    assert float(hi[mask.reshape(-1) == 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("prec,tol", [(hip.PREC_BF16X3, 2e-5), (hip.PREC_BF16, 3e-3)])
+def test_token_weights(prec, tol):
+    x = problem(1001, 16, 24, 12, 128)
+    P = params()
+    Pg = {k: v.to(DEV) for k, v in P.items()}
+    for feat, mask, prefix in ((x["text_feat"], x["text_mask"], "text_weight_fc"),
+                               (x["mb_feat_v"], x["mb_mask_v"], "video_weight_fc")):
+        n, N, _ = feat.shape
+        prep = ops.prepare_tokens(feat.to(DEV), mask.to(DEV))
+        w, logits = _tw(prep, mask.to(DEV), Pg, prefix, n, N, prec)
+        w_ref = O.token_weights(feat, mask, P, prefix)
+        assert maxdiff(w, w_ref) < tol
+        lg_ref = O.token_weight_logits(feat, P, prefix)
+        valid = mask.bool()
+        assert maxdiff(logits.cpu()[valid], lg_ref[valid]) < tol * 10
+
+
+SHAPES = [
+    # A, Nt, Bv, Nv
+    (16, 24, 16, 12),      # C1 batch x batch
+    (16, 24, 128, 12),     # C1 batch x bank
+    (37, 24, 19, 12),      # ragged tile edges
+    (8, 64, 8, 64),        # ActivityNet token counts
+    (9, 20, 11, 7),        # token counts that do not divide the tile
+    (5, 3, 7, 6),          # merged-token counts of the C4 global level
+    (4, 77, 3, 100),       # one sample per tile
+]
+
+
+@pytest.mark.parametrize("A,Nt,Bv,Nv", SHAPES)
+@pytest.mark.parametrize("prec,tol", [(hip.PREC_BF16X3, 2e-6), (hip.PREC_BF16, 1e-3)])
+def test_local_level_matches_oracle(A, Nt, Bv, Nv, prec, tol):
+    g = torch.Generator().manual_seed(A * 1000 + Bv)
+    base = torch.randn(max(A, Bv), 1, 512, generator=g)
+    t = base[:A] + 4 * torch.randn(A, Nt, 512, generator=g)
+    v = base[:Bv] + 4 * torch.randn(Bv, Nv, 512, generator=g)
+    tm = (torch.arange(Nt)[None] < torch.randint(1, Nt + 1, (A, 1), generator=g)).long()
+    vm = (torch.arange(Nv)[None] < torch.randint(1, Nv + 1, (Bv, 1), generator=g)).long()
+    if Bv > 2:
+        vm[2] = 0                                   # a fully masked video: exact-zero column
+    w_t = torch.softmax(torch.randn(A, Nt, generator=g), -1)
+    w_v = torch.softmax(torch.randn(Bv, Nv, generator=g), -1)
+    # oracle with the same token weights
+    tn = torch.nn.functional.normalize(t, dim=-1) * tm[..., None]
+    vn = torch.nn.functional.normalize(v, dim=-1) * vm[..., None]
+    R = torch.einsum("atd,bvd->abtv", tn.double(), vn.double())
+    pm, av = R.max(-1)
+    qm, at = R.max(-2)
+    S_ref = 0.5 * ((pm * w_t[:, None, :].double()).sum(-1) + (qm * w_v[None].double()).sum(-1))
+
+    pt = ops.prepare_tokens(t.to(DEV), tm.to(DEV))
+    pv = ops.prepare_tokens(v.to(DEV), vm.to(DEV))
+    S, arg_v, arg_t = ops.local_level(pt, pv, w_t.to(DEV), w_v.to(DEV), A, Nt, Bv, Nv, prec, hip.OUT_FULL, want_arg=True)
+    assert maxdiff(S, S_ref) < tol
+    if Bv > 2:
+        assert float(S[:, 2].abs().max()) == 0.0
+    if prec == hip.PREC_BF16X3:
+        # arg-max must point at an entry equal (to rounding) to the true max
+        Rf = R.float()
+        got_p = torch.gather(Rf, 3, arg_v.cpu().long()[..., None]).squeeze(-1)
+        assert maxdiff(got_p, pm) < 1e-5
+        got_q = torch.gather(Rf, 2, arg_t.cpu().long()[:, :, None, :]).squeeze(2)
+        assert maxdiff(got_q, qm) < 1e-5
+    # bank modes: row / column sums of the same matrix
+    nr, nc = hip.local_level_tiles(A, Nt, Bv, Nv)
+    rs, _, _ = ops.local_level(pt, pv, w_t.to(DEV), w_v.to(DEV), A, Nt, Bv, Nv, prec, hip.OUT_ROWSUM)
+    cs, _, _ = ops.local_level(pt, pv, w_t.to(DEV), w_v.to(DEV), A, Nt, Bv, Nv, prec, hip.OUT_COLSUM)
+    assert rs.shape == (nc, A) and cs.shape == (nr, Bv)
+    assert maxdiff(ops.reduce_parts(rs, 1.0 / Bv), S_ref.mean(1)) < tol
+    assert maxdiff(ops.reduce_parts(cs, 1.0 / A), S_ref.mean(0)) < tol
+
+
+def test_local_level_end_to_end_golden_c1():
+    """prepare -> scorer -> similarity against the REFERENCE's own S (tests/golden/c1_b16.npz)."""
+    from util import golden
+    gd = golden("c1_b16")
+    x = problem(1001, 16, 24, 12, 128, device=DEV)
+    P = params(device=DEV)
+    pt = ops.prepare_tokens(x["text_feat"], x["text_mask"])
+    pv = ops.prepare_tokens(x["video_feat"], x["video_mask"])
+    w_t, _ = _tw(pt, x["text_mask"], P, "text_weight_fc", 16, 24, hip.PREC_BF16X3)
+    w_v, _ = _tw(pv, x["video_mask"], P, "video_weight_fc", 16, 12, hip.PREC_BF16X3)
+    assert maxdiff(w_t, gd["w_t"]) < 2e-5 and maxdiff(w_v, gd["w_v"]) < 2e-5
+    S, _, _ = ops.local_level(pt, pv, w_t, w_v, 16, 24, 16, 12, hip.PREC_BF16X3)
+    assert maxdiff(S, gd["S"]) < 2e-6
+    w_t1, _ = _tw(pt, x["text_mask"], P, "text_weight_fc", 16, 24, hip.PREC_BF16)
+    w_v1, _ = _tw(pv, x["video_mask"], P, "video_weight_fc", 16, 12, hip.PREC_BF16)
+    S1, _, _ = ops.local_level(pt, pv, w_t1, w_v1, 16, 24, 16, 12, hip.PREC_BF16)
+    assert maxdiff(S1, gd["S"]) < 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 16, 512), (128, 128, 512), (37, 50, 64), (8, 24, 512)])
+def test_gemm_nt_f32(M, N, K):
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    c = ops.gemm_nt_f32(a.to(DEV), b.to(DEV))
+    ref = a.double() @ b.double().t()
+    assert maxdiff(c, ref) < 2e-5 * float(ref.abs().max())
+
+
+def test_centrality_weights():
+    x = problem(1001, 16, 24, 12, 128)
+    g = torch.Generator().manual_seed(3)
+    gt = torch.randn(16, 1, 512, generator=g)
+    gv = torch.randn(16, 1, 512, generator=g)
+    wt_ref, wv_ref = O.centrality_weights(x["text_feat"], x["video_feat"], gt, gv, 0.3)
+    pt = ops.prepare_tokens(x["text_feat"].to(DEV), x["text_mask"].to(DEV), want_colsum=True)
+    pv = ops.prepare_tokens(x["video_feat"].to(DEV), x["video_mask"].to(DEV), want_colsum=True)
+    wt, _, _ = ops.centrality_weights(gt[:, 0].to(DEV), pt.colsum, pt.n_tok, 0.3)
+    wv, _, _ = ops.centrality_weights(gv[:, 0].to(DEV), pv.colsum, pv.n_tok, 0.3)
+    assert maxdiff(wt, wt_ref) < 1e-6 and maxdiff(wv, wv_ref) < 1e-6
+
+
+@pytest.mark.parametrize("B", [16, 100, 128, 200])
+def test_sinkhorn_targets(B):
+    g = torch.Generator().manual_seed(B)
+    G = torch.randn(B, B, generator=g) * 9 + torch.eye(B) * 10
+    tr, tc = ops.sinkhorn_targets(G.to(DEV), 0.7, 50)
+    ref_r = O.sinkhorn_targets(G.double(), 0.7)
+    ref_c = O.sinkhorn_targets(G.double().t(), 0.7)
+    assert maxdiff(tr, ref_r) < 2e-5
+    assert maxdiff(tc, ref_c) < 2e-5
+    # column sums of Q are 1/... : property the reference's plan has
+    Q = (tr.cpu().double() - 0.3 * torch.eye(B, dtype=torch.float64)) / 0.7
+    assert maxdiff(Q.sum(0), torch.ones(B, dtype=torch.float64)) < 1e-4
+
+
+@pytest.mark.parametrize("B,K", [(16, 8), (32, 8), (128, 20), (200, 20), (16, 15)])
+def test_row_losses(B, K):
+    g = torch.Generator().manual_seed(B + K)
+    S = torch.rand(B, B, generator=g) * 0.12 + torch.eye(B) * 0.02
+    G = torch.randn(B, B, generator=g) * 9
+    c0 = torch.rand(B, generator=g) * 0.1
+    c1 = torch.rand(B, generator=g) * 0.1
+    wt = torch.exp(torch.randn(B, generator=g) * 0.01)
+    wv = torch.exp(torch.randn(B, generator=g) * 0.01)
+    ls = torch.tensor([100.0])
+    T = 3.0
+    d = lambda t: t.double()
+    tr = O.sinkhorn_targets(d(G), 0.7)
+    tc = O.sinkhorn_targets(d(G).t(), 0.7)
+    # oracle, term by term (bank matrices with the given row means)
+    bank_v2t = d(c0)[:, None].expand(B, 4)
+    bank_t2v = d(c1)[:, None].expand(B, 4)
+    ref = [O.centrality_loss(d(S), d(wt), d(wv), 100.0),
+           (-(torch.log_softmax(d(G) * T, -1) * tr).sum(-1).mean() - (torch.log_softmax(d(G).t() * T, -1) * tc).sum(-1).mean()) / 2,
+           O.neighbor_loss(d(S), bank_t2v, bank_v2t, K, T),
+           O.kl_loss(d(G), d(S))]
+    rl = ops.row_losses(S.to(DEV), G.to(DEV), tr.float().contiguous().to(DEV), tc.float().contiguous().to(DEV), c0.to(DEV), c1.to(DEV),
+                        wt.to(DEV), wv.to(DEV), ls.to(DEV), K, T)
+    losses = ops.loss_finalize(rl, 1.0, 1.0, 1.0).cpu().double()
+    for k, r in enumerate(ref):
+        assert abs(float(losses[k + 1]) - float(r)) < 1e-4 * max(1.0, abs(float(r))), (k, float(losses[k + 1]), float(r))
+    assert abs(float(losses[0]) - float(sum(ref))) < 2e-4 * float(sum(ref))
+
+
+def test_row_losses_rejects_bad_k():
+    B = 16
+    z = torch.zeros(B, B, device=DEV)
+    v = torch.zeros(B, device=DEV)
+    with pytest.raises(hip.NrHipError):
+        ops.row_losses(z, z, z, z, v, v, v, v, torch.ones(1, device=DEV), 20, 3.0)   # K > B: reference raises too
+
+
+def test_bank_push_fifo():
+    bank = torch.arange(10 * 6, dtype=torch.float32, device=DEV).reshape(10, 2, 3)
+    ref = bank.clone()
+    for n_new in (3, 10, 12, 1):
+        batch = torch.randn(n_new, 2, 3, device=DEV)
+        ref = torch.cat((batch, ref), 0)[:10]
+        ops.bank_push(bank, batch)
+        assert torch.equal(bank, ref)
+
+
+def test_diag_ranks_match_reference_metrics():
+    from util import golden
+    from neighborretr_amd import synth
+    n = 256
+    S = (synth.normal(42, "metrics/S", (n, n)) * 0.1).astype(np.float32)
+    S[np.arange(n), np.arange(n)] += 0.25
+    for i in range(0, n, 16):
+        S[i, (i + 3) % n] = S[i, i]
+    for i in range(5, n, 16):
+        S[i, (i + 7) % n] = np.nextafter(S[i, i], np.float32(10))
+        S[i, (i + 9) % n] = np.nextafter(S[i, i], np.float32(-10))
+    gr, eq = ops.diag_ranks(torch.from_numpy(S).to(DEV))
+    gr, eq = gr.cpu().numpy(), eq.cpu().numpy()
+    cols = np.concatenate([np.arange(g, g + e) for g, e in zip(gr, eq)])
+    assert np.array_equal(cols, golden("metrics256")["cols"])
