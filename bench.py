@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""Benchmark of the NeighborRetr similarity / loss head on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One STEP = one pass of the hot path over one synthetic batch already resident in HBM:
+    [N>1: RCCL all-gather of the per-rank feature/mask shards]  ->  token clustering (global
+    tokens)  ->  prepare / scorer / fused local_level x3 / Sinkhorn / row losses  ->  memory-bank
+    FIFO push,   i.e. `NeighborRetr.forward` in training mode minus the encoders, loss-only
+    forward (BASELINE.json configs[0] "loss-only forward").
+Workload = BASELINE.json configs[1]: global B=128, d=512, Nt=24, Nv=12, M=512, K=20 (MSR-VTT shape).
+For N>1 the GLOBAL batch stays 128 (the metric is quoted at global B=128): each rank holds b=128/N
+samples, gathers, and -- like the reference (modeling.py:274-298) -- evaluates the full loss, so
+`scaling` is "strong".  The JSON line also carries:
+  roofline     the fused local_level kernel (the dominant kernel): algorithmic flops per launch
+               (F_sim / 3 launches) / its average duration, timed live
+               with HIP events on the launch stream, against the dense bf16 MFMA peak;
+  cpu_baseline the CPU oracle (a port of the reference algorithm, oracle/nr_oracle.py) timed on this
+               host's cores on the same workload (N=1, rank 0 only; bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+CFG = dict(B=128, Nt=24, Nv=12, M=512, K=20, d=512)
+
+
+def algorithmic_flops(B, Nt, Nv, M, d=512, H=1024):
+    f_sim = 2 * d * ((B * Nt) * (B * Nv) + (B * Nt) * (M * Nv) + (M * Nt) * (B * Nv))
+    f_mlp = (2 * d * H + 2 * H) * (B + M) * (Nt + Nv)
+    return f_sim, f_mlp
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "bf16_all"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backward", action="store_true", help="also time forward+backward (reported as extra fields)")
+    return ap.parse_args()
+
+
+def build_model(precision, device):
+    from neighborretr_amd import modeling, synth
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=CFG["K"]), precision=precision)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}, strict=False)
+    m = m.to(device).train()
+    with torch.no_grad():
+        m.clip.logit_scale.fill_(float(np.log(100.0)))
+    return m
+
+
+def cpu_baseline(steps=5):
+    """The CPU port of the reference algorithm on the same workload; forward only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nr_oracle as O
+    from neighborretr_amd import synth
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    torch.set_num_threads(threads)
+    c = CFG
+    prob = {k: torch.from_numpy(v) for k, v in synth.make_problem(1002, c["B"], c["Nt"], c["Nv"], c["M"]).items()}
+    P = {k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}
+    nz = {k: torch.from_numpy(v) for k, v in synth.make_noise(1002, c["B"], c["Nt"], c["Nv"]).items()}
+    hp = dict(synth.DEFAULT_HP, num_neighbors=c["K"])
+    ls = torch.tensor(100.0)
+
+    def one():
+        with torch.no_grad():
+            return O.compute_losses(prob["text_feat"], prob["video_feat"], prob["text_mask"], prob["video_mask"],
+                                    prob["mb_feat_t"], prob["mb_feat_v"], prob["mb_mask_t"], prob["mb_mask_v"], P, hp, ls, nz)
+    one(); one()
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"value": 1.0 / med, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} forward steps of configs[1] (B=128,Nt=24,Nv=12,M=512,K=20) after 2 warm-ups, median; "
+                      f"torch CPU ops, {threads} threads", "ms_per_step": med * 1e3}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from neighborretr_amd import hip, ops, synth
+    c = CFG
+    if c["B"] % world:
+        raise SystemExit("global batch 128 must divide over the ranks")
+    b = c["B"] // world
+    model = build_model(args.precision, dev)
+    model.config.world_size, model.config.local_rank = world, rank
+    full = synth.make_problem(1002, c["B"], c["Nt"], c["Nv"], c["M"])
+    sl = slice(rank * b, (rank + 1) * b)
+    shard = {k: torch.from_numpy(full[k][sl]).to(dev) for k in ("text_feat", "video_feat", "text_mask", "video_mask", "idx")}
+    bank = {k: torch.from_numpy(full[k]).to(dev) for k in ("mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v")}
+    model.mb_feat_t, model.mb_feat_v = bank["mb_feat_t"], bank["mb_feat_v"]
+    model.mb_mask_t, model.mb_mask_v = bank["mb_mask_t"], bank["mb_mask_v"]
+    model.mb_ind = torch.arange(10 ** 6, 10 ** 6 + c["M"], device=dev)
+    out = torch.zeros(5, device=dev)
+
+    def step():
+        with torch.no_grad():
+            losses = model(shard["text_feat"], shard["text_mask"], shard["video_feat"], shard["video_mask"], shard["idx"], 0)
+            out.copy_(torch.stack(losses))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- optional HIP-graph capture of the whole step (single-GPU: no collective inside) --------------
+    graph = None
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    if not args.no_graph and world == 1:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            graph = g
+        except Exception as e:          # graphs are an optimisation, never a requirement
+            print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+
+    for _ in range(args.warmup):
+        run()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    losses = out.cpu().numpy().tolist()
+
+    extra = {}
+    if args.backward and world == 1:
+        tf = shard["text_feat"].clone().requires_grad_(True)
+        vf = shard["video_feat"].clone().requires_grad_(True)
+
+        def fb():
+            model.zero_grad(set_to_none=True)
+            tf.grad = vf.grad = None
+            ls = model(tf, shard["text_mask"], vf, shard["video_mask"], shard["idx"], 0)
+            ls[0].backward()
+        for _ in range(5):
+            fb()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nfb = max(10, args.steps // 10)
+        for _ in range(nfb):
+            fb()
+        torch.cuda.synchronize()
+        extra["fwd_bwd_ms_per_step"] = (time.perf_counter() - t1) / nfb * 1e3
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------------
+    roofline = None
+    if rank == 0:
+        f_sim, f_mlp = algorithmic_flops(c["B"], c["Nt"], c["Nv"], c["M"])
+        from neighborretr_amd import head
+        p_bb, p_mlp, p_bank = head.precision_plan(model._prec())
+        B, Nt, Nv, M = c["B"], c["Nt"], c["Nv"], c["M"]
+        allf = {k: torch.from_numpy(full[k]).to(dev) for k in ("text_feat", "video_feat", "text_mask", "video_mask")}
+        with torch.no_grad():
+            pt = ops.prepare_tokens(allf["text_feat"], allf["text_mask"])
+            pv = ops.prepare_tokens(allf["video_feat"], allf["video_mask"])
+            pbt = ops.prepare_tokens(bank["mb_feat_t"], bank["mb_mask_t"])
+            pbv = ops.prepare_tokens(bank["mb_feat_v"], bank["mb_mask_v"])
+            w = lambda n, N: torch.full((n, N), 1.0 / N, device=dev)
+            w_t, w_v, w_bt, w_bv = w(B, Nt), w(B, Nv), w(M, Nt), w(M, Nv)
+
+            def three():
+                ops.local_level(pt, pv, w_t, w_v, B, Nt, B, Nv, p_bb, hip.OUT_FULL)
+                ops.local_level(pt, pbv, w_t, w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM)
+                ops.local_level(pbt, pv, w_bt, w_v, M, Nt, B, Nv, p_bank, hip.OUT_COLSUM)
+            for _ in range(5):
+                three()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 50
+            e0.record()
+            for _ in range(reps):
+                three()
+            e1.record()
+            torch.cuda.synchronize()
+        per_launch_s = e0.elapsed_time(e1) * 1e-3 / (3 * reps)
+        achieved = (f_sim / 3) / per_launch_s / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "kernel": "nr_sim_kernel (fused local_level, 3 launches/step)",
+                    "avg_launch_us": round(per_launch_s * 1e6, 2),
+                    "algorithmic_flops_per_launch": f_sim / 3}
+
+    if rank == 0:
+        line = {
+            "metric": "sim+loss steps/sec at global B=128, d=512",
+            "value": round(args.steps / dt, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: B=128 d=512 Nt=24 Nv=12 M=512 K=20 (MSR-VTT shape), "
+                                   "loss-only forward incl. token clustering and bank push",
+                       "global_batch": c["B"], "per_rank_batch": b, "precision_plan": args.precision,
+                       "hip_graph": graph is not None, "parallelism": f"dp{world} (all-gather + replicated loss)"},
+            "losses": [round(float(x), 5) for x in losses],
+            "roofline": roofline,
+        }
+        line.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

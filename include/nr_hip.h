@@ -69,12 +69,15 @@ int nr_token_softmax(const float* logit_part, int n_parts, const float* b2, cons
 /* Fused local_level (modeling.py:499-512): token-token cosine products on MFMA, max-pool over
  * each token axis, weighted sums, (t2v+v2t)/2.  The [A,Bv,Nt,Nv] tensor is never materialised.
  *   t_hi/lo [A*Nt,d], v_hi/lo [Bv*Nv,d] prepared tokens; w_t [A*Nt], w_v [Bv*Nv] token weights;
- *   out per out_mode (see NR_OUT_*); arg_v [A,Bv,Nt] / arg_t [A,Bv,Nv] u8 arg-max indices or NULL.
+ *   out per out_mode (see NR_OUT_*).  Optional outputs kept for the backward pass (all or none):
+ *   arg_v [A,Bv,Nt] / arg_t [A,Bv,Nv] u8 arg-max indices, pmax [A,Bv,Nt] / qmax [A,Bv,Nv] f32 the
+ *   pooled maxima themselves.
  * nr_local_level_tiles reports the tile grid the kernel will use (sizes of the partial outputs). */
 int nr_local_level_tiles(int A, int Nt, int Bv, int Nv, int* n_row_tiles, int* n_col_tiles);
 int nr_local_level_fwd(const uint16_t* t_hi, const uint16_t* t_lo, const uint16_t* v_hi, const uint16_t* v_lo,
                        const float* w_t, const float* w_v, int A, int Nt, int Bv, int Nv, int d,
-                       int prec, int out_mode, float* out, uint8_t* arg_v, uint8_t* arg_t, void* stream);
+                       int prec, int out_mode, float* out, uint8_t* arg_v, uint8_t* arg_t,
+                       float* pmax, float* qmax, void* stream);
 
 /* out[i] = scale * sum_p part[p, i]   (memory-bank centrality, until_module.py:181) */
 int nr_reduce_parts(const float* part, int n_parts, int n, float scale, float* out, void* stream);
@@ -111,25 +114,50 @@ int nr_row_losses_fwd(const float* S, const float* G, const float* tgt_rows, con
 int nr_loss_finalize(const float* rowloss, int B, float uniform_weight, float neighbor_weight, float kl_weight,
                      float* losses, void* stream);
 
-/* Backward of nr_row_losses_fwd + nr_loss_finalize for d(total): recomputes the row statistics.
- *   g_losses [5] upstream gradients of (total, centrality, uniform, neighbour, kl) (device);
- *   dS_dir [2,B,B] (direction 1 in the transposed frame), dG_dir [2,B,B], d_bank_c [2,B]
- *   (per-row contributions are reduced inside), d_wc [2,B], d_logit_scale_rows [2,B].        */
+/* Backward of nr_row_losses_fwd: recomputes the row statistics, then differentiates all four
+ * terms.  g_rowloss [2,4,B] = d(objective)/d(rowloss) (for the fused objective: the constants of
+ * nr_loss_finalize).  Outputs, all in the direction's own frame (direction 1 = transposed):
+ *   dS_dir [2,B,B], dG_dir [2,B,B], d_c_rows [2,B,B] (row i's contribution to d bank_c[dir][j];
+ *   the caller sums over i), d_wc [2,B], d_ls_rows [2,B] (summed by the caller).               */
 int nr_row_losses_bwd(const float* S, const float* G, const float* tgt_rows, const float* tgt_cols,
                       const float* bank_c0, const float* bank_c1, const float* wc_text, const float* wc_video,
-                      const float* logit_scale, int B, int K, float temperature,
-                      float uniform_weight, float neighbor_weight, float kl_weight, const float* g_losses,
-                      float* dS_dir, float* dG_dir, float* d_bank_c_rows, float* d_wc, float* d_ls_rows,
-                      void* stream);
+                      const float* logit_scale, int B, int K, float temperature, const float* g_rowloss,
+                      float* dS_dir, float* dG_dir, float* d_c_rows, float* d_wc, float* d_ls_rows, void* stream);
 
-/* Backward of nr_local_level_fwd w.r.t. the prepared (normalised, masked) tokens and the token
- * weights, routed through the stored arg-max indices (max-pool backward = scatter to the arg-max).
- *   dS [A,Bv] upstream (for the bank modes the caller expands d_mean/M into it);
- *   t_n/v_n: normalised masked tokens as f32 [A*Nt,d] / [Bv*Nv,d];
- *   d_tn [A*Nt,d], d_vn [Bv*Nv,d] (either may be NULL), d_wt [A*Nt], d_wv [Bv*Nv] out.       */
-int nr_local_level_bwd(const float* dS, const float* t_n, const float* v_n, const float* w_t, const float* w_v,
-                       const uint8_t* arg_v, const uint8_t* arg_t, int A, int Nt, int Bv, int Nv, int d,
-                       float* d_tn, float* d_vn, float* d_wt, float* d_wv, void* stream);
+/* out[i,j] = a[i,j] + b[j,i]  (folds the direction-1 gradients back into the row-major frame);
+ * colsum variant: out[j] = sum_i a[i,j].                                                        */
+int nr_add_transposed(const float* a, const float* b, int B, float* out, void* stream);
+int nr_colsum(const float* a, int rows, int cols, float* out, void* stream);
+
+/* Backward of nr_local_level_fwd through the stored arg-max indices (max-pool backward = route to
+ * the arg-max) for ONE side of the product.
+ *   side 0: gradients of the ROW (text) operand: d_x [A*Nt,d], d_w [A*Nt]; one workgroup per text,
+ *           looping over the Bv videos.  side 1: the COLUMN (video) operand: d_x [Bv*Nv,d], d_w [Bv*Nv].
+ *   dS: upstream gradient; ds_mode 0: dS[A,Bv] full, 1: dS[a,b] = vec[a] (row-mean modes),
+ *       2: dS[a,b] = vec[b] (column-mean modes); `ds_scale` multiplies it (1/M for the means).
+ *   o_hi/o_lo: prepared tokens of the OTHER operand (lo may be NULL: hi only);
+ *   w_self / w_other: token weights of this / the other operand;
+ *   d_x may be NULL (weights-only: memory-bank side, whose features get no gradient);
+ *   accumulate != 0 adds into d_x / d_w instead of overwriting.                                 */
+int nr_local_level_bwd(int side, const float* dS, int ds_mode, float ds_scale,
+                       const uint16_t* o_hi, const uint16_t* o_lo, const float* w_self, const float* w_other,
+                       const uint8_t* arg_v, const uint8_t* arg_t, const float* pmax, const float* qmax,
+                       int A, int Nt, int Bv, int Nv, int d, float* d_x, float* d_w, int accumulate, void* stream);
+
+/* Backward of F.normalize + mask + the centrality mean (nr_prepare_tokens):
+ *   g = mask*d_xn + dmean/n_tok;  dx = (g - xhat <xhat,g>) / ||x||,  xhat = x/||x||.
+ *   x [n_tok,d] original features, norm [n_tok], mask [n_tok] or NULL, d_xn [n_tok,d] or NULL,
+ *   dmean [d] or NULL.                                                                          */
+int nr_normalize_bwd(const float* x, const float* norm, const float* mask, const float* d_xn, const float* dmean,
+                     int n_tok, int d, float* dx, void* stream);
+
+/* Backward of nr_token_softmax: dlogit = w * (dw - sum_t w dw) per sample ([n_samples,N]). */
+int nr_token_softmax_bwd(const float* w, const float* dw, int n_samples, int N, float* dlogit, void* stream);
+
+/* Backward of nr_centrality_weights:  a_i = dw_i * w_i * scale;
+ *   dg_i = a_i * (mean - ghat_i <ghat_i, mean>) / ||g_i||;   dmean = sum_i a_i ghat_i.           */
+int nr_centrality_weights_bwd(const float* g, const float* gnorm, const float* mean, const float* w, const float* dw,
+                              int B, int d, float scale, float* dg, float* dmean, void* stream);
 
 /* Memory-bank FIFO push (modeling.py:237-249): bank <- cat(batch, bank)[:capacity] done as an
  * in-place shift; rows are `row_bytes` wide.  Requires 0 < n_new; if n_new >= capacity the bank

@@ -1,0 +1,192 @@
+"""torch.autograd.Function wrappers whose forward AND backward run on the HIP kernels.
+
+Gradient structure of the head (verified against the reference's autograd through the golden
+vectors, SURVEY.md 8a "Autograd and edge-case facts"): nothing is detached except the Sinkhorn
+targets and the top-K / arg-max index choices, so gradients flow
+  losses -> S (three local_level calls), G, bank centralities, centrality weights, logit_scale
+         -> max-pool arg-max routes -> normalised tokens -> features
+         -> token weights -> softmax -> scorer MLP (parameters and features)
+         -> centrality weights -> global tokens and the mean of the normalised tokens.
+The memory-bank FEATURES get no gradient; the bank tokens' scorer weights do (parameters only).
+"""
+import torch
+
+from . import head, hip, ops
+
+
+def _coef_rowloss(g, hp, B):
+    """d(objective)/d(rowloss[dir,term,row]) for upstream g [5] on (total, cent, unif, neigh, kl)."""
+    wu, wn, wkl = hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"]
+    c = torch.stack((g[0] + g[1], g[0] * wu + g[2], g[0] * wn + g[3], (g[0] * wkl + g[4]) / B)) * (0.5 / B)
+    return c.float()[None, :, None].expand(2, 4, B).contiguous()
+
+
+def _mlp_backward(feats, dlogits, w1, b1, w2, n_dx, exact):
+    """Backward of Linear(d,H)-ReLU-Linear(H,1) over the concatenation of `feats` (list of
+    [n_i,d] tensors) with upstream `dlogits` (list of [n_i]).  Plain GEMMs -> library matmul
+    (bf16 inputs / fp32 accumulate, or fp32 when `exact`).  Returns dW1, db1, dW2, db2 and dX of
+    the first `n_dx` rows (or None)."""
+    X = torch.cat([f.reshape(-1, f.shape[-1]) for f in feats], 0).float()
+    dl = torch.cat([d.reshape(-1) for d in dlogits], 0).float()
+    cd = torch.float32 if exact else torch.bfloat16
+    Xc, W1c = X.to(cd), w1.to(cd)
+    h = (Xc @ W1c.t()).float() + b1.float()
+    act = h > 0
+    a = torch.where(act, h, torch.zeros_like(h))
+    dW2 = (dl[None, :] @ a)                                   # [1,H]
+    db2 = dl.sum().reshape(1)
+    dh = torch.where(act, dl[:, None] * w2.float().reshape(1, -1), torch.zeros_like(h))
+    dhc = dh.to(cd)
+    dW1 = (dhc.t() @ Xc).float()
+    db1 = dh.sum(0)
+    dX = (dhc[:n_dx] @ W1c).float() if n_dx else None
+    return dW1, db1, dW2, db2, dX
+
+
+class HeadLossFn(torch.autograd.Function):
+    """Fused _compute_losses (modeling.py:314-360) given the global tokens."""
+
+    @staticmethod
+    def forward(ctx, model, hp, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
+                text_feat, video_feat, gt, gv, logit_scale, w1t, b1t, w2t, b2t, w1v, b1v, w2v, b2v):
+        prec = model._prec()
+        losses, sv = head.head_forward(text_feat.detach(), video_feat.detach(), text_mask, video_mask,
+                                       mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v, gt.detach(), gv.detach(),
+                                       model.scorer_weights("text_weight_fc"), model.scorer_weights("video_weight_fc"),
+                                       hp, logit_scale.detach(), prec, keep=True)
+        ctx.sv, ctx.hp, ctx.exact = sv, dict(hp), prec == hip.PREC_BF16X3
+        ctx.masks = (text_mask, video_mask)
+        ctx.shapes = (text_feat.shape, video_feat.shape, mb_feat_t.shape, mb_feat_v.shape, gt.shape, gv.shape)
+        ctx.save_for_backward(text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        sv, hp = ctx.sv, ctx.hp
+        text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v = ctx.saved_tensors
+        (B, Nt, d), (_, Nv, _), (M, _, _), _, gt_shape, gv_shape = ctx.shapes
+        text_mask, video_mask = ctx.masks
+        K, T = int(hp["num_neighbors"]), hp["temperature"]
+        g = g.float().contiguous()
+        coef = _coef_rowloss(g, hp, B)
+        dS_dir, dG_dir, dC_rows, dwc, dls_rows = ops.row_losses_bwd(sv["S"], sv["G"], sv["tgt_r"], sv["tgt_c"], sv["c0"],
+                                                                    sv["c1"], sv["wc_t"], sv["wc_v"], sv["ls"], K, T, coef)
+        dS = ops.add_transposed(dS_dir[0], dS_dir[1])
+        dG = ops.add_transposed(dG_dir[0], dG_dir[1])
+        d_c0 = ops.colsum(dC_rows[0])
+        d_c1 = ops.colsum(dC_rows[1])
+        d_ls = dls_rows.sum()
+        # global logits G = gt gv^T   (tiny plain GEMMs)
+        d_gt = dG @ sv["gv2"]
+        d_gv = dG.t() @ sv["gt2"]
+        # centrality weights
+        cs = hp["centrality_scale"]
+        dg_t, dmean_t = ops.centrality_weights_bwd(sv["gt2"], sv["gn_t"], sv["mean_t"], sv["wc_t"], dwc[0], cs)
+        dg_v, dmean_v = ops.centrality_weights_bwd(sv["gv2"], sv["gn_v"], sv["mean_v"], sv["wc_v"], dwc[1], cs)
+        d_gt = (d_gt + dg_t).reshape(gt_shape)
+        d_gv = (d_gv + dg_v).reshape(gv_shape)
+        # similarity kernels: batch x batch, text x bank-video (row mean), bank-text x video (col mean)
+        pt, pv, pbt, pbv = sv["pt"], sv["pv"], sv["pbt"], sv["pbv"]
+        lo = ctx.exact
+        aux0, aux1, aux2 = sv["aux"]
+        d_tn, d_wt = ops.local_level_bwd(0, dS, 0, 1.0, pv, sv["w_t"], sv["w_v"], aux0, B, Nt, B, Nv, use_lo=lo)
+        d_vn, d_wv = ops.local_level_bwd(1, dS, 0, 1.0, pt, sv["w_v"], sv["w_t"], aux0, B, Nt, B, Nv, use_lo=lo)
+        ops.local_level_bwd(0, d_c1, 1, 1.0 / M, pbv, sv["w_t"], sv["w_bv"], aux1, B, Nt, M, Nv, d_x=d_tn, d_w=d_wt,
+                            accumulate=True, use_lo=lo)
+        _, d_wbv = ops.local_level_bwd(1, d_c1, 1, 1.0 / M, pt, sv["w_bv"], sv["w_t"], aux1, B, Nt, M, Nv, want_dx=False)
+        ops.local_level_bwd(1, d_c0, 2, 1.0 / M, pbt, sv["w_v"], sv["w_bt"], aux2, M, Nt, B, Nv, d_x=d_vn, d_w=d_wv,
+                            accumulate=True, use_lo=lo)
+        _, d_wbt = ops.local_level_bwd(0, d_c0, 2, 1.0 / M, pv, sv["w_bt"], sv["w_v"], aux2, M, Nt, B, Nv, want_dx=False)
+        # normalise / mask / centrality-mean backward
+        d_text = ops.normalize_bwd(text_feat, pt.norm, text_mask, d_tn, dmean_t)
+        d_video = ops.normalize_bwd(video_feat, pv.norm, video_mask, d_vn, dmean_v)
+        # token weights -> logits -> scorer MLPs
+        dl_t = ops.token_softmax_bwd(sv["w_t"], d_wt.view(B, Nt))
+        dl_v = ops.token_softmax_bwd(sv["w_v"], d_wv.view(B, Nv))
+        dl_bt = ops.token_softmax_bwd(sv["w_bt"], d_wbt.view(M, Nt))
+        dl_bv = ops.token_softmax_bwd(sv["w_bv"], d_wbv.view(M, Nv))
+        dW1t, db1t, dW2t, db2t, dXt = _mlp_backward([text_feat, mb_feat_t], [dl_t, dl_bt], w1t, b1t, w2t, B * Nt, ctx.exact)
+        dW1v, db1v, dW2v, db2v, dXv = _mlp_backward([video_feat, mb_feat_v], [dl_v, dl_bv], w1v, b1v, w2v, B * Nv, ctx.exact)
+        d_text = d_text + dXt.view_as(d_text)
+        d_video = d_video + dXv.view_as(d_video)
+        ctx.sv = None
+        return (None, None, None, None, None, None, None, None,
+                d_text, d_video, d_gt, d_gv, d_ls,
+                dW1t, db1t, dW2t, db2t, dW1v, db1v, dW2v, db2v)
+
+
+class LocalLevelFn(torch.autograd.Function):
+    """local_level / get_similarity_logits (modeling.py:483-514)."""
+
+    @staticmethod
+    def forward(ctx, model, text_mask, video_mask, text_feat, video_feat, w1t, b1t, w2t, b2t, w1v, b1v, w2v, b2v):
+        prec = model._prec(for_head=False)
+        A, Nt, d = text_feat.shape
+        Bv, Nv, _ = video_feat.shape
+        sw_t, sw_v = model.scorer_weights("text_weight_fc"), model.scorer_weights("video_weight_fc")
+        pt = ops.prepare_tokens(text_feat.detach(), text_mask)
+        pv = ops.prepare_tokens(video_feat.detach(), video_mask)
+        w_t, _ = head.token_weights(pt, text_mask, sw_t, A, Nt, prec)
+        w_v, _ = head.token_weights(pv, video_mask, sw_v, Bv, Nv, prec)
+        S, aux = ops.local_level(pt, pv, w_t, w_v, A, Nt, Bv, Nv, prec, hip.OUT_FULL, want_arg=True)
+        ctx.st = (pt, pv, w_t, w_v, aux, text_mask, video_mask, prec == hip.PREC_BF16X3)
+        ctx.save_for_backward(text_feat, video_feat, w1t, b1t, w2t, w1v, b1v, w2v)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        pt, pv, w_t, w_v, aux, text_mask, video_mask, exact = ctx.st
+        text_feat, video_feat, w1t, b1t, w2t, w1v, b1v, w2v = ctx.saved_tensors
+        A, Nt, d = text_feat.shape
+        Bv, Nv, _ = video_feat.shape
+        dS = dS.float().contiguous()
+        d_tn, d_wt = ops.local_level_bwd(0, dS, 0, 1.0, pv, w_t, w_v, aux, A, Nt, Bv, Nv, use_lo=exact)
+        d_vn, d_wv = ops.local_level_bwd(1, dS, 0, 1.0, pt, w_v, w_t, aux, A, Nt, Bv, Nv, use_lo=exact)
+        d_text = ops.normalize_bwd(text_feat, pt.norm, text_mask, d_tn, None)
+        d_video = ops.normalize_bwd(video_feat, pv.norm, video_mask, d_vn, None)
+        dl_t = ops.token_softmax_bwd(w_t, d_wt.view(A, Nt))
+        dl_v = ops.token_softmax_bwd(w_v, d_wv.view(Bv, Nv))
+        dW1t, db1t, dW2t, db2t, dXt = _mlp_backward([text_feat], [dl_t], w1t, b1t, w2t, A * Nt, exact)
+        dW1v, db1v, dW2v, db2v, dXv = _mlp_backward([video_feat], [dl_v], w1v, b1v, w2v, Bv * Nv, exact)
+        ctx.st = None
+        return (None, None, None, d_text + dXt.view_as(d_text), d_video + dXv.view_as(d_video),
+                dW1t, db1t, dW2t, db2t, dW1v, db1v, dW2v, db2v)
+
+
+class GlobalLogitsFn(torch.autograd.Function):
+    """One-global-token global_level: G = gt gv^T in exact fp32 (modeling.py:526-537)."""
+
+    @staticmethod
+    def forward(ctx, gt, gv):
+        a = gt.detach().reshape(gt.shape[0], -1).float().contiguous()
+        b = gv.detach().reshape(gv.shape[0], -1).float().contiguous()
+        ctx.save_for_backward(a, b)
+        ctx.shapes = (gt.shape, gv.shape)
+        return ops.gemm_nt_f32(a, b)
+
+    @staticmethod
+    def backward(ctx, dG):
+        a, b = ctx.saved_tensors
+        return (dG @ b).reshape(ctx.shapes[0]), (dG.t() @ a).reshape(ctx.shapes[1])
+
+
+class RowLossFn(torch.autograd.Function):
+    """Raw per-row loss terms [2,4,B] with the HIP backward (used by the until_module classes)."""
+
+    @staticmethod
+    def forward(ctx, S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, K, T):
+        args = [t.detach().float().contiguous() for t in (S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video)]
+        ls = logit_scale.detach().float().reshape(1).contiguous()
+        ctx.save_for_backward(*args, ls)
+        ctx.KT = (int(K), float(T))
+        return ops.row_losses(*args, ls, K, T)
+
+    @staticmethod
+    def backward(ctx, g):
+        *args, ls = ctx.saved_tensors
+        K, T = ctx.KT
+        dS_dir, dG_dir, dC_rows, dwc, dls_rows = ops.row_losses_bwd(*args, ls, K, T, g.float().contiguous())
+        dS = ops.add_transposed(dS_dir[0], dS_dir[1])
+        dG = ops.add_transposed(dG_dir[0], dG_dir[1])
+        return (dS, dG, None, None, ops.colsum(dC_rows[0]), ops.colsum(dC_rows[1]), dwc[0], dwc[1],
+                dls_rows.sum().reshape(1), None, None)

@@ -1,0 +1,242 @@
+// Backward kernels of the similarity path: arg-max-routed gradient of the fused local_level,
+// normalisation / mask / centrality-mean backward, token-softmax backward, centrality-weight
+// backward, and two small layout helpers.
+//
+// local_level backward (reference autograd of modeling.py:499-512): with P = max_v R, Q = max_t R,
+//   dR[a,b,t,argv] += 0.5 dS[a,b] w_t[a,t],  dR[a,b,argt,v] += 0.5 dS[a,b] w_v[b,v],
+// so every (text, video) pair touches only Nt + Nv token-token products.  One workgroup owns one
+// sample of the differentiated operand and a slice of the feature dimension and walks over all
+// samples of the other operand; each thread owns ONE feature column, keeps the other sample's
+// tokens and its own accumulators in a private LDS column (dynamic token index, no bank conflicts,
+// no barriers), and never needs atomics: results are bitwise reproducible.
+#include "nr_common.h"
+#include "../../include/nr_hip.h"
+
+struct NrSimBwdArgs {
+    const float* dS; int ds_mode; float ds_scale;
+    const uint16_t *o_hi, *o_lo;
+    const float *w_self, *w_other;
+    const uint8_t *gath_arg, *scat_arg;   // [pair, Ns] -> other token ; [pair, No] -> self token
+    const float* pool;                    // pooled maxima [pair, Ns]
+    int side, A, Bv, Ns, No, d, n_loop;
+    float *d_x, *d_w;
+    int accumulate;
+};
+
+__global__ void nr_sim_bwd_kernel(NrSimBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int DS = blockDim.x;
+    const int k = threadIdx.x;
+    const int self = blockIdx.x;              // sample of the differentiated operand
+    const int dim = blockIdx.y * DS + k;
+    const bool live = dim < p.d;
+    float* acc = lds;                          // [Ns][DS]
+    float* ov = lds + (size_t)p.Ns * DS;       // [No][DS]
+    const int Ns = p.Ns, No = p.No;
+    for (int n = 0; n < Ns; ++n) acc[n * DS + k] = 0.f;
+    float dw = 0.f;                            // thread n < Ns of slice 0 accumulates d_w[self, n]
+    const bool do_w = (blockIdx.y == 0) && (k < Ns) && p.d_w;
+
+    for (int o = 0; o < p.n_loop; ++o) {
+        const int a = p.side == 0 ? self : o;
+        const int b = p.side == 0 ? o : self;
+        const size_t pair = (size_t)a * p.Bv + b;
+        float g;
+        if (p.ds_mode == 0) g = p.dS[pair];
+        else if (p.ds_mode == 1) g = p.dS[a];
+        else g = p.dS[b];
+        g *= 0.5f * p.ds_scale;
+        if (do_w) dw += g * p.pool[pair * Ns + k];
+        if (!p.d_x) continue;
+        const uint8_t* ga = p.gath_arg + pair * Ns;
+        const uint8_t* sa = p.scat_arg + pair * No;
+        const float* wo = p.w_other + (size_t)o * No;
+        const size_t obase = (size_t)o * No * p.d + dim;
+        // scatter part while streaming the other sample's tokens through the private column
+        for (int m = 0; m < No; ++m) {
+            float val = 0.f;
+            if (live) {
+                val = nr_bf2f(p.o_hi[obase + (size_t)m * p.d]);
+                if (p.o_lo) val += nr_bf2f(p.o_lo[obase + (size_t)m * p.d]);
+            }
+            ov[m * DS + k] = val;
+            int tgt = sa[m];
+            acc[tgt * DS + k] += g * wo[m] * val;
+        }
+        // gather part
+        const float* ws = p.w_self + (size_t)self * Ns;
+        for (int n = 0; n < Ns; ++n) acc[n * DS + k] += g * ws[n] * ov[(int)ga[n] * DS + k];
+    }
+    if (p.d_x && live) {
+        for (int n = 0; n < Ns; ++n) {
+            size_t idx = ((size_t)self * Ns + n) * p.d + dim;
+            p.d_x[idx] = (p.accumulate ? p.d_x[idx] : 0.f) + acc[n * DS + k];
+        }
+    }
+    if (do_w) {
+        size_t idx = (size_t)self * Ns + k;
+        p.d_w[idx] = (p.accumulate ? p.d_w[idx] : 0.f) + dw;
+    }
+}
+
+extern "C" int nr_local_level_bwd(int side, const float* dS, int ds_mode, float ds_scale, const uint16_t* o_hi,
+                                  const uint16_t* o_lo, const float* w_self, const float* w_other, const uint8_t* arg_v,
+                                  const uint8_t* arg_t, const float* pmax, const float* qmax, int A, int Nt, int Bv, int Nv,
+                                  int d, float* d_x, float* d_w, int accumulate, void* stream) {
+    if (!dS || !w_self || !w_other || !arg_v || !arg_t || !pmax || !qmax) return NR_EINVAL;
+    if (side < 0 || side > 1 || ds_mode < 0 || ds_mode > 2 || A <= 0 || Bv <= 0 || Nt <= 0 || Nv <= 0 || d <= 0) return NR_EINVAL;
+    if (d_x && !o_hi) return NR_EINVAL;
+    if (!d_x && !d_w) return NR_EINVAL;
+    NrSimBwdArgs p;
+    p.dS = dS; p.ds_mode = ds_mode; p.ds_scale = ds_scale; p.o_hi = o_hi; p.o_lo = o_lo;
+    p.w_self = w_self; p.w_other = w_other; p.side = side; p.A = A; p.Bv = Bv; p.d = d;
+    p.d_x = d_x; p.d_w = d_w; p.accumulate = accumulate;
+    if (side == 0) { p.Ns = Nt; p.No = Nv; p.gath_arg = arg_v; p.scat_arg = arg_t; p.pool = pmax; p.n_loop = Bv; }
+    else           { p.Ns = Nv; p.No = Nt; p.gath_arg = arg_t; p.scat_arg = arg_v; p.pool = qmax; p.n_loop = A; }
+    int DS = 256;
+    while (DS > 64 && (size_t)(p.Ns + p.No) * DS * 4 > 150 * 1024) DS >>= 1;
+    if (DS < p.Ns) return NR_EUNSUPPORTED;                 // d_w needs one thread per token
+    size_t lds = (size_t)(p.Ns + p.No) * DS * 4;
+    if (lds > 160 * 1024) return NR_EUNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)nr_sim_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(side == 0 ? A : Bv, d_x ? (d + DS - 1) / DS : 1);
+    hipLaunchKernelGGL(nr_sim_bwd_kernel, grid, dim3(DS), lds, (hipStream_t)stream, p);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// ---- F.normalize + mask (+ centrality mean) backward ---------------------------------------------
+__global__ __launch_bounds__(256) void nr_normalize_bwd_kernel(const float* __restrict__ x, const float* __restrict__ norm,
+                                                               const float* __restrict__ mask, const float* __restrict__ d_xn,
+                                                               const float* __restrict__ dmean, int n_tok, int d,
+                                                               float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_tok) return;
+    const float inv = 1.0f / norm[row];
+    const float mk = mask ? mask[row] : 1.0f;
+    const float invn = 1.0f / (float)n_tok;
+    const float* xr = x + (size_t)row * d;
+    float dot = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        float g = (d_xn ? mk * d_xn[(size_t)row * d + c] : 0.f) + (dmean ? dmean[c] * invn : 0.f);
+        dot += g * xr[c] * inv;
+    }
+    dot = nr_wave_sum(dot);
+    for (int c = lane; c < d; c += 64) {
+        float g = (d_xn ? mk * d_xn[(size_t)row * d + c] : 0.f) + (dmean ? dmean[c] * invn : 0.f);
+        dx[(size_t)row * d + c] = (g - xr[c] * inv * dot) * inv;
+    }
+}
+
+extern "C" int nr_normalize_bwd(const float* x, const float* norm, const float* mask, const float* d_xn, const float* dmean,
+                                int n_tok, int d, float* dx, void* stream) {
+    if (!x || !norm || !dx || n_tok <= 0 || d <= 0 || (!d_xn && !dmean)) return NR_EINVAL;
+    hipLaunchKernelGGL(nr_normalize_bwd_kernel, dim3((n_tok + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, norm, mask, d_xn,
+                       dmean, n_tok, d, dx);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// ---- token softmax backward ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nr_token_softmax_bwd_kernel(const float* __restrict__ w, const float* __restrict__ dw,
+                                                                   int n_samples, int N, float* __restrict__ dlogit) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_samples) return;
+    float dot = 0.f;
+    for (int t = lane; t < N; t += 64) dot += w[(size_t)s * N + t] * dw[(size_t)s * N + t];
+    dot = nr_wave_sum(dot);
+    for (int t = lane; t < N; t += 64) {
+        size_t i = (size_t)s * N + t;
+        dlogit[i] = w[i] * (dw[i] - dot);
+    }
+}
+
+extern "C" int nr_token_softmax_bwd(const float* w, const float* dw, int n_samples, int N, float* dlogit, void* stream) {
+    if (!w || !dw || !dlogit || n_samples <= 0 || N <= 0) return NR_EINVAL;
+    hipLaunchKernelGGL(nr_token_softmax_bwd_kernel, dim3((n_samples + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, dw,
+                       n_samples, N, dlogit);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// ---- centrality weights backward ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nr_centrality_bwd_dg_kernel(const float* __restrict__ g, const float* __restrict__ gnorm,
+                                                                   const float* __restrict__ mean, const float* __restrict__ w,
+                                                                   const float* __restrict__ dw, int B, int d, float scale,
+                                                                   float* __restrict__ dg) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    const float inv = 1.0f / gnorm[i];
+    const float a = dw[i] * w[i] * scale;
+    const float* gi = g + (size_t)i * d;
+    float dot = 0.f;
+    for (int c = lane; c < d; c += 64) dot += gi[c] * inv * mean[c];
+    dot = nr_wave_sum(dot);
+    for (int c = lane; c < d; c += 64) dg[(size_t)i * d + c] = a * (mean[c] - gi[c] * inv * dot) * inv;
+}
+
+__global__ __launch_bounds__(256) void nr_centrality_bwd_dmean_kernel(const float* __restrict__ g, const float* __restrict__ gnorm,
+                                                                      const float* __restrict__ w, const float* __restrict__ dw,
+                                                                      int B, int d, float scale, float* __restrict__ dmean) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    float s = 0.f;
+    for (int i = 0; i < B; ++i) s += dw[i] * w[i] * scale * g[(size_t)i * d + c] / gnorm[i];
+    dmean[c] = s;
+}
+
+extern "C" int nr_centrality_weights_bwd(const float* g, const float* gnorm, const float* mean, const float* w, const float* dw,
+                                         int B, int d, float scale, float* dg, float* dmean, void* stream) {
+    if (!g || !gnorm || !mean || !w || !dw || !dg || !dmean || B <= 0 || d <= 0) return NR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(nr_centrality_bwd_dg_kernel, dim3((B + 3) / 4), dim3(256), 0, st, g, gnorm, mean, w, dw, B, d, scale, dg);
+    hipLaunchKernelGGL(nr_centrality_bwd_dmean_kernel, dim3((d + 255) / 256), dim3(256), 0, st, g, gnorm, w, dw, B, d, scale, dmean);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// ---- layout helpers ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nr_add_transposed_kernel(const float* __restrict__ a, const float* __restrict__ b, int B,
+                                                                float* __restrict__ out) {
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    // tile (blockIdx.y, blockIdx.x) of `out`; needs tile (blockIdx.x, blockIdx.y) of b
+    for (int r = ty; r < 32; r += 8) {
+        int bi = blockIdx.x * 32 + r, bj = blockIdx.y * 32 + tx;
+        if (bi < B && bj < B) t[r][tx] = b[(size_t)bi * B + bj];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int i = blockIdx.y * 32 + r, j = blockIdx.x * 32 + tx;
+        if (i < B && j < B) out[(size_t)i * B + j] = a[(size_t)i * B + j] + t[tx][r];
+    }
+}
+
+extern "C" int nr_add_transposed(const float* a, const float* b, int B, float* out, void* stream) {
+    if (!a || !b || !out || B <= 0) return NR_EINVAL;
+    dim3 grid((B + 31) / 32, (B + 31) / 32);
+    hipLaunchKernelGGL(nr_add_transposed_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, b, B, out);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+__global__ __launch_bounds__(256) void nr_colsum_kernel(const float* __restrict__ a, int rows, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += a[(size_t)r * cols + c];
+    out[c] = s;
+}
+
+extern "C" int nr_colsum(const float* a, int rows, int cols, float* out, void* stream) {
+    if (!a || !out || rows <= 0 || cols <= 0) return NR_EINVAL;
+    hipLaunchKernelGGL(nr_colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, rows, cols, out);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}

@@ -17,6 +17,18 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #define NR_EINVAL (-1)
 #define NR_EUNSUPPORTED (-2)
 
+// Every launch first clears the thread's sticky "last error" (the host process -- PyTorch's lazy
+// runtime initialisation, for one -- may have left an unrelated one behind), so that
+// NR_LAUNCH_CHECK reports only errors of our own launches.
+#ifdef hipLaunchKernelGGL
+#undef hipLaunchKernelGGL
+#endif
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                  \
+    do {                                                                                                  \
+        (void)hipGetLastError();                                                                          \
+        kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);                \
+    } while (0)
+
 #define NR_LAUNCH_CHECK()                              \
     do {                                               \
         hipError_t e__ = hipGetLastError();            \

@@ -5,7 +5,8 @@
 #include "nr_common.h"
 #include "../../include/nr_hip.h"
 
-#define NR_PREP_MAX_PARTS 256
+#define NR_PREP_MAX_PARTS 64     // column-sum partials (kept few: their consumer reduces them serially)
+#define NR_PREP_MAX_GRID 2048
 #define NR_PREP_MAX_CHUNKS 4   // d <= 1024
 
 extern "C" int nr_prepare_parts(int n_tok) {
@@ -77,7 +78,13 @@ extern "C" int nr_prepare_tokens(const float* x, const float* mask, int n_tok, i
                                  uint16_t* lo, float* norm, float* colsum_part, void* stream) {
     if (!x || !hi || n_tok <= 0 || d <= 0) return NR_EINVAL;
     if ((d % 256) != 0 || d / 256 > NR_PREP_MAX_CHUNKS) return NR_EUNSUPPORTED;
+    // column sums wanted: one partial per workgroup, so few workgroups (the batch tensors are small);
+    // otherwise (memory bank) enough workgroups to stream at HBM rate
     int grid = nr_prepare_parts(n_tok);
+    if (!colsum_part) {
+        grid = (n_tok + 15) / 16;
+        if (grid > NR_PREP_MAX_GRID) grid = NR_PREP_MAX_GRID;
+    }
     hipStream_t st = (hipStream_t)stream;
     switch (d / 256) {
         case 1: hipLaunchKernelGGL(nr_prepare_kernel<1>, dim3(grid), dim3(256), 0, st, x, mask, n_tok, d, normalize, hi, lo, norm, colsum_part); break;

@@ -255,3 +255,153 @@ extern "C" int nr_loss_finalize(const float* rowloss, int B, float uniform_weigh
     NR_LAUNCH_CHECK();
     return NR_OK;
 }
+
+// ================================= backward ======================================================
+// wave arg-min / arg-max over a predicate, ties towards the lower index
+__device__ __forceinline__ void nr_wave_argmin(float& v, int& idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(v, o);
+        int oi = __shfl_xor(idx, o);
+        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+template <int NE>
+__global__ __launch_bounds__(256) void nr_row_losses_bwd_kernel(NrRowArgs a, const float* __restrict__ g_rowloss,
+                                                                float* __restrict__ dS_dir, float* __restrict__ dG_dir,
+                                                                float* __restrict__ d_c_rows, float* __restrict__ d_wc,
+                                                                float* __restrict__ d_ls_rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int dir = blockIdx.y;
+    const int B = a.B;
+    if (row >= B) return;
+    NrRowState<NE> r;
+    r.load(a, row, dir, lane);
+    r.stats(a.K, lane);
+    const float gC = g_rowloss[(size_t)(dir * 4 + 0) * B + row];
+    const float gU = g_rowloss[(size_t)(dir * 4 + 1) * B + row];
+    const float gN = g_rowloss[(size_t)(dir * 4 + 2) * B + row];
+    const float gK = g_rowloss[(size_t)(dir * 4 + 3) * B + row];
+
+    // ---- pass 1: row scalars -------------------------------------------------------------------
+    float tsum = 0.f, kl = 0.f, pcs = 0.f, pe = 0.f, psum = 0.f;
+    float mns = INFINITY, mxs = -INFINITY, mnc = INFINITY, mxc = -INFINITY;
+    int imns = 0x7fffffff, imxs = 0x7fffffff, imnc = 0x7fffffff, imxc = 0x7fffffff;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        if (!r.valid[e]) continue;
+        const int j = e * 64 + lane;
+        tsum += r.tg[e];
+        float lp = r.s[e] - r.lse_s;
+        kl += expf(lp) * (lp - (r.g[e] - r.lse_g));
+        pcs += expf(r.s[e] * r.ls - r.lse_c) * r.s[e];
+        float p = r.posw(e);
+        pe += p * (r.s[e] - r.lse_e);
+        psum += p;
+        if (r.rest[e]) {
+            if (r.s[e] < mns) { mns = r.s[e]; imns = j; }
+            if (r.s[e] > mxs) { mxs = r.s[e]; imxs = j; }
+            if (r.c[e] < mnc) { mnc = r.c[e]; imnc = j; }
+            if (r.c[e] > mxc) { mxc = r.c[e]; imxc = j; }
+        }
+    }
+    tsum = nr_wave_sum(tsum);
+    kl = nr_wave_sum(kl);
+    pcs = nr_wave_sum(pcs);
+    pe = nr_wave_sum(pe);
+    psum = nr_wave_sum(psum) + 1.0f;
+    nr_wave_argmin(mns, imns);
+    nr_wave_argmin(mnc, imnc);
+    nr_wave_argmax(mxs, imxs);
+    nr_wave_argmax(mxc, imxc);
+
+    const float rs = 1.0f / (r.max_s - r.min_s), rc = 1.0f / (r.max_c - r.min_c);
+    // neighbour: dz_j = p_j * (-1/ps) * (e_j - pe);  dadj_j = T * dz_j
+    float Dmin_s = 0.f, Dmax_s = 0.f, Dmin_c = 0.f, Dmax_c = 0.f;
+    float dadj[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        dadj[e] = 0.f;
+        if (r.valid[e] && r.sel[e]) {
+            float p = r.posw(e);
+            float ej = r.s[e] - r.lse_e;
+            dadj[e] = r.T * p * (-1.0f / psum) * (ej - pe);
+            float ns = (r.s[e] - r.min_s) * rs, nc = (r.c[e] - r.min_c) * rc;
+            Dmin_s += dadj[e] * rs * (ns - 1.0f);
+            Dmax_s -= dadj[e] * ns * rs;
+            Dmin_c += dadj[e] * rc * (1.0f - nc);
+            Dmax_c += dadj[e] * nc * rc;
+        }
+    }
+    Dmin_s = nr_wave_sum(Dmin_s); Dmax_s = nr_wave_sum(Dmax_s);
+    Dmin_c = nr_wave_sum(Dmin_c); Dmax_c = nr_wave_sum(Dmax_c);
+
+    // ---- pass 2: per-entry gradients --------------------------------------------------------------
+    float* dSr = dS_dir + ((size_t)dir * B + row) * B;
+    float* dGr = dG_dir + ((size_t)dir * B + row) * B;
+    float* dCr = d_c_rows + ((size_t)dir * B + row) * B;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        if (!r.valid[e]) continue;
+        const int j = e * 64 + lane;
+        const bool diag = j == row;
+        // centrality
+        float pc = expf(r.s[e] * r.ls - r.lse_c);
+        float ds = gC * (-r.wci * r.ls) * ((diag ? 1.0f : 0.f) - pc);
+        // uniform CE
+        float pu = expf(r.g[e] * r.T - r.lse_u);
+        float dg = gU * (-r.T) * (r.tg[e] - tsum * pu);
+        // KL
+        float lp = r.s[e] - r.lse_s, p = expf(lp);
+        float qg = expf(r.g[e] - r.lse_g);
+        ds += gK * p * ((lp - (r.g[e] - r.lse_g)) - kl);
+        dg += gK * (qg - p);
+        // neighbour
+        float dn = 0.f, dc = 0.f;
+        if (r.sel[e] || diag) {
+            float wk = diag ? 1.0f : r.posw(e);
+            dn += expf(r.s[e] - r.lse_e) - wk / psum;
+        }
+        if (r.sel[e]) {
+            dn += rs * dadj[e];
+            dc -= rc * dadj[e];
+        }
+        if (j == imns) dn += Dmin_s;
+        if (j == imxs) dn += Dmax_s;
+        if (j == imnc) dc += Dmin_c;
+        if (j == imxc) dc += Dmax_c;
+        ds += gN * dn;
+        dSr[j] = ds;
+        dGr[j] = dg;
+        dCr[j] = gN * dc;
+    }
+    if (lane == 0) {
+        d_wc[(size_t)dir * B + row] = gC * -(r.s_ii * r.ls - r.lse_c);
+        d_ls_rows[(size_t)dir * B + row] = gC * -r.wci * (r.s_ii - pcs);
+    }
+}
+
+extern "C" int nr_row_losses_bwd(const float* S, const float* G, const float* tgt_rows, const float* tgt_cols,
+                                 const float* bank_c0, const float* bank_c1, const float* wc_text, const float* wc_video,
+                                 const float* logit_scale, int B, int K, float temperature, const float* g_rowloss,
+                                 float* dS_dir, float* dG_dir, float* d_c_rows, float* d_wc, float* d_ls_rows,
+                                 void* stream) {
+    if (!S || !G || !tgt_rows || !tgt_cols || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale || !g_rowloss ||
+        !dS_dir || !dG_dir || !d_c_rows || !d_wc || !d_ls_rows)
+        return NR_EINVAL;
+    if (B <= 0 || K < 0 || K > B) return NR_EINVAL;
+    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature};
+    dim3 grid((B + 3) / 4, 2);
+    hipStream_t st = (hipStream_t)stream;
+#define NR_BWD_CASE(N_) \
+    case N_: hipLaunchKernelGGL(nr_row_losses_bwd_kernel<N_>, grid, dim3(256), 0, st, a, g_rowloss, dS_dir, dG_dir, d_c_rows, d_wc, d_ls_rows); break;
+    switch (nr_row_ne(B)) {
+        NR_BWD_CASE(2) NR_BWD_CASE(4) NR_BWD_CASE(8) NR_BWD_CASE(16) NR_BWD_CASE(32)
+        default: return NR_EUNSUPPORTED;
+    }
+#undef NR_BWD_CASE
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}

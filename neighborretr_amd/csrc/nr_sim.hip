@@ -19,6 +19,7 @@ struct NrSimArgs {
     const float *w_t, *w_v;
     float* out;
     uint8_t *arg_v, *arg_t;
+    float *pmax, *qmax;
     int A, Nt, Bv, Nv, K;
     int TA, TB;
     int out_mode;
@@ -68,7 +69,11 @@ __global__ __launch_bounds__(256) void nr_sim_kernel(NrSimArgs p) {
         }
         float w = ok ? p.w_t[row0 + r] : 0.f;
         sPW[i] = ok ? m * w : 0.f;
-        if (p.arg_v && ok) p.arg_v[((size_t)ag * p.Bv + bg) * Nt + t] = (uint8_t)am;
+        if (p.arg_v && ok) {
+            size_t o = ((size_t)ag * p.Bv + bg) * Nt + t;
+            p.arg_v[o] = (uint8_t)am;
+            p.pmax[o] = m;
+        }
     }
     // ---- phase B: max over the text tokens of each (text, col) ------------------------------
     for (int i = tid; i < TA * ncol; i += 256) {
@@ -85,7 +90,11 @@ __global__ __launch_bounds__(256) void nr_sim_kernel(NrSimArgs p) {
         }
         float w = ok ? p.w_v[col0 + c] : 0.f;
         sQW[i] = ok ? m * w : 0.f;
-        if (p.arg_t && ok) p.arg_t[((size_t)ag * p.Bv + bg) * Nv + v] = (uint8_t)am;
+        if (p.arg_t && ok) {
+            size_t o = ((size_t)ag * p.Bv + bg) * Nv + v;
+            p.arg_t[o] = (uint8_t)am;
+            p.qmax[o] = m;
+        }
     }
     __syncthreads();
 
@@ -184,12 +193,13 @@ static int nr_sim_launch(NrSimArgs& a, dim3 grid, size_t lds, hipStream_t st) {
 extern "C" int nr_local_level_fwd(const uint16_t* t_hi, const uint16_t* t_lo, const uint16_t* v_hi,
                                   const uint16_t* v_lo, const float* w_t, const float* w_v, int A, int Nt, int Bv,
                                   int Nv, int d, int prec, int out_mode, float* out, uint8_t* arg_v,
-                                  uint8_t* arg_t, void* stream) {
+                                  uint8_t* arg_t, float* pmax, float* qmax, void* stream) {
     if (!t_hi || !v_hi || !w_t || !w_v || !out) return NR_EINVAL;
     if (A <= 0 || Bv <= 0 || Nt <= 0 || Nv <= 0 || d <= 0 || (d % 64) != 0) return NR_EINVAL;
     if (prec != NR_PREC_BF16 && prec != NR_PREC_BF16X3) return NR_EINVAL;
     if (prec == NR_PREC_BF16X3 && (!t_lo || !v_lo)) return NR_EINVAL;
     if (out_mode < 0 || out_mode > 2) return NR_EINVAL;
+    if ((arg_v || arg_t || pmax || qmax) && !(arg_v && arg_t && pmax && qmax)) return NR_EINVAL;
     if (Nt > 255 || Nv > 255) return NR_EUNSUPPORTED;   // arg-max indices are u8
     int mi = 0, ni = 0;
     int TA = nr_pick_extent(Nt, &mi), TB = nr_pick_extent(Nv, &ni);
@@ -199,7 +209,7 @@ extern "C" int nr_local_level_fwd(const uint16_t* t_hi, const uint16_t* t_lo, co
 
     NrSimArgs a;
     a.t_hi = t_hi; a.t_lo = t_lo; a.v_hi = v_hi; a.v_lo = v_lo;
-    a.w_t = w_t; a.w_v = w_v; a.out = out; a.arg_v = arg_v; a.arg_t = arg_t;
+    a.w_t = w_t; a.w_v = w_v; a.out = out; a.arg_v = arg_v; a.arg_t = arg_t; a.pmax = pmax; a.qmax = qmax;
     a.A = A; a.Nt = Nt; a.Bv = Bv; a.Nv = Nv; a.K = d; a.TA = TA; a.TB = TB; a.out_mode = out_mode;
     const int BM = 32 * mi, BN = 32 * ni;
     a.ldc = BN + 4;

@@ -6,18 +6,32 @@
 extern "C" int nr_version(void) { return NR_ABI_VERSION; }
 
 // ---- out[i] = scale * sum_p part[p,i]  (until_module.py:181) -----------------------------------
+// 64 outputs per workgroup; wave w sums the parts p = w, w+4, ... (independent loads in flight),
+// the four partial sums meet in LDS -- fixed order, deterministic.
 __global__ __launch_bounds__(256) void nr_reduce_parts_kernel(const float* __restrict__ part, int n_parts, int n,
                                                               float scale, float* __restrict__ out) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < n_parts; ++p) s += part[(size_t)p * n + i];
-    out[i] = s * scale;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int p = wave;
+        for (; p + 12 < n_parts; p += 16) {
+            s0 += part[(size_t)p * n + i];
+            s1 += part[(size_t)(p + 4) * n + i];
+            s2 += part[(size_t)(p + 8) * n + i];
+            s3 += part[(size_t)(p + 12) * n + i];
+        }
+        for (; p < n_parts; p += 4) s0 += part[(size_t)p * n + i];
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && i < n) out[i] = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * scale;
 }
 
 extern "C" int nr_reduce_parts(const float* part, int n_parts, int n, float scale, float* out, void* stream) {
     if (!part || !out || n_parts <= 0 || n <= 0) return NR_EINVAL;
-    hipLaunchKernelGGL(nr_reduce_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, n_parts,
+    hipLaunchKernelGGL(nr_reduce_parts_kernel, dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, n_parts,
                        n, scale, out);
     NR_LAUNCH_CHECK();
     return NR_OK;
@@ -69,9 +83,16 @@ __global__ __launch_bounds__(256) void nr_centrality_kernel(const float* __restr
                                                             float* __restrict__ gnorm, float* __restrict__ mean_out) {
     __shared__ float s_mean[1024];
     for (int k = threadIdx.x; k < d; k += 256) {
-        float s = 0.f;
-        for (int p = 0; p < n_parts; ++p) s += colsum_part[(size_t)p * d + k];
-        s *= inv_tok;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = 0;
+        for (; p + 3 < n_parts; p += 4) {          // four independent loads in flight per column
+            s0 += colsum_part[(size_t)p * d + k];
+            s1 += colsum_part[(size_t)(p + 1) * d + k];
+            s2 += colsum_part[(size_t)(p + 2) * d + k];
+            s3 += colsum_part[(size_t)(p + 3) * d + k];
+        }
+        for (; p < n_parts; ++p) s0 += colsum_part[(size_t)p * d + k];
+        float s = ((s0 + s1) + (s2 + s3)) * inv_tok;
         s_mean[k] = s;
         if (mean_out && blockIdx.x == 0) mean_out[k] = s;
     }

@@ -1,0 +1,139 @@
+"""Orchestration of the HIP kernels for one step of the NeighborRetr loss head.
+
+`head_losses(...)` is the fused equivalent of the reference's `_compute_losses`
+(NeighborRetr/models/modeling.py:314-360) minus the token-clustering stage, whose outputs (the
+global text/video tokens) come in as arguments:
+
+    prepare (normalise+mask+bf16 split)  x4     modeling.py:495-496, :500-501
+    token scorer MLP + masked softmax    x4     modeling.py:485-492
+    fused local_level  BxB / BxM / MxB          modeling.py:499-512, :389-390
+    global logits G (exact fp32 MFMA)           modeling.py:516-539
+    Sinkhorn targets (both directions)          until_module.py:235-266
+    centrality weights                          modeling.py:403-430
+    row losses + finalize                       until_module.py:56-211, :285-289, :303-359
+
+It is differentiable: `HeadLossFn` is a torch.autograd.Function whose backward runs the HIP
+backward kernels (row losses, arg-max-routed similarity gradient, normalisation) and library
+GEMMs for the scorer MLP.  Nothing here falls back to eager PyTorch for the forward math.
+"""
+import torch
+
+from . import hip, ops
+
+MLP_KEYS = ("0.weight", "0.bias", "2.weight", "2.bias")
+
+
+class ScorerWeights:
+    """bf16 hi/lo split of one token-scorer MLP (re-split whenever the parameters change)."""
+
+    def __init__(self, w1, b1, w2, b2, want_lo=True):
+        self.w1_hi, self.w1_lo = ops.split_bf16(w1.detach(), want_lo)
+        self.b1 = b1.detach().float().contiguous()
+        self.w2 = w2.detach().float().reshape(-1).contiguous()
+        self.b2 = b2.detach().float().reshape(1).contiguous()
+
+
+def token_weights(prep, mask, sw, n, N, prec, want_logits=False, scale_override=None):
+    p = prep if scale_override is None else prep._replace(norm=scale_override)
+    parts = ops.token_logit_parts(p, sw.w1_hi, sw.w1_lo, sw.b1, sw.w2, prec)
+    return ops.token_softmax(parts, sw.b2, mask, n, N, want_logits)
+
+
+def similarity_matrix(text_feat, video_feat, text_mask, video_mask, sw_t, sw_v, prec=hip.PREC_BF16X3):
+    """local_level forward only (eval path): [A,Nt,d] x [Bv,Nv,d] -> S [A,Bv]."""
+    A, Nt, _ = text_feat.shape
+    Bv, Nv, _ = video_feat.shape
+    lo = prec == hip.PREC_BF16X3
+    pt = ops.prepare_tokens(text_feat, text_mask, want_lo=lo)
+    pv = ops.prepare_tokens(video_feat, video_mask, want_lo=lo)
+    w_t, _ = token_weights(pt, text_mask, sw_t, A, Nt, prec)
+    w_v, _ = token_weights(pv, video_mask, sw_v, Bv, Nv, prec)
+    S, _ = ops.local_level(pt, pv, w_t, w_v, A, Nt, Bv, Nv, prec)
+    return S
+
+
+def global_logits(gt, gv, sw_t1=None, sw_v1=None):
+    """global_level (modeling.py:516-539).  One global token per sample: an exact-fp32 GEMM.
+    Several tokens (ActivityNet token counts): the fused kernel on un-normalised tokens, split-bf16."""
+    B, Ngt, d = gt.shape
+    Ngv = gv.shape[1]
+    if Ngt == 1 and Ngv == 1:
+        return ops.gemm_nt_f32(gt.reshape(B, d), gv.reshape(gv.shape[0], d))
+    pt = ops.prepare_tokens(gt, None, normalize=False)
+    pv = ops.prepare_tokens(gv, None, normalize=False)
+    ones_t = torch.ones_like(pt.norm)
+    ones_v = torch.ones_like(pv.norm)
+    w_t, _ = token_weights(pt, None, sw_t1, B, Ngt, hip.PREC_BF16X3, scale_override=ones_t)
+    w_v, _ = token_weights(pv, None, sw_v1, gv.shape[0], Ngv, hip.PREC_BF16X3, scale_override=ones_v)
+    G, _ = ops.local_level(pt, pv, w_t, w_v, B, Ngt, gv.shape[0], Ngv, hip.PREC_BF16X3)
+    return G
+
+
+PREC_MIXED = 2   # host-level plan: split-bf16 where logit_scale amplifies the error, bf16 elsewhere
+
+
+def precision_plan(prec):
+    """(batch x batch similarity, batch-token scorer, memory-bank paths) kernel precisions.
+
+    The centrality term feeds S*logit_scale (x100) into a log-softmax, so single-pass bf16 error on
+    the B x B similarity (~1.5e-4) shows up as ~2e-3 on that loss at small B.  The mixed plan keeps
+    the B x B product (11% of the contraction flops at the MSR-VTT shape) in split-bf16 and runs the
+    two memory-bank products -- whose outputs are only consumed as means over M entries -- and the
+    bank-side scorer in one bf16 pass."""
+    if prec == PREC_MIXED:
+        return hip.PREC_BF16X3, hip.PREC_BF16X3, hip.PREC_BF16
+    return prec, prec, prec
+
+
+def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
+                 gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None):
+    """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None)."""
+    B, Nt, d = text_feat.shape
+    Nv = video_feat.shape[1]
+    M = mb_feat_v.shape[0]
+    K = int(hp["num_neighbors"])
+    if K > B:
+        raise ValueError(f"num_neighbors={K} > batch={B}: the reference raises IndexError here "
+                         "(until_module.py:119-123)")
+    if M == 0 or mb_feat_t.shape[0] != M:
+        raise ValueError("empty or inconsistent memory bank")
+    if gt.shape[1] != 1 or gv.shape[1] != 1:
+        raise RuntimeError("more than one global token per sample: the reference's centrality term "
+                           "fails to broadcast at this shape (until_module.py:321); parity unpinned")
+    p_bb, p_mlp, p_bank = precision_plan(prec)
+    lo_b = keep or hip.PREC_BF16X3 in (p_bb, p_mlp, p_bank)
+    lo_k = keep or p_bank == hip.PREC_BF16X3
+    pt = ops.prepare_tokens(text_feat, text_mask, want_lo=lo_b, want_colsum=True)
+    pv = ops.prepare_tokens(video_feat, video_mask, want_lo=lo_b, want_colsum=True)
+    pbt = ops.prepare_tokens(mb_feat_t, mb_mask_t, want_lo=lo_k)
+    pbv = ops.prepare_tokens(mb_feat_v, mb_mask_v, want_lo=lo_k)
+    w_t, lg_t = token_weights(pt, text_mask, sw_t, B, Nt, p_mlp, keep)
+    w_v, lg_v = token_weights(pv, video_mask, sw_v, B, Nv, p_mlp, keep)
+    w_bt, lg_bt = token_weights(pbt, mb_mask_t, sw_t, M, Nt, p_bank, keep)
+    w_bv, lg_bv = token_weights(pbv, mb_mask_v, sw_v, M, Nv, p_bank, keep)
+
+    S, aux0 = ops.local_level(pt, pv, w_t, w_v, B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
+    # text x bank-video, row mean  -> centrality of text j  (used by the v2t neighbour loss)
+    p1, aux1 = ops.local_level(pt, pbv, w_t, w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM, keep)
+    # bank-text x video, column mean -> centrality of video j (used by the t2v neighbour loss)
+    p0, aux2 = ops.local_level(pbt, pv, w_bt, w_v, M, Nt, B, Nv, p_bank, hip.OUT_COLSUM, keep)
+    c1 = ops.reduce_parts(p1, 1.0 / M)
+    c0 = ops.reduce_parts(p0, 1.0 / M)
+
+    G = global_logits(gt, gv, sw_t1, sw_v1)
+    tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
+    gt2 = gt.reshape(B, d).float().contiguous()
+    gv2 = gv.reshape(B, d).float().contiguous()
+    wc_t, gn_t, mean_t = ops.centrality_weights(gt2, pt.colsum, pt.n_tok, hp["centrality_scale"], keep)
+    wc_v, gn_v, mean_v = ops.centrality_weights(gv2, pv.colsum, pv.n_tok, hp["centrality_scale"], keep)
+    ls = logit_scale.detach().float().reshape(1).contiguous()
+    rowloss = ops.row_losses(S, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"])
+    losses = ops.loss_finalize(rowloss, hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
+    saved = None
+    if keep:
+        saved = dict(pt=pt, pv=pv, pbt=pbt, pbv=pbv, w_t=w_t, w_v=w_v, w_bt=w_bt, w_bv=w_bv,
+                     lg_t=lg_t, lg_v=lg_v, lg_bt=lg_bt, lg_bv=lg_bv,
+                     aux=(aux0, aux1, aux2), S=S, G=G, tgt_r=tgt_r, tgt_c=tgt_c,
+                     c0=c0, c1=c1, wc_t=wc_t, wc_v=wc_v, gn_t=gn_t, gn_v=gn_v, mean_t=mean_t, mean_v=mean_v,
+                     ls=ls, gt2=gt2, gv2=gv2)
+    return losses, saved

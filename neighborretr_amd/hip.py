@@ -31,7 +31,7 @@ _SIGNATURES = {
     "nr_token_logits_fwd": ([_P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     "nr_token_softmax": ([_P, _I, _P, _P, _I, _I, _P, _P, _P], _I),
     "nr_local_level_tiles": ([_I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)], _I),
-    "nr_local_level_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P], _I),
+    "nr_local_level_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),
     "nr_reduce_parts": ([_P, _I, _I, _F, _P, _P], _I),
     "nr_gemm_nt_f32": ([_P, _P, _I, _I, _I, _P, _P], _I),
     "nr_centrality_weights": ([_P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P], _I),
@@ -39,8 +39,13 @@ _SIGNATURES = {
     "nr_sinkhorn_targets": ([_P, _I, _F, _I, _P, _P, _P, _P], _I),
     "nr_row_losses_fwd": ([_P] * 9 + [_I, _I, _F, _P, _P], _I),
     "nr_loss_finalize": ([_P, _I, _F, _F, _F, _P, _P], _I),
-    "nr_row_losses_bwd": ([_P] * 9 + [_I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P], _I),
-    "nr_local_level_bwd": ([_P] * 7 + [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P], _I),
+    "nr_row_losses_bwd": ([_P] * 9 + [_I, _I, _F, _P, _P, _P, _P, _P, _P, _P], _I),
+    "nr_add_transposed": ([_P, _P, _I, _P, _P], _I),
+    "nr_colsum": ([_P, _I, _I, _P, _P], _I),
+    "nr_local_level_bwd": ([_I, _P, _I, _F] + [_P] * 8 + [_I, _I, _I, _I, _I, _P, _P, _I, _P], _I),
+    "nr_normalize_bwd": ([_P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
+    "nr_token_softmax_bwd": ([_P, _P, _I, _I, _P, _P], _I),
+    "nr_centrality_weights_bwd": ([_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P], _I),
     "nr_bank_push": ([_P, _P, _I, _I, _Z, _P, _P], _I),
     "nr_diag_ranks": ([_P, _I, _P, _P, _P], _I),
 }

@@ -1,0 +1,69 @@
+"""Retrieval metrics with the rank counting done on the GPU.
+
+Same interface as the reference's NeighborRetr/utils/metrics.py:14-79 (`RetrievalMetrics`,
+`compute_metrics` returning R1/R5/R10/R50/MR/MedianR/MeanR/cols).  The reference sorts every row
+on the host (np.sort) and looks up where the diagonal landed; the rank of the diagonal is just
+#{j : S[i,j] > S[i,i]}, and its exact-equality tie rule (`where(sx - d == 0)`) yields one hit per
+entry EQUAL to the diagonal, at consecutive ranks.  nr_diag_ranks counts both on the device in
+one pass over S; only 2N integers come back to the host.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+class RetrievalMetrics:
+    def __init__(self, logger=None):
+        self.best_mean_r1 = 0.00001
+        self.best_t2v_r1 = 0.00001
+        self.best_v2t_r1 = 0.00001
+        self.best_t2v_metrics = None
+        self.best_v2t_metrics = None
+        self.logger = logger
+
+    @staticmethod
+    def diagonal_ranks(similarity_matrix):
+        """`ind` of metrics.py:58-66: for row i the ranks greater[i] .. greater[i]+equal[i]-1."""
+        S = similarity_matrix
+        if not torch.is_tensor(S):
+            S = torch.from_numpy(np.ascontiguousarray(S, dtype=np.float32))
+        if not S.is_cuda:
+            S = S.cuda()
+        greater, equal = ops.diag_ranks(S)
+        greater, equal = greater.cpu().numpy(), equal.cpu().numpy()
+        return np.repeat(greater, equal) + (np.arange(int(equal.sum())) - np.repeat(np.cumsum(equal) - equal, equal))
+
+    @staticmethod
+    def compute_metrics(similarity_matrix):
+        ind = RetrievalMetrics.diagonal_ranks(similarity_matrix)
+        n = len(ind)
+        m = {
+            "R1": float(np.sum(ind == 0)) * 100 / n,
+            "R5": float(np.sum(ind < 5)) * 100 / n,
+            "R10": float(np.sum(ind < 10)) * 100 / n,
+            "R50": float(np.sum(ind < 50)) * 100 / n,
+            "MR": float(np.median(ind)) + 1,
+        }
+        m["MedianR"] = m["MR"]
+        m["MeanR"] = float(np.mean(ind)) + 1
+        m["cols"] = [int(i) for i in ind]
+        return m
+
+    def print_metrics(self, metrics, prefix=""):
+        msg = (f"{prefix}R@1: {metrics['R1']:.1f} - R@5: {metrics['R5']:.1f} - R@10: {metrics['R10']:.1f} - "
+               f"R@50: {metrics['R50']:.1f} - Median R: {metrics['MR']:.1f} - Mean R: {metrics['MeanR']:.1f}")
+        (self.logger.info if self.logger else print)(msg)
+
+    def update_best_metrics(self, t2v_metrics, v2t_metrics):
+        """Keep the best t2v / v2t / mean R@1 seen so far; returns True when the mean improved."""
+        improved = False
+        mean_r1 = (t2v_metrics["R1"] + v2t_metrics["R1"]) / 2
+        if t2v_metrics["R1"] > self.best_t2v_r1:
+            self.best_t2v_r1, self.best_t2v_metrics = t2v_metrics["R1"], dict(t2v_metrics)
+        if v2t_metrics["R1"] > self.best_v2t_r1:
+            self.best_v2t_r1, self.best_v2t_metrics = v2t_metrics["R1"], dict(v2t_metrics)
+        if mean_r1 > self.best_mean_r1:
+            self.best_mean_r1 = mean_r1
+            improved = True
+        return improved

@@ -1,0 +1,227 @@
+"""Host-side mirror of the reference's model API for the similarity / loss path.
+
+`NeighborRetr` keeps the constructor, method names, argument order, return tuples, plain
+`mb_*` attributes and state-dict parameter names of NeighborRetr/models/modeling.py:46-658, so
+the reference's trainer / evaluator / MemoryBankManager can drive it unchanged, while every
+method on the hot path dispatches to the HIP kernels (neighborretr_amd.head / .ops).
+
+Out of scope here: the CLIP towers and the temporal transformer.  They are
+feature PRODUCERS; pass any module with `encode_text` / `encode_image` + `logit_scale` as `clip=`
+(e.g. the reference's own CLIP on PyTorch-ROCm).  Without one the model runs in feature mode:
+`text_ids` / `video` given to forward() are taken to be the token features [b,Nt,d] / [b,Nv,d]
+already -- which is what bench.py, the tests and `main_retrieval.py --synthetic` use.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import head, hip, ops
+from .cluster import CTM, TCBlock
+from .until_module import (AllGather, CentralityWeightingLoss, KLDivergenceLoss, NeighborAdjustingLoss,
+                           UniformRegularizationLoss)
+
+allgather = AllGather.apply
+
+DEFAULTS = dict(centrality_scale=0.3, beta=0.7, num_neighbors=20, temperature=3.0, uniform_weight=1.0,
+                neighbor_weight=1.0, kl_weight=1.0, world_size=1, local_rank=0)   # args_parser.py:26-41
+
+
+class FeatureModeCLIP(nn.Module):
+    """Stand-in for the CLIP tower in feature mode: holds only `logit_scale` (CLIP's init, ln(1/0.07))."""
+
+    def __init__(self):
+        super().__init__()
+        self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
+
+
+class NeighborRetr(nn.Module):
+    def __init__(self, config, clip=None, width=512, precision="bf16"):
+        super().__init__()
+        self.config = config
+        for k, v in DEFAULTS.items():
+            if not hasattr(config, k):
+                setattr(config, k, v)
+        self.transformer_width = width
+        self.clip = clip if clip is not None else FeatureModeCLIP()
+        self.feature_mode = clip is None
+        # "bf16"    training plan: bank products / bank scorer one bf16 pass, B x B product split-bf16
+        # "bf16x3"  everything split-bf16 (rank-exact eval, golden parity)
+        # "bf16_all" everything one bf16 pass (fastest; ~2e-3 on the centrality loss at small B)
+        self.precision = precision
+        # token scorers -- all eight exist for checkpoint compatibility; only text/video_weight_fc
+        # and *_fc1 are ever used (modeling.py:137-146)
+        for name in ("text_weight_fc", "video_weight_fc", "text_weight_fc0", "video_weight_fc0",
+                     "text_weight_fc1", "video_weight_fc1", "text_weight_intra", "video_weight_intra"):
+            setattr(self, name, self._scorer(width))
+        self.centrality_weighting_loss = CentralityWeightingLoss()
+        self.neighbor_adjusting_loss = NeighborAdjustingLoss()
+        self.uniform_regularization_loss = UniformRegularizationLoss()
+        self.kl_loss = KLDivergenceLoss()
+        self._init_memory_bank()
+        self.apply(self._init_weights)
+        # token clustering (modeling.py:186-197)
+        self.text_ctm0 = CTM(sample_ratio=1 / 6, embed_dim=width, dim_out=width, k=3)
+        self.text_block0 = TCBlock(dim=width, num_heads=8)
+        self.text_ctm1 = CTM(sample_ratio=1 / 4, embed_dim=width, dim_out=width, k=3)
+        self.text_block1 = TCBlock(dim=width, num_heads=8)
+        self.video_ctm0 = CTM(sample_ratio=1 / 4, embed_dim=width, dim_out=width, k=3)
+        self.video_block0 = TCBlock(dim=width, num_heads=8)
+        self.video_ctm1 = CTM(sample_ratio=1 / 3, embed_dim=width, dim_out=width, k=3)
+        self.video_block1 = TCBlock(dim=width, num_heads=8)
+        self._scorer_cache = {}
+
+    # ------------------------------------------------------------------ construction helpers
+    @staticmethod
+    def _scorer(width):
+        return nn.Sequential(nn.Linear(width, 2 * width), nn.ReLU(inplace=True), nn.Linear(2 * width, 1))
+
+    @staticmethod
+    def _init_weights(module):
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=0.02)       # modeling.py:648-658
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    def _init_memory_bank(self):
+        cpu = torch.device("cpu")
+        self.mb_ind = torch.tensor([], dtype=torch.long, device=cpu)
+        self.mb_feat_t = torch.empty((0, 0, 0), dtype=torch.float, device=cpu)
+        self.mb_feat_v = torch.empty((0, 0, 0), dtype=torch.float, device=cpu)
+        self.mb_mask_t = torch.empty((0, 0), dtype=torch.float, device=cpu)
+        self.mb_mask_v = torch.empty((0, 0), dtype=torch.float, device=cpu)
+        self.mb_batch = 0
+
+    # ------------------------------------------------------------------ scorer weights (bf16 split)
+    def _prec(self, for_head=True):
+        if self.precision == "bf16x3":
+            return hip.PREC_BF16X3
+        if self.precision == "bf16_all":
+            return hip.PREC_BF16
+        return head.PREC_MIXED if for_head else hip.PREC_BF16X3
+
+    def scorer_weights(self, name):
+        """bf16 hi/lo images of one scorer MLP, re-split when the parameters were updated."""
+        mlp = getattr(self, name)
+        ver = tuple(p._version for p in mlp.parameters()) + tuple(p.data_ptr() for p in mlp.parameters())
+        hit = self._scorer_cache.get(name)
+        if hit is None or hit[0] != ver:
+            sw = head.ScorerWeights(mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
+            self._scorer_cache[name] = (ver, sw)
+            return sw
+        return hit[1]
+
+    # ------------------------------------------------------------------ memory bank (modeling.py:222-249)
+    def update_memory_bank(self, idx, text_feat, video_feat, text_mask, video_mask):
+        if self.mb_feat_v.size(0) == 0:
+            self.mb_ind = idx.clone()
+            self.mb_feat_v = video_feat.detach().clone()
+            self.mb_feat_t = text_feat.detach().clone()
+            self.mb_mask_t = text_mask.clone()
+            self.mb_mask_v = video_mask.clone()
+            self.mb_batch = idx.size(0)
+            return
+        new = (idx, video_feat.detach(), text_feat.detach(), text_mask, video_mask)
+        names = ("mb_ind", "mb_feat_v", "mb_feat_t", "mb_mask_t", "mb_mask_v")
+        for name, batch in zip(names, new):
+            bank = getattr(self, name)
+            if bank.is_cuda and bank.is_contiguous() and batch.dtype == bank.dtype:
+                ops.bank_push(bank, batch.contiguous())       # in place: no per-step reallocation
+            else:
+                setattr(self, name, torch.cat((batch.to(bank.dtype), bank), 0)[:bank.size(0)])
+
+    # ------------------------------------------------------------------ forward (modeling.py:251-312)
+    def forward(self, text_ids, text_mask, video, video_mask=None, idx=None, global_step=0, logger=None):
+        text_mask = text_mask.view(-1, text_mask.shape[-1])
+        video_mask = video_mask.view(-1, video_mask.shape[-1])
+        text_feat, video_feat = self.get_text_video_feat(text_ids, text_mask, video, video_mask, shaped=True)
+        if not self.training:
+            return None
+        if torch.cuda.is_available() and getattr(self.config, "world_size", 1) > 1:
+            idx = allgather(idx, self.config)
+            text_feat = allgather(text_feat, self.config)
+            video_feat = allgather(video_feat, self.config)
+            text_mask = allgather(text_mask, self.config)
+            video_mask = allgather(video_mask, self.config)
+        logit_scale = self.clip.logit_scale.exp()
+        cfg = self.config
+        losses = self._compute_losses(text_feat, video_feat, text_mask, video_mask,
+                                      self.mb_feat_t, self.mb_feat_v, self.mb_mask_t, self.mb_mask_v,
+                                      cfg.centrality_scale, cfg.beta, cfg.num_neighbors, cfg.temperature,
+                                      logit_scale)
+        with torch.no_grad():
+            self.update_memory_bank(idx, text_feat, video_feat, text_mask, video_mask)
+        return losses
+
+    # ------------------------------------------------------------------ losses (modeling.py:314-360)
+    def _hp(self, centrality_scale, beta, num_neighbors, temperature):
+        c = self.config
+        return dict(centrality_scale=centrality_scale, beta=beta, num_neighbors=num_neighbors,
+                    temperature=temperature, uniform_weight=c.uniform_weight, neighbor_weight=c.neighbor_weight,
+                    kl_weight=c.kl_weight)
+
+    def _compute_losses(self, text_feat, video_feat, text_mask, video_mask,
+                        mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
+                        centrality_scale, beta, num_neighbors, temperature, logit_scale, noise=None):
+        hp = self._hp(centrality_scale, beta, num_neighbors, temperature)
+        gt, gv = self.merge_global_features(text_feat, video_feat, text_mask, video_mask, noise)
+        from .functional import head_losses
+        losses = head_losses(self, text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v,
+                             mb_mask_t, mb_mask_v, gt, gv, hp, logit_scale)
+        return losses[0], losses[1], losses[2], losses[3], losses[4]
+
+    # ------------------------------------------------------------------ token clustering (modeling.py:446-481)
+    def merge_global_features(self, text_feat, video_feat, text_mask, video_mask, noise=None):
+        nz = noise or {}
+        t = {"x": text_feat, "mask": text_mask.detach()}
+        v = {"x": video_feat, "mask": video_mask.detach()}
+        t = self.text_block0(self.text_ctm0(t, nz.get("t0")))
+        v = self.video_block0(self.video_ctm0(v, nz.get("v0")))
+        t = self.text_block1(self.text_ctm1(t, nz.get("t1")))
+        v = self.video_block1(self.video_ctm1(v, nz.get("v1")))
+        return t["x"], v["x"]
+
+    # ------------------------------------------------------------------ similarity API
+    def local_level(self, text_feat, video_feat, text_mask, video_mask):
+        """(S, S.T) with S [A,Bv] -- modeling.py:483-514, fused on the GPU; differentiable."""
+        from .functional import local_level_sim
+        S = local_level_sim(self, text_feat, video_feat, text_mask, video_mask)
+        return S, S.T
+
+    def global_level(self, text_feat, video_feat):
+        """modeling.py:516-539."""
+        from .functional import global_level_sim
+        G = global_level_sim(self, text_feat, video_feat)
+        return G, G.T
+
+    def get_similarity_logits(self, text_feat, video_feat, text_mask, video_mask, shaped=False):
+        if shaped is False:
+            text_mask = text_mask.view(-1, text_mask.shape[-1])
+            video_mask = video_mask.view(-1, video_mask.shape[-1])
+        S, _ = self.local_level(text_feat, video_feat, text_mask, video_mask)
+        return S, S.T
+
+    # ------------------------------------------------------------------ feature producers
+    def get_text_feat(self, text_ids, text_mask, shaped=False):
+        if self.feature_mode:
+            return torch.as_tensor(text_ids).float().view(-1, text_ids.shape[-2], text_ids.shape[-1])
+        if shaped is False:
+            text_ids = text_ids.view(-1, text_ids.shape[-1])
+            text_mask = text_mask.view(-1, text_mask.shape[-1])
+        bs = text_ids.size(0)
+        _, feat = self.clip.encode_text(text_ids, return_hidden=True, mask=text_mask)
+        return feat.float().view(bs, -1, feat.size(-1))
+
+    def get_video_feat(self, video, video_mask, shaped=False):
+        if self.feature_mode:
+            return torch.as_tensor(video).float().view(-1, video.shape[-2], video.shape[-1])
+        raise NotImplementedError("pixel input needs a CLIP tower and temporal transformer (out of scope, "
+                                  "SURVEY.md 2.1); construct NeighborRetr(config, clip=...) and override")
+
+    def get_text_video_feat(self, text_ids, text_mask, video, video_mask, shaped=False):
+        return self.get_text_feat(text_ids, text_mask, shaped), self.get_video_feat(video, video_mask, shaped)
+
+
+def default_config(**over):
+    return SimpleNamespace(**{**DEFAULTS, **over})

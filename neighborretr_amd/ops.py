@@ -68,7 +68,8 @@ def token_softmax(parts, b2, mask, n_samples, N, want_logits=False):
 
 
 def local_level(prep_t, prep_v, w_t, w_v, A, Nt, Bv, Nv, prec=hip.PREC_BF16, out_mode=hip.OUT_FULL, want_arg=False):
-    """Fused token-token similarity (nr_local_level_fwd).  Returns (out, arg_v, arg_t)."""
+    """Fused token-token similarity (nr_local_level_fwd).  Returns (out, aux); aux = None or
+    (arg_v, arg_t, pmax, qmax) kept for the backward pass."""
     dev = prep_t.hi.device
     if prep_t.n_tok != A * Nt or prep_v.n_tok != Bv * Nv:
         raise ValueError("prepared token counts do not match A*Nt / Bv*Nv")
@@ -77,13 +78,18 @@ def local_level(prep_t, prep_v, w_t, w_v, A, Nt, Bv, Nv, prec=hip.PREC_BF16, out
     else:
         nr, nc = hip.local_level_tiles(A, Nt, Bv, Nv)
         out = torch.empty((nc, A) if out_mode == hip.OUT_ROWSUM else (nr, Bv), dtype=torch.float32, device=dev)
-    arg_v = torch.empty((A, Bv, Nt), dtype=torch.uint8, device=dev) if want_arg else None
-    arg_t = torch.empty((A, Bv, Nv), dtype=torch.uint8, device=dev) if want_arg else None
+    arg_v = arg_t = pmax = qmax = None
+    if want_arg:
+        arg_v = torch.empty((A, Bv, Nt), dtype=torch.uint8, device=dev)
+        arg_t = torch.empty((A, Bv, Nv), dtype=torch.uint8, device=dev)
+        pmax = torch.empty((A, Bv, Nt), dtype=torch.float32, device=dev)
+        qmax = torch.empty((A, Bv, Nv), dtype=torch.float32, device=dev)
     hip.call("nr_local_level_fwd", hip.ptr(prep_t.hi), hip.ptr(prep_t.lo, allow_none=True), hip.ptr(prep_v.hi),
              hip.ptr(prep_v.lo, allow_none=True), hip.ptr(w_t, torch.float32), hip.ptr(w_v, torch.float32),
              A, Nt, Bv, Nv, prep_t.d, prec, out_mode, hip.ptr(out), hip.ptr(arg_v, allow_none=True),
-             hip.ptr(arg_t, allow_none=True), hip.stream_ptr())
-    return out, arg_v, arg_t
+             hip.ptr(arg_t, allow_none=True), hip.ptr(pmax, allow_none=True), hip.ptr(qmax, allow_none=True),
+             hip.stream_ptr())
+    return out, ((arg_v, arg_t, pmax, qmax) if want_arg else None)
 
 
 def reduce_parts(parts, scale):
@@ -139,6 +145,88 @@ def loss_finalize(rowloss, wu, wn, wkl):
     losses = torch.empty((5,), dtype=torch.float32, device=rowloss.device)
     hip.call("nr_loss_finalize", hip.ptr(rowloss), B, float(wu), float(wn), float(wkl), hip.ptr(losses), hip.stream_ptr())
     return losses
+
+
+def row_losses_bwd(S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, K, T, g_rowloss):
+    """-> dS_dir [2,B,B], dG_dir [2,B,B], d_c_rows [2,B,B], d_wc [2,B], d_ls_rows [2,B]  (nr_row_losses_bwd)."""
+    B = S.shape[0]
+    dev = S.device
+    dS = torch.empty((2, B, B), dtype=torch.float32, device=dev)
+    dG = torch.empty((2, B, B), dtype=torch.float32, device=dev)
+    dC = torch.empty((2, B, B), dtype=torch.float32, device=dev)
+    dwc = torch.empty((2, B), dtype=torch.float32, device=dev)
+    dls = torch.empty((2, B), dtype=torch.float32, device=dev)
+    hip.call("nr_row_losses_bwd", hip.ptr(S, torch.float32), hip.ptr(G, torch.float32), hip.ptr(tgt_rows), hip.ptr(tgt_cols),
+             hip.ptr(bank_c0, torch.float32), hip.ptr(bank_c1, torch.float32), hip.ptr(wc_text, torch.float32),
+             hip.ptr(wc_video, torch.float32), hip.ptr(logit_scale, torch.float32), B, int(K), float(T),
+             hip.ptr(g_rowloss, torch.float32), hip.ptr(dS), hip.ptr(dG), hip.ptr(dC), hip.ptr(dwc), hip.ptr(dls),
+             hip.stream_ptr())
+    return dS, dG, dC, dwc, dls
+
+
+def add_transposed(a, b):
+    """a + b.T for square fp32 matrices."""
+    B = a.shape[0]
+    out = torch.empty((B, B), dtype=torch.float32, device=a.device)
+    hip.call("nr_add_transposed", hip.ptr(a, torch.float32), hip.ptr(b, torch.float32), B, hip.ptr(out), hip.stream_ptr())
+    return out
+
+
+def colsum(a):
+    rows, cols = a.shape
+    out = torch.empty((cols,), dtype=torch.float32, device=a.device)
+    hip.call("nr_colsum", hip.ptr(a, torch.float32), rows, cols, hip.ptr(out), hip.stream_ptr())
+    return out
+
+
+def local_level_bwd(side, dS, ds_mode, ds_scale, other, w_self, w_other, aux, A, Nt, Bv, Nv, d_x=None, d_w=None,
+                    want_dx=True, accumulate=False, use_lo=True):
+    """Arg-max-routed gradient for one operand (nr_local_level_bwd).  `other` is the Prepared
+    token set of the opposite operand.  Returns (d_x [n_self*N, d] or None, d_w [n_self*N])."""
+    arg_v, arg_t, pmax, qmax = aux
+    n_self = (A * Nt) if side == 0 else (Bv * Nv)
+    d = other.d
+    dev = w_self.device
+    if accumulate and ((want_dx and d_x is None) or d_w is None):
+        raise ValueError("accumulate=True needs existing d_x / d_w buffers")
+    if want_dx and d_x is None:
+        d_x = torch.empty((n_self, d), dtype=torch.float32, device=dev)
+    if d_w is None:
+        d_w = torch.empty((n_self,), dtype=torch.float32, device=dev)
+    hip.call("nr_local_level_bwd", int(side), hip.ptr(dS, torch.float32), int(ds_mode), float(ds_scale),
+             hip.ptr(other.hi), hip.ptr(other.lo if use_lo else None, allow_none=True), hip.ptr(w_self, torch.float32),
+             hip.ptr(w_other, torch.float32), hip.ptr(arg_v), hip.ptr(arg_t), hip.ptr(pmax), hip.ptr(qmax),
+             A, Nt, Bv, Nv, d, hip.ptr(d_x if want_dx else None, allow_none=True), hip.ptr(d_w),
+             1 if accumulate else 0, hip.stream_ptr())
+    return (d_x if want_dx else None), d_w
+
+
+def normalize_bwd(x, norm, mask, d_xn, dmean):
+    x = _f32(x).contiguous()
+    d = x.shape[-1]
+    n_tok = x.numel() // d
+    dx = torch.empty_like(x)
+    m = _f32(mask).contiguous() if mask is not None else None
+    hip.call("nr_normalize_bwd", hip.ptr(x), hip.ptr(norm, torch.float32), hip.ptr(m, allow_none=True),
+             hip.ptr(d_xn, allow_none=True), hip.ptr(dmean, allow_none=True), n_tok, d, hip.ptr(dx), hip.stream_ptr())
+    return dx
+
+
+def token_softmax_bwd(w, dw):
+    n, N = w.shape
+    out = torch.empty_like(w)
+    hip.call("nr_token_softmax_bwd", hip.ptr(w, torch.float32), hip.ptr(dw.contiguous(), torch.float32), n, N, hip.ptr(out),
+             hip.stream_ptr())
+    return out
+
+
+def centrality_weights_bwd(g, gnorm, mean, w, dw, scale):
+    B, d = g.shape
+    dg = torch.empty_like(g)
+    dmean = torch.empty((d,), dtype=torch.float32, device=g.device)
+    hip.call("nr_centrality_weights_bwd", hip.ptr(g, torch.float32), hip.ptr(gnorm), hip.ptr(mean), hip.ptr(w),
+             hip.ptr(dw.contiguous(), torch.float32), B, d, float(scale), hip.ptr(dg), hip.ptr(dmean), hip.stream_ptr())
+    return dg, dmean
 
 
 def bank_push(bank, batch, scratch=None):

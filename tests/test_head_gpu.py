@@ -1,0 +1,169 @@
+"""GPU: the drop-in model API end to end -- forward losses and gradients against (a) the vectors
+captured from the reference (tests/golden) and (b) the CPU oracle's autograd on the same inputs.
+
+Tolerances: split-bf16 ("bf16x3") path <= 2e-4 on every loss and 1e-3 relative on gradients;
+single-pass bf16 path <= 1e-3 on losses / logits (BASELINE.json north_star) and retrieval ranks
+identical on the bf16x3 path.
+"""
+import numpy as np
+import pytest
+import torch
+
+import nr_oracle as O
+from neighborretr_amd import modeling, synth
+from util import golden, maxdiff, noise, params, problem
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(precision, K=20):
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K), precision=precision)
+    missing, unexpected = m.load_state_dict(params(), strict=False)
+    assert not unexpected
+    m = m.to(DEV)
+    with torch.no_grad():
+        m.clip.logit_scale.fill_(float(np.log(100.0)))
+    return m.train()
+
+
+def _losses(m, x, nz, K):
+    c = m.config
+    return m._compute_losses(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"], x["mb_feat_t"],
+                             x["mb_feat_v"], x["mb_mask_t"], x["mb_mask_v"], c.centrality_scale, c.beta, K,
+                             c.temperature, m.clip.logit_scale.exp(), noise=nz)
+
+
+@pytest.mark.parametrize("name", ["c1_b16", "c2_b128"])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-4), ("bf16", 1e-3)])
+def test_forward_losses_match_reference(name, precision, tol):
+    g = golden(name)
+    B, Nt, Nv, M, K = (int(g[k]) for k in ("B", "Nt", "Nv", "M", "K"))
+    x = problem(int(g["seed"]), B, Nt, Nv, M, device=DEV)
+    nz = noise(int(g["seed"]), B, Nt, Nv, device=DEV)
+    m = _model(precision, K)
+    with torch.no_grad():
+        losses = torch.stack(_losses(m, x, nz, K)).cpu().numpy()
+        S, St = m.get_similarity_logits(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"])
+    assert np.max(np.abs(losses - g["losses"])) < tol * max(1.0, float(np.abs(g["losses"]).max()) / 10), (losses, g["losses"])
+    assert maxdiff(S, g["S"]) < (2e-6 if precision == "bf16x3" else 1e-3)
+    assert torch.equal(St, S.T)
+    if precision == "bf16x3":
+        # identical retrieval ranks (north_star): same `cols` as the reference's metrics on its own S
+        from neighborretr_amd.metrics import RetrievalMetrics
+        mine = RetrievalMetrics.compute_metrics(S.cpu().numpy())
+        ref = O.compute_metrics(g["S"])
+        assert mine["cols"] == ref["cols"] and mine["R1"] == ref["R1"]
+
+
+@pytest.mark.parametrize("name", ["c1_b16", "c2_b128"])
+def test_backward_matches_reference(name):
+    g = golden(name)
+    B, Nt, Nv, M, K = (int(g[k]) for k in ("B", "Nt", "Nv", "M", "K"))
+    x = problem(int(g["seed"]), B, Nt, Nv, M, device=DEV)
+    nz = noise(int(g["seed"]), B, Nt, Nv, device=DEV)
+    m = _model("bf16x3", K)
+    x["text_feat"].requires_grad_(True)
+    x["video_feat"].requires_grad_(True)
+    losses = _losses(m, x, nz, K)
+    losses[0].backward()
+    gt, gv = x["text_feat"].grad, x["video_feat"].grad
+    assert abs(float(gt.norm()) - float(g["g_text_norm"])) < 2e-3 * float(g["g_text_norm"])
+    assert abs(float(gv.norm()) - float(g["g_video_norm"])) < 2e-3 * float(g["g_video_norm"])
+    scale_t = float(np.abs(g["g_text_slice"]).max())
+    scale_v = float(np.abs(g["g_video_slice"]).max())
+    assert maxdiff(gt[:2, :4, :64], g["g_text_slice"]) < 5e-3 * scale_t
+    assert maxdiff(gv[:2, :4, :64], g["g_video_slice"]) < 5e-3 * scale_v
+    assert maxdiff(gt.sum(-1), g["g_text_rowsum"]) < 5e-3 * float(np.abs(g["g_text_rowsum"]).max())
+    assert maxdiff(gv.sum(-1), g["g_video_rowsum"]) < 5e-3 * float(np.abs(g["g_video_rowsum"]).max())
+    ls_grad = float(m.clip.logit_scale.grad) / 100.0            # d/d(exp(p)) = d/dp / exp(p)
+    assert abs(ls_grad - float(g["g_logit_scale"])) < 2e-3 * abs(float(g["g_logit_scale"])) + 1e-7
+    named = dict(m.named_parameters())
+    for n, ref in zip([str(s) for s in g["param_names"]], g["param_grad_norms"]):
+        mine = 0.0 if named[n].grad is None else float(named[n].grad.norm())
+        assert abs(mine - ref) < 5e-3 * max(ref, 1e-3), (n, mine, ref)
+
+
+def test_local_level_backward_matches_oracle_autograd():
+    A, Nt, Bv, Nv = 10, 24, 14, 12
+    x = problem(31, max(A, Bv), Nt, Nv, 4)
+    P = params()
+    tf = x["text_feat"][:A].clone().requires_grad_(True)
+    vf = x["video_feat"][:Bv].clone().requires_grad_(True)
+    tm, vm = x["text_mask"][:A], x["video_mask"][:Bv]
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    S_ref, _ = O.local_level(tf, vf, tm, vm, Pg)
+    W = torch.from_numpy(synth.normal(5, "dS", (A, Bv)).astype(np.float32))
+    (S_ref * W).sum().backward()
+
+    m = _model("bf16x3")
+    tf2 = x["text_feat"][:A].to(DEV).requires_grad_(True)
+    vf2 = x["video_feat"][:Bv].to(DEV).requires_grad_(True)
+    S, _ = m.local_level(tf2, vf2, tm.to(DEV), vm.to(DEV))
+    assert maxdiff(S, S_ref) < 2e-6
+    (S * W.to(DEV)).sum().backward()
+    assert maxdiff(tf2.grad, tf.grad) < 2e-3 * float(tf.grad.abs().max())
+    assert maxdiff(vf2.grad, vf.grad) < 2e-3 * float(vf.grad.abs().max())
+    # masked tokens never receive gradient through the similarity
+    for n in ("text_weight_fc", "video_weight_fc"):
+        for k in ("0.weight", "0.bias", "2.weight", "2.bias"):
+            ref = Pg[f"{n}.{k}"].grad
+            mine = dict(m.named_parameters())[f"{n}.{k}"].grad
+            # the last bias shifts every logit of a sample equally: its true gradient is 0 (softmax
+            # invariance), what is left on both sides is rounding noise
+            atol = 1e-6 if k == "2.bias" else 1e-9
+            assert maxdiff(mine, ref) < 3e-3 * float(ref.abs().max()) + atol, (n, k)
+
+
+def test_until_module_classes_forward_and_backward():
+    from neighborretr_amd.until_module import (CentralityWeightingLoss, KLDivergenceLoss, NeighborAdjustingLoss,
+                                               UniformRegularizationLoss)
+    B, K, M = 32, 8, 40
+    gen = torch.Generator().manual_seed(9)
+    S = (torch.rand(B, B, generator=gen) * 0.12)
+    G = torch.randn(B, B, generator=gen) * 9
+    bank = torch.rand(B, M, generator=gen) * 0.1
+    w = torch.exp(torch.randn(B, generator=gen) * 0.05)
+    cases = [
+        (lambda S_, G_, b_, w_: CentralityWeightingLoss()(S_ * 100.0, w_), lambda S_, G_, b_, w_: O.centrality_weighting_loss(S_ * 100.0, w_)),
+        (lambda S_, G_, b_, w_: NeighborAdjustingLoss()(S_, b_, K, 3.0), lambda S_, G_, b_, w_: O.neighbor_adjusting_loss(S_, b_, K, 3.0)),
+        (lambda S_, G_, b_, w_: UniformRegularizationLoss()(G_, 3.0, 0.7), lambda S_, G_, b_, w_: O.uniform_regularization_loss(G_, 3.0, 0.7)),
+        (lambda S_, G_, b_, w_: KLDivergenceLoss()(G_, S_), lambda S_, G_, b_, w_: O.kl_divergence_loss(G_, S_)),
+    ]
+    for mine_fn, ref_fn in cases:
+        cpu = [t.clone().double().requires_grad_(True) for t in (S, G, bank, w)]
+        gpu = [t.clone().to(DEV).requires_grad_(True) for t in (S, G, bank, w)]
+        ref = ref_fn(*cpu)
+        mine = mine_fn(*gpu)
+        assert abs(float(mine) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+        ref.backward()
+        mine.backward()
+        for a, b in zip(gpu, cpu):
+            if b.grad is None:
+                assert a.grad is None or float(a.grad.abs().max()) == 0.0
+            else:
+                assert maxdiff(a.grad, b.grad) < 2e-3 * float(b.grad.abs().max()) + 1e-8
+    with pytest.raises(IndexError):
+        NeighborAdjustingLoss()(S.to(DEV), bank.to(DEV), B + 1, 3.0)
+
+
+def test_forward_updates_memory_bank_fifo_and_eval_returns_none():
+    B, Nt, Nv, M = 16, 24, 12, 40
+    x = problem(1001, B, Nt, Nv, M, device=DEV)
+    m = _model("bf16", K=8)
+    m.mb_feat_t, m.mb_feat_v = x["mb_feat_t"].clone(), x["mb_feat_v"].clone()
+    m.mb_mask_t, m.mb_mask_v = x["mb_mask_t"].clone(), x["mb_mask_v"].clone()
+    m.mb_ind = torch.arange(1000, 1000 + M, device=DEV)
+    ref_ind = torch.cat((x["idx"], m.mb_ind))[:M]
+    ref_v = torch.cat((x["video_feat"], m.mb_feat_v))[:M]
+    out = m(x["text_feat"], x["text_mask"], x["video_feat"], x["video_mask"], x["idx"], 0)
+    assert len(out) == 5 and all(o.dim() == 0 for o in out)
+    assert torch.equal(m.mb_ind, ref_ind) and torch.equal(m.mb_feat_v, ref_v)
+    assert m.mb_feat_v.shape[0] == M
+    m.eval()
+    assert m(x["text_feat"], x["text_mask"], x["video_feat"], x["video_mask"], x["idx"], 0) is None
+    # K > B is rejected like the reference's IndexError (until_module.py:119-123)
+    m.train()
+    m.config.num_neighbors = 20
+    with pytest.raises((ValueError, IndexError)):
+        m(x["text_feat"], x["text_mask"], x["video_feat"], x["video_mask"], x["idx"], 0)

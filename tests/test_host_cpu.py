@@ -1,0 +1,85 @@
+"""CPU: host-side logic that needs no GPU -- the token-clustering stage against the oracle, the
+C-ABI surface of the built library, loud failure of the product path without a device."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import nr_oracle as O
+from neighborretr_amd import hip, modeling, synth
+from util import maxdiff, noise, params, problem
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(P):
+    m = modeling.NeighborRetr(modeling.default_config())
+    missing, unexpected = m.load_state_dict(P, strict=False)
+    assert not unexpected
+    assert all(k.startswith("clip.") for k in missing), missing
+    return m
+
+
+@pytest.mark.parametrize("B,Nt,Nv,blank", [(16, 24, 12, None), (8, 64, 64, None), (6, 20, 9, None)])
+def test_merge_global_features_matches_oracle(B, Nt, Nv, blank):
+    x = problem(77, B, Nt, Nv, 4)
+    P = params()
+    nz = noise(77, B, Nt, Nv)
+    m = _model(P)
+    gt, gv = m.merge_global_features(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"], nz)
+    gt_o, gv_o = O.merge_global_features(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"], P, nz)
+    assert gt.shape == gt_o.shape and gv.shape == gv_o.shape
+    assert maxdiff(gt, gt_o) < 1e-5 and maxdiff(gv, gv_o) < 1e-5
+
+
+def test_state_dict_names_cover_reference_head():
+    m = modeling.NeighborRetr(modeling.default_config())
+    have = set(m.state_dict().keys())
+    want = set(synth.head_param_shapes().keys())
+    assert want <= have, sorted(want - have)
+    for k, shp in synth.head_param_shapes().items():
+        assert tuple(m.state_dict()[k].shape) == tuple(shp), k
+    assert "clip.logit_scale" in have
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(hip.LIB_PATH), "build the extension first (python -m neighborretr_amd.build)"
+    header = open(os.path.join(ROOT, "include", "nr_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|size_t)\s+(nr_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(hip.exported_symbols()), declared ^ set(hip.exported_symbols())
+    assert lib.nr_version() == 1
+    assert lib.nr_prepare_parts(10) == 1 and lib.nr_prepare_parts(10 ** 6) == 64
+
+
+def test_tile_query_no_gpu_needed():
+    assert hip.local_level_tiles(128, 24, 128, 12) == (32, 16)      # 4 texts x 8 videos per 96x96 block
+    assert hip.local_level_tiles(128, 64, 1024, 64) == (64, 512)    # 2 x 2 per 128x128 block
+    with pytest.raises(hip.NrHipError):
+        hip.local_level_tiles(4, 200, 4, 12)                         # > 128 tokens per sample: unsupported
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    from neighborretr_amd import ops
+    with pytest.raises(hip.NrHipError):
+        ops.prepare_tokens(torch.randn(4, 3, 512))
+    m = modeling.NeighborRetr(modeling.default_config())
+    x = problem(1, 4, 24, 12, 8)
+    with pytest.raises(hip.NrHipError):
+        with torch.no_grad():
+            m.local_level(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"])
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "neighborretr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "nr_oracle" not in src and "import oracle" not in src, f

@@ -97,7 +97,7 @@ def test_local_level_matches_oracle(A, Nt, Bv, Nv, prec, tol):
 
     pt = ops.prepare_tokens(t.to(DEV), tm.to(DEV))
     pv = ops.prepare_tokens(v.to(DEV), vm.to(DEV))
-    S, arg_v, arg_t = ops.local_level(pt, pv, w_t.to(DEV), w_v.to(DEV), A, Nt, Bv, Nv, prec, hip.OUT_FULL, want_arg=True)
+    S, (arg_v, arg_t, pmax, qmax) = ops.local_level(pt, pv, w_t.to(DEV), w_v.to(DEV), A, Nt, Bv, Nv, prec, hip.OUT_FULL, want_arg=True)
     assert maxdiff(S, S_ref) < tol
     if Bv > 2:
         assert float(S[:, 2].abs().max()) == 0.0
@@ -108,10 +108,11 @@ def test_local_level_matches_oracle(A, Nt, Bv, Nv, prec, tol):
         assert maxdiff(got_p, pm) < 1e-5
         got_q = torch.gather(Rf, 2, arg_t.cpu().long()[:, :, None, :]).squeeze(2)
         assert maxdiff(got_q, qm) < 1e-5
+        assert maxdiff(pmax, pm) < 2e-6 and maxdiff(qmax, qm) < 2e-6
     # bank modes: row / column sums of the same matrix
     nr, nc = hip.local_level_tiles(A, Nt, Bv, Nv)
-    rs, _, _ = ops.local_level(pt, pv, w_t.to(DEV), w_v.to(DEV), A, Nt, Bv, Nv, prec, hip.OUT_ROWSUM)
-    cs, _, _ = ops.local_level(pt, pv, w_t.to(DEV), w_v.to(DEV), A, Nt, Bv, Nv, prec, hip.OUT_COLSUM)
+    rs, _ = ops.local_level(pt, pv, w_t.to(DEV), w_v.to(DEV), A, Nt, Bv, Nv, prec, hip.OUT_ROWSUM)
+    cs, _ = ops.local_level(pt, pv, w_t.to(DEV), w_v.to(DEV), A, Nt, Bv, Nv, prec, hip.OUT_COLSUM)
     assert rs.shape == (nc, A) and cs.shape == (nr, Bv)
     assert maxdiff(ops.reduce_parts(rs, 1.0 / Bv), S_ref.mean(1)) < tol
     assert maxdiff(ops.reduce_parts(cs, 1.0 / A), S_ref.mean(0)) < tol
@@ -128,11 +129,11 @@ def test_local_level_end_to_end_golden_c1():
     w_t, _ = _tw(pt, x["text_mask"], P, "text_weight_fc", 16, 24, hip.PREC_BF16X3)
     w_v, _ = _tw(pv, x["video_mask"], P, "video_weight_fc", 16, 12, hip.PREC_BF16X3)
     assert maxdiff(w_t, gd["w_t"]) < 2e-5 and maxdiff(w_v, gd["w_v"]) < 2e-5
-    S, _, _ = ops.local_level(pt, pv, w_t, w_v, 16, 24, 16, 12, hip.PREC_BF16X3)
+    S, _ = ops.local_level(pt, pv, w_t, w_v, 16, 24, 16, 12, hip.PREC_BF16X3)
     assert maxdiff(S, gd["S"]) < 2e-6
     w_t1, _ = _tw(pt, x["text_mask"], P, "text_weight_fc", 16, 24, hip.PREC_BF16)
     w_v1, _ = _tw(pv, x["video_mask"], P, "video_weight_fc", 16, 12, hip.PREC_BF16)
-    S1, _, _ = ops.local_level(pt, pv, w_t1, w_v1, 16, 24, 16, 12, hip.PREC_BF16)
+    S1, _ = ops.local_level(pt, pv, w_t1, w_v1, 16, 24, 16, 12, hip.PREC_BF16)
     assert maxdiff(S1, gd["S"]) < 1e-3
 
 
