@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""DDP entry point for the similarity / loss path (the reference's main.py:189-437, launched in its
+README as main_retrieval.py).  Same flag names, same per-epoch sequence
+  load memory bank -> train epoch -> eval -> save -> clear bank,
+same training-step contract (trainer.py:66-203): model(...) -> 5 losses -> backward ->
+clip_grad_norm_(1.0) -> optimizer step -> clamp logit_scale <= ln 100 -> reduce the 5 scalars to
+rank 0.  One process per GPU (torchrun / torch.distributed.run; RCCL is torch's "nccl" backend).
+
+The encoders and the video/text datasets are out of this build's scope, so the
+runnable mode is `--synthetic`: seeded CLIP-shaped token features stand in for the encoder outputs
+and the model runs in feature mode.  With real encoders, construct
+`NeighborRetr(args, clip=<module with encode_text/encode_image/logit_scale>)` instead.
+
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 main_retrieval.py \\
+      --do_train 1 --synthetic --batch_size 128 --max_words 24 --max_frames 12 --mb_batch 4 --epochs 1
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def get_args():
+    p = argparse.ArgumentParser("NeighborRetr on MI355X")
+    # loss parameters (args_parser.py:25-41)
+    p.add_argument("--centrality_scale", default=0.3, type=float)
+    p.add_argument("--kl_weight", default=1.0, type=float)
+    p.add_argument("--uniform_weight", default=1.0, type=float)
+    p.add_argument("--ot_temperature", default=0.1, type=float, help="parsed and unused, as in the reference")
+    p.add_argument("--beta", default=0.7, type=float)
+    p.add_argument("--num_neighbors", default=20, type=int)
+    p.add_argument("--temperature", default=3.0, type=float)
+    p.add_argument("--neighbor_weight", default=1.0, type=float)
+    # data loading / modes / dataset (accepted for command-line compatibility)
+    p.add_argument("--workers", default=8, type=int)
+    p.add_argument("--pin_memory", action="store_true")
+    p.add_argument("--prefetch_factor", default=4, type=int)
+    p.add_argument("--persistent_workers", action="store_true")
+    p.add_argument("--video_cache_size", default=64, type=int)
+    p.add_argument("--use_prefetch", action="store_true")
+    p.add_argument("--timeout", default=0, type=int)
+    p.add_argument("--save_model", action="store_true")
+    p.add_argument("--do_train", type=int, default=0)
+    p.add_argument("--do_eval", type=int, default=0)
+    p.add_argument("--detect_grad", action="store_true")
+    p.add_argument("--datatype", default="msrvtt", type=str)
+    p.add_argument("--anno_path", type=str, default="data/MSR-VTT/anno")
+    p.add_argument("--video_path", type=str, default="data/MSR-VTT/videos")
+    p.add_argument("--output_dir", default="output", type=str)
+    p.add_argument("--seed", type=int, default=42)
+    # optimisation
+    p.add_argument("--lr", type=float, default=1e-4)
+    p.add_argument("--coef_lr", type=float, default=1e-3)
+    p.add_argument("--warmup_proportion", default=0.1, type=float)
+    p.add_argument("--weight_decay", type=float, default=0.2)
+    p.add_argument("--epochs", type=int, default=5)
+    # batch
+    p.add_argument("--batch_size", type=int, default=128, help="GLOBAL batch (data_dataloaders.py:38)")
+    p.add_argument("--batch_size_val", type=int, default=128)
+    p.add_argument("--memory_size", type=int, default=512, help="parsed and unused, as in the reference")
+    p.add_argument("--mb_batch", type=int, default=10)
+    p.add_argument("--max_words", type=int, default=24)
+    p.add_argument("--max_frames", type=int, default=12)
+    p.add_argument("--video_framerate", type=int, default=1)
+    # distributed / model
+    p.add_argument("--device", default="cpu", type=str)
+    p.add_argument("--world_size", default=1, type=int)
+    p.add_argument("--local_rank", "--local-rank", default=0, type=int)
+    p.add_argument("--distributed", default=0, type=int)
+    p.add_argument("--n_display", type=int, default=50)
+    p.add_argument("--base_encoder", default="ViT-B/32", type=str)
+    p.add_argument("--num_hidden_layers", type=int, default=4)
+    p.add_argument("--init_model", default=None, type=str)
+    # this build
+    p.add_argument("--synthetic", action="store_true", help="seeded token features instead of encoders + datasets")
+    p.add_argument("--synthetic_train", type=int, default=2048, help="synthetic training pairs")
+    p.add_argument("--synthetic_test", type=int, default=1000, help="synthetic test pairs (MSR-VTT 1k-A size)")
+    p.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "bf16_all"])
+    args = p.parse_args()
+    if args.batch_size % max(1, int(os.environ.get("WORLD_SIZE", "1"))):
+        raise ValueError("--batch_size must divide over the ranks (args_parser.py:149-165)")
+    return args
+
+
+def setup_distributed(args):
+    """One process per GPU; rendezvous from the torchrun environment (setup.py:44-69)."""
+    args.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    args.rank = int(os.environ.get("RANK", "0"))
+    args.local_rank = int(os.environ.get("LOCAL_RANK", str(args.local_rank)))
+    if not torch.cuda.is_available():
+        raise RuntimeError("the HIP path needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(args.local_rank)
+    args.device = torch.device("cuda", args.local_rank)
+    if args.world_size > 1:
+        dist.init_process_group("nccl", device_id=args.device)      # "nccl" is RCCL on ROCm
+    # AllGather / packed_allgather slice gradients by GLOBAL rank
+    args.local_rank = args.rank
+    return args
+
+
+def log(args, msg):
+    if args.rank == 0:
+        print(time.strftime("%H:%M:%S"), msg, flush=True)
+
+
+class SyntheticFeatures:
+    """Per-rank shard of seeded (text, video) token features: the encoders' stand-in."""
+
+    def __init__(self, args, n, stream, seed):
+        from neighborretr_amd import synth
+        t, v, tm, vm = synth.make_samples(seed, stream, n, args.max_words, args.max_frames)
+        self.t, self.v, self.tm, self.vm = (torch.from_numpy(a) for a in (t, v, tm, vm))
+        self.n = n
+        self.b = args.batch_size // args.world_size
+        self.W, self.rank, self.B = args.world_size, args.rank, args.batch_size
+
+    def __len__(self):
+        return self.n // self.B
+
+    def batch(self, i, device):
+        lo = i * self.B + self.rank * self.b
+        sl = slice(lo, lo + self.b)
+        idx = torch.arange(lo, lo + self.b)
+        return tuple(x.to(device, non_blocking=True) for x in (self.t[sl], self.tm[sl], self.v[sl], self.vm[sl], idx))
+
+
+def load_memory_bank(args, model, data):
+    """memory_bank.py:80-229: run mb_batch batches through the (feature-mode) encoders under no_grad,
+    gather them over the ranks, hand them to the model as plain attributes."""
+    from neighborretr_amd.dist import packed_allgather
+    n = min(args.mb_batch, len(data))
+    feats = [data.batch(i, args.device) for i in range(n)]
+    with torch.no_grad():
+        tf, tm, vf, vm, idx = (torch.cat([f[k] for f in feats], 0) for k in range(5))
+        tf, vf, idx, tm, vm = packed_allgather(tf, vf, idx, tm, vm, args)
+    model.mb_ind, model.mb_feat_t, model.mb_feat_v = idx, tf.contiguous(), vf.contiguous()
+    model.mb_mask_t, model.mb_mask_v, model.mb_batch = tm.contiguous(), vm.contiguous(), n
+    log(args, f"memory bank: {tf.shape[0]} samples ({n} batches x {args.batch_size})")
+    return tf.shape[0]
+
+
+def clear_memory_bank(model):
+    model._init_memory_bank()
+
+
+def train_epoch(args, model, ddp, data, optimizer, epoch, global_step):
+    from neighborretr_amd.dist import reduce_losses
+    model.train()
+    t0 = time.time()
+    for i in range(len(data)):
+        global_step += 1
+        text, text_mask, video, video_mask, idx = data.batch(i, args.device)
+        losses = ddp(text, text_mask, video, video_mask, idx, global_step)
+        loss = losses[0]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+        torch.clamp_(model.clip.logit_scale.data, max=float(np.log(100)))        # trainer.py:114-119
+        if global_step % args.n_display == 0 or i == len(data) - 1:
+            red = reduce_losses(losses, args).tolist()                            # one reduce instead of five
+            log(args, f"epoch {epoch} step {i + 1}/{len(data)} loss {red[0]:.4f} centrality {red[1]:.4f} "
+                      f"uniform {red[2]:.4f} neighbor {red[3]:.4f} kl {red[4]:.4f} "
+                      f"({(time.time() - t0) / (i + 1) * 1e3:.1f} ms/step)")
+    return global_step
+
+
+def eval_epoch(args, model, test):
+    """evaluator.py:66-291 for the single-sentence case: full N x N similarity (every rank, like the
+    reference), ranks counted on the GPU."""
+    from neighborretr_amd.metrics import RetrievalMetrics
+    model.eval()
+    dev = args.device
+    t, tm, v, vm = (x.to(dev) for x in (test.t, test.tm, test.v, test.vm))
+    old = model.precision
+    model.precision = "bf16x3"                      # rank-exact path for retrieval
+    rows = []
+    with torch.no_grad():
+        for lo in range(0, t.shape[0], 256):
+            S, _ = model.get_similarity_logits(t[lo:lo + 256], v, tm[lo:lo + 256], vm)
+            rows.append(S)
+    model.precision = old
+    S = torch.cat(rows, 0)
+    t2v = RetrievalMetrics.compute_metrics(S)
+    v2t = RetrievalMetrics.compute_metrics(S.t().contiguous())
+    log(args, f"text->video R@1 {t2v['R1']:.1f} R@5 {t2v['R5']:.1f} R@10 {t2v['R10']:.1f} MedR {t2v['MR']:.1f} | "
+              f"video->text R@1 {v2t['R1']:.1f} R@5 {v2t['R5']:.1f} R@10 {v2t['R10']:.1f} MedR {v2t['MR']:.1f}")
+    return t2v, v2t
+
+
+def main():
+    args = get_args()
+    args = setup_distributed(args)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    if not args.synthetic:
+        raise SystemExit("datasets / CLIP towers are outside this build (SURVEY.md 2.1): run with --synthetic, "
+                         "or import neighborretr_amd.modeling.NeighborRetr into the reference's main.py")
+    from neighborretr_amd.modeling import NeighborRetr
+    model = NeighborRetr(args, precision=args.precision)
+    if args.init_model:
+        sd = torch.load(args.init_model, map_location="cpu")
+        missing, unexpected = model.load_state_dict(sd, strict=False)          # main.py:60-67
+        log(args, f"init_model: {len(missing)} missing / {len(unexpected)} unexpected keys")
+    model = model.to(args.device)
+    ddp = model
+    if args.world_size > 1:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[args.local_rank % torch.cuda.device_count()],
+                                                        find_unused_parameters=True)   # optimizer.py:79-84
+    train = SyntheticFeatures(args, args.synthetic_train, "train", args.seed)
+    test = SyntheticFeatures(args, args.synthetic_test, "test", args.seed + 1)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    os.makedirs(args.output_dir, exist_ok=True)
+    global_step = 0
+    if args.do_train:
+        for epoch in range(args.epochs):
+            load_memory_bank(args, model, train)
+            global_step = train_epoch(args, model, ddp, train, optimizer, epoch + 1, global_step)
+            eval_epoch(args, model, test)
+            if args.rank == 0 and args.save_model:
+                torch.save(model.state_dict(), os.path.join(args.output_dir, f"pytorch_model.bin.{epoch}"))
+            clear_memory_bank(model)
+    elif args.do_eval:
+        eval_epoch(args, model, test)
+    if args.world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

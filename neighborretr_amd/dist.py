@@ -1,0 +1,87 @@
+"""The path's one exchange step: gathering every rank's features / masks / ids before the
+batch x batch similarity (reference: 5 x all_gather + barrier, modeling.py:274-280 via
+until_module.py:367-388).
+
+`packed_allgather` moves all five tensors in ONE collective: each rank packs
+[text_feat f32 | video_feat f32 | idx i64 | text_mask u8 | video_mask u8] into one byte buffer,
+one all_gather_into_tensor (RCCL over xGMI on the GPU box; gloo in the CPU tests) fills a
+[W, bytes] buffer, and the pieces are sliced back out.  At b=16, Nt=24, Nv=12 a shard is ~1.2 MB:
+the step is latency-bound, so one launch instead of five (plus the reference's barrier, which is
+dropped: the collective already orders the data) is what matters.
+
+Backward keeps the reference's semantics (AllGather.backward): every rank differentiates the
+full replicated loss, so the gradient of the gathered features is just this rank's slice -- no
+reduction.
+"""
+import torch
+import torch.distributed as dist
+
+
+def _world(args):
+    return int(getattr(args, "world_size", 1))
+
+
+class PackedAllGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, text_feat, video_feat, idx, text_mask, video_mask, args):
+        W = _world(args)
+        b = text_feat.shape[0]
+        ctx.rank, ctx.b, ctx.W = int(getattr(args, "local_rank", 0)), b, W
+        if dist.is_initialized():
+            ctx.rank = dist.get_rank()
+        if W == 1:
+            return text_feat.view_as(text_feat), video_feat.view_as(video_feat), idx, text_mask, video_mask
+        dev = text_feat.device
+        tf = text_feat.detach().float().contiguous()
+        vf = video_feat.detach().float().contiguous()
+        ix = idx.to(torch.int64).contiguous()
+        tm = text_mask.to(torch.uint8).contiguous()
+        vm = video_mask.to(torch.uint8).contiguous()
+        parts = [tf.view(-1).view(torch.uint8), vf.view(-1).view(torch.uint8), ix.view(-1).view(torch.uint8),
+                 tm.view(-1), vm.view(-1)]
+        sizes = [p.numel() for p in parts]
+        total = (sum(sizes) + 15) // 16 * 16
+        send = torch.empty(total, dtype=torch.uint8, device=dev)
+        off = 0
+        for p, n in zip(parts, sizes):
+            send[off:off + n] = p
+            off += n
+        recv = torch.empty(W * total, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(recv, send)
+        recv = recv.view(W, total)
+
+        def take(k, dtype, shape):
+            o = sum(sizes[:k])
+            return recv[:, o:o + sizes[k]].contiguous().view(-1).view(dtype).view((W * b,) + tuple(shape))
+        g_tf = take(0, torch.float32, tf.shape[1:])
+        g_vf = take(1, torch.float32, vf.shape[1:])
+        g_ix = take(2, torch.int64, ix.shape[1:])
+        g_tm = take(3, torch.uint8, tm.shape[1:]).to(text_mask.dtype)
+        g_vm = take(4, torch.uint8, vm.shape[1:]).to(video_mask.dtype)
+        ctx.mark_non_differentiable(g_ix, g_tm, g_vm)
+        return g_tf, g_vf, g_ix, g_tm, g_vm
+
+    @staticmethod
+    def backward(ctx, g_tf, g_vf, g_ix, g_tm, g_vm):
+        if ctx.W == 1:
+            return g_tf, g_vf, None, None, None, None
+        sl = slice(ctx.b * ctx.rank, ctx.b * (ctx.rank + 1))
+        return g_tf[sl], g_vf[sl], None, None, None, None
+
+
+def packed_allgather(text_feat, video_feat, idx, text_mask, video_mask, args):
+    """-> (text_feat, video_feat, idx, text_mask, video_mask) with the batch dim multiplied by W."""
+    return PackedAllGather.apply(text_feat, video_feat, idx, text_mask, video_mask, args)
+
+
+def reduce_losses(losses, args):
+    """The trainer's five reduce(dst=0) calls for logging (setup.py:72-94) as one: rank 0 receives
+    the mean over ranks of the stacked scalars."""
+    W = _world(args)
+    stacked = torch.stack([l.detach().float() for l in losses])
+    if W < 2:
+        return stacked
+    dist.reduce(stacked, dst=0)
+    if dist.get_rank() == 0:
+        stacked /= W
+    return stacked

@@ -138,12 +138,11 @@ class NeighborRetr(nn.Module):
         text_feat, video_feat = self.get_text_video_feat(text_ids, text_mask, video, video_mask, shaped=True)
         if not self.training:
             return None
-        if torch.cuda.is_available() and getattr(self.config, "world_size", 1) > 1:
-            idx = allgather(idx, self.config)
-            text_feat = allgather(text_feat, self.config)
-            video_feat = allgather(video_feat, self.config)
-            text_mask = allgather(text_mask, self.config)
-            video_mask = allgather(video_mask, self.config)
+        if getattr(self.config, "world_size", 1) > 1:
+            # the reference's 5 all_gathers + barrier (modeling.py:274-280) as one packed collective
+            from .dist import packed_allgather
+            text_feat, video_feat, idx, text_mask, video_mask = packed_allgather(
+                text_feat, video_feat, idx, text_mask, video_mask, self.config)
         logit_scale = self.clip.logit_scale.exp()
         cfg = self.config
         losses = self._compute_losses(text_feat, video_feat, text_mask, video_mask,

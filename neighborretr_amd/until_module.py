@@ -124,6 +124,10 @@ class AllGather2(torch.autograd.Function):
         if ctx.world_size == 1:
             return grad_output, None
         g = grad_output.contiguous()
+        if torch.distributed.get_backend() == "gloo":          # gloo has no reduce_scatter: the
+            g = g.clone()                                       # reference's all_reduce + slice
+            torch.distributed.all_reduce(g)
+            return g[ctx.rank * ctx.batch_size:(ctx.rank + 1) * ctx.batch_size], None
         out = torch.empty((ctx.batch_size,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
         torch.distributed.reduce_scatter_tensor(out, g)
         return out, None
