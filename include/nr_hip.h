@@ -93,6 +93,15 @@ int nr_gemm_nt_f32(const float* a, const float* b, int M, int N, int K, float* c
 int nr_centrality_weights(const float* g, int B, int d, const float* colsum_part, int n_parts, int n_tok,
                           float scale, float* w, float* gnorm, float* mean_out, void* stream);
 
+/* DPC-KNN cluster assignment of every token (cluster.py:453-509; index-only, no gradient):
+ *   x [n_samples,N,C] f32 tokens; mask [n_samples,N] f32 (>0 = valid) or NULL; noise [n_samples,N]
+ *   f32 in [0,1) (the reference's torch.rand tie-break draw, cluster.py:483); k nearest neighbours for
+ *   the density; cluster_num centres; assign [n_samples,N] i64 out (cluster id in [0,cluster_num)).
+ *   N <= 64.  workspace: nr_dpc_workspace_bytes(n_samples, N).                                  */
+size_t nr_dpc_workspace_bytes(int n_samples, int N);
+int nr_dpc_knn_assign(const float* x, const float* mask, const float* noise, int n_samples, int N, int C, int k,
+                      int cluster_num, int64_t* assign, void* workspace, void* stream);
+
 /* Log-domain Sinkhorn targets, both directions in one launch (until_module.py:235-266):
  *   tgt_rows = beta*Q(G) + (1-beta)*I,  tgt_cols = beta*Q(G^T) + (1-beta)*I  (each [B,B],
  *   tgt_cols indexed in the transposed frame).  workspace: nr_sinkhorn_workspace_bytes(B).    */

@@ -23,6 +23,9 @@ def dpc_knn_assign(x, cluster_num, k, mask=None, noise=None):
 
     x [B,N,C]; mask [B,N] (>0 = valid) or None; noise [B,N] in [0,1) replaces the reference's
     torch.rand tie-break draw (cluster.py:483) when given, so tests can be deterministic."""
+    if x.is_cuda and x.shape[1] <= 64:
+        from . import ops                      # two HIP launches instead of ~25 tiny ATen kernels
+        return ops.dpc_knn_assign(x, cluster_num, k, mask, noise)
     with torch.no_grad():
         B, N, C = x.shape
         dist = torch.cdist(x, x) / math.sqrt(C)

@@ -1,16 +1,22 @@
-// Log-domain Sinkhorn targets for the uniform-regularisation loss.
+// Sinkhorn targets for the uniform-regularisation loss.
 // Reference: UniformRegularizationLoss.sinkhorn_algorithm, until_module.py:235-266 --
 //   mu = nu = -log(2B); u = v = 0; 50 x { u = mu - LSE_j(G + v);  v = nu - LSE_i(G + u) };
 //   Q = exp(G + u + v - norm);  target = beta*Q + (1-beta)*I.
 // The reference runs it on G and, separately, on G^T (modeling.py:440-441); both problems are
 // solved in one launch (blockIdx.x = direction).
 //
-// B <= 128: ONE persistent workgroup of 1024 threads per direction.  The 100 dependent
-// reductions never leave the CU: 8 lanes share a row (or column), every thread keeps its <=16
-// matrix entries for the row pass AND its <=16 entries for the column pass in registers (G is
-// constant across iterations), only the dual vectors u, v travel through LDS.
+// B <= 128: ONE persistent workgroup of 1024 threads per direction; the 100 dependent reductions
+// never leave the CU.  8 lanes share a line; every thread keeps 16 contiguous entries of its row
+// (row pass) AND 16 of its column (column pass) in registers.  The first iteration runs in the log
+// domain exactly as the reference (safe for any logit range); from then on the plan
+// P = exp(G + u + v) itself is carried in registers and each half-iteration is the equivalent
+// multiplicative update   P_ij *= mu / rowsum_i   /   P_ij *= nu / colsum_j
+// (u_i <- mu - LSE_j(G_ij + v_j)  <=>  scale row i so that it sums to e^mu).  That replaces 2 x 16
+// exp per thread and half-iteration by adds and multiplies: the kernel is VALU-bound on one CU and
+// this is what shortens the step's critical path.  After the first iteration every entry of P is
+// <= 1/(2B), so nothing can overflow.
 // B > 128: the matrix stays in L2/MALL; one launch per half-iteration (wave per row, coalesced),
-// the column pass running on a transposed copy held in the workspace.
+// the column pass running on a transposed copy held in the workspace (log domain throughout).
 #include "nr_common.h"
 #include "../../include/nr_hip.h"
 
@@ -18,53 +24,49 @@
 
 __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __restrict__ G, int B, float beta, int iters,
                                                                  float* __restrict__ tgt_rows, float* __restrict__ tgt_cols) {
-    __shared__ float s_u[128], s_v[128];
+    __shared__ __attribute__((aligned(16))) float s_a[128];
+    __shared__ __attribute__((aligned(16))) float s_b[128];
     const int dir = blockIdx.x;                 // 0: problem on G, 1: problem on G^T
     float* tgt = dir == 0 ? tgt_rows : tgt_cols;
     const int tid = threadIdx.x;
-    const int line = tid >> 3, sub = tid & 7;   // `line` = row in the u-pass, column in the v-pass
+    const int line = tid >> 3, sub = tid & 7;   // `line` = row in the row pass, column in the column pass
     const float norm = -logf((float)(2 * B));
+    const float mass = 1.0f / (float)(2 * B);   // e^mu = e^nu
     const bool live = line < B;
 
-    // X[i][j] = G[i][j] (dir 0) or G[j][i] (dir 1)
-    float gr[SK_EPT], gc[SK_EPT];
+    // X[i][j] = G[i][j] (dir 0) or G[j][i] (dir 1);  pr[k] = X[line][16 sub + k],  pc[k] = X[16 sub + k][line]
+    float pr[SK_EPT], pc[SK_EPT];
 #pragma unroll
     for (int k = 0; k < SK_EPT; ++k) {
-        int o = sub + 8 * k;
+        int o = sub * SK_EPT + k;
         bool ok = live && o < B;
-        size_t ir = dir == 0 ? (size_t)line * B + o : (size_t)o * B + line;   // X[line][o]
-        size_t ic = dir == 0 ? (size_t)o * B + line : (size_t)line * B + o;   // X[o][line]
-        gr[k] = ok ? G[ir] : -INFINITY;
-        gc[k] = ok ? G[ic] : -INFINITY;
+        size_t ir = dir == 0 ? (size_t)line * B + o : (size_t)o * B + line;
+        size_t ic = dir == 0 ? (size_t)o * B + line : (size_t)line * B + o;
+        pr[k] = ok ? G[ir] : -INFINITY;
+        pc[k] = ok ? G[ic] : -INFINITY;
     }
-    if (tid < 128) { s_u[tid] = 0.f; s_v[tid] = 0.f; }
+    if (tid < 128) { s_a[tid] = 0.f; s_b[tid] = 0.f; }
     __syncthreads();
 
-    for (int it = 0; it < iters; ++it) {
-        // u_i = norm - LSE_j(X_ij + v_j)
+    if (iters > 0) {
+        // ---- iteration 1, log domain: s_a <- u, s_b <- v ------------------------------------------
         {
-            float x[SK_EPT], m = -INFINITY;
+            float m = -INFINITY;
 #pragma unroll
-            for (int k = 0; k < SK_EPT; ++k) {
-                int o = sub + 8 * k;
-                x[k] = gr[k] + s_v[o & 127];
-                m = fmaxf(m, x[k]);
-            }
+            for (int k = 0; k < SK_EPT; ++k) m = fmaxf(m, pr[k]);                 // v = 0
             m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < SK_EPT; ++k) s += __expf(x[k] - m);
+            for (int k = 0; k < SK_EPT; ++k) s += __expf(pr[k] - m);
             s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-            if (live && sub == 0) s_u[line] = norm - (m + __logf(s));
+            if (live && sub == 0) s_a[line] = norm - (m + __logf(s));
         }
         __syncthreads();
-        // v_j = norm - LSE_i(X_ij + u_i)
         {
             float x[SK_EPT], m = -INFINITY;
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) {
-                int o = sub + 8 * k;
-                x[k] = gc[k] + s_u[o & 127];
+                x[k] = pc[k] + s_a[sub * SK_EPT + k];
                 m = fmaxf(m, x[k]);
             }
             m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
@@ -72,19 +74,62 @@ __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) s += __expf(x[k] - m);
             s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-            if (live && sub == 0) s_v[line] = norm - (m + __logf(s));
+            if (live && sub == 0) s_b[line] = norm - (m + __logf(s));
         }
         __syncthreads();
     }
-    if (live) {
-        const float ui = s_u[line];
+    // ---- the plan itself: P = exp(X + u + v)   (u = v = 0 when iters == 0) -----------------------------
+    {
+        const float ul = live ? s_a[line] : 0.f, vl = live ? s_b[line] : 0.f;
 #pragma unroll
         for (int k = 0; k < SK_EPT; ++k) {
-            int o = sub + 8 * k;
-            if (o < B) {
-                float q = __expf(gr[k] + ui + s_v[o] - norm);
-                tgt[(size_t)line * B + o] = beta * q + (o == line ? 1.0f - beta : 0.f);
+            int o = sub * SK_EPT + k;
+            pr[k] = __expf(pr[k] + ul + s_b[o]);      // -inf entries -> 0
+            pc[k] = __expf(pc[k] + s_a[o] + vl);
+        }
+    }
+    __syncthreads();
+    // ---- iterations 2..iters: multiplicative updates ---------------------------------------------------
+    for (int it = 1; it < iters; ++it) {
+        {   // rows sum to e^mu
+            float r = 0.f;
+#pragma unroll
+            for (int k = 0; k < SK_EPT; ++k) r += pr[k];
+            r += __shfl_xor(r, 1); r += __shfl_xor(r, 2); r += __shfl_xor(r, 4);
+            float al = live ? mass / r : 0.f;
+#pragma unroll
+            for (int k = 0; k < SK_EPT; ++k) pr[k] *= al;
+            if (sub == 0 && tid < 1024) s_a[line] = al;
+        }
+        __syncthreads();
+        {   // the column-layout copy sees the same row factors, then columns sum to e^nu
+            float c = 0.f;
+#pragma unroll
+            for (int k = 0; k < SK_EPT; k += 4) {
+                f32x4_t f = *reinterpret_cast<const f32x4_t*>(&s_a[sub * SK_EPT + k]);
+                pc[k] *= f[0]; pc[k + 1] *= f[1]; pc[k + 2] *= f[2]; pc[k + 3] *= f[3];
+                c += (pc[k] + pc[k + 1]) + (pc[k + 2] + pc[k + 3]);
             }
+            c += __shfl_xor(c, 1); c += __shfl_xor(c, 2); c += __shfl_xor(c, 4);
+            float be = live ? mass / c : 0.f;
+#pragma unroll
+            for (int k = 0; k < SK_EPT; ++k) pc[k] *= be;
+            if (sub == 0) s_b[line] = be;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SK_EPT; k += 4) {
+            f32x4_t f = *reinterpret_cast<const f32x4_t*>(&s_b[sub * SK_EPT + k]);
+            pr[k] *= f[0]; pr[k + 1] *= f[1]; pr[k + 2] *= f[2]; pr[k + 3] *= f[3];
+        }
+    }
+    // ---- Q = P / e^norm = 2B * P;  target = beta*Q + (1-beta)*I ---------------------------------------
+    if (live) {
+        const float sc = beta * (float)(2 * B);
+#pragma unroll
+        for (int k = 0; k < SK_EPT; ++k) {
+            int o = sub * SK_EPT + k;
+            if (o < B) tgt[(size_t)line * B + o] = sc * pr[k] + (o == line ? 1.0f - beta : 0.f);
         }
     }
 }

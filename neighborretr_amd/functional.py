@@ -35,7 +35,8 @@ def head_losses(model, text_feat, video_feat, text_mask, video_mask, mb_feat_t, 
                                 text_feat, video_feat, gt, gv, logit_scale, *pt_params, *pv_params)
     losses, _ = head.head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t,
                                   mb_mask_v, gt, gv, model.scorer_weights("text_weight_fc"),
-                                  model.scorer_weights("video_weight_fc"), hp, logit_scale, model._prec())
+                                  model.scorer_weights("video_weight_fc"), hp, logit_scale, model._prec(),
+                                  join=model._take_join())
     return losses
 
 

@@ -86,8 +86,12 @@ def precision_plan(prec):
 
 
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
-                 gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None):
-    """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None)."""
+                 gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None):
+    """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None).
+
+    `join`: optional callable run right before the first use of gt / gv -- the caller produces the
+    global tokens on side streams while the local branch (prepare, scorer, three products) runs here,
+    and joins the streams in it."""
     B, Nt, d = text_feat.shape
     Nv = video_feat.shape[1]
     M = mb_feat_v.shape[0]
@@ -120,6 +124,8 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     c1 = ops.reduce_parts(p1, 1.0 / M)
     c0 = ops.reduce_parts(p0, 1.0 / M)
 
+    if join is not None:
+        join()
     G = global_logits(gt, gv, sw_t1, sw_v1)
     tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
     gt2 = gt.reshape(B, d).float().contiguous()

@@ -35,6 +35,8 @@ _SIGNATURES = {
     "nr_reduce_parts": ([_P, _I, _I, _F, _P, _P], _I),
     "nr_gemm_nt_f32": ([_P, _P, _I, _I, _I, _P, _P], _I),
     "nr_centrality_weights": ([_P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P], _I),
+    "nr_dpc_workspace_bytes": ([_I, _I], _Z),
+    "nr_dpc_knn_assign": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     "nr_sinkhorn_workspace_bytes": ([_I], _Z),
     "nr_sinkhorn_targets": ([_P, _I, _F, _I, _P, _P, _P, _P], _I),
     "nr_row_losses_fwd": ([_P] * 9 + [_I, _I, _F, _P, _P], _I),

@@ -71,6 +71,9 @@ class NeighborRetr(nn.Module):
         self.video_ctm1 = CTM(sample_ratio=1 / 3, embed_dim=width, dim_out=width, k=3)
         self.video_block1 = TCBlock(dim=width, num_heads=8)
         self._scorer_cache = {}
+        self._streams = None
+        self._join_global = None
+        self.use_side_streams = True
 
     # ------------------------------------------------------------------ construction helpers
     @staticmethod
@@ -164,22 +167,55 @@ class NeighborRetr(nn.Module):
                         mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                         centrality_scale, beta, num_neighbors, temperature, logit_scale, noise=None):
         hp = self._hp(centrality_scale, beta, num_neighbors, temperature)
-        gt, gv = self.merge_global_features(text_feat, video_feat, text_mask, video_mask, noise)
         from .functional import head_losses
+        if text_feat.is_cuda and self.use_side_streams:
+            # three independent branches: text clustering | video clustering | local products.
+            # The two clustering branches run on side streams (in a captured HIP graph: parallel
+            # branches) and are joined right before the global logits need them.
+            cur = torch.cuda.current_stream()
+            s_t, s_v = self._side_streams(text_feat.device)
+            s_t.wait_stream(cur)
+            s_v.wait_stream(cur)
+            nz = noise or {}
+            with torch.cuda.stream(s_t):
+                gt = self._merge_one("text", text_feat, text_mask, nz.get("t0"), nz.get("t1"))
+            with torch.cuda.stream(s_v):
+                gv = self._merge_one("video", video_feat, video_mask, nz.get("v0"), nz.get("v1"))
+            gt.record_stream(cur)
+            gv.record_stream(cur)
+
+            def join():
+                cur.wait_stream(s_t)
+                cur.wait_stream(s_v)
+            self._join_global = join
+        else:
+            gt, gv = self.merge_global_features(text_feat, video_feat, text_mask, video_mask, noise)
         losses = head_losses(self, text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v,
                              mb_mask_t, mb_mask_v, gt, gv, hp, logit_scale)
+        self._take_join()      # joined by now; never leave a stale closure behind
         return losses[0], losses[1], losses[2], losses[3], losses[4]
 
     # ------------------------------------------------------------------ token clustering (modeling.py:446-481)
     def merge_global_features(self, text_feat, video_feat, text_mask, video_mask, noise=None):
         nz = noise or {}
-        t = {"x": text_feat, "mask": text_mask.detach()}
-        v = {"x": video_feat, "mask": video_mask.detach()}
-        t = self.text_block0(self.text_ctm0(t, nz.get("t0")))
-        v = self.video_block0(self.video_ctm0(v, nz.get("v0")))
-        t = self.text_block1(self.text_ctm1(t, nz.get("t1")))
-        v = self.video_block1(self.video_ctm1(v, nz.get("v1")))
-        return t["x"], v["x"]
+        return (self._merge_one("text", text_feat, text_mask, nz.get("t0"), nz.get("t1")),
+                self._merge_one("video", video_feat, video_mask, nz.get("v0"), nz.get("v1")))
+
+    def _merge_one(self, which, feat, mask, noise0=None, noise1=None):
+        """Two CTM + TCBlock stages of one modality: [B,N,d] -> [B,1,d] at the MSR-VTT token counts."""
+        ctm0, blk0 = getattr(self, which + "_ctm0"), getattr(self, which + "_block0")
+        ctm1, blk1 = getattr(self, which + "_ctm1"), getattr(self, which + "_block1")
+        t = blk0(ctm0({"x": feat, "mask": mask.detach()}, noise0))
+        return blk1(ctm1(t, noise1))["x"]
+
+    def _side_streams(self, device):
+        if self._streams is None or self._streams[0].device != device:
+            self._streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return self._streams
+
+    def _take_join(self):
+        j, self._join_global = self._join_global, None
+        return j
 
     # ------------------------------------------------------------------ similarity API
     def local_level(self, text_feat, video_feat, text_mask, video_mask):

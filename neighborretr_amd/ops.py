@@ -119,6 +119,21 @@ def centrality_weights(g, colsum, n_tok, scale, want_aux=False):
     return w, gnorm, mean
 
 
+def dpc_knn_assign(x, cluster_num, k, mask=None, noise=None):
+    """Cluster id [B,N] (int64) of every token by DPC-KNN (nr_dpc_knn_assign)."""
+    x = _f32(x.detach()).contiguous()
+    B, N, C = x.shape
+    if noise is None:
+        noise = torch.rand((B, N), device=x.device, dtype=torch.float32)
+    noise = _f32(noise).contiguous()
+    m = _f32(mask).contiguous() if mask is not None else None
+    assign = torch.empty((B, N), dtype=torch.int64, device=x.device)
+    ws = torch.empty((int(hip.lib().nr_dpc_workspace_bytes(B, N)),), dtype=torch.uint8, device=x.device)
+    hip.call("nr_dpc_knn_assign", hip.ptr(x), hip.ptr(m, allow_none=True), hip.ptr(noise), B, N, C, int(k), int(cluster_num),
+             hip.ptr(assign), hip.ptr(ws), hip.stream_ptr())
+    return assign
+
+
 def sinkhorn_targets(G, beta, iters=50):
     G = _f32(G).contiguous()
     B = G.shape[0]

@@ -211,6 +211,29 @@ def test_row_losses_rejects_bad_k():
         ops.row_losses(z, z, z, z, v, v, v, v, torch.ones(1, device=DEV), 20, 3.0)   # K > B: reference raises too
 
 
+@pytest.mark.parametrize("B,N,cnum,masked", [(16, 24, 4, True), (16, 12, 3, True), (16, 4, 1, False), (16, 3, 1, False),
+                                             (8, 64, 11, True), (8, 16, 6, False), (128, 12, 3, True)])
+def test_dpc_knn_assign_matches_oracle(B, N, cnum, masked):
+    g = torch.Generator().manual_seed(B * 100 + N)
+    x = torch.randn(B, N, 512, generator=g)
+    x = torch.nn.functional.layer_norm(x + 0.5 * x[:, :1], (512,))
+    mask = None
+    if masked:
+        ln = torch.randint(1, N + 1, (B, 1), generator=g)
+        ln[0] = 1                                   # a sample with a single valid token
+        ln[1] = min(2, N)
+        mask = (torch.arange(N)[None] < ln).long()
+    noise = torch.rand(B, N, generator=g)
+    ref = O.dpc_knn(x, cnum, 3, mask, noise)
+    got = ops.dpc_knn_assign(x.to(DEV), cnum, 3, None if mask is None else mask.to(DEV), noise.to(DEV)).cpu()
+    # cluster ids of the VALID tokens must agree; ids of all-padding clusters are tie-break dependent
+    if mask is None:
+        assert torch.equal(got, ref)
+    else:
+        enough = mask.sum(1) >= cnum                # fewer valid tokens than centres: zero-score ties
+        assert torch.equal(got[enough], ref[enough])
+
+
 def test_bank_push_fifo():
     bank = torch.arange(10 * 6, dtype=torch.float32, device=DEV).reshape(10, 2, 3)
     ref = bank.clone()
