@@ -102,6 +102,26 @@ size_t nr_dpc_workspace_bytes(int n_samples, int N);
 int nr_dpc_knn_assign(const float* x, const float* mask, const float* noise, int n_samples, int N, int C, int k,
                       int cluster_num, int64_t* assign, void* workspace, void* stream);
 
+/* Forward pieces of one CTM + TCBlock stage (cluster.py:689-717, :834-888, :938-965) between the
+ * library GEMMs (no gradient: the training path keeps these ops on autograd):
+ *   nr_shift_concat     x [n_samples,N,C] -> out [n_samples*N, 3C] = (x[n-1] | x[n] | x[n+1]), zero at
+ *                       the sample borders: the k=3, padding=1 token convolution becomes one GEMM.
+ *   nr_ctm_norm_score   y [n_rows,C] (= x + conv) -> xn = LayerNorm(y), score = xn.sc_w + sc_b (masked
+ *                       rows -> -inf, cluster.py:703-705), tokw = exp(score), kvn = norm1(xn).
+ *   nr_merge_ln         merge_tokens (cluster.py:512-561): merged [n_samples,cnum,C] weighted cluster
+ *                       means, merged_pb = merged + proj_b, qn = norm1(merged).
+ *   nr_tc_attention     out [n_samples,cnum,C] = softmax_n(q.k/8 + score[n]) v over H heads of 64;
+ *                       q [n_samples,cnum,C], kv [n_samples,N,2C] (k | v), score [n_samples,N].     */
+int nr_shift_concat(const float* x, int n_samples, int N, int C, float* out, void* stream);
+int nr_ctm_norm_score(const float* y, const float* mask, int n_rows, int C, const float* ln_w, const float* ln_b,
+                      const float* sc_w, const float* sc_b, const float* n1_w, const float* n1_b, float eps,
+                      float* xn, float* kvn, float* score, float* tokw, void* stream);
+int nr_merge_ln(const float* xn, const int64_t* assign, const float* tokw, int n_samples, int N, int C, int cnum,
+                const float* n1_w, const float* n1_b, const float* proj_b, float eps, float* merged,
+                float* merged_pb, float* qn, void* stream);
+int nr_tc_attention(const float* q, const float* kv, const float* score, int n_samples, int N, int C, int cnum,
+                    int H, float* out, void* stream);
+
 /* Log-domain Sinkhorn targets, both directions in one launch (until_module.py:235-266):
  *   tgt_rows = beta*Q(G) + (1-beta)*I,  tgt_cols = beta*Q(G^T) + (1-beta)*I  (each [B,B],
  *   tgt_cols indexed in the transposed frame).  workspace: nr_sinkhorn_workspace_bytes(B).    */
@@ -173,6 +193,12 @@ int nr_centrality_weights_bwd(const float* g, const float* gnorm, const float* m
  * becomes the first `capacity` rows of the batch.  scratch: capacity*row_bytes bytes.          */
 int nr_bank_push(void* bank, const void* batch, int capacity, int n_new, size_t row_bytes, void* scratch,
                  void* stream);
+
+/* The same FIFO kept as a ring (logical order L[i] = S[(head+i) mod capacity]): writes the n_new batch
+ * rows of up to 8 tensors at rows [head_new, head_new+n_new) mod capacity in one launch.
+ * banks / batches / row_bytes are HOST arrays of n_tensors device pointers / row sizes.          */
+int nr_bank_ring_push(int n_tensors, void* const* banks, const void* const* batches, const size_t* row_bytes,
+                      int capacity, int head_new, int n_new, void* stream);
 
 /* Rank of the diagonal in every row under the reference's tie rule (metrics.py:58-66):
  *   greater[i] = #{j : S[i,j] > S[i,i]},  equal[i] = #{j : S[i,j] == S[i,i]} (includes j=i). */

@@ -1,0 +1,83 @@
+"""No-grad forward of the token-clustering stage on fused HIP kernels + library GEMMs.
+
+Same arithmetic as neighborretr_amd/cluster.py (and the reference's cluster.py:670-965); used when no
+gradient is required (loss-only forward, evaluation), where the ~45 ATen launches of one
+CTM + TCBlock stage collapse to 11:
+    nr_shift_concat -> GEMM(+residual) -> nr_ctm_norm_score -> rand -> nr_dpc (2) -> nr_merge_ln
+    -> GEMM q, GEMM kv -> nr_tc_attention -> GEMM proj (+residual+bias)
+The training path keeps the autograd-traced torch ops of cluster.py.
+"""
+import math
+
+import torch
+
+from . import hip
+
+
+def _p(t, dtype=torch.float32):
+    return hip.ptr(t, dtype)
+
+
+class _StageWeights:
+    """Per-stage derived weights (conv kernel as a [3C,C] matrix, transposed linears), rebuilt when
+    any parameter of the stage changed."""
+
+    def __init__(self, ctm, blk):
+        w = ctm.conv.conv.weight.detach()
+        self.wcat = w.permute(2, 1, 0).reshape(3 * w.shape[1], w.shape[0]).contiguous()
+        self.wq_t = blk.attn.q.weight.detach().t().contiguous()
+        self.wkv_t = blk.attn.kv.weight.detach().t().contiguous()
+        self.wp_t = blk.attn.proj.weight.detach().t().contiguous()
+
+
+def _stage_weights(cache, key, ctm, blk):
+    params = list(ctm.parameters()) + list(blk.parameters())
+    ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+    hit = cache.get(key)
+    if hit is None or hit[0] != ver:
+        cache[key] = (ver, _StageWeights(ctm, blk))
+    return cache[key][1]
+
+
+def ctm_stage_fused(x, mask, ctm, blk, noise, cache, key):
+    """One CTM + TCBlock stage, forward only.  x [B,N,C] f32, mask [B,N] fp32 or None -> [B,cnum,C]."""
+    x = x.detach().float().contiguous()
+    B, N, C = x.shape
+    dev = x.device
+    sw = _stage_weights(cache, key, ctm, blk)
+    st = hip.stream_ptr()
+    f32 = dict(dtype=torch.float32, device=dev)
+    # token convolution k=3 as one GEMM with the residual folded in: y = x + cat @ Wcat
+    cat = torch.empty((B * N, 3 * C), **f32)
+    hip.call("nr_shift_concat", _p(x), B, N, C, _p(cat), st)
+    y = torch.addmm(x.view(B * N, C), cat, sw.wcat)
+    # LayerNorm, score, exp, norm1
+    xn = torch.empty((B, N, C), **f32)
+    kvn = torch.empty((B * N, C), **f32)
+    score = torch.empty((B, N), **f32)
+    tokw = torch.empty((B, N), **f32)
+    m = None
+    if mask is not None:
+        m = mask if mask.dtype == torch.float32 else mask.float()
+        m = m.contiguous()
+    attn = blk.attn
+    hip.call("nr_ctm_norm_score", _p(y), hip.ptr(m, allow_none=True), B * N, C, _p(ctm.norm.weight), _p(ctm.norm.bias),
+             _p(ctm.score.weight), _p(ctm.score.bias), _p(blk.norm1.weight), _p(blk.norm1.bias), float(ctm.norm.eps),
+             _p(xn), _p(kvn), _p(score), _p(tokw), st)
+    # DPC-KNN assignment (2 launches)
+    from . import ops
+    cnum = max(math.ceil(N * ctm.sample_ratio), 1)
+    assign = ops.dpc_knn_assign(xn, cnum, ctm.k, m, noise)
+    # weighted cluster means + norm1
+    merged = torch.empty((B * cnum, C), **f32)
+    merged_pb = torch.empty((B * cnum, C), **f32)
+    qn = torch.empty((B * cnum, C), **f32)
+    hip.call("nr_merge_ln", _p(xn), hip.ptr(assign, torch.int64), _p(tokw), B, N, C, cnum, _p(blk.norm1.weight),
+             _p(blk.norm1.bias), _p(attn.proj.bias), float(blk.norm1.eps), _p(merged), _p(merged_pb), _p(qn), st)
+    # projections (library GEMMs) and the score-biased attention
+    q = torch.addmm(attn.q.bias, qn, sw.wq_t) if attn.q.bias is not None else qn @ sw.wq_t
+    kv = torch.addmm(attn.kv.bias, kvn, sw.wkv_t) if attn.kv.bias is not None else kvn @ sw.wkv_t
+    att = torch.empty((B * cnum, C), **f32)
+    hip.call("nr_tc_attention", _p(q), _p(kv), _p(score), B, N, C, cnum, attn.num_heads, _p(att), st)
+    out = torch.addmm(merged_pb, att, sw.wp_t)          # merged + proj(att) + proj.bias
+    return out.view(B, cnum, C)

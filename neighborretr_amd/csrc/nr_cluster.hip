@@ -2,7 +2,7 @@
 // NeighborRetr/models/cluster.py:453-509).  Index-only work under no_grad in the reference; here two
 // launches instead of ~25 tiny ATen kernels per call (4 calls per step):
 //   nr_dpc_dist_kernel    one workgroup per sample: tokens into LDS, all N x N Euclidean distances
-//                         (/sqrt(C)), one wave per pair, plus the sample's maximum;
+//                         (/sqrt(C)), 16 waves, one row of the upper triangle per wave, plus the sample's maximum;
 //   nr_dpc_assign_kernel  one workgroup per sample: mask columns to (GLOBAL max + 1) -- the reference's
 //                         dist_matrix.max() runs over the whole batch --, k-NN density + tie-break
 //                         noise, distance to the nearest denser token, score = dist * density, top
@@ -11,44 +11,70 @@
 #include "nr_common.h"
 #include "../../include/nr_hip.h"
 
-__global__ __launch_bounds__(256) void nr_dpc_dist_kernel(const float* __restrict__ x, int N, int C, float inv_sqrt_c,
-                                                          float* __restrict__ dist, float* __restrict__ smax) {
+#define DPC_DIST_THREADS 1024
+#define DPC_MAX_CPL 16      // C <= 1024: at most 16 channels per lane
+
+__global__ __launch_bounds__(DPC_DIST_THREADS) void nr_dpc_dist_kernel(const float* __restrict__ x, int N, int C, float inv_sqrt_c,
+                                                                       float* __restrict__ dist, float* __restrict__ smax) {
     extern __shared__ __attribute__((aligned(16))) float sx[];      // [N][C]
-    __shared__ float s_wmax[4];
+    __shared__ float s_wmax[DPC_DIST_THREADS / 64];
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = DPC_DIST_THREADS / 64;
     const float* xb = x + (size_t)b * N * C;
-    for (int i = tid * 4; i < N * C; i += 256 * 4)
+    for (int i = tid * 4; i < N * C; i += DPC_DIST_THREADS * 4)
         *reinterpret_cast<f32x4_t*>(sx + i) = *reinterpret_cast<const f32x4_t*>(xb + i);
     __syncthreads();
     float wmax = 0.f;
     float* db = dist + (size_t)b * N * N;
-    const int npair = N * (N + 1) / 2;
-    for (int p = wave; p < npair; p += 4) {
-        // unrank p -> (i <= j) over the upper triangle, row by row
-        int i = 0, rem = p;
-        while (rem >= N - i) { rem -= N - i; ++i; }
-        int j = i + rem;
-        float s = 0.f;
-        if (i != j) {
-            const float* xi = sx + i * C;
-            const float* xj = sx + j * C;
-            for (int c = lane; c < C; c += 64) {
-                float df = xi[c] - xj[c];
-                s += df * df;
-            }
-            s = nr_wave_sum(s);
+    const int cpl = (C + 63) / 64;
+    for (int i = wave; i < N; i += NW) {      // wave per row of the upper triangle
+        float xi[DPC_MAX_CPL];
+#pragma unroll
+        for (int q = 0; q < DPC_MAX_CPL; ++q) {
+            int c = q * 64 + lane;
+            xi[q] = (q < cpl && c < C) ? sx[i * C + c] : 0.f;
         }
-        float dv = sqrtf(s) * inv_sqrt_c;
-        wmax = fmaxf(wmax, dv);
-        if (lane == 0) {
-            db[i * N + j] = dv;
-            db[j * N + i] = dv;
+        if (lane == 0) db[i * N + i] = 0.f;
+        for (int j = i + 1; j < N; j += 2) {
+            const bool two = j + 1 < N;
+            const float* xj0 = sx + j * C;
+            const float* xj1 = sx + (two ? j + 1 : j) * C;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < DPC_MAX_CPL; ++q) {
+                int c = q * 64 + lane;
+                if (q < cpl && c < C) {
+                    float d0 = xi[q] - xj0[c], d1 = xi[q] - xj1[c];
+                    s0 += d0 * d0;
+                    s1 += d1 * d1;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                s0 += __shfl_xor(s0, o);
+                s1 += __shfl_xor(s1, o);
+            }
+            float dv0 = sqrtf(s0) * inv_sqrt_c, dv1 = sqrtf(s1) * inv_sqrt_c;
+            wmax = fmaxf(wmax, dv0);
+            if (two) wmax = fmaxf(wmax, dv1);
+            if (lane == 0) {
+                db[i * N + j] = dv0;
+                db[j * N + i] = dv0;
+                if (two) {
+                    db[i * N + j + 1] = dv1;
+                    db[(j + 1) * N + i] = dv1;
+                }
+            }
         }
     }
     if (lane == 0) s_wmax[wave] = wmax;
     __syncthreads();
-    if (tid == 0) smax[b] = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]));
+    if (tid == 0) {
+        float m = 0.f;
+        for (int w = 0; w < NW; ++w) m = fmaxf(m, s_wmax[w]);
+        smax[b] = m;
+    }
 }
 
 __global__ __launch_bounds__(256) void nr_dpc_assign_kernel(const float* __restrict__ dist, const float* __restrict__ smax,
@@ -154,7 +180,7 @@ extern "C" int nr_dpc_knn_assign(const float* x, const float* mask, const float*
                                  int cluster_num, int64_t* assign, void* workspace, void* stream) {
     if (!x || !noise || !assign || !workspace || n_samples <= 0 || N <= 0 || C <= 0) return NR_EINVAL;
     if (k <= 0 || k > N || cluster_num <= 0 || cluster_num > N) return NR_EINVAL;   // torch.topk raises the same
-    if (N > 64 || (C % 4) != 0) return NR_EUNSUPPORTED;
+    if (N > 64 || (C % 4) != 0 || C > 64 * DPC_MAX_CPL) return NR_EUNSUPPORTED;
     size_t lds = (size_t)N * C * sizeof(float);
     if (lds > 150 * 1024) return NR_EUNSUPPORTED;
     float* dist = reinterpret_cast<float*>(workspace);
@@ -164,7 +190,7 @@ extern "C" int nr_dpc_knn_assign(const float* x, const float* mask, const float*
         hipError_t e = hipFuncSetAttribute((const void*)nr_dpc_dist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(nr_dpc_dist_kernel, dim3(n_samples), dim3(256), lds, st, x, N, C, 1.0f / sqrtf((float)C), dist, smax);
+    hipLaunchKernelGGL(nr_dpc_dist_kernel, dim3(n_samples), dim3(DPC_DIST_THREADS), lds, st, x, N, C, 1.0f / sqrtf((float)C), dist, smax);
     hipLaunchKernelGGL(nr_dpc_assign_kernel, dim3(n_samples), dim3(256), 0, st, dist, smax, n_samples, mask, noise, N, k,
                        cluster_num, assign);
     NR_LAUNCH_CHECK();

@@ -75,31 +75,50 @@ extern "C" int nr_gemm_nt_f32(const float* a, const float* b, int M, int N, int 
 
 // ---- centrality weights (modeling.py:403-430) ---------------------------------------------------
 // mean over ALL tokens of g_hat . x_hat  ==  g_hat . (mean of x_hat): a mat-vec instead of the
-// reference's [B,d] x [d,B*N] GEMM.  32 samples per workgroup; every workgroup rebuilds the mean
-// vector from the per-workgroup column sums written by nr_prepare_tokens (L2-resident).
+// reference's [B,d] x [d,B*N] GEMM.  8 samples per workgroup; every workgroup rebuilds the mean
+// vector from the <=64 per-workgroup column sums written by nr_prepare_tokens (L2-resident) with
+// 32 independent loads in flight per thread -- the kernel is latency-bound, not bandwidth-bound.
+#define NR_CW_SAMPLES 8
 __global__ __launch_bounds__(256) void nr_centrality_kernel(const float* __restrict__ g, int B, int d,
                                                             const float* __restrict__ colsum_part, int n_parts,
                                                             float inv_tok, float scale, float* __restrict__ w,
                                                             float* __restrict__ gnorm, float* __restrict__ mean_out) {
+    __shared__ float s_part[4][1024];
     __shared__ float s_mean[1024];
-    for (int k = threadIdx.x; k < d; k += 256) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int p = 0;
-        for (; p + 3 < n_parts; p += 4) {          // four independent loads in flight per column
-            s0 += colsum_part[(size_t)p * d + k];
-            s1 += colsum_part[(size_t)(p + 1) * d + k];
-            s2 += colsum_part[(size_t)(p + 2) * d + k];
-            s3 += colsum_part[(size_t)(p + 3) * d + k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave `wave` sums the parts p = wave, wave+4, ... for all columns (8 columns x 4 parts in flight)
+    for (int c0 = 0; c0 < d; c0 += 512) {
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        for (int p = wave; p < n_parts; p += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int pp = p + 4 * u;
+                if (pp < n_parts) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        int c = c0 + q * 64 + lane;
+                        if (c < d) acc[q] += colsum_part[(size_t)pp * d + c];
+                    }
+                }
+            }
         }
-        for (; p < n_parts; ++p) s0 += colsum_part[(size_t)p * d + k];
-        float s = ((s0 + s1) + (s2 + s3)) * inv_tok;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int c = c0 + q * 64 + lane;
+            if (c < d) s_part[wave][c] = acc[q];
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < d; k += 256) {
+        float s = ((s_part[0][k] + s_part[1][k]) + (s_part[2][k] + s_part[3][k])) * inv_tok;
         s_mean[k] = s;
         if (mean_out && blockIdx.x == 0) mean_out[k] = s;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int q = wave; q < 32; q += 4) {
-        int i = blockIdx.x * 32 + q;
+    for (int q = wave; q < NR_CW_SAMPLES; q += 4) {
+        int i = blockIdx.x * NR_CW_SAMPLES + q;
         if (i >= B) break;
         const float* gi = g + (size_t)i * d;
         float dot = 0.f, ss = 0.f;
@@ -121,8 +140,8 @@ __global__ __launch_bounds__(256) void nr_centrality_kernel(const float* __restr
 extern "C" int nr_centrality_weights(const float* g, int B, int d, const float* colsum_part, int n_parts, int n_tok,
                                      float scale, float* w, float* gnorm, float* mean_out, void* stream) {
     if (!g || !colsum_part || !w || B <= 0 || d <= 0 || d > 1024 || n_parts <= 0 || n_tok <= 0) return NR_EINVAL;
-    hipLaunchKernelGGL(nr_centrality_kernel, dim3((B + 31) / 32), dim3(256), 0, (hipStream_t)stream, g, B, d,
-                       colsum_part, n_parts, 1.0f / (float)n_tok, scale, w, gnorm, mean_out);
+    hipLaunchKernelGGL(nr_centrality_kernel, dim3((B + NR_CW_SAMPLES - 1) / NR_CW_SAMPLES), dim3(256), 0,
+                       (hipStream_t)stream, g, B, d, colsum_part, n_parts, 1.0f / (float)n_tok, scale, w, gnorm, mean_out);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }
@@ -145,6 +164,51 @@ extern "C" int nr_bank_push(void* bank, const void* batch, int capacity, int n_n
     if (e != hipSuccess) return (int)e;
     e = hipMemcpyAsync(bank, batch, (size_t)n_new * row_bytes, hipMemcpyDeviceToDevice, st);
     return e == hipSuccess ? NR_OK : (int)e;
+}
+
+// ---- memory bank as a ring: O(batch) bytes per push instead of O(bank) --------------------------
+// Logical FIFO order (newest first, modeling.py:237-249) is L[i] = S[(head + i) mod capacity]; a push
+// moves head back by n_new and writes the batch there.  All tensors of the bank (ids, features,
+// masks) go in ONE launch: blockIdx.y = tensor, blockIdx.x = batch row.
+#define NR_RING_MAX 8
+struct NrRingArgs {
+    void* bank[NR_RING_MAX];
+    const void* batch[NR_RING_MAX];
+    unsigned long long row_bytes[NR_RING_MAX];
+    int capacity, head_new, n_new;
+};
+
+__global__ __launch_bounds__(256) void nr_bank_ring_kernel(NrRingArgs a) {
+    const int t = blockIdx.y, r = blockIdx.x;
+    const size_t rb = a.row_bytes[t];
+    int dr = a.head_new + r;
+    if (dr >= a.capacity) dr -= a.capacity;
+    const char* src = (const char*)a.batch[t] + (size_t)r * rb;
+    char* dst = (char*)a.bank[t] + (size_t)dr * rb;
+    if ((rb & 15) == 0 && (((size_t)src | (size_t)dst) & 15) == 0) {
+        const u32x4_t* s4 = reinterpret_cast<const u32x4_t*>(src);
+        u32x4_t* d4 = reinterpret_cast<u32x4_t*>(dst);
+        for (size_t i = threadIdx.x; i < rb / 16; i += 256) d4[i] = s4[i];
+    } else {
+        for (size_t i = threadIdx.x; i < rb; i += 256) dst[i] = src[i];
+    }
+}
+
+extern "C" int nr_bank_ring_push(int n_tensors, void* const* banks, const void* const* batches, const size_t* row_bytes,
+                                 int capacity, int head_new, int n_new, void* stream) {
+    if (n_tensors <= 0 || n_tensors > NR_RING_MAX || !banks || !batches || !row_bytes) return NR_EINVAL;
+    if (capacity <= 0 || n_new <= 0 || n_new > capacity || head_new < 0 || head_new >= capacity) return NR_EINVAL;
+    NrRingArgs a;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!banks[i] || !batches[i] || row_bytes[i] == 0) return NR_EINVAL;
+        a.bank[i] = banks[i];
+        a.batch[i] = batches[i];
+        a.row_bytes[i] = row_bytes[i];
+    }
+    a.capacity = capacity; a.head_new = head_new; a.n_new = n_new;
+    hipLaunchKernelGGL(nr_bank_ring_kernel, dim3(n_new, n_tensors), dim3(256), 0, (hipStream_t)stream, a);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
 }
 
 // ---- diagonal ranks (metrics.py:58-66) ----------------------------------------------------------

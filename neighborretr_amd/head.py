@@ -105,6 +105,9 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         raise RuntimeError("more than one global token per sample: the reference's centrality term "
                            "fails to broadcast at this shape (until_module.py:321); parity unpinned")
     p_bb, p_mlp, p_bank = precision_plan(prec)
+    # masks as fp32 once (the loaders hand over int64); the kernels read them as multipliers
+    text_mask, video_mask, mb_mask_t, mb_mask_v = (m if m.dtype == torch.float32 else m.float()
+                                                   for m in (text_mask, video_mask, mb_mask_t, mb_mask_v))
     lo_b = keep or hip.PREC_BF16X3 in (p_bb, p_mlp, p_bank)
     lo_k = keep or p_bank == hip.PREC_BF16X3
     pt = ops.prepare_tokens(text_feat, text_mask, want_lo=lo_b, want_colsum=True)

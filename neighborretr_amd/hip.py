@@ -37,6 +37,10 @@ _SIGNATURES = {
     "nr_centrality_weights": ([_P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P], _I),
     "nr_dpc_workspace_bytes": ([_I, _I], _Z),
     "nr_dpc_knn_assign": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], _I),
+    "nr_shift_concat": ([_P, _I, _I, _I, _P, _P], _I),
+    "nr_ctm_norm_score": ([_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
+    "nr_merge_ln": ([_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P], _I),
+    "nr_tc_attention": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P], _I),
     "nr_sinkhorn_workspace_bytes": ([_I], _Z),
     "nr_sinkhorn_targets": ([_P, _I, _F, _I, _P, _P, _P, _P], _I),
     "nr_row_losses_fwd": ([_P] * 9 + [_I, _I, _F, _P, _P], _I),
@@ -49,6 +53,7 @@ _SIGNATURES = {
     "nr_token_softmax_bwd": ([_P, _P, _I, _I, _P, _P], _I),
     "nr_centrality_weights_bwd": ([_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P], _I),
     "nr_bank_push": ([_P, _P, _I, _I, _Z, _P, _P], _I),
+    "nr_bank_ring_push": ([_I, _P, _P, _P, _I, _I, _I, _P], _I),
     "nr_diag_ranks": ([_P, _I, _P, _P, _P], _I),
 }
 

@@ -74,6 +74,8 @@ class NeighborRetr(nn.Module):
         self._streams = None
         self._join_global = None
         self.use_side_streams = True
+        self.fuse_clustering = True
+        self._ctm_cache = {}
 
     # ------------------------------------------------------------------ construction helpers
     @staticmethod
@@ -89,12 +91,42 @@ class NeighborRetr(nn.Module):
 
     def _init_memory_bank(self):
         cpu = torch.device("cpu")
-        self.mb_ind = torch.tensor([], dtype=torch.long, device=cpu)
-        self.mb_feat_t = torch.empty((0, 0, 0), dtype=torch.float, device=cpu)
-        self.mb_feat_v = torch.empty((0, 0, 0), dtype=torch.float, device=cpu)
-        self.mb_mask_t = torch.empty((0, 0), dtype=torch.float, device=cpu)
-        self.mb_mask_v = torch.empty((0, 0), dtype=torch.float, device=cpu)
+        self._mb = {
+            "mb_ind": torch.tensor([], dtype=torch.long, device=cpu),
+            "mb_feat_t": torch.empty((0, 0, 0), dtype=torch.float, device=cpu),
+            "mb_feat_v": torch.empty((0, 0, 0), dtype=torch.float, device=cpu),
+            "mb_mask_t": torch.empty((0, 0), dtype=torch.float, device=cpu),
+            "mb_mask_v": torch.empty((0, 0), dtype=torch.float, device=cpu),
+        }
+        self._mb_head = 0
         self.mb_batch = 0
+
+    # The bank attributes keep the reference's names and FIFO meaning (newest sample first; written
+    # wholesale by MemoryBankManager, memory_bank.py:206-211).  Internally the bank is a RING: a push
+    # rewrites only the batch rows (nr_bank_ring_push) instead of shifting the whole bank.  Reading an
+    # attribute from outside materialises the FIFO order first; the forward pass reads the raw ring,
+    # whose order is irrelevant (the bank is only consumed through means over its samples).
+    def _bank_fifo(self):
+        if self._mb_head:
+            h = self._mb_head
+            self._mb = {k: torch.roll(v, shifts=-h, dims=0) for k, v in self._mb.items()}
+            self._mb_head = 0
+
+    def _bank_get(self, name):
+        self._bank_fifo()
+        return self._mb[name]
+
+    def _bank_set(self, name, value):
+        self._bank_fifo()
+        if name.startswith("mb_mask") and torch.is_tensor(value) and value.dtype != torch.float32:
+            value = value.float()        # masks live as fp32 (the reference's own initial dtype, :182-183)
+        self._mb[name] = value
+
+    mb_ind = property(lambda self: self._bank_get("mb_ind"), lambda self, v: self._bank_set("mb_ind", v))
+    mb_feat_t = property(lambda self: self._bank_get("mb_feat_t"), lambda self, v: self._bank_set("mb_feat_t", v))
+    mb_feat_v = property(lambda self: self._bank_get("mb_feat_v"), lambda self, v: self._bank_set("mb_feat_v", v))
+    mb_mask_t = property(lambda self: self._bank_get("mb_mask_t"), lambda self, v: self._bank_set("mb_mask_t", v))
+    mb_mask_v = property(lambda self: self._bank_get("mb_mask_v"), lambda self, v: self._bank_set("mb_mask_v", v))
 
     # ------------------------------------------------------------------ scorer weights (bf16 split)
     def _prec(self, for_head=True):
@@ -117,22 +149,25 @@ class NeighborRetr(nn.Module):
 
     # ------------------------------------------------------------------ memory bank (modeling.py:222-249)
     def update_memory_bank(self, idx, text_feat, video_feat, text_mask, video_mask):
-        if self.mb_feat_v.size(0) == 0:
-            self.mb_ind = idx.clone()
-            self.mb_feat_v = video_feat.detach().clone()
-            self.mb_feat_t = text_feat.detach().clone()
-            self.mb_mask_t = text_mask.clone()
-            self.mb_mask_v = video_mask.clone()
+        new = {"mb_ind": idx, "mb_feat_v": video_feat.detach(), "mb_feat_t": text_feat.detach(),
+               "mb_mask_t": text_mask, "mb_mask_v": video_mask}
+        mb = self._mb
+        if mb["mb_feat_v"].size(0) == 0:                       # empty bank adopts the batch (:224-231)
+            self._mb = {k: (v.float() if k.startswith("mb_mask") else v.clone()) for k, v in new.items()}
+            self._mb_head = 0
             self.mb_batch = idx.size(0)
             return
-        new = (idx, video_feat.detach(), text_feat.detach(), text_mask, video_mask)
-        names = ("mb_ind", "mb_feat_v", "mb_feat_t", "mb_mask_t", "mb_mask_v")
-        for name, batch in zip(names, new):
-            bank = getattr(self, name)
-            if bank.is_cuda and bank.is_contiguous() and batch.dtype == bank.dtype:
-                ops.bank_push(bank, batch.contiguous())       # in place: no per-step reallocation
-            else:
-                setattr(self, name, torch.cat((batch.to(bank.dtype), bank), 0)[:bank.size(0)])
+        cap, b = mb["mb_feat_v"].size(0), idx.size(0)
+        on_gpu = all(t.is_cuda and t.is_contiguous() for t in mb.values())
+        if b >= cap or not on_gpu:
+            # B >= capacity: the bank becomes the first rows of the batch (:244-249); CPU banks: plain cat
+            self._bank_fifo()
+            self._mb = {k: torch.cat((new[k].to(v.dtype), v), 0)[:cap].contiguous() for k, v in self._mb.items()}
+            return
+        head = (self._mb_head - b) % cap
+        names = list(mb)
+        ops.bank_ring_push([mb[k] for k in names], [new[k].to(mb[k].dtype) for k in names], head)
+        self._mb_head = head
 
     # ------------------------------------------------------------------ forward (modeling.py:251-312)
     def forward(self, text_ids, text_mask, video, video_mask=None, idx=None, global_step=0, logger=None):
@@ -149,7 +184,7 @@ class NeighborRetr(nn.Module):
         logit_scale = self.clip.logit_scale.exp()
         cfg = self.config
         losses = self._compute_losses(text_feat, video_feat, text_mask, video_mask,
-                                      self.mb_feat_t, self.mb_feat_v, self.mb_mask_t, self.mb_mask_v,
+                                      self._mb["mb_feat_t"], self._mb["mb_feat_v"], self._mb["mb_mask_t"], self._mb["mb_mask_v"],
                                       cfg.centrality_scale, cfg.beta, cfg.num_neighbors, cfg.temperature,
                                       logit_scale)
         with torch.no_grad():
@@ -205,8 +240,20 @@ class NeighborRetr(nn.Module):
         """Two CTM + TCBlock stages of one modality: [B,N,d] -> [B,1,d] at the MSR-VTT token counts."""
         ctm0, blk0 = getattr(self, which + "_ctm0"), getattr(self, which + "_block0")
         ctm1, blk1 = getattr(self, which + "_ctm1"), getattr(self, which + "_block1")
+        if self._can_fuse_clustering(feat, (ctm0, blk0, ctm1, blk1)):
+            from .cluster_fused import ctm_stage_fused
+            t = ctm_stage_fused(feat, mask, ctm0, blk0, noise0, self._ctm_cache, which + "0")
+            return ctm_stage_fused(t, None, ctm1, blk1, noise1, self._ctm_cache, which + "1")
         t = blk0(ctm0({"x": feat, "mask": mask.detach()}, noise0))
         return blk1(ctm1(t, noise1))["x"]
+
+    def _can_fuse_clustering(self, feat, mods):
+        """Fused forward kernels when no gradient is wanted; autograd-traced torch ops otherwise."""
+        if not (feat.is_cuda and self.fuse_clustering and feat.shape[1] <= 64 and feat.shape[2] % 64 == 0):
+            return False
+        if not torch.is_grad_enabled():
+            return True
+        return not (feat.requires_grad or any(p.requires_grad for m in mods for p in m.parameters()))
 
     def _side_streams(self, device):
         if self._streams is None or self._streams[0].device != device:

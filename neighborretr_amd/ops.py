@@ -257,6 +257,24 @@ def bank_push(bank, batch, scratch=None):
     return bank
 
 
+def bank_ring_push(banks, batches, head_new):
+    """Ring-buffer push of several bank tensors in one launch (nr_bank_ring_push)."""
+    import ctypes
+    n = len(banks)
+    cap, n_new = banks[0].shape[0], batches[0].shape[0]
+    bs = [b.contiguous() for b in batches]
+    for bank, batch in zip(banks, bs):
+        if bank.dtype != batch.dtype or bank[0].numel() != batch[0].numel() or bank.shape[0] != cap:
+            raise ValueError("bank / batch layout mismatch")
+    PA = ctypes.c_void_p * n
+    pb = PA(*[b.data_ptr() for b in banks])
+    pn = PA(*[b.data_ptr() for b in bs])
+    rb = (ctypes.c_size_t * n)(*[b[0].numel() * b.element_size() for b in banks])
+    for b in list(banks) + bs:
+        hip.ptr(b)                      # device / contiguity check
+    hip.call("nr_bank_ring_push", n, pb, pn, rb, cap, int(head_new), n_new, hip.stream_ptr())
+
+
 def diag_ranks(S):
     S = _f32(S).contiguous()
     N = S.shape[0]
