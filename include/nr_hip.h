@@ -93,6 +93,12 @@ int nr_gemm_nt_f32(const float* a, const float* b, int M, int N, int K, float* c
 int nr_centrality_weights(const float* g, int B, int d, const float* colsum_part, int n_parts, int n_tok,
                           float scale, float* w, float* gnorm, float* mean_out, void* stream);
 
+/* Same weights for both modalities in one launch, from the finished token means
+ * (mean = nr_reduce_parts(colsum_part, 1/n_tok)): w = exp(scale * <g/||g||, mean>).            */
+int nr_centrality_weights_pair(const float* g_text, const float* g_video, int B, int d, const float* mean_text,
+                               const float* mean_video, float scale, float* w_text, float* w_video,
+                               float* gnorm_text, float* gnorm_video, void* stream);
+
 /* DPC-KNN cluster assignment of every token (cluster.py:453-509; index-only, no gradient):
  *   x [n_samples,N,C] f32 tokens; mask [n_samples,N] f32 (>0 = valid) or NULL; noise [n_samples,N]
  *   f32 in [0,1) (the reference's torch.rand tie-break draw, cluster.py:483); k nearest neighbours for

@@ -50,11 +50,8 @@ __global__ __launch_bounds__(DPC_DIST_THREADS) void nr_dpc_dist_kernel(const flo
                     s1 += d1 * d1;
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                s0 += __shfl_xor(s0, o);
-                s1 += __shfl_xor(s1, o);
-            }
+            s0 = nr_wave_sum(s0);
+            s1 = nr_wave_sum(s1);
             float dv0 = sqrtf(s0) * inv_sqrt_c, dv1 = sqrtf(s1) * inv_sqrt_c;
             wmax = fmaxf(wmax, dv0);
             if (two) wmax = fmaxf(wmax, dv1);
@@ -117,12 +114,7 @@ __global__ __launch_bounds__(256) void nr_dpc_assign_kernel(const float* __restr
         for (int r = 0; r < k; ++r) {
             float m = v;
             int idx = lane;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                float om = __shfl_xor(m, o);
-                int oi = __shfl_xor(idx, o);
-                if (om < m || (om == m && oi < idx)) { m = om; idx = oi; }
-            }
+            nr_wave_argmin(m, idx);
             acc += m * m;
             if (lane == idx) v = INFINITY;
         }
@@ -147,12 +139,7 @@ __global__ __launch_bounds__(256) void nr_dpc_assign_kernel(const float* __restr
         for (int c = 0; c < cnum; ++c) {
             float m = v;
             int idx = lane;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                float om = __shfl_xor(m, o);
-                int oi = __shfl_xor(idx, o);
-                if (om > m || (om == m && oi < idx)) { m = om; idx = oi; }
-            }
+            nr_wave_argmax(m, idx);
             if (lane == 0) s_centre[c] = idx;
             if (lane == idx) v = -INFINITY;
         }

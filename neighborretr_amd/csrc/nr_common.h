@@ -45,18 +45,87 @@ __device__ __forceinline__ float nr_bf2f(uint16_t h) {
     return __builtin_bit_cast(float, ((uint32_t)h) << 16);
 }
 
-__device__ __forceinline__ float nr_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// ---- cross-lane reductions on DPP (data-parallel primitives): VALU-latency steps instead of the
+// LDS-crossbar round trip of ds_bpermute that __shfl_xor compiles to.  Steps: quad_perm xor-1, xor-2,
+// row_half_mirror (8 lanes), row_mirror (16 lanes), row_bcast15 / row_bcast31 (across the four rows);
+// the wave-wide result lands in lane 63 and is broadcast with v_readlane.
+#define NR_DPP_XOR1 0xB1
+#define NR_DPP_XOR2 0x4E
+#define NR_DPP_HALF_MIRROR 0x141
+#define NR_DPP_MIRROR 0x140
+#define NR_DPP_BCAST15 0x142
+#define NR_DPP_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float nr_dpp(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                  CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int nr_dpp(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ float nr_lane63(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// reductions over aligned groups of 8 lanes (result in all 8 lanes)
+__device__ __forceinline__ float nr_group8_sum(float v) {
+    v += nr_dpp<NR_DPP_XOR1>(v, v);
+    v += nr_dpp<NR_DPP_XOR2>(v, v);
+    v += nr_dpp<NR_DPP_HALF_MIRROR>(v, v);
     return v;
+}
+__device__ __forceinline__ float nr_group8_max(float v) {
+    v = fmaxf(v, nr_dpp<NR_DPP_XOR1>(v, v));
+    v = fmaxf(v, nr_dpp<NR_DPP_XOR2>(v, v));
+    v = fmaxf(v, nr_dpp<NR_DPP_HALF_MIRROR>(v, v));
+    return v;
+}
+
+__device__ __forceinline__ float nr_wave_sum(float v) {
+    v = nr_group8_sum(v);
+    v += nr_dpp<NR_DPP_MIRROR>(v, v);
+    v += nr_dpp<NR_DPP_BCAST15, 0xA>(0.f, v);
+    v += nr_dpp<NR_DPP_BCAST31, 0xC>(0.f, v);
+    return nr_lane63(v);
 }
 __device__ __forceinline__ float nr_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = nr_group8_max(v);
+    v = fmaxf(v, nr_dpp<NR_DPP_MIRROR>(v, v));
+    v = fmaxf(v, nr_dpp<NR_DPP_BCAST15, 0xA>(v, v));
+    v = fmaxf(v, nr_dpp<NR_DPP_BCAST31, 0xC>(v, v));
+    return nr_lane63(v);
 }
 __device__ __forceinline__ float nr_wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
+    v = fminf(v, nr_dpp<NR_DPP_XOR1>(v, v));
+    v = fminf(v, nr_dpp<NR_DPP_XOR2>(v, v));
+    v = fminf(v, nr_dpp<NR_DPP_HALF_MIRROR>(v, v));
+    v = fminf(v, nr_dpp<NR_DPP_MIRROR>(v, v));
+    v = fminf(v, nr_dpp<NR_DPP_BCAST15, 0xA>(v, v));
+    v = fminf(v, nr_dpp<NR_DPP_BCAST31, 0xC>(v, v));
+    return nr_lane63(v);
 }
+
+// wave arg-max / arg-min of (value, index) pairs; ties go to the LOWER index.  Result in all lanes.
+template <bool MAX, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void nr_arg_step(float& v, int& idx) {
+    float ov = nr_dpp<CTRL, ROW_MASK>(v, v);
+    int oi = nr_dpp<CTRL, ROW_MASK>(idx, idx);
+    bool take = MAX ? (ov > v || (ov == v && oi < idx)) : (ov < v || (ov == v && oi < idx));
+    v = take ? ov : v;
+    idx = take ? oi : idx;
+}
+template <bool MAX>
+__device__ __forceinline__ void nr_wave_arg(float& v, int& idx) {
+    nr_arg_step<MAX, NR_DPP_XOR1, 0xF>(v, idx);
+    nr_arg_step<MAX, NR_DPP_XOR2, 0xF>(v, idx);
+    nr_arg_step<MAX, NR_DPP_HALF_MIRROR, 0xF>(v, idx);
+    nr_arg_step<MAX, NR_DPP_MIRROR, 0xF>(v, idx);
+    nr_arg_step<MAX, NR_DPP_BCAST15, 0xA>(v, idx);
+    nr_arg_step<MAX, NR_DPP_BCAST31, 0xC>(v, idx);
+    v = nr_lane63(v);
+    idx = __builtin_amdgcn_readlane(idx, 63);
+}
+__device__ __forceinline__ void nr_wave_argmax(float& v, int& idx) { nr_wave_arg<true>(v, idx); }
+__device__ __forceinline__ void nr_wave_argmin(float& v, int& idx) { nr_wave_arg<false>(v, idx); }

@@ -180,14 +180,14 @@ extern "C" int nr_merge_ln(const float* xn, const int64_t* assign, const float* 
 }
 
 // ---- score-biased multi-head attention: merged tokens (queries) over un-merged tokens ---------------------
-// one wave per (head, query); lane = key for the logits / softmax, lane = channel for the value sum.
+// 16 waves, one per (head, query); lane = key for the logits / softmax, lane = channel for the value sum.
 // head_dim = 64, N <= 64.
-__global__ __launch_bounds__(256) void nr_tc_attention_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+__global__ __launch_bounds__(1024) void nr_tc_attention_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                               const float* __restrict__ score, int N, int C, int cnum, int H,
                                                               float scale, float* __restrict__ out) {
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* kvb = kv + (size_t)b * N * 2 * C;
-    for (int job = wave; job < H * cnum; job += 4) {
+    for (int job = wave; job < H * cnum; job += 16) {
         const int h = job / cnum, cl = job - h * cnum;
         const float* qr = q + ((size_t)b * cnum + cl) * C + h * 64;
         float logit = -INFINITY;
@@ -219,7 +219,7 @@ extern "C" int nr_tc_attention(const float* q, const float* kv, const float* sco
                                int H, float* out, void* stream) {
     if (!q || !kv || !score || !out || n_samples <= 0 || N <= 0 || cnum <= 0 || H <= 0) return NR_EINVAL;
     if (N > 64 || C != H * 64) return NR_EUNSUPPORTED;
-    hipLaunchKernelGGL(nr_tc_attention_kernel, dim3(n_samples), dim3(256), 0, (hipStream_t)stream, q, kv, score, N, C, cnum, H,
+    hipLaunchKernelGGL(nr_tc_attention_kernel, dim3(n_samples), dim3(1024), 0, (hipStream_t)stream, q, kv, score, N, C, cnum, H,
                        1.0f / sqrtf(64.0f), out);
     NR_LAUNCH_CHECK();
     return NR_OK;

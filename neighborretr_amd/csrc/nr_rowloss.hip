@@ -20,16 +20,6 @@ struct NrRowArgs {
     float T;
 };
 
-// wave arg-max with ties broken towards the lower index
-__device__ __forceinline__ void nr_wave_argmax(float& v, int& idx) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_xor(v, o);
-        int oi = __shfl_xor(idx, o);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
-}
-
 // Everything the forward and the backward need about one row, recomputed identically in both.
 template <int NE>
 struct NrRowState {
@@ -257,16 +247,6 @@ extern "C" int nr_loss_finalize(const float* rowloss, int B, float uniform_weigh
 }
 
 // ================================= backward ======================================================
-// wave arg-min / arg-max over a predicate, ties towards the lower index
-__device__ __forceinline__ void nr_wave_argmin(float& v, int& idx) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_xor(v, o);
-        int oi = __shfl_xor(idx, o);
-        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
-}
-
 template <int NE>
 __global__ __launch_bounds__(256) void nr_row_losses_bwd_kernel(NrRowArgs a, const float* __restrict__ g_rowloss,
                                                                 float* __restrict__ dS_dir, float* __restrict__ dG_dir,

@@ -54,11 +54,11 @@ __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __
             float m = -INFINITY;
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) m = fmaxf(m, pr[k]);                 // v = 0
-            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+            m = nr_group8_max(m);
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) s += __expf(pr[k] - m);
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            s = nr_group8_sum(s);
             if (live && sub == 0) s_a[line] = norm - (m + __logf(s));
         }
         __syncthreads();
@@ -69,11 +69,11 @@ __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __
                 x[k] = pc[k] + s_a[sub * SK_EPT + k];
                 m = fmaxf(m, x[k]);
             }
-            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+            m = nr_group8_max(m);
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) s += __expf(x[k] - m);
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            s = nr_group8_sum(s);
             if (live && sub == 0) s_b[line] = norm - (m + __logf(s));
         }
         __syncthreads();
@@ -92,26 +92,25 @@ __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __
     // ---- iterations 2..iters: multiplicative updates ---------------------------------------------------
     for (int it = 1; it < iters; ++it) {
         {   // rows sum to e^mu
-            float r = 0.f;
-#pragma unroll
-            for (int k = 0; k < SK_EPT; ++k) r += pr[k];
-            r += __shfl_xor(r, 1); r += __shfl_xor(r, 2); r += __shfl_xor(r, 4);
-            float al = live ? mass / r : 0.f;
+            float r = (((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]))) +
+                      (((pr[8] + pr[9]) + (pr[10] + pr[11])) + ((pr[12] + pr[13]) + (pr[14] + pr[15])));
+            r = nr_group8_sum(r);
+            float al = live ? mass * __builtin_amdgcn_rcpf(r) : 0.f;
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) pr[k] *= al;
             if (sub == 0 && tid < 1024) s_a[line] = al;
         }
         __syncthreads();
         {   // the column-layout copy sees the same row factors, then columns sum to e^nu
-            float c = 0.f;
+            float c4[4];
 #pragma unroll
             for (int k = 0; k < SK_EPT; k += 4) {
                 f32x4_t f = *reinterpret_cast<const f32x4_t*>(&s_a[sub * SK_EPT + k]);
                 pc[k] *= f[0]; pc[k + 1] *= f[1]; pc[k + 2] *= f[2]; pc[k + 3] *= f[3];
-                c += (pc[k] + pc[k + 1]) + (pc[k + 2] + pc[k + 3]);
+                c4[k >> 2] = (pc[k] + pc[k + 1]) + (pc[k + 2] + pc[k + 3]);
             }
-            c += __shfl_xor(c, 1); c += __shfl_xor(c, 2); c += __shfl_xor(c, 4);
-            float be = live ? mass / c : 0.f;
+            float c = nr_group8_sum((c4[0] + c4[1]) + (c4[2] + c4[3]));
+            float be = live ? mass * __builtin_amdgcn_rcpf(c) : 0.f;
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) pc[k] *= be;
             if (sub == 0) s_b[line] = be;

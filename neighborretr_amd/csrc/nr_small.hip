@@ -146,6 +146,48 @@ extern "C" int nr_centrality_weights(const float* g, int B, int d, const float* 
     return NR_OK;
 }
 
+// Both modalities in one launch from FINISHED token means (mean = nr_reduce_parts over the prepared
+// column sums, issued on the local branch long before the global tokens exist): one wave per
+// (sample, modality), blockIdx.y = modality.
+__global__ __launch_bounds__(256) void nr_centrality_pair_kernel(const float* __restrict__ g0, const float* __restrict__ g1,
+                                                                 int B, int d, const float* __restrict__ mean0,
+                                                                 const float* __restrict__ mean1, float scale,
+                                                                 float* __restrict__ w0, float* __restrict__ w1,
+                                                                 float* __restrict__ gn0, float* __restrict__ gn1) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    const bool second = blockIdx.y == 1;
+    const float* gi = (second ? g1 : g0) + (size_t)i * d;
+    const float* mean = second ? mean1 : mean0;
+    float dot = 0.f, ss = 0.f;
+    for (int k = lane * 4; k < d; k += 256) {
+        f32x4_t x = *reinterpret_cast<const f32x4_t*>(gi + k);
+        f32x4_t m = *reinterpret_cast<const f32x4_t*>(mean + k);
+        dot += x[0] * m[0] + x[1] * m[1] + x[2] * m[2] + x[3] * m[3];
+        ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    }
+    dot = nr_wave_sum(dot);
+    ss = nr_wave_sum(ss);
+    float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    if (lane == 0) {
+        (second ? w1 : w0)[i] = expf(dot / nrm * scale);
+        float* gn = second ? gn1 : gn0;
+        if (gn) gn[i] = nrm;
+    }
+}
+
+extern "C" int nr_centrality_weights_pair(const float* g_text, const float* g_video, int B, int d, const float* mean_text,
+                                          const float* mean_video, float scale, float* w_text, float* w_video,
+                                          float* gnorm_text, float* gnorm_video, void* stream) {
+    if (!g_text || !g_video || !mean_text || !mean_video || !w_text || !w_video || B <= 0 || d <= 0 || (d % 4) != 0)
+        return NR_EINVAL;
+    hipLaunchKernelGGL(nr_centrality_pair_kernel, dim3((B + 3) / 4, 2), dim3(256), 0, (hipStream_t)stream, g_text, g_video, B,
+                       d, mean_text, mean_video, scale, w_text, w_video, gnorm_text, gnorm_video);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
 // ---- memory-bank FIFO (modeling.py:237-249) -----------------------------------------------------
 extern "C" int nr_bank_push(void* bank, const void* batch, int capacity, int n_new, size_t row_bytes, void* scratch,
                             void* stream) {

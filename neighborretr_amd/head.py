@@ -126,6 +126,9 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     p0, aux2 = ops.local_level(pbt, pv, w_bt, w_v, M, Nt, B, Nv, p_bank, hip.OUT_COLSUM, keep)
     c1 = ops.reduce_parts(p1, 1.0 / M)
     c0 = ops.reduce_parts(p0, 1.0 / M)
+    # mean of the (unmasked) normalised tokens for the centrality weights -- still on the local branch
+    mean_t = ops.reduce_parts(pt.colsum, 1.0 / pt.n_tok)
+    mean_v = ops.reduce_parts(pv.colsum, 1.0 / pv.n_tok)
 
     if join is not None:
         join()
@@ -133,8 +136,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
     gt2 = gt.reshape(B, d).float().contiguous()
     gv2 = gv.reshape(B, d).float().contiguous()
-    wc_t, gn_t, mean_t = ops.centrality_weights(gt2, pt.colsum, pt.n_tok, hp["centrality_scale"], keep)
-    wc_v, gn_v, mean_v = ops.centrality_weights(gv2, pv.colsum, pv.n_tok, hp["centrality_scale"], keep)
+    wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
     ls = logit_scale.detach().float().reshape(1).contiguous()
     rowloss = ops.row_losses(S, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"])
     losses = ops.loss_finalize(rowloss, hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])

@@ -119,6 +119,20 @@ def centrality_weights(g, colsum, n_tok, scale, want_aux=False):
     return w, gnorm, mean
 
 
+def centrality_weights_pair(gt, gv, mean_t, mean_v, scale, want_aux=False):
+    """(w_text, w_video, gnorm_text, gnorm_video) from finished token means (nr_centrality_weights_pair)."""
+    B, d = gt.shape
+    dev = gt.device
+    w_t = torch.empty((B,), dtype=torch.float32, device=dev)
+    w_v = torch.empty((B,), dtype=torch.float32, device=dev)
+    gn_t = torch.empty((B,), dtype=torch.float32, device=dev) if want_aux else None
+    gn_v = torch.empty((B,), dtype=torch.float32, device=dev) if want_aux else None
+    hip.call("nr_centrality_weights_pair", hip.ptr(gt, torch.float32), hip.ptr(gv, torch.float32), B, d,
+             hip.ptr(mean_t, torch.float32), hip.ptr(mean_v, torch.float32), float(scale), hip.ptr(w_t), hip.ptr(w_v),
+             hip.ptr(gn_t, allow_none=True), hip.ptr(gn_v, allow_none=True), hip.stream_ptr())
+    return w_t, w_v, gn_t, gn_v
+
+
 def dpc_knn_assign(x, cluster_num, k, mask=None, noise=None):
     """Cluster id [B,N] (int64) of every token by DPC-KNN (nr_dpc_knn_assign)."""
     x = _f32(x.detach()).contiguous()
