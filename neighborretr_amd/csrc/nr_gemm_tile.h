@@ -2,10 +2,14 @@
 //
 // C[BM x BN] = A[BM x K] * B[BN x K]^T with both operands row-major bf16 ("NT" product), fp32
 // accumulate on v_mfma_f32_16x16x32_bf16.  256 threads = 4 waves laid out 2 x 2; each wave owns
-// MI x NI sub-tiles of 16 x 16 (BM = 32*MI, BN = 32*NI).  K is walked in BK = 64 slices:
-// global -> registers (16-byte loads, issued one slice ahead so HBM/L2 latency hides under the
-// MFMAs of the current slice) -> LDS (XOR-swizzled 128-byte rows, conflict-free ds_read_b128)
-// -> fragments.
+// MI x NI sub-tiles of 16 x 16 (BM = 32*MI, BN = 32*NI).  K is walked in BK = 64 slices through a
+// 2-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS with no VGPR staging and
+// no ds_write pass -- the store side of the LDS, ~79 B/clk/CU, was the bottleneck of the register-
+// staged version).  One DMA instruction writes 1 KiB of LDS linearly (wave base + lane*16), i.e.
+// 8 rows x 128 B; the bank-conflict swizzle (16-B chunk ^= row&7, conflict-free ds_read_b128 of
+// the fragments) is applied on the per-lane SOURCE address, the LDS image stays linear per wave.
+// Slice kt+1 is in flight while slice kt is multiplied: counted s_waitcnt vmcnt + raw s_barrier
+// (a __syncthreads() would drain the DMA).
 //
 // X3 = split-bf16 mode: every operand is carried as hi + lo (two bf16 arrays) and the product is
 // accumulated as Ah*Bh + Ah*Bl + Al*Bh (the ~2^-18 lo*lo term is dropped), giving ~fp32-grade
@@ -13,7 +17,10 @@
 #pragma once
 #include "nr_common.h"
 
-template <int MI, int NI, bool X3>
+typedef __attribute__((address_space(3))) void* nr_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* nr_glb_ptr_t;
+
+template <int MI, int NI, bool X3, int TPS_A = 16, int TPS_B = 16>
 struct NrGemmTile {
     static constexpr int BM = 32 * MI;
     static constexpr int BN = 32 * NI;
@@ -21,8 +28,20 @@ struct NrGemmTile {
     static constexpr int A_BYTES = BM * BK * 2;
     static constexpr int B_BYTES = BN * BK * 2;
     static constexpr int STAGE_BYTES = (A_BYTES + B_BYTES) * (X3 ? 2 : 1);
+    static constexpr int RING_BYTES = 2 * STAGE_BYTES;
+    static constexpr int DMA_PER_STAGE = (MI + NI) * (X3 ? 2 : 1);   // per wave
 
     f32x4_t acc[MI][NI];
+
+    // Fragment row `f` (0..15) of sub-tile `m` of a wave strip -> row of the strip in memory order.
+    // TPS = 16: identity.  TPS = 8 / 4: the strip holds 16/TPS samples of MI*TPS tokens each and a
+    // sub-tile takes TPS consecutive tokens of every sample, so that (sample, token) splits cleanly
+    // over (lane group, register) in the accumulator layout -- see nr_sim_reg.hip.
+    template <int TPS, int XI>
+    __device__ static __forceinline__ int strip_row(int m, int f) {
+        if constexpr (TPS == 16) return m * 16 + f;
+        else return (f / TPS) * (TPS * XI) + m * TPS + (f % TPS);
+    }
 
     // byte offset of 16-byte chunk `kc` (0..7) of row `r` inside a [rows][64] bf16 LDS image
     __device__ static __forceinline__ int lds_off(int r, int kc) { return r * 128 + ((kc ^ (r & 7)) << 4); }
@@ -36,87 +55,88 @@ struct NrGemmTile {
 
     // Runs the whole K loop.  a_hi/a_lo: [a_rows, K]; rows [a_row0, a_row0+BM) are used, clamped to
     // a_rows-1 (the caller discards results of clamped rows).  Same for B.  K % 64 == 0.
+    // smem: RING_BYTES of dynamic LDS (the ONLY __shared__ object of the kernel).  On return all
+    // waves have passed the final barrier: smem may be reused.
     __device__ __forceinline__ void run(const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
                                         int a_row0, int a_rows,
                                         const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
                                         int b_row0, int b_rows, int K, char* smem) {
         const int tid = threadIdx.x;
         const int lane = tid & 63;
-        const int wave = tid >> 6;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int wr = wave >> 1, wc = wave & 1;
 
-        char* sAh = smem;
-        char* sBh = smem + A_BYTES;
-        char* sAl = smem + A_BYTES + B_BYTES;
-        char* sBl = sAl + A_BYTES;
-
-        // per-thread staging slots: chunk c = tid + i*256 -> row c>>3, k-chunk c&7
-        u32x4_t ra_h[MI], rb_h[NI], ra_l[X3 ? MI : 1], rb_l[X3 ? NI : 1];
-        const uint16_t* pa_h[MI];
-        const uint16_t* pb_h[NI];
-        const uint16_t* pa_l[X3 ? MI : 1];
-        const uint16_t* pb_l[X3 ? NI : 1];
-        int oa[MI], ob[NI];
+        // DMA piece i of an operand = LDS rows [8i, 8i+8); waves take pieces i = wave, wave+4, ...
+        // lane -> (row 8i + lane/8, LDS slot lane%8) which must receive global chunk slot ^ (row&7)
+        const char* ga_h[MI];
+        const char* gb_h[NI];
+        const char* ga_l[X3 ? MI : 1];
+        const char* gb_l[X3 ? NI : 1];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            int c = tid + i * 256, r = c >> 3, kc = c & 7;
+            int r = (wave + 4 * i) * 8 + (lane >> 3);
+            int kc = (lane & 7) ^ (r & 7);
             int gr = min(a_row0 + r, a_rows - 1);
-            pa_h[i] = a_hi + (size_t)gr * K + kc * 8;
-            if constexpr (X3) pa_l[i] = a_lo + (size_t)gr * K + kc * 8;
-            oa[i] = lds_off(r, kc);
+            ga_h[i] = reinterpret_cast<const char*>(a_hi + (size_t)gr * K + kc * 8);
+            if constexpr (X3) ga_l[i] = reinterpret_cast<const char*>(a_lo + (size_t)gr * K + kc * 8);
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            int c = tid + i * 256, r = c >> 3, kc = c & 7;
+            int r = (wave + 4 * i) * 8 + (lane >> 3);
+            int kc = (lane & 7) ^ (r & 7);
             int gr = min(b_row0 + r, b_rows - 1);
-            pb_h[i] = b_hi + (size_t)gr * K + kc * 8;
-            if constexpr (X3) pb_l[i] = b_lo + (size_t)gr * K + kc * 8;
-            ob[i] = lds_off(r, kc);
+            gb_h[i] = reinterpret_cast<const char*>(b_hi + (size_t)gr * K + kc * 8);
+            if constexpr (X3) gb_l[i] = reinterpret_cast<const char*>(b_lo + (size_t)gr * K + kc * 8);
         }
-        auto gload = [&](int k0) {
+        auto issue = [&](int kt) {
+            char* st = smem + (kt & 1) * STAGE_BYTES;
+            const int kb = kt * BK * 2;                 // byte offset along K
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                ra_h[i] = *reinterpret_cast<const u32x4_t*>(pa_h[i] + k0);
-                if constexpr (X3) ra_l[i] = *reinterpret_cast<const u32x4_t*>(pa_l[i] + k0);
+                char* dst = st + (wave + 4 * i) * 1024;
+                __builtin_amdgcn_global_load_lds((nr_glb_ptr_t)(ga_h[i] + kb), (nr_lds_ptr_t)dst, 16, 0, 0);
+                if constexpr (X3)
+                    __builtin_amdgcn_global_load_lds((nr_glb_ptr_t)(ga_l[i] + kb), (nr_lds_ptr_t)(dst + A_BYTES + B_BYTES), 16, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                rb_h[i] = *reinterpret_cast<const u32x4_t*>(pb_h[i] + k0);
-                if constexpr (X3) rb_l[i] = *reinterpret_cast<const u32x4_t*>(pb_l[i] + k0);
+                char* dst = st + A_BYTES + (wave + 4 * i) * 1024;
+                __builtin_amdgcn_global_load_lds((nr_glb_ptr_t)(gb_h[i] + kb), (nr_lds_ptr_t)dst, 16, 0, 0);
+                if constexpr (X3)
+                    __builtin_amdgcn_global_load_lds((nr_glb_ptr_t)(gb_l[i] + kb), (nr_lds_ptr_t)(dst + A_BYTES + B_BYTES), 16, 0, 0);
             }
         };
 
         // fragment addresses (lane-constant): row within the wave's strip, k-chunk lane>>4
         const int frow = lane & 15, fq = lane >> 4;
-
-        gload(0);
         const int KT = K / BK;
+        issue(0);
         for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                *reinterpret_cast<u32x4_t*>(sAh + oa[i]) = ra_h[i];
-                if constexpr (X3) *reinterpret_cast<u32x4_t*>(sAl + oa[i]) = ra_l[i];
+            if (kt + 1 < KT) {
+                issue(kt + 1);
+                // everything but the DMA of slice kt+1 has landed (this wave's share)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                *reinterpret_cast<u32x4_t*>(sBh + ob[i]) = rb_h[i];
-                if constexpr (X3) *reinterpret_cast<u32x4_t*>(sBl + ob[i]) = rb_l[i];
-            }
-            __syncthreads();
-            if (kt + 1 < KT) gload((kt + 1) * BK);
+            __builtin_amdgcn_s_barrier();               // ... and every other wave's share
+            const char* sAh = smem + (kt & 1) * STAGE_BYTES;
+            const char* sBh = sAh + A_BYTES;
+            const char* sAl = sAh + A_BYTES + B_BYTES;
+            const char* sBl = sAl + A_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8_t fa_h[MI], fb_h[NI], fa_l[X3 ? MI : 1], fb_l[X3 ? NI : 1];
 #pragma unroll
                 for (int m = 0; m < MI; ++m) {
-                    int r = wr * 16 * MI + m * 16 + frow;
+                    int r = wr * 16 * MI + strip_row<TPS_A, MI>(m, frow);
                     int off = lds_off(r, ks * 4 + fq);
                     fa_h[m] = *reinterpret_cast<const bf16x8_t*>(sAh + off);
                     if constexpr (X3) fa_l[m] = *reinterpret_cast<const bf16x8_t*>(sAl + off);
                 }
 #pragma unroll
                 for (int n = 0; n < NI; ++n) {
-                    int r = wc * 16 * NI + n * 16 + frow;
+                    int r = wc * 16 * NI + strip_row<TPS_B, NI>(n, frow);
                     int off = lds_off(r, ks * 4 + fq);
                     fb_h[n] = *reinterpret_cast<const bf16x8_t*>(sBh + off);
                     if constexpr (X3) fb_l[n] = *reinterpret_cast<const bf16x8_t*>(sBl + off);
@@ -132,7 +152,10 @@ struct NrGemmTile {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[m], fb_h[n], acc[m][n], 0, 0, 0);
                     }
             }
-            __syncthreads();
+            // all fragment reads of this slice are done (their values fed the MFMAs above) before any
+            // wave refills this stage at the next issue
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
     }
 

@@ -64,11 +64,13 @@ extern "C" int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_l
     dim3 grid(H / 128, (n_tok + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
     if (prec == NR_PREC_BF16X3) {
-        size_t lds = NrGemmTile<4, 4, true>::STAGE_BYTES;
+        size_t lds = NrGemmTile<4, 4, true>::RING_BYTES;
+        hipError_t e = hipFuncSetAttribute((const void*)nr_mlp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(nr_mlp_kernel<true>, grid, dim3(256), lds, st, tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo,
                            b1, w2, H, logit_part);
     } else {
-        size_t lds = NrGemmTile<4, 4, false>::STAGE_BYTES;
+        size_t lds = NrGemmTile<4, 4, false>::RING_BYTES;
         hipLaunchKernelGGL(nr_mlp_kernel<false>, grid, dim3(256), lds, st, tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo,
                            b1, w2, H, logit_part);
     }

@@ -11,6 +11,7 @@
 //   phase D: optional row / column sums of S over the block (memory-bank centrality).
 // Masked tokens were zeroed by nr_prepare_tokens, so their products are exactly 0 and take part
 // in the max like the reference's mask multiply (modeling.py:500-501).
+#include <stdlib.h>
 #include "nr_gemm_tile.h"
 #include "../../include/nr_hip.h"
 
@@ -25,75 +26,121 @@ struct NrSimArgs {
     int out_mode;
     int ldc;      // floats per LDS C row
     int J;        // lanes per pair in phase C (power of two, <= 64)
-    int off_pw, off_qw, off_sp;   // byte offsets of the LDS scratch arrays
+    int off_pw, off_qw, off_sp, off_wt;   // byte offsets of the LDS scratch arrays
+    int dbg;
 };
 
 template <int MI, int NI, bool X3>
 __global__ __launch_bounds__(256) void nr_sim_kernel(NrSimArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Tile = NrGemmTile<MI, NI, X3>;
-    constexpr int BM = Tile::BM;
+    constexpr int BM = Tile::BM, BN = Tile::BN;
     const int tid = threadIdx.x;
     const int bx = blockIdx.x, by = blockIdx.y;
     const int Nt = p.Nt, Nv = p.Nv, TA = p.TA, TB = p.TB;
     const int row0 = by * TA * Nt;
     const int col0 = bx * TB * Nv;
-
-    Tile tile;
-    tile.zero();
-    tile.run(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
+    const int nrow = TA * Nt;     // tile rows that belong to whole texts
+    const int ncol = TB * Nv;
 
     float* sC = reinterpret_cast<float*>(smem);
     float* sPW = reinterpret_cast<float*>(smem + p.off_pw);
     float* sQW = reinterpret_cast<float*>(smem + p.off_qw);
     float* sSP = reinterpret_cast<float*>(smem + p.off_sp);
+    float* sWT = reinterpret_cast<float*>(smem + p.off_wt);     // token weights of the tile's rows / columns,
+    float* sWV = sWT + BM;                                      // 0 for rows / columns outside the problem
+
+    // token weights into LDS up front: their global latency hides under the main loop
+    for (int r = tid; r < BM; r += 256) {
+        int ag = by * TA + r / Nt;
+        sWT[r] = (r < nrow && ag < p.A) ? p.w_t[row0 + r] : 0.f;
+    }
+    for (int c = tid; c < BN; c += 256) {
+        int bg = bx * TB + c / Nv;
+        sWV[c] = (c < ncol && bg < p.Bv) ? p.w_v[col0 + c] : 0.f;
+    }
+
+    Tile tile;
+    tile.zero();
+    if (p.dbg != 2) tile.run(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
+    if (p.dbg == 1) {
+        float s = 0.f;
+        for (int m = 0; m < MI; ++m) for (int n = 0; n < NI; ++n) s += tile.acc[m][n][0] + tile.acc[m][n][1] + tile.acc[m][n][2] + tile.acc[m][n][3];
+        if (s == 123.456f) p.out[0] = s;
+        return;
+    }
+
     const int ldc = p.ldc;
     tile.store_lds(sC, ldc);
     __syncthreads();
 
-    const int nrow = TA * Nt;     // tile rows that belong to whole texts
-    const int ncol = TB * Nv;
-
     // ---- phase A: max over the video tokens of each (row, video) ----------------------------
+    const bool vec_a = (Nv & 3) == 0;
     for (int i = tid; i < nrow * TB; i += 256) {
         int r = i / TB, bl = i - r * TB;
-        int al = r / Nt, t = r - al * Nt;
-        int ag = by * TA + al, bg = bx * TB + bl;
-        bool ok = (ag < p.A) && (bg < p.Bv);
         const float* c = sC + r * ldc + bl * Nv;
-        float m = c[0];
+        float m;
         int am = 0;
-        for (int v = 1; v < Nv; ++v) {
-            float x = c[v];
-            if (x > m) { m = x; am = v; }
+        if (vec_a) {
+            f32x4_t x = *reinterpret_cast<const f32x4_t*>(c);
+            m = x[0];
+            if (x[1] > m) { m = x[1]; am = 1; }
+            if (x[2] > m) { m = x[2]; am = 2; }
+            if (x[3] > m) { m = x[3]; am = 3; }
+            for (int v = 4; v < Nv; v += 4) {
+                x = *reinterpret_cast<const f32x4_t*>(c + v);
+                if (x[0] > m) { m = x[0]; am = v; }
+                if (x[1] > m) { m = x[1]; am = v + 1; }
+                if (x[2] > m) { m = x[2]; am = v + 2; }
+                if (x[3] > m) { m = x[3]; am = v + 3; }
+            }
+        } else {
+            m = c[0];
+            for (int v = 1; v < Nv; ++v) {
+                float x = c[v];
+                if (x > m) { m = x; am = v; }
+            }
         }
-        float w = ok ? p.w_t[row0 + r] : 0.f;
-        sPW[i] = ok ? m * w : 0.f;
-        if (p.arg_v && ok) {
-            size_t o = ((size_t)ag * p.Bv + bg) * Nt + t;
-            p.arg_v[o] = (uint8_t)am;
-            p.pmax[o] = m;
+        sPW[i] = m * sWT[r];
+        if (p.arg_v) {
+            int al = r / Nt, t = r - al * Nt;
+            int ag = by * TA + al, bg = bx * TB + bl;
+            if (ag < p.A && bg < p.Bv) {
+                size_t o = ((size_t)ag * p.Bv + bg) * Nt + t;
+                p.arg_v[o] = (uint8_t)am;
+                p.pmax[o] = m;
+            }
         }
     }
-    // ---- phase B: max over the text tokens of each (text, col) ------------------------------
-    for (int i = tid; i < TA * ncol; i += 256) {
-        int al = i / ncol, c = i - al * ncol;
-        int bl = c / Nv, v = c - bl * Nv;
-        int ag = by * TA + al, bg = bx * TB + bl;
-        bool ok = (ag < p.A) && (bg < p.Bv);
-        const float* col = sC + (al * Nt) * ldc + c;
-        float m = col[0];
-        int am = 0;
+    // ---- phase B: max over the text tokens of each (text, col); 4 adjacent columns per thread ----
+    const int ngrp = (ncol + 3) >> 2;
+    for (int i = tid; i < TA * ngrp; i += 256) {
+        int al = i / ngrp, cg = i - al * ngrp;
+        const float* col = sC + (al * Nt) * ldc + cg * 4;
+        f32x4_t m = *reinterpret_cast<const f32x4_t*>(col);
+        int am0 = 0, am1 = 0, am2 = 0, am3 = 0;
         for (int t = 1; t < Nt; ++t) {
-            float x = col[t * ldc];
-            if (x > m) { m = x; am = t; }
+            f32x4_t x = *reinterpret_cast<const f32x4_t*>(col + t * ldc);
+            if (x[0] > m[0]) { m[0] = x[0]; am0 = t; }
+            if (x[1] > m[1]) { m[1] = x[1]; am1 = t; }
+            if (x[2] > m[2]) { m[2] = x[2]; am2 = t; }
+            if (x[3] > m[3]) { m[3] = x[3]; am3 = t; }
         }
-        float w = ok ? p.w_v[col0 + c] : 0.f;
-        sQW[i] = ok ? m * w : 0.f;
-        if (p.arg_t && ok) {
-            size_t o = ((size_t)ag * p.Bv + bg) * Nv + v;
-            p.arg_t[o] = (uint8_t)am;
-            p.qmax[o] = m;
+        const int am[4] = {am0, am1, am2, am3};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int c = cg * 4 + e;
+            if (c >= ncol) break;
+            sQW[al * ncol + c] = m[e] * sWV[c];
+            if (p.arg_t) {
+                int bl = c / Nv, v = c - bl * Nv;
+                int ag = by * TA + al, bg = bx * TB + bl;
+                if (ag < p.A && bg < p.Bv) {
+                    size_t o = ((size_t)ag * p.Bv + bg) * Nv + v;
+                    p.arg_t[o] = (uint8_t)am[e];
+                    p.qmax[o] = m[e];
+                }
+            }
         }
     }
     __syncthreads();
@@ -143,8 +190,11 @@ __global__ __launch_bounds__(256) void nr_sim_kernel(NrSimArgs p) {
             if (bg < p.Bv) p.out[(size_t)by * p.Bv + bg] = s;
         }
     }
-    (void)BM;
 }
+
+int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16_t* v_hi, const uint16_t* v_lo,
+                        const float* w_t, const float* w_v, int A, int Nt, int Bv, int Nv, int d, int prec, int out_mode,
+                        float* out, uint8_t* arg_v, uint8_t* arg_t, float* pmax, float* qmax, hipStream_t st);
 
 // ---- host side -------------------------------------------------------------------------------
 // pick the tile extent (64 / 96 / 128 rows) that wastes the fewest MFMA rows on padding
@@ -201,6 +251,16 @@ extern "C" int nr_local_level_fwd(const uint16_t* t_hi, const uint16_t* t_lo, co
     if (out_mode < 0 || out_mode > 2) return NR_EINVAL;
     if ((arg_v || arg_t || pmax || qmax) && !(arg_v && arg_t && pmax && qmax)) return NR_EINVAL;
     if (Nt > 255 || Nv > 255) return NR_EUNSUPPORTED;   // arg-max indices are u8
+    // token counts with a register-level epilogue (nr_sim_reg.hip); NR_SIM_GENERIC=1 forces this file's
+    // LDS epilogue (test hook)
+    {
+        const char* e = getenv("NR_SIM_GENERIC");
+        if (!(e && atoi(e))) {
+            int rc = nr_sim_reg_dispatch(t_hi, t_lo, v_hi, v_lo, w_t, w_v, A, Nt, Bv, Nv, d, prec, out_mode, out, arg_v, arg_t,
+                                         pmax, qmax, (hipStream_t)stream);
+            if (rc != NR_EUNSUPPORTED) return rc;
+        }
+    }
     int mi = 0, ni = 0;
     int TA = nr_pick_extent(Nt, &mi), TB = nr_pick_extent(Nv, &ni);
     if (TA == 0 || TB == 0) return NR_EUNSUPPORTED;
@@ -210,6 +270,7 @@ extern "C" int nr_local_level_fwd(const uint16_t* t_hi, const uint16_t* t_lo, co
     NrSimArgs a;
     a.t_hi = t_hi; a.t_lo = t_lo; a.v_hi = v_hi; a.v_lo = v_lo;
     a.w_t = w_t; a.w_v = w_v; a.out = out; a.arg_v = arg_v; a.arg_t = arg_t; a.pmax = pmax; a.qmax = qmax;
+    { const char* e = getenv("NR_SIM_DEBUG"); a.dbg = e ? atoi(e) : 0; }
     a.A = A; a.Nt = Nt; a.Bv = Bv; a.Nv = Nv; a.K = d; a.TA = TA; a.TB = TB; a.out_mode = out_mode;
     const int BM = 32 * mi, BN = 32 * ni;
     a.ldc = BN + 4;
@@ -217,7 +278,7 @@ extern "C" int nr_local_level_fwd(const uint16_t* t_hi, const uint16_t* t_lo, co
     int J = 64;
     while (J > 1 && J * npair > 256) J >>= 1;
     a.J = J;
-    size_t stage = (size_t)(BM + BN) * 128 * (prec == NR_PREC_BF16X3 ? 2 : 1);
+    size_t stage = 2 * (size_t)(BM + BN) * 128 * (prec == NR_PREC_BF16X3 ? 2 : 1);   // 2-deep DMA ring
     size_t cbytes = (size_t)BM * a.ldc * 4;
     size_t base = stage > cbytes ? stage : cbytes;
     base = (base + 15) & ~(size_t)15;
@@ -226,7 +287,9 @@ extern "C" int nr_local_level_fwd(const uint16_t* t_hi, const uint16_t* t_lo, co
     a.off_qw = (int)(base + pw);
     size_t qw = ((size_t)TA * TB * Nv * 4 + 15) & ~(size_t)15;
     a.off_sp = (int)(base + pw + qw);
-    size_t lds = base + pw + qw + (((size_t)npair * 4 + 15) & ~(size_t)15);
+    size_t sp = ((size_t)npair * 4 + 15) & ~(size_t)15;
+    a.off_wt = (int)(base + pw + qw + sp);
+    size_t lds = base + pw + qw + sp + (size_t)(BM + BN) * 4;
     if (lds > 160 * 1024) return NR_EUNSUPPORTED;
 
     dim3 grid((Bv + TB - 1) / TB, (A + TA - 1) / TA);

@@ -1,0 +1,223 @@
+// Fused local_level forward with the max-pools done IN REGISTERS (no LDS round trip of the block).
+// Reference: NeighborRetr/models/modeling.py:499-512.  Same block decomposition as nr_sim.hip
+// (whole (text, video) pairs per workgroup, 2 x 2 waves), but the token -> MFMA-fragment mapping is
+// permuted so that in the 16x16 accumulator layout (row = 4*(lane>>4) + reg, col = lane&15)
+//   * a wave strip of 16*MI rows holds 16/TPS texts of Nt = MI*TPS tokens: sub-tile i carries tokens
+//     [TPS*i, TPS*i+TPS) of each of them  ->  text = (lane>>4) / (TPS/4), token = TPS*i + 4*((lane>>4) % (TPS/4)) + reg;
+//   * a wave strip of 16*NI columns holds 16/FPS videos of Nv = NI*FPS frames: sub-tile n carries frames
+//     [FPS*n, FPS*n+FPS)  ->  video = (lane&15) / FPS, frame = FPS*n + (lane&15) % FPS.
+// max over the frames of a video  = max over n (registers) + DPP max over FPS adjacent lanes;
+// max over the tokens of a text   = max over (i, reg) (registers) + lane exchange at distance 16 / 32;
+// the weighted sums follow the same two patterns.  ~150 VALU instructions per wave replace the
+// store of the 96x96 block to LDS and three LDS reduction phases.
+// Supported token counts: Nt = MI*TPS, Nv = NI*FPS with (MI,TPS) in {(3,8),(4,16)}, (NI,FPS) in
+// {(3,4),(4,16)}: 24/64 text tokens, 12/64 frames; everything else runs nr_sim.hip.
+#include "nr_gemm_tile.h"
+#include "../../include/nr_hip.h"
+
+struct NrSimRegArgs {
+    const uint16_t *t_hi, *t_lo, *v_hi, *v_lo;
+    const float *w_t, *w_v;
+    float* out;
+    uint8_t *arg_v, *arg_t;
+    float *pmax, *qmax;
+    int A, Bv, K, out_mode;
+};
+
+template <int W>   // max over W adjacent lanes (W = 4, 8, 16) with the index of the first maximum
+__device__ __forceinline__ void nr_lanes_argmax(float& v, int& idx) {
+    nr_arg_step<true, NR_DPP_XOR1, 0xF>(v, idx);
+    nr_arg_step<true, NR_DPP_XOR2, 0xF>(v, idx);
+    if constexpr (W >= 8) nr_arg_step<true, NR_DPP_HALF_MIRROR, 0xF>(v, idx);
+    if constexpr (W >= 16) nr_arg_step<true, NR_DPP_MIRROR, 0xF>(v, idx);
+}
+template <int W>
+__device__ __forceinline__ float nr_lanes_max(float v) {
+    v = fmaxf(v, nr_dpp<NR_DPP_XOR1>(v, v));
+    v = fmaxf(v, nr_dpp<NR_DPP_XOR2>(v, v));
+    if constexpr (W >= 8) v = fmaxf(v, nr_dpp<NR_DPP_HALF_MIRROR>(v, v));
+    if constexpr (W >= 16) v = fmaxf(v, nr_dpp<NR_DPP_MIRROR>(v, v));
+    return v;
+}
+template <int W>
+__device__ __forceinline__ float nr_lanes_sum(float v) {
+    v += nr_dpp<NR_DPP_XOR1>(v, v);
+    v += nr_dpp<NR_DPP_XOR2>(v, v);
+    if constexpr (W >= 8) v += nr_dpp<NR_DPP_HALF_MIRROR>(v, v);
+    if constexpr (W >= 16) v += nr_dpp<NR_DPP_MIRROR>(v, v);
+    return v;
+}
+
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS>
+__global__ __launch_bounds__(256) void nr_sim_reg_kernel(NrSimRegArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Tile = NrGemmTile<MI, NI, X3, TPS, FPS>;
+    constexpr int Nt = MI * TPS, Nv = NI * FPS;
+    constexpr int TAW = 16 / TPS, TBW = 16 / FPS;     // texts / videos per wave
+    constexpr int TA = 2 * TAW, TB = 2 * TBW;         // per workgroup
+    constexpr int GX = TPS / 4;                       // lane groups (of 16) that share a text
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int row0 = by * TA * Nt, col0 = bx * TB * Nv;
+
+    const int g = lane >> 4, kap = lane & 15;
+    const int al = g / GX, tau0 = 4 * (g % GX);       // text within the wave, first token of this lane's regs
+    const int bl = kap / FPS, phi = kap % FPS;        // video within the wave, frame offset
+    const int ag = by * TA + wr * TAW + al;
+    const int bg = bx * TB + wc * TBW + bl;
+    const bool ok = ag < p.A && bg < p.Bv;
+    const int agc = min(ag, p.A - 1), bgc = min(bg, p.Bv - 1);
+    // this lane's token weights, fetched before the main loop so their latency hides under it
+    float wt[MI][4], wv[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        f32x4_t q = *reinterpret_cast<const f32x4_t*>(p.w_t + (size_t)agc * Nt + TPS * i + tau0);
+        wt[i][0] = q[0]; wt[i][1] = q[1]; wt[i][2] = q[2]; wt[i][3] = q[3];
+    }
+#pragma unroll
+    for (int n = 0; n < NI; ++n) wv[n] = p.w_v[(size_t)bgc * Nv + FPS * n + phi];
+
+    Tile tile;
+    tile.zero();
+    tile.run(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
+
+    // ---- t2v: P[t] = max over the video's frames; sum_t w_t[t] * P[t] -------------------------------
+    float t2v = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = TPS * i + tau0 + j;
+            float m = tile.acc[i][0][j];
+            int av = phi;
+#pragma unroll
+            for (int n = 1; n < NI; ++n) {
+                float x = tile.acc[i][n][j];
+                if (x > m) { m = x; av = FPS * n + phi; }
+            }
+            if constexpr (ARGS) {
+                nr_lanes_argmax<FPS>(m, av);
+                if (ok && phi == 0) {
+                    size_t o = ((size_t)ag * p.Bv + bg) * Nt + t;
+                    p.arg_v[o] = (uint8_t)av;
+                    p.pmax[o] = m;
+                }
+            } else {
+                m = nr_lanes_max<FPS>(m);
+            }
+            t2v += m * wt[i][j];
+        }
+    if constexpr (GX >= 2) t2v += __shfl_xor(t2v, 16);
+    if constexpr (GX >= 4) t2v += __shfl_xor(t2v, 32);
+
+    // ---- v2t: Q[v] = max over the text's tokens; sum_v w_v[v] * Q[v] --------------------------------
+    float v2t = 0.f;
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+        const int v = FPS * n + phi;
+        float m = tile.acc[0][n][0];
+        int at = tau0;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (i == 0 && j == 0) continue;
+                float x = tile.acc[i][n][j];
+                if (x > m) { m = x; at = TPS * i + tau0 + j; }
+            }
+        if constexpr (GX >= 2) {
+            float om = __shfl_xor(m, 16);
+            int oa = __shfl_xor(at, 16);
+            if (om > m || (om == m && oa < at)) { m = om; at = oa; }
+        }
+        if constexpr (GX >= 4) {
+            float om = __shfl_xor(m, 32);
+            int oa = __shfl_xor(at, 32);
+            if (om > m || (om == m && oa < at)) { m = om; at = oa; }
+        }
+        if constexpr (ARGS) {
+            if (ok && (g % GX) == 0) {
+                size_t o = ((size_t)ag * p.Bv + bg) * Nv + v;
+                p.arg_t[o] = (uint8_t)at;
+                p.qmax[o] = m;
+            }
+        }
+        v2t += m * wv[n];
+    }
+    v2t = nr_lanes_sum<FPS>(v2t);
+
+    const float S = 0.5f * (t2v + v2t);
+    const bool writer = (phi == 0) && ((g % GX) == 0);
+    if (p.out_mode == NR_OUT_FULL) {
+        if (writer && ok) p.out[(size_t)ag * p.Bv + bg] = S;
+        return;
+    }
+    // ---- block-level row / column sums of S (fixed order => deterministic) ---------------------------
+    float* sSP = reinterpret_cast<float*>(smem);       // the ring is free: run() ended with a barrier
+    if (writer) sSP[(wr * TAW + al) * TB + wc * TBW + bl] = ok ? S : 0.f;
+    __syncthreads();
+    if (p.out_mode == NR_OUT_ROWSUM) {
+        if (tid < TA) {
+            float s = 0.f;
+            for (int b = 0; b < TB; ++b) s += sSP[tid * TB + b];
+            int a = by * TA + tid;
+            if (a < p.A) p.out[(size_t)bx * p.A + a] = s;
+        }
+    } else {
+        if (tid < TB) {
+            float s = 0.f;
+            for (int a = 0; a < TA; ++a) s += sSP[a * TB + tid];
+            int b = bx * TB + tid;
+            if (b < p.Bv) p.out[(size_t)by * p.Bv + b] = s;
+        }
+    }
+}
+
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS>
+static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
+    using Tile = NrGemmTile<MI, NI, X3, TPS, FPS>;
+    constexpr int TA = 2 * (16 / TPS), TB = 2 * (16 / FPS);
+    auto kern = nr_sim_reg_kernel<MI, NI, TPS, FPS, X3, ARGS>;
+    size_t lds = Tile::RING_BYTES;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid((a.Bv + TB - 1) / TB, (a.A + TA - 1) / TA);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// tile shape this path would use: texts / videos per workgroup; 0 if the token count is not covered
+extern "C" int nr_sim_reg_tile(int Nt, int Nv, int* TA, int* TB) {
+    int ta = Nt == 24 ? 4 : (Nt == 64 ? 2 : 0);
+    int tb = Nv == 12 ? 8 : (Nv == 64 ? 2 : 0);
+    if (!ta || !tb) return 0;
+    if (TA) *TA = ta;
+    if (TB) *TB = tb;
+    return 1;
+}
+
+// returns NR_EUNSUPPORTED when the shape is not covered (the caller falls back to nr_sim.hip)
+int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16_t* v_hi, const uint16_t* v_lo,
+                        const float* w_t, const float* w_v, int A, int Nt, int Bv, int Nv, int d, int prec, int out_mode,
+                        float* out, uint8_t* arg_v, uint8_t* arg_t, float* pmax, float* qmax, hipStream_t st) {
+    if (!nr_sim_reg_tile(Nt, Nv, nullptr, nullptr)) return NR_EUNSUPPORTED;
+    NrSimRegArgs a{t_hi, t_lo, v_hi, v_lo, w_t, w_v, out, arg_v, arg_t, pmax, qmax, A, Bv, d, out_mode};
+    const bool x3 = prec == NR_PREC_BF16X3, args = arg_v != nullptr;
+#define NR_REG_CASE(MI_, TPS_, NI_, FPS_)                                                              \
+    if (Nt == MI_ * TPS_ && Nv == NI_ * FPS_) {                                                        \
+        if (x3) return args ? nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, true, true>(a, st)               \
+                            : nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, true, false>(a, st);             \
+        return args ? nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, false, true>(a, st)                      \
+                    : nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, false, false>(a, st);                    \
+    }
+    NR_REG_CASE(3, 8, 3, 4)      // 24 text tokens x 12 frames (MSR-VTT)
+    NR_REG_CASE(4, 16, 4, 16)    // 64 x 64 (ActivityNet)
+    NR_REG_CASE(3, 8, 4, 16)     // 24 x 64
+    NR_REG_CASE(4, 16, 3, 4)     // 64 x 12
+#undef NR_REG_CASE
+    return NR_EUNSUPPORTED;
+}

@@ -64,6 +64,8 @@ def test_token_weights(prec, tol):
 
 SHAPES = [
     # A, Nt, Bv, Nv
+    (5, 24, 3, 64),        # mixed: 24 text tokens x 64 frames
+    (3, 64, 21, 12),       # mixed: 64 x 12
     (16, 24, 16, 12),      # C1 batch x batch
     (16, 24, 128, 12),     # C1 batch x bank
     (37, 24, 19, 12),      # ragged tile edges
@@ -74,9 +76,17 @@ SHAPES = [
 ]
 
 
+@pytest.fixture(params=[0, 1], ids=["auto", "lds-epilogue"])
+def sim_variant(request, monkeypatch):
+    """0: let the library pick (register epilogue for 24/64-token shapes); 1: force the generic LDS
+    epilogue of nr_sim.hip (NR_SIM_GENERIC is read by the host entry point on every call)."""
+    monkeypatch.setenv("NR_SIM_GENERIC", str(request.param))
+    return request.param
+
+
 @pytest.mark.parametrize("A,Nt,Bv,Nv", SHAPES)
 @pytest.mark.parametrize("prec,tol", [(hip.PREC_BF16X3, 2e-6), (hip.PREC_BF16, 1e-3)])
-def test_local_level_matches_oracle(A, Nt, Bv, Nv, prec, tol):
+def test_local_level_matches_oracle(A, Nt, Bv, Nv, prec, tol, sim_variant):
     g = torch.Generator().manual_seed(A * 1000 + Bv)
     base = torch.randn(max(A, Bv), 1, 512, generator=g)
     t = base[:A] + 4 * torch.randn(A, Nt, 512, generator=g)
