@@ -10,11 +10,12 @@
 // (row pass) AND 16 of its column (column pass) in registers.  The first iteration runs in the log
 // domain exactly as the reference (safe for any logit range); from then on the plan
 // P = exp(G + u + v) itself is carried in registers and each half-iteration is the equivalent
-// multiplicative update   P_ij *= mu / rowsum_i   /   P_ij *= nu / colsum_j
+// matrix-scaling form: P_ij = a_i K_ij b_j with K = exp(G + u1 + v1) fixed in registers and
+//   a_i = e^mu / sum_j K_ij b_j,   b_j = e^nu / sum_i K_ij a_i
 // (u_i <- mu - LSE_j(G_ij + v_j)  <=>  scale row i so that it sums to e^mu).  That replaces 2 x 16
-// exp per thread and half-iteration by adds and multiplies: the kernel is VALU-bound on one CU and
-// this is what shortens the step's critical path.  After the first iteration every entry of P is
-// <= 1/(2B), so nothing can overflow.
+// exp per thread and half-iteration by 16 FMAs: the kernel is VALU-issue-bound on one CU and this is
+// what shortens the step's critical path.  After the first iteration every entry of K is <= 1/(2B)
+// and a = b = 1, so nothing can overflow.
 // B > 128: the matrix stays in L2/MALL; one launch per half-iteration (wave per row, coalesced),
 // the column pass running on a transposed copy held in the workspace (log domain throughout).
 #include "nr_common.h"
@@ -35,15 +36,20 @@ __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __
     const bool live = line < B;
 
     // X[i][j] = G[i][j] (dir 0) or G[j][i] (dir 1);  pr[k] = X[line][16 sub + k],  pc[k] = X[16 sub + k][line]
+    // (unconditional loads at clamped indices + select: a load under a per-element branch would cost
+    // one dependent L2 round trip each)
     float pr[SK_EPT], pc[SK_EPT];
+    const int lc = min(line, B - 1);
 #pragma unroll
     for (int k = 0; k < SK_EPT; ++k) {
         int o = sub * SK_EPT + k;
+        int oc = min(o, B - 1);
+        size_t ir = dir == 0 ? (size_t)lc * B + oc : (size_t)oc * B + lc;
+        size_t ic = dir == 0 ? (size_t)oc * B + lc : (size_t)lc * B + oc;
+        float xr = G[ir], xc = G[ic];
         bool ok = live && o < B;
-        size_t ir = dir == 0 ? (size_t)line * B + o : (size_t)o * B + line;
-        size_t ic = dir == 0 ? (size_t)o * B + line : (size_t)line * B + o;
-        pr[k] = ok ? G[ir] : -INFINITY;
-        pc[k] = ok ? G[ic] : -INFINITY;
+        pr[k] = ok ? xr : -INFINITY;
+        pc[k] = ok ? xc : -INFINITY;
     }
     if (tid < 128) { s_a[tid] = 0.f; s_b[tid] = 0.f; }
     __syncthreads();
@@ -78,7 +84,9 @@ __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __
         }
         __syncthreads();
     }
-    // ---- the plan itself: P = exp(X + u + v)   (u = v = 0 when iters == 0) -----------------------------
+    // ---- the kernel matrix after iteration 1: K = exp(X + u + v)   (u = v = 0 when iters == 0) ---------
+    // From here on the plan is P_ij = a_i K_ij b_j with scaling vectors a, b (= 1 now): K stays in
+    // registers untouched, one half-iteration is  a_i = e^mu / sum_j K_ij b_j  (16 FMAs per thread).
     {
         const float ul = live ? s_a[line] : 0.f, vl = live ? s_b[line] : 0.f;
 #pragma unroll
@@ -89,46 +97,42 @@ __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __
         }
     }
     __syncthreads();
-    // ---- iterations 2..iters: multiplicative updates ---------------------------------------------------
+    if (tid < 128) { s_a[tid] = 1.f; s_b[tid] = 1.f; }
+    __syncthreads();
+    float a_own = 1.f, b_own = 1.f;
     for (int it = 1; it < iters; ++it) {
-        {   // rows sum to e^mu
-            float r = (((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]))) +
-                      (((pr[8] + pr[9]) + (pr[10] + pr[11])) + ((pr[12] + pr[13]) + (pr[14] + pr[15])));
-            r = nr_group8_sum(r);
-            float al = live ? mass * __builtin_amdgcn_rcpf(r) : 0.f;
+        {   // a_i = e^mu / sum_j K_ij b_j
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
 #pragma unroll
-            for (int k = 0; k < SK_EPT; ++k) pr[k] *= al;
-            if (sub == 0 && tid < 1024) s_a[line] = al;
+            for (int k = 0; k < SK_EPT; k += 4) {
+                f32x4_t f = *reinterpret_cast<const f32x4_t*>(&s_b[sub * SK_EPT + k]);
+                r0 += pr[k] * f[0]; r1 += pr[k + 1] * f[1]; r2 += pr[k + 2] * f[2]; r3 += pr[k + 3] * f[3];
+            }
+            float r = nr_group8_sum((r0 + r1) + (r2 + r3));
+            a_own = live ? mass * __builtin_amdgcn_rcpf(r) : 0.f;
+            if (sub == 0) s_a[line] = a_own;
         }
         __syncthreads();
-        {   // the column-layout copy sees the same row factors, then columns sum to e^nu
-            float c4[4];
+        {   // b_j = e^nu / sum_i K_ij a_i
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
 #pragma unroll
             for (int k = 0; k < SK_EPT; k += 4) {
                 f32x4_t f = *reinterpret_cast<const f32x4_t*>(&s_a[sub * SK_EPT + k]);
-                pc[k] *= f[0]; pc[k + 1] *= f[1]; pc[k + 2] *= f[2]; pc[k + 3] *= f[3];
-                c4[k >> 2] = (pc[k] + pc[k + 1]) + (pc[k + 2] + pc[k + 3]);
+                c0 += pc[k] * f[0]; c1 += pc[k + 1] * f[1]; c2 += pc[k + 2] * f[2]; c3 += pc[k + 3] * f[3];
             }
-            float c = nr_group8_sum((c4[0] + c4[1]) + (c4[2] + c4[3]));
-            float be = live ? mass * __builtin_amdgcn_rcpf(c) : 0.f;
-#pragma unroll
-            for (int k = 0; k < SK_EPT; ++k) pc[k] *= be;
-            if (sub == 0) s_b[line] = be;
+            float c = nr_group8_sum((c0 + c1) + (c2 + c3));
+            b_own = live ? mass * __builtin_amdgcn_rcpf(c) : 0.f;
+            if (sub == 0) s_b[line] = b_own;
         }
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < SK_EPT; k += 4) {
-            f32x4_t f = *reinterpret_cast<const f32x4_t*>(&s_b[sub * SK_EPT + k]);
-            pr[k] *= f[0]; pr[k + 1] *= f[1]; pr[k + 2] *= f[2]; pr[k + 3] *= f[3];
-        }
     }
-    // ---- Q = P / e^norm = 2B * P;  target = beta*Q + (1-beta)*I ---------------------------------------
+    // ---- Q = P / e^norm = 2B * a_i K_ij b_j;  target = beta*Q + (1-beta)*I ----------------------------
     if (live) {
-        const float sc = beta * (float)(2 * B);
+        const float sc = beta * (float)(2 * B) * a_own;
 #pragma unroll
         for (int k = 0; k < SK_EPT; ++k) {
             int o = sub * SK_EPT + k;
-            if (o < B) tgt[(size_t)line * B + o] = sc * pr[k] + (o == line ? 1.0f - beta : 0.f);
+            if (o < B) tgt[(size_t)line * B + o] = sc * pr[k] * s_b[o] + (o == line ? 1.0f - beta : 0.f);
         }
     }
 }
