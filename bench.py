@@ -10,8 +10,8 @@ One STEP = one pass of the hot path over one synthetic batch already resident in
     forward (BASELINE.json configs[0] "loss-only forward").
 Workload = BASELINE.json configs[1]: global B=128, d=512, Nt=24, Nv=12, M=512, K=20 (MSR-VTT shape).
 For N>1 the GLOBAL batch stays 128 (the metric is quoted at global B=128): each rank holds b=128/N
-samples, gathers, and -- like the reference (modeling.py:274-298) -- evaluates the full loss, so
-`scaling` is "strong".  The JSON line also carries:
+samples, gathers (one packed RCCL all-gather, eager), and -- like the reference (modeling.py:274-298)
+-- evaluates the full loss (replayed from a HIP graph), so `scaling` is "strong".  The JSON line also carries:
   roofline     the fused local_level kernel (the dominant kernel): algorithmic flops per launch
                (F_sim / 3 launches) / its average duration, timed live
                with HIP events on the launch stream, against the dense bf16 MFMA peak;
@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "bf16_all"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N>1 (nccl = RCCL; gloo only to rehearse ranks that share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backward", action="store_true", help="also time forward+backward (reported as extra fields)")
     return ap.parse_args()
@@ -103,10 +105,14 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N")
     import torch.distributed as dist
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from neighborretr_amd import hip, ops, synth
     c = CFG
@@ -134,22 +140,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- optional HIP-graph capture of the whole step (single-GPU: no collective inside) --------------
+    # ---- HIP-graph capture.  N=1: the whole step.  N>1: the exchange step (one packed all-gather) stays
+    # eager on the collective stream and fills static buffers; everything after it is replayed from a graph.
     graph = None
+    static = None
+    if world > 1:
+        from neighborretr_amd.dist import packed_allgather
+
+        def gather():
+            return packed_allgather(shard["text_feat"], shard["video_feat"], shard["idx"], shard["text_mask"],
+                                    shard["video_mask"], model.config)
+        static = [t.clone() for t in gather()]
+
+        def after_gather():
+            with torch.no_grad():
+                tf, vf, ix, tm, vm = static
+                out.copy_(torch.stack(model.loss_step(tf, vf, tm, vm, ix)))
+
+        def step():                                        # noqa: F811
+            with torch.no_grad():
+                for dst, src in zip(static, gather()):
+                    dst.copy_(src)
+            (graph.replay if graph is not None else after_gather)()
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    if not args.no_graph and world == 1:
+    if not args.no_graph:
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                step()
+                (step if world == 1 else after_gather)()
             graph = g
         except Exception as e:          # graphs are an optimisation, never a requirement
             print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
-    run = graph.replay if graph is not None else step
+    run = graph.replay if (graph is not None and world == 1) else step
 
     for _ in range(args.warmup):
         run()

@@ -181,6 +181,16 @@ class NeighborRetr(nn.Module):
             from .dist import packed_allgather
             text_feat, video_feat, idx, text_mask, video_mask = packed_allgather(
                 text_feat, video_feat, idx, text_mask, video_mask, self.config)
+        return self.loss_step(text_feat, video_feat, text_mask, video_mask, idx)
+
+    def loss_step(self, text_feat, video_feat, text_mask, video_mask, idx):
+        """Everything after the exchange step: the five losses on the (gathered) global batch and the
+        memory-bank push (modeling.py:283-312).  Collective-free, so it captures into a HIP graph."""
+        # masks as fp32 once per step: every kernel reads them as multipliers
+        if text_mask.dtype != torch.float32:
+            text_mask = text_mask.float()
+        if video_mask.dtype != torch.float32:
+            video_mask = video_mask.float()
         logit_scale = self.clip.logit_scale.exp()
         cfg = self.config
         losses = self._compute_losses(text_feat, video_feat, text_mask, video_mask,
