@@ -133,7 +133,11 @@ def main():
     def step():
         with torch.no_grad():
             losses = model(shard["text_feat"], shard["text_mask"], shard["video_feat"], shard["video_mask"], shard["idx"], 0)
-            out.copy_(torch.stack(losses))
+            out.copy_(_as_vector(losses))
+
+    def _as_vector(losses):
+        base = losses[0]._base                  # the five scalars are views of one [5] tensor
+        return base if base is not None and base.numel() == 5 else torch.stack(losses)
 
     def sync():
         if world > 1:
@@ -155,7 +159,7 @@ def main():
         def after_gather():
             with torch.no_grad():
                 tf, vf, ix, tm, vm = static
-                out.copy_(torch.stack(model.loss_step(tf, vf, tm, vm, ix)))
+                out.copy_(_as_vector(model.loss_step(tf, vf, tm, vm, ix)))
 
         def step():                                        # noqa: F811
             with torch.no_grad():

@@ -128,6 +128,19 @@ int nr_merge_ln(const float* xn, const int64_t* assign, const float* tokw, int n
 int nr_tc_attention(const float* q, const float* kv, const float* score, int n_samples, int N, int C, int cnum,
                     int H, float* out, void* stream);
 
+/* Two-launch form of the same stage pieces, one workgroup per sample (what the step actually runs):
+ *   nr_ctm_front = nr_ctm_norm_score + the distance half of nr_dpc_knn_assign
+ *                  (dist [n_samples,N,N], smax [n_samples] out);
+ *   nr_ctm_back  = the assignment half of nr_dpc_knn_assign + nr_merge_ln (assign may be NULL).   */
+int nr_ctm_front(const float* y, const float* mask, int n_samples, int N, int C, const float* ln_w,
+                 const float* ln_b, const float* sc_w, const float* sc_b, const float* n1_w, const float* n1_b,
+                 float eps, float* xn, float* kvn, float* score, float* tokw, float* dist, float* smax,
+                 void* stream);
+int nr_ctm_back(const float* dist, const float* smax, const float* mask, const float* noise, const float* xn,
+                const float* tokw, int n_samples, int N, int C, int k, int cluster_num, const float* n1_w,
+                const float* n1_b, const float* proj_b, float eps, float* merged, float* merged_pb, float* qn,
+                int64_t* assign, void* stream);
+
 /* Log-domain Sinkhorn targets, both directions in one launch (until_module.py:235-266):
  *   tgt_rows = beta*Q(G) + (1-beta)*I,  tgt_cols = beta*Q(G^T) + (1-beta)*I  (each [B,B],
  *   tgt_cols indexed in the transposed frame).  workspace: nr_sinkhorn_workspace_bytes(B).    */

@@ -2,8 +2,8 @@
 
 Same arithmetic as neighborretr_amd/cluster.py (and the reference's cluster.py:670-965); used when no
 gradient is required (loss-only forward, evaluation), where the ~45 ATen launches of one
-CTM + TCBlock stage collapse to 11:
-    nr_shift_concat -> GEMM(+residual) -> nr_ctm_norm_score -> rand -> nr_dpc (2) -> nr_merge_ln
+CTM + TCBlock stage collapse to 8:
+    nr_shift_concat -> GEMM(+residual) -> nr_ctm_front -> nr_ctm_back
     -> GEMM q, GEMM kv -> nr_tc_attention -> GEMM proj (+residual+bias)
 The training path keeps the autograd-traced torch ops of cluster.py.
 """
@@ -51,29 +51,32 @@ def ctm_stage_fused(x, mask, ctm, blk, noise, cache, key):
     cat = torch.empty((B * N, 3 * C), **f32)
     hip.call("nr_shift_concat", _p(x), B, N, C, _p(cat), st)
     y = torch.addmm(x.view(B * N, C), cat, sw.wcat)
-    # LayerNorm, score, exp, norm1
+    # LayerNorm, score, exp, norm1 + pairwise distances  (one launch, workgroup per sample)
     xn = torch.empty((B, N, C), **f32)
     kvn = torch.empty((B * N, C), **f32)
     score = torch.empty((B, N), **f32)
     tokw = torch.empty((B, N), **f32)
+    dist = torch.empty((B, N, N), **f32)
+    smax = torch.empty((B,), **f32)
     m = None
     if mask is not None:
         m = mask if mask.dtype == torch.float32 else mask.float()
         m = m.contiguous()
     attn = blk.attn
-    hip.call("nr_ctm_norm_score", _p(y), hip.ptr(m, allow_none=True), B * N, C, _p(ctm.norm.weight), _p(ctm.norm.bias),
+    hip.call("nr_ctm_front", _p(y), hip.ptr(m, allow_none=True), B, N, C, _p(ctm.norm.weight), _p(ctm.norm.bias),
              _p(ctm.score.weight), _p(ctm.score.bias), _p(blk.norm1.weight), _p(blk.norm1.bias), float(ctm.norm.eps),
-             _p(xn), _p(kvn), _p(score), _p(tokw), st)
-    # DPC-KNN assignment (2 launches)
-    from . import ops
+             _p(xn), _p(kvn), _p(score), _p(tokw), _p(dist), _p(smax), st)
+    # DPC-KNN assignment + weighted cluster means + norm1  (one launch)
     cnum = max(math.ceil(N * ctm.sample_ratio), 1)
-    assign = ops.dpc_knn_assign(xn, cnum, ctm.k, m, noise)
-    # weighted cluster means + norm1
+    if noise is None:
+        noise = torch.rand((B, N), **f32)
+    noise = noise.float().contiguous()
     merged = torch.empty((B * cnum, C), **f32)
     merged_pb = torch.empty((B * cnum, C), **f32)
     qn = torch.empty((B * cnum, C), **f32)
-    hip.call("nr_merge_ln", _p(xn), hip.ptr(assign, torch.int64), _p(tokw), B, N, C, cnum, _p(blk.norm1.weight),
-             _p(blk.norm1.bias), _p(attn.proj.bias), float(blk.norm1.eps), _p(merged), _p(merged_pb), _p(qn), st)
+    hip.call("nr_ctm_back", _p(dist), _p(smax), hip.ptr(m, allow_none=True), _p(noise), _p(xn), _p(tokw), B, N, C, int(ctm.k),
+             cnum, _p(blk.norm1.weight), _p(blk.norm1.bias), _p(attn.proj.bias), float(blk.norm1.eps), _p(merged),
+             _p(merged_pb), _p(qn), None, st)
     # projections (library GEMMs) and the score-biased attention
     q = torch.addmm(attn.q.bias, qn, sw.wq_t) if attn.q.bias is not None else qn @ sw.wq_t
     kv = torch.addmm(attn.kv.bias, kvn, sw.wkv_t) if attn.kv.bias is not None else kvn @ sw.wkv_t

@@ -213,6 +213,8 @@ class NeighborRetr(nn.Module):
                         centrality_scale, beta, num_neighbors, temperature, logit_scale, noise=None):
         hp = self._hp(centrality_scale, beta, num_neighbors, temperature)
         from .functional import head_losses
+        if noise is None and text_feat.is_cuda:
+            noise = self._draw_noise(text_feat.shape[0], text_feat.shape[1], video_feat.shape[1], text_feat.device)
         if text_feat.is_cuda and self.use_side_streams:
             # three independent branches: text clustering | video clustering | local products.
             # The two clustering branches run on side streams (in a captured HIP graph: parallel
@@ -265,8 +267,21 @@ class NeighborRetr(nn.Module):
             return True
         return not (feat.requires_grad or any(p.requires_grad for m in mods for p in m.parameters()))
 
+    @staticmethod
+    def _draw_noise(B, Nt, Nv, device):
+        """The four DPC-KNN tie-break draws of one step (cluster.py:483) from ONE torch.rand launch."""
+        t0, v0 = max(math.ceil(Nt / 6), 1), max(math.ceil(Nv / 4), 1)
+        sizes = {"t0": Nt, "t1": t0, "v0": Nv, "v1": v0}
+        flat = torch.rand(B * sum(sizes.values()), device=device, dtype=torch.float32)
+        out, off = {}, 0
+        for k, n in sizes.items():
+            out[k] = flat[off:off + B * n].view(B, n)
+            off += B * n
+        return out
+
     def _side_streams(self, device):
         if self._streams is None or self._streams[0].device != device:
+            # default priority: high-priority side streams made the captured graph 1.8x SLOWER on ROCm 7.2
             self._streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
         return self._streams
 
