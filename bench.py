@@ -246,8 +246,13 @@ def main():
             torch.cuda.synchronize()
         per_launch_s = e0.elapsed_time(e1) * 1e-3 / (3 * reps)
         achieved = (f_sim / 3) / per_launch_s / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_sim.json")
+        if os.path.exists(pmc):     # PMC counters need rocprofv3; the committed pass is quoted, not re-measured
+            traffic = json.load(open(pmc)).get("bytes_per_launch_avg_over_step")
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r01_pmc_sim.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch)",
                     "kernel": "nr_sim_kernel (fused local_level, 3 launches/step)",
                     "avg_launch_us": round(per_launch_s * 1e6, 2),
                     "algorithmic_flops_per_launch": f_sim / 3}
