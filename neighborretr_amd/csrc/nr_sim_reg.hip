@@ -22,6 +22,7 @@ struct NrSimRegArgs {
     uint8_t *arg_v, *arg_t;
     float *pmax, *qmax;
     int A, Bv, K, out_mode;
+    int ntx, nty, PR, PC;      // tile grid and its partition over the 8 XCDs (PR*PC == 8, or PR == 0: none)
 };
 
 template <int W>   // max over W adjacent lanes (W = 4, 8, 16) with the index of the first maximum
@@ -58,7 +59,23 @@ __global__ __launch_bounds__(256) void nr_sim_reg_kernel(NrSimRegArgs p) {
     constexpr int GX = TPS / 4;                       // lane groups (of 16) that share a text
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int bx = blockIdx.x, by = blockIdx.y;
+    // XCD-aware tile order: workgroups b and b+8 land on the same XCD (round-robin dispatch), so XCD x is
+    // given one contiguous PR x PC part of the tile grid and its private L2 pulls only that part's
+    // operand rows.  Pure speed: any placement computes the same tiles.
+    int bx, by;
+    {
+        const int bid = blockIdx.x;
+        if (p.PR > 0) {
+            const int xcd = bid & 7, slot = bid >> 3;
+            const int sub_w = p.ntx / p.PC, sub_h = p.nty / p.PR;
+            bx = (xcd % p.PC) * sub_w + slot % sub_w;
+            by = (xcd / p.PC) * sub_h + slot / sub_w;
+            (void)sub_h;
+        } else {
+            bx = bid % p.ntx;
+            by = bid / p.ntx;
+        }
+    }
     const int row0 = by * TA * Nt, col0 = bx * TB * Nv;
 
     const int g = lane >> 4, kap = lane & 15;
@@ -184,8 +201,21 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid((a.Bv + TB - 1) / TB, (a.A + TA - 1) / TA);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    a.ntx = (a.Bv + TB - 1) / TB;
+    a.nty = (a.A + TA - 1) / TA;
+    // partition of the tile grid over the 8 XCDs that minimises the operand bytes each L2 has to hold
+    a.PR = a.PC = 0;
+    {
+        const int cand[4][2] = {{2, 4}, {4, 2}, {1, 8}, {8, 1}};
+        double best = 1e300;
+        for (int c = 0; c < 4; ++c) {
+            int pr = cand[c][0], pc = cand[c][1];
+            if (a.nty % pr || a.ntx % pc) continue;
+            double cost = (double)a.nty * TA * (MI * TPS) / pr + (double)a.ntx * TB * (NI * FPS) / pc;
+            if (cost < best) { best = cost; a.PR = pr; a.PC = pc; }
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(a.ntx * a.nty), dim3(256), lds, st, a);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }
