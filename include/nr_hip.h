@@ -186,11 +186,14 @@ int nr_colsum(const float* a, int rows, int cols, float* out, void* stream);
  *   o_hi/o_lo: prepared tokens of the OTHER operand (lo may be NULL: hi only);
  *   w_self / w_other: token weights of this / the other operand;
  *   d_x may be NULL (weights-only: memory-bank side, whose features get no gradient);
- *   accumulate != 0 adds into d_x / d_w instead of overwriting.                                 */
+ *   accumulate != 0 adds into d_x / d_w instead of overwriting.
+ *   workspace: nr_local_level_bwd_workspace_bytes(...) (chunk partials, reduced in fixed order). */
+size_t nr_local_level_bwd_workspace_bytes(int side, int A, int Nt, int Bv, int Nv, int d);
 int nr_local_level_bwd(int side, const float* dS, int ds_mode, float ds_scale,
                        const uint16_t* o_hi, const uint16_t* o_lo, const float* w_self, const float* w_other,
                        const uint8_t* arg_v, const uint8_t* arg_t, const float* pmax, const float* qmax,
-                       int A, int Nt, int Bv, int Nv, int d, float* d_x, float* d_w, int accumulate, void* stream);
+                       int A, int Nt, int Bv, int Nv, int d, float* d_x, float* d_w, int accumulate,
+                       void* workspace, void* stream);
 
 /* Backward of F.normalize + mask + the centrality mean (nr_prepare_tokens):
  *   g = mask*d_xn + dmean/n_tok;  dx = (g - xhat <xhat,g>) / ||x||,  xhat = x/||x||.

@@ -18,9 +18,9 @@ struct NrSimBwdArgs {
     const float *w_self, *w_other;
     const uint8_t *gath_arg, *scat_arg;   // [pair, Ns] -> other token ; [pair, No] -> self token
     const float* pool;                    // pooled maxima [pair, Ns]
-    int side, A, Bv, Ns, No, d, n_loop;
-    float *d_x, *d_w;
-    int accumulate;
+    int side, A, Bv, Ns, No, d, n_loop, chunk_len;
+    float *d_x, *d_w;          // partial outputs: [n_chunks][n_self*Ns*d] and [n_chunks][n_self*Ns]
+    size_t x_stride, w_stride;
 };
 
 __global__ void nr_sim_bwd_kernel(NrSimBwdArgs p) {
@@ -37,7 +37,9 @@ __global__ void nr_sim_bwd_kernel(NrSimBwdArgs p) {
     float dw = 0.f;                            // thread n < Ns of slice 0 accumulates d_w[self, n]
     const bool do_w = (blockIdx.y == 0) && (k < Ns) && p.d_w;
 
-    for (int o = 0; o < p.n_loop; ++o) {
+    const int o_begin = blockIdx.z * p.chunk_len;
+    const int o_end = min(o_begin + p.chunk_len, p.n_loop);
+    for (int o = o_begin; o < o_end; ++o) {
         const int a = p.side == 0 ? self : o;
         const int b = p.side == 0 ? o : self;
         const size_t pair = (size_t)a * p.Bv + b;
@@ -68,31 +70,67 @@ __global__ void nr_sim_bwd_kernel(NrSimBwdArgs p) {
         for (int n = 0; n < Ns; ++n) acc[n * DS + k] += g * ws[n] * ov[(int)ga[n] * DS + k];
     }
     if (p.d_x && live) {
-        for (int n = 0; n < Ns; ++n) {
-            size_t idx = ((size_t)self * Ns + n) * p.d + dim;
-            p.d_x[idx] = (p.accumulate ? p.d_x[idx] : 0.f) + acc[n * DS + k];
+        float* px = p.d_x + (size_t)blockIdx.z * p.x_stride;
+        for (int n = 0; n < Ns; ++n) px[((size_t)self * Ns + n) * p.d + dim] = acc[n * DS + k];
+    }
+    if (do_w) p.d_w[(size_t)blockIdx.z * p.w_stride + (size_t)self * Ns + k] = dw;
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_c part[c][i]   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void nr_sum_chunks_kernel(const float* __restrict__ part, int n_chunks, size_t n,
+                                                            float* __restrict__ out, int accumulate) {
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n && (n & 3) == 0) {         // rows of every chunk stay 16-byte aligned
+        f32x4_t s = accumulate ? *reinterpret_cast<const f32x4_t*>(out + i) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < n_chunks; ++c) s += *reinterpret_cast<const f32x4_t*>(part + (size_t)c * n + i);
+        *reinterpret_cast<f32x4_t*>(out + i) = s;
+    } else {
+        for (size_t e = i + 4; i < n && i < e; ++i) {
+            float s = accumulate ? out[i] : 0.f;
+            for (int c = 0; c < n_chunks; ++c) s += part[(size_t)c * n + i];
+            out[i] = s;
         }
     }
-    if (do_w) {
-        size_t idx = (size_t)self * Ns + k;
-        p.d_w[idx] = (p.accumulate ? p.d_w[idx] : 0.f) + dw;
-    }
+}
+
+static int nr_bwd_chunks(int n_loop) {
+    int c = n_loop / 8;
+    if (c < 1) c = 1;
+    return c > 16 ? 16 : c;
+}
+
+extern "C" size_t nr_local_level_bwd_workspace_bytes(int side, int A, int Nt, int Bv, int Nv, int d) {
+    size_t n_self = side == 0 ? (size_t)A * Nt : (size_t)Bv * Nv;
+    int nch = nr_bwd_chunks(side == 0 ? Bv : A);
+    return (size_t)nch * (n_self * d + n_self) * sizeof(float) + 256;
 }
 
 extern "C" int nr_local_level_bwd(int side, const float* dS, int ds_mode, float ds_scale, const uint16_t* o_hi,
                                   const uint16_t* o_lo, const float* w_self, const float* w_other, const uint8_t* arg_v,
                                   const uint8_t* arg_t, const float* pmax, const float* qmax, int A, int Nt, int Bv, int Nv,
-                                  int d, float* d_x, float* d_w, int accumulate, void* stream) {
-    if (!dS || !w_self || !w_other || !arg_v || !arg_t || !pmax || !qmax) return NR_EINVAL;
+                                  int d, float* d_x, float* d_w, int accumulate, void* workspace, void* stream) {
+    if (!dS || !w_self || !w_other || !arg_v || !arg_t || !pmax || !qmax || !workspace) return NR_EINVAL;
     if (side < 0 || side > 1 || ds_mode < 0 || ds_mode > 2 || A <= 0 || Bv <= 0 || Nt <= 0 || Nv <= 0 || d <= 0) return NR_EINVAL;
     if (d_x && !o_hi) return NR_EINVAL;
     if (!d_x && !d_w) return NR_EINVAL;
+    if ((d % 4) != 0) return NR_EUNSUPPORTED;
     NrSimBwdArgs p;
     p.dS = dS; p.ds_mode = ds_mode; p.ds_scale = ds_scale; p.o_hi = o_hi; p.o_lo = o_lo;
     p.w_self = w_self; p.w_other = w_other; p.side = side; p.A = A; p.Bv = Bv; p.d = d;
-    p.d_x = d_x; p.d_w = d_w; p.accumulate = accumulate;
     if (side == 0) { p.Ns = Nt; p.No = Nv; p.gath_arg = arg_v; p.scat_arg = arg_t; p.pool = pmax; p.n_loop = Bv; }
     else           { p.Ns = Nv; p.No = Nt; p.gath_arg = arg_t; p.scat_arg = arg_v; p.pool = qmax; p.n_loop = A; }
+    // the walk over the other operand's samples is cut into chunks handled by different workgroups
+    // (partial sums in the workspace, then one fixed-order reduction): 16x the parallelism
+    const int nch = nr_bwd_chunks(p.n_loop);
+    p.chunk_len = (p.n_loop + nch - 1) / nch;
+    const size_t n_self = (size_t)(side == 0 ? A : Bv) * p.Ns;
+    float* ws_x = reinterpret_cast<float*>(workspace);
+    float* ws_w = ws_x + (size_t)nch * n_self * d;
+    p.x_stride = n_self * d;
+    p.w_stride = n_self;
+    p.d_x = d_x ? ws_x : nullptr;
+    p.d_w = d_w ? ws_w : nullptr;
     int DS = 256;
     while (DS > 64 && (size_t)(p.Ns + p.No) * DS * 4 > 150 * 1024) DS >>= 1;
     if (DS < p.Ns) return NR_EUNSUPPORTED;                 // d_w needs one thread per token
@@ -102,8 +140,15 @@ extern "C" int nr_local_level_bwd(int side, const float* dS, int ds_mode, float 
         hipError_t e = hipFuncSetAttribute((const void*)nr_sim_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid(side == 0 ? A : Bv, d_x ? (d + DS - 1) / DS : 1);
-    hipLaunchKernelGGL(nr_sim_bwd_kernel, grid, dim3(DS), lds, (hipStream_t)stream, p);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(side == 0 ? A : Bv, d_x ? (d + DS - 1) / DS : 1, nch);
+    hipLaunchKernelGGL(nr_sim_bwd_kernel, grid, dim3(DS), lds, st, p);
+    if (d_x) {
+        size_t n = n_self * d;
+        hipLaunchKernelGGL(nr_sum_chunks_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, st, ws_x, nch, n, d_x, accumulate);
+    }
+    if (d_w)
+        hipLaunchKernelGGL(nr_sum_chunks_kernel, dim3((unsigned)((n_self / 4 + 255) / 256 + 1)), dim3(256), 0, st, ws_w, nch, n_self, d_w, accumulate);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

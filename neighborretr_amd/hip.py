@@ -51,7 +51,8 @@ _SIGNATURES = {
     "nr_row_losses_bwd": ([_P] * 9 + [_I, _I, _F, _P, _P, _P, _P, _P, _P, _P], _I),
     "nr_add_transposed": ([_P, _P, _I, _P, _P], _I),
     "nr_colsum": ([_P, _I, _I, _P, _P], _I),
-    "nr_local_level_bwd": ([_I, _P, _I, _F] + [_P] * 8 + [_I, _I, _I, _I, _I, _P, _P, _I, _P], _I),
+    "nr_local_level_bwd_workspace_bytes": ([_I, _I, _I, _I, _I, _I], _Z),
+    "nr_local_level_bwd": ([_I, _P, _I, _F] + [_P] * 8 + [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P], _I),
     "nr_normalize_bwd": ([_P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     "nr_token_softmax_bwd": ([_P, _P, _I, _I, _P, _P], _I),
     "nr_centrality_weights_bwd": ([_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P], _I),

@@ -222,11 +222,13 @@ def local_level_bwd(side, dS, ds_mode, ds_scale, other, w_self, w_other, aux, A,
         d_x = torch.empty((n_self, d), dtype=torch.float32, device=dev)
     if d_w is None:
         d_w = torch.empty((n_self,), dtype=torch.float32, device=dev)
+    ws = torch.empty((int(hip.lib().nr_local_level_bwd_workspace_bytes(int(side), A, Nt, Bv, Nv, d)),), dtype=torch.uint8,
+                     device=dev)
     hip.call("nr_local_level_bwd", int(side), hip.ptr(dS, torch.float32), int(ds_mode), float(ds_scale),
              hip.ptr(other.hi), hip.ptr(other.lo if use_lo else None, allow_none=True), hip.ptr(w_self, torch.float32),
              hip.ptr(w_other, torch.float32), hip.ptr(arg_v), hip.ptr(arg_t), hip.ptr(pmax), hip.ptr(qmax),
              A, Nt, Bv, Nv, d, hip.ptr(d_x if want_dx else None, allow_none=True), hip.ptr(d_w),
-             1 if accumulate else 0, hip.stream_ptr())
+             1 if accumulate else 0, hip.ptr(ws), hip.stream_ptr())
     return (d_x if want_dx else None), d_w
 
 
