@@ -130,16 +130,25 @@ int nr_tc_attention(const float* q, const float* kv, const float* score, int n_s
 
 /* Two-launch form of the same stage pieces, one workgroup per sample (what the step actually runs):
  *   nr_ctm_front = nr_ctm_norm_score + the distance half of nr_dpc_knn_assign
- *                  (dist [n_samples,N,N], smax [n_samples] out);
+ *                  (dist [n_samples,N,N], smax [n_samples] out); norm1(xn) goes either to kvn (f32) or,
+ *                  when kvn_hi/kvn_lo are given, straight to the split-bf16 operand of nr_linear_x3;
  *   nr_ctm_back  = the assignment half of nr_dpc_knn_assign + nr_merge_ln (assign may be NULL).   */
 int nr_ctm_front(const float* y, const float* mask, int n_samples, int N, int C, const float* ln_w,
                  const float* ln_b, const float* sc_w, const float* sc_b, const float* n1_w, const float* n1_b,
-                 float eps, float* xn, float* kvn, float* score, float* tokw, float* dist, float* smax,
-                 void* stream);
+                 float eps, float* xn, float* kvn, uint16_t* kvn_hi, uint16_t* kvn_lo, float* score, float* tokw,
+                 float* dist, float* smax, void* stream);
 int nr_ctm_back(const float* dist, const float* smax, const float* mask, const float* noise, const float* xn,
                 const float* tokw, int n_samples, int N, int C, int k, int cluster_num, const float* n1_w,
                 const float* n1_b, const float* proj_b, float eps, float* merged, float* merged_pb, float* qn,
                 int64_t* assign, void* stream);
+
+/* Y[M,N] = X[M,K] W[N,K]^T (+ bias[N]) (+ residual[M,N]) in split-bf16 on the MFMA tile engine: the big
+ * fp32 GEMMs of the clustering stage (token convolution cluster.py:664, kv projection :866).
+ * x_hi/x_lo [M,K], w_hi/w_lo [N,K] bf16 pairs; out [M,N] f32; K % 64 == 0.
+ * nr_shift_concat_split = nr_shift_concat writing the bf16 pair directly.                        */
+int nr_linear_x3(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* w_hi, const uint16_t* w_lo,
+                 const float* bias, const float* residual, int M, int N, int K, float* out, void* stream);
+int nr_shift_concat_split(const float* x, int n_samples, int N, int C, uint16_t* hi, uint16_t* lo, void* stream);
 
 /* Log-domain Sinkhorn targets, both directions in one launch (until_module.py:235-266):
  *   tgt_rows = beta*Q(G) + (1-beta)*I,  tgt_cols = beta*Q(G^T) + (1-beta)*I  (each [B,B],

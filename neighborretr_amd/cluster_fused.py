@@ -23,8 +23,12 @@ class _StageWeights:
     any parameter of the stage changed."""
 
     def __init__(self, ctm, blk):
+        from . import ops
         w = ctm.conv.conv.weight.detach()
         self.wcat = w.permute(2, 1, 0).reshape(3 * w.shape[1], w.shape[0]).contiguous()
+        # [C_out, 3*C_in] = the conv kernel as the W[N,K] operand of nr_linear_x3, split-bf16
+        self.wconv_hi, self.wconv_lo = ops.split_bf16(self.wcat.t().contiguous())
+        self.wkv_hi, self.wkv_lo = ops.split_bf16(blk.attn.kv.weight.detach())
         self.wq_t = blk.attn.q.weight.detach().t().contiguous()
         self.wkv_t = blk.attn.kv.weight.detach().t().contiguous()
         self.wp_t = blk.attn.proj.weight.detach().t().contiguous()
@@ -47,17 +51,32 @@ def ctm_stage_fused(x, mask, ctm, blk, noise, cache, key):
     sw = _stage_weights(cache, key, ctm, blk)
     st = hip.stream_ptr()
     f32 = dict(dtype=torch.float32, device=dev)
-    # token convolution k=3 as one GEMM with the residual folded in: y = x + cat @ Wcat
-    cat = torch.empty((B * N, 3 * C), **f32)
-    hip.call("nr_shift_concat", _p(x), B, N, C, _p(cat), st)
-    y = torch.addmm(x.view(B * N, C), cat, sw.wcat)
+    # token convolution k=3 as one GEMM with the residual folded in: y = x + cat @ Wcat.
+    # Big operand (stage 0): split-bf16 on the MFMA tile engine; small (stage 1): library GEMM.
+    big = B * N >= 1024 and C % 64 == 0
+    if big:
+        cat_hi = torch.empty((B * N, 3 * C), dtype=torch.int16, device=dev)
+        cat_lo = torch.empty((B * N, 3 * C), dtype=torch.int16, device=dev)
+        hip.call("nr_shift_concat_split", _p(x), B, N, C, hip.ptr(cat_hi), hip.ptr(cat_lo), st)
+        y = torch.empty((B * N, C), **f32)
+        hip.call("nr_linear_x3", hip.ptr(cat_hi), hip.ptr(cat_lo), hip.ptr(sw.wconv_hi), hip.ptr(sw.wconv_lo), None,
+                 _p(x), B * N, C, 3 * C, _p(y), st)
+    else:
+        cat = torch.empty((B * N, 3 * C), **f32)
+        hip.call("nr_shift_concat", _p(x), B, N, C, _p(cat), st)
+        y = torch.addmm(x.view(B * N, C), cat, sw.wcat)
     # LayerNorm, score, exp, norm1 + pairwise distances  (one launch, workgroup per sample)
     xn = torch.empty((B, N, C), **f32)
-    kvn = torch.empty((B * N, C), **f32)
     score = torch.empty((B, N), **f32)
     tokw = torch.empty((B, N), **f32)
     dist = torch.empty((B, N, N), **f32)
     smax = torch.empty((B,), **f32)
+    kvn = kvn_hi = kvn_lo = None
+    if big:
+        kvn_hi = torch.empty((B * N, C), dtype=torch.int16, device=dev)
+        kvn_lo = torch.empty((B * N, C), dtype=torch.int16, device=dev)
+    else:
+        kvn = torch.empty((B * N, C), **f32)
     m = None
     if mask is not None:
         m = mask if mask.dtype == torch.float32 else mask.float()
@@ -65,7 +84,8 @@ def ctm_stage_fused(x, mask, ctm, blk, noise, cache, key):
     attn = blk.attn
     hip.call("nr_ctm_front", _p(y), hip.ptr(m, allow_none=True), B, N, C, _p(ctm.norm.weight), _p(ctm.norm.bias),
              _p(ctm.score.weight), _p(ctm.score.bias), _p(blk.norm1.weight), _p(blk.norm1.bias), float(ctm.norm.eps),
-             _p(xn), _p(kvn), _p(score), _p(tokw), _p(dist), _p(smax), st)
+             _p(xn), hip.ptr(kvn, allow_none=True), hip.ptr(kvn_hi, allow_none=True), hip.ptr(kvn_lo, allow_none=True),
+             _p(score), _p(tokw), _p(dist), _p(smax), st)
     # DPC-KNN assignment + weighted cluster means + norm1  (one launch)
     cnum = max(math.ceil(N * ctm.sample_ratio), 1)
     if noise is None:
@@ -79,7 +99,12 @@ def ctm_stage_fused(x, mask, ctm, blk, noise, cache, key):
              _p(merged_pb), _p(qn), None, st)
     # projections (library GEMMs) and the score-biased attention
     q = torch.addmm(attn.q.bias, qn, sw.wq_t) if attn.q.bias is not None else qn @ sw.wq_t
-    kv = torch.addmm(attn.kv.bias, kvn, sw.wkv_t) if attn.kv.bias is not None else kvn @ sw.wkv_t
+    if big:
+        kv = torch.empty((B * N, 2 * C), **f32)
+        hip.call("nr_linear_x3", hip.ptr(kvn_hi), hip.ptr(kvn_lo), hip.ptr(sw.wkv_hi), hip.ptr(sw.wkv_lo),
+                 hip.ptr(attn.kv.bias, allow_none=True), None, B * N, 2 * C, C, _p(kv), st)
+    else:
+        kv = torch.addmm(attn.kv.bias, kvn, sw.wkv_t) if attn.kv.bias is not None else kvn @ sw.wkv_t
     att = torch.empty((B * cnum, C), **f32)
     hip.call("nr_tc_attention", _p(q), _p(kv), _p(score), B, N, C, cnum, attn.num_heads, _p(att), st)
     out = torch.addmm(merged_pb, att, sw.wp_t)          # merged + proj(att) + proj.bias

@@ -20,6 +20,7 @@ struct NrCtmFrontArgs {
     float eps, inv_sqrt_c;
     int N, C;
     float *xn, *kvn, *score, *tokw, *dist, *smax;
+    uint16_t *kvn_hi, *kvn_lo;       // when set, norm1(xn) is written split-bf16 (operand of the kv GEMM) instead of f32
 };
 
 __global__ __launch_bounds__(CF_THREADS) void nr_ctm_front_kernel(NrCtmFrontArgs p) {
@@ -73,7 +74,14 @@ __global__ __launch_bounds__(CF_THREADS) void nr_ctm_front_kernel(NrCtmFrontArgs
         for (int q = 0; q < CF_MAX_CPL; ++q)
             if (q < cpl) {
                 int c = q * 64 + lane;
-                p.kvn[row * C + c] = (v[q] - mu2) * rstd2 * p.n1_w[c] + p.n1_b[c];
+                float kv = (v[q] - mu2) * rstd2 * p.n1_w[c] + p.n1_b[c];
+                if (p.kvn_hi) {
+                    uint16_t h = nr_f2bf(kv);
+                    p.kvn_hi[row * C + c] = h;
+                    p.kvn_lo[row * C + c] = nr_f2bf(kv - nr_bf2f(h));
+                } else {
+                    p.kvn[row * C + c] = kv;
+                }
             }
     }
     __syncthreads();
@@ -124,10 +132,10 @@ __global__ __launch_bounds__(CF_THREADS) void nr_ctm_front_kernel(NrCtmFrontArgs
 
 extern "C" int nr_ctm_front(const float* y, const float* mask, int n_samples, int N, int C, const float* ln_w,
                             const float* ln_b, const float* sc_w, const float* sc_b, const float* n1_w, const float* n1_b,
-                            float eps, float* xn, float* kvn, float* score, float* tokw, float* dist, float* smax,
-                            void* stream) {
-    if (!y || !ln_w || !ln_b || !sc_w || !sc_b || !n1_w || !n1_b || !xn || !kvn || !score || !tokw || !dist || !smax)
-        return NR_EINVAL;
+                            float eps, float* xn, float* kvn, uint16_t* kvn_hi, uint16_t* kvn_lo, float* score, float* tokw,
+                            float* dist, float* smax, void* stream) {
+    if (!y || !ln_w || !ln_b || !sc_w || !sc_b || !n1_w || !n1_b || !xn || !score || !tokw || !dist || !smax) return NR_EINVAL;
+    if (!kvn && !(kvn_hi && kvn_lo)) return NR_EINVAL;
     if (n_samples <= 0 || N <= 0 || N > 64 || C <= 0 || (C % 64) != 0 || C > 64 * CF_MAX_CPL) return NR_EUNSUPPORTED;
     size_t lds = (size_t)N * C * sizeof(float);
     if (lds > 150 * 1024) return NR_EUNSUPPORTED;
@@ -135,7 +143,8 @@ extern "C" int nr_ctm_front(const float* y, const float* mask, int n_samples, in
         hipError_t e = hipFuncSetAttribute((const void*)nr_ctm_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    NrCtmFrontArgs p{y, mask, ln_w, ln_b, sc_w, sc_b, n1_w, n1_b, eps, 1.0f / sqrtf((float)C), N, C, xn, kvn, score, tokw, dist, smax};
+    NrCtmFrontArgs p{y, mask, ln_w, ln_b, sc_w, sc_b, n1_w, n1_b, eps, 1.0f / sqrtf((float)C), N, C, xn, kvn, score, tokw, dist, smax,
+                     kvn_hi, kvn_lo};
     hipLaunchKernelGGL(nr_ctm_front_kernel, dim3(n_samples), dim3(CF_THREADS), lds, (hipStream_t)stream, p);
     NR_LAUNCH_CHECK();
     return NR_OK;

@@ -42,7 +42,9 @@ _SIGNATURES = {
     "nr_ctm_norm_score": ([_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
     "nr_merge_ln": ([_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P], _I),
     "nr_tc_attention": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P], _I),
-    "nr_ctm_front": ([_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P], _I),
+    "nr_ctm_front": ([_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "nr_linear_x3": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
+    "nr_shift_concat_split": ([_P, _I, _I, _I, _P, _P, _P], _I),
     "nr_ctm_back": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
     "nr_sinkhorn_workspace_bytes": ([_I], _Z),
     "nr_sinkhorn_targets": ([_P, _I, _F, _I, _P, _P, _P, _P], _I),
