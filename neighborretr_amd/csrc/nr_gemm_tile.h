@@ -3,13 +3,13 @@
 // C[BM x BN] = A[BM x K] * B[BN x K]^T with both operands row-major bf16 ("NT" product), fp32
 // accumulate on v_mfma_f32_16x16x32_bf16.  256 threads = 4 waves laid out 2 x 2; each wave owns
 // MI x NI sub-tiles of 16 x 16 (BM = 32*MI, BN = 32*NI).  K is walked in BK = 64 slices through a
-// 2-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS with no VGPR staging and
+// STAGES-deep LDS ring (default 3) filled by LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS with no VGPR staging and
 // no ds_write pass -- the store side of the LDS, ~79 B/clk/CU, was the bottleneck of the register-
 // staged version).  One DMA instruction writes 1 KiB of LDS linearly (wave base + lane*16), i.e.
 // 8 rows x 128 B; the bank-conflict swizzle (16-B chunk ^= row&7, conflict-free ds_read_b128 of
 // the fragments) is applied on the per-lane SOURCE address, the LDS image stays linear per wave.
-// Slice kt+1 is in flight while slice kt is multiplied: counted s_waitcnt vmcnt + raw s_barrier
-// (a __syncthreads() would drain the DMA).
+// Later slices are in flight while slice kt is multiplied, one raw s_barrier per slice, counted
+// s_waitcnt vmcnt (a __syncthreads() would drain the DMA).
 //
 // X3 = split-bf16 mode: every operand is carried as hi + lo (two bf16 arrays) and the product is
 // accumulated as Ah*Bh + Ah*Bl + Al*Bh (the ~2^-18 lo*lo term is dropped), giving ~fp32-grade
@@ -20,7 +20,14 @@
 typedef __attribute__((address_space(3))) void* nr_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* nr_glb_ptr_t;
 
-template <int MI, int NI, bool X3, int TPS_A = 16, int TPS_B = 16>
+// Ring depth is the caller's choice.  Measured on MI355X: with >= ~2 workgroups per CU in the grid a
+// SINGLE stage wins (smallest LDS footprint -> more resident workgroups, which hide the DMA latency of
+// each other: split-bf16 bank product 79 -> 52 us, bank scorer 27 -> 23 us); small grids (one workgroup
+// per CU) need the 2-deep ring to overlap their own loads (batch scorer 19.5 vs 25 us); 3 stages lose to 2
+// everywhere (26.5 -> 29.9 us).
+constexpr int nr_pick_stages(long n_workgroups) { return n_workgroups >= 512 ? 1 : 2; }
+
+template <int MI, int NI, bool X3, int TPS_A = 16, int TPS_B = 16, int STAGES = 2>
 struct NrGemmTile {
     static constexpr int BM = 32 * MI;
     static constexpr int BN = 32 * NI;
@@ -28,7 +35,7 @@ struct NrGemmTile {
     static constexpr int A_BYTES = BM * BK * 2;
     static constexpr int B_BYTES = BN * BK * 2;
     static constexpr int STAGE_BYTES = (A_BYTES + B_BYTES) * (X3 ? 2 : 1);
-    static constexpr int RING_BYTES = 2 * STAGE_BYTES;
+    static constexpr int RING_BYTES = STAGES * STAGE_BYTES;
     static constexpr int DMA_PER_STAGE = (MI + NI) * (X3 ? 2 : 1);   // per wave
 
     f32x4_t acc[MI][NI];
@@ -89,7 +96,7 @@ struct NrGemmTile {
             if constexpr (X3) gb_l[i] = reinterpret_cast<const char*>(b_lo + (size_t)gr * K + kc * 8);
         }
         auto issue = [&](int kt) {
-            char* st = smem + (kt & 1) * STAGE_BYTES;
+            char* st = smem + (kt % STAGES) * STAGE_BYTES;
             const int kb = kt * BK * 2;                 // byte offset along K
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -110,17 +117,33 @@ struct NrGemmTile {
         // fragment addresses (lane-constant): row within the wave's strip, k-chunk lane>>4
         const int frow = lane & 15, fq = lane >> 4;
         const int KT = K / BK;
-        issue(0);
+        // STAGES-deep ring, ONE barrier per slice: slices kt+1 .. kt+STAGES-2 are in flight while slice kt is
+        // multiplied.  The barrier at the top of iteration kt (a) publishes slice kt (every wave waited for
+        // its own share first) and (b) proves every wave has finished reading slice kt-1, whose stage is the
+        // one refilled right after it.
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < KT) issue(s);
         for (int kt = 0; kt < KT; ++kt) {
-            if (kt + 1 < KT) {
-                issue(kt + 1);
-                // everything but the DMA of slice kt+1 has landed (this wave's share)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
-            } else {
+            if constexpr (STAGES == 1) {
+                // single stage: refill after everyone is done with the previous slice, no prefetch; the
+                // other resident workgroups of the CU cover the DMA latency (smallest LDS footprint)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                issue(kt);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                // this wave's share of slice kt has landed once at most min(STAGES-2, KT-1-kt) younger groups are pending
+                const int younger = min(STAGES - 2, KT - 1 - kt);
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_STAGE) : "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragment reads of slice kt-1 are complete
+                __builtin_amdgcn_s_barrier();
+                if (kt + STAGES - 1 < KT) issue(kt + STAGES - 1);
             }
-            __builtin_amdgcn_s_barrier();               // ... and every other wave's share
-            const char* sAh = smem + (kt & 1) * STAGE_BYTES;
+            const char* sAh = smem + (kt % STAGES) * STAGE_BYTES;
             const char* sBh = sAh + A_BYTES;
             const char* sAl = sAh + A_BYTES + B_BYTES;
             const char* sBl = sAl + A_BYTES;
@@ -152,11 +175,10 @@ struct NrGemmTile {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[m], fb_h[n], acc[m][n], 0, 0, 0);
                     }
             }
-            // all fragment reads of this slice are done (their values fed the MFMAs above) before any
-            // wave refills this stage at the next issue
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
         }
+        // every wave is done with the ring before the caller reuses the LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
     // C element (m, n, j) of this lane sits at tile row/col:

@@ -14,10 +14,10 @@ struct NrLinearArgs {
     int M, N, K;
 };
 
-template <int MI, int NI>
+template <int MI, int NI, int STAGES>
 __global__ __launch_bounds__(256) void nr_linear_kernel(NrLinearArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Tile = NrGemmTile<MI, NI, true>;
+    using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int row0 = blockIdx.y * Tile::BM, col0 = blockIdx.x * Tile::BN;
@@ -43,18 +43,25 @@ __global__ __launch_bounds__(256) void nr_linear_kernel(NrLinearArgs p) {
     }
 }
 
-template <int MI, int NI>
-static int nr_linear_launch(NrLinearArgs& a, hipStream_t st) {
-    using Tile = NrGemmTile<MI, NI, true>;
+template <int MI, int NI, int STAGES>
+static int nr_linear_launch_s(NrLinearArgs& a, hipStream_t st) {
+    using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES>;
     size_t lds = Tile::RING_BYTES;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)nr_linear_kernel<MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)nr_linear_kernel<MI, NI, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid((a.N + Tile::BN - 1) / Tile::BN, (a.M + Tile::BM - 1) / Tile::BM);
-    hipLaunchKernelGGL((nr_linear_kernel<MI, NI>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((nr_linear_kernel<MI, NI, STAGES>), grid, dim3(256), lds, st, a);
     NR_LAUNCH_CHECK();
     return NR_OK;
+}
+
+template <int MI, int NI>
+static int nr_linear_launch(NrLinearArgs& a, hipStream_t st) {
+    long n_wg = (long)((a.N + 32 * NI - 1) / (32 * NI)) * ((a.M + 32 * MI - 1) / (32 * MI));
+    if (nr_pick_stages(n_wg) == 1) return nr_linear_launch_s<MI, NI, 1>(a, st);
+    return nr_linear_launch_s<MI, NI, 2>(a, st);
 }
 
 extern "C" int nr_linear_x3(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* w_hi, const uint16_t* w_lo,

@@ -9,14 +9,14 @@
 #include "nr_gemm_tile.h"
 #include "../../include/nr_hip.h"
 
-template <bool X3>
+template <bool X3, int STAGES>
 __global__ __launch_bounds__(256) void nr_mlp_kernel(const uint16_t* __restrict__ tok_hi, const uint16_t* __restrict__ tok_lo,
                                                      const float* __restrict__ norm, int n_tok, int d,
                                                      const uint16_t* __restrict__ w1_hi, const uint16_t* __restrict__ w1_lo,
                                                      const float* __restrict__ b1, const float* __restrict__ w2, int H,
                                                      float* __restrict__ logit_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Tile = NrGemmTile<4, 4, X3>;
+    using Tile = NrGemmTile<4, 4, X3, 16, 16, STAGES>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;
@@ -63,17 +63,22 @@ extern "C" int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_l
     if (prec == NR_PREC_BF16X3 && (!tok_lo || !w1_lo)) return NR_EINVAL;
     dim3 grid(H / 128, (n_tok + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
-    if (prec == NR_PREC_BF16X3) {
-        size_t lds = NrGemmTile<4, 4, true>::RING_BYTES;
-        hipError_t e = hipFuncSetAttribute((const void*)nr_mlp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(nr_mlp_kernel<true>, grid, dim3(256), lds, st, tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo,
-                           b1, w2, H, logit_part);
-    } else {
-        size_t lds = NrGemmTile<4, 4, false>::RING_BYTES;
-        hipLaunchKernelGGL(nr_mlp_kernel<false>, grid, dim3(256), lds, st, tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo,
-                           b1, w2, H, logit_part);
+    const bool x3 = prec == NR_PREC_BF16X3;
+    const int stages = nr_pick_stages((long)grid.x * grid.y);
+#define NR_MLP_CASE(X3_, ST_)                                                                                          \
+    if (x3 == X3_ && stages == ST_) {                                                                                  \
+        size_t lds = NrGemmTile<4, 4, X3_, 16, 16, ST_>::RING_BYTES;                                                   \
+        if (lds < 1024) lds = 1024;                                                                                    \
+        if (lds > 64 * 1024) {                                                                                         \
+            hipError_t e = hipFuncSetAttribute((const void*)nr_mlp_kernel<X3_, ST_>,                                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+            if (e != hipSuccess) return (int)e;                                                                        \
+        }                                                                                                              \
+        hipLaunchKernelGGL((nr_mlp_kernel<X3_, ST_>), grid, dim3(256), lds, st, tok_hi, tok_lo, norm, n_tok, d, w1_hi, \
+                           w1_lo, b1, w2, H, logit_part);                                                              \
     }
+    NR_MLP_CASE(true, 1) NR_MLP_CASE(true, 2) NR_MLP_CASE(false, 1) NR_MLP_CASE(false, 2)
+#undef NR_MLP_CASE
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

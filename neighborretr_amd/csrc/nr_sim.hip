@@ -270,7 +270,7 @@ extern "C" int nr_local_level_fwd(const uint16_t* t_hi, const uint16_t* t_lo, co
     int J = 64;
     while (J > 1 && J * npair > 256) J >>= 1;
     a.J = J;
-    size_t stage = 2 * (size_t)(BM + BN) * 128 * (prec == NR_PREC_BF16X3 ? 2 : 1);   // 2-deep DMA ring
+    size_t stage = (size_t)2 * (BM + BN) * 128 * (prec == NR_PREC_BF16X3 ? 2 : 1);   // DMA ring
     size_t cbytes = (size_t)BM * a.ldc * 4;
     size_t base = stage > cbytes ? stage : cbytes;
     base = (base + 15) & ~(size_t)15;

@@ -49,10 +49,10 @@ __device__ __forceinline__ float nr_lanes_sum(float v) {
     return v;
 }
 
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS>
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES>
 __global__ __launch_bounds__(256) void nr_sim_reg_kernel(NrSimRegArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Tile = NrGemmTile<MI, NI, X3, TPS, FPS>;
+    using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES>;
     constexpr int Nt = MI * TPS, Nv = NI * FPS;
     constexpr int TAW = 16 / TPS, TBW = 16 / FPS;     // texts / videos per wave
     constexpr int TA = 2 * TAW, TB = 2 * TBW;         // per workgroup
@@ -191,16 +191,23 @@ __global__ __launch_bounds__(256) void nr_sim_reg_kernel(NrSimRegArgs p) {
     }
 }
 
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS>
-static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
-    using Tile = NrGemmTile<MI, NI, X3, TPS, FPS>;
-    constexpr int TA = 2 * (16 / TPS), TB = 2 * (16 / FPS);
-    auto kern = nr_sim_reg_kernel<MI, NI, TPS, FPS, X3, ARGS>;
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES>
+static int nr_sim_reg_launch_s(NrSimRegArgs& a, hipStream_t st) {
+    using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES>;
+    auto kern = nr_sim_reg_kernel<MI, NI, TPS, FPS, X3, ARGS, STAGES>;
     size_t lds = Tile::RING_BYTES;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    hipLaunchKernelGGL(kern, dim3(a.ntx * a.nty), dim3(256), lds, st, a);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS>
+static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
+    constexpr int TA = 2 * (16 / TPS), TB = 2 * (16 / FPS);
     a.ntx = (a.Bv + TB - 1) / TB;
     a.nty = (a.A + TA - 1) / TA;
     // partition of the tile grid over the 8 XCDs that minimises the operand bytes each L2 has to hold
@@ -215,9 +222,8 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
             if (cost < best) { best = cost; a.PR = pr; a.PC = pc; }
         }
     }
-    hipLaunchKernelGGL(kern, dim3(a.ntx * a.nty), dim3(256), lds, st, a);
-    NR_LAUNCH_CHECK();
-    return NR_OK;
+    if (nr_pick_stages((long)a.ntx * a.nty) == 1) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 1>(a, st);
+    return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 2>(a, st);
 }
 
 // tile shape this path would use: texts / videos per workgroup; 0 if the token count is not covered
