@@ -50,6 +50,38 @@ class RetrievalMetrics:
         m["cols"] = [int(i) for i in ind]
         return m
 
+    @staticmethod
+    def tensor_text_to_video_metrics(sim_tensor, top_k=(1, 5, 10, 50)):
+        """Multi-sentence text->video metrics (utils/metrics.py:82-126).  `sim_tensor[i, s, j]` is the score of
+        sentence s of video i against video j, padded with -inf / NaN where video i has fewer sentences (the
+        layout the double argsort and the two diagonals of the reference imply); every valid (i, s) contributes
+        the rank of video i in its row."""
+        if not torch.is_tensor(sim_tensor):
+            sim_tensor = torch.tensor(sim_tensor)
+        stacked = sim_tensor.permute(1, 0, 2)
+        first = torch.argsort(stacked, dim=-1, descending=True)
+        second = torch.argsort(first, dim=-1, descending=False)
+        ranks = torch.flatten(torch.diagonal(second, dim1=1, dim2=2))
+        diag = torch.flatten(torch.diagonal(sim_tensor, dim1=0, dim2=2))
+        valid = ranks[~torch.logical_or(torch.isinf(diag), torch.isnan(diag))].cpu()
+        res = {f"R{k}": float(torch.sum(valid < k) * 100 / len(valid)) for k in top_k}
+        res["MedianR"] = float(torch.median(valid + 1))
+        res["MeanR"] = float(np.mean(valid.numpy() + 1))
+        res["Std_Rank"] = float(np.std(valid.numpy() + 1))
+        res["MR"] = res["MedianR"]
+        return res
+
+    @staticmethod
+    def tensor_video_to_text_sim(sim_tensor):
+        """[n_video, max_sentences, n_video] -> [n_video, n_video] video->text matrix holding, for every
+        (video j, caption group i), the best of group i's sentences (utils/metrics.py:128-148).  Unlike the
+        reference this does not overwrite the NaNs of the caller's tensor."""
+        if not torch.is_tensor(sim_tensor):
+            sim_tensor = torch.tensor(sim_tensor)
+        sim_tensor = torch.where(sim_tensor != sim_tensor, torch.full_like(sim_tensor, float("-inf")), sim_tensor)
+        values, _ = torch.max(sim_tensor, dim=1, keepdim=True)
+        return torch.squeeze(values).T
+
     def print_metrics(self, metrics, prefix=""):
         msg = (f"{prefix}R@1: {metrics['R1']:.1f} - R@5: {metrics['R5']:.1f} - R@10: {metrics['R10']:.1f} - "
                f"R@50: {metrics['R50']:.1f} - Median R: {metrics['MR']:.1f} - Mean R: {metrics['MeanR']:.1f}")

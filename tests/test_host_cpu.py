@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -83,3 +84,30 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "nr_oracle" not in src and "import oracle" not in src, f
+
+
+def test_multi_sentence_metrics_against_counting():
+    """utils/metrics.py:82-148 semantics by brute force: sim[i, s, j] = sentence s of video i vs video j."""
+    from neighborretr_amd.metrics import RetrievalMetrics
+    g = torch.Generator().manual_seed(1)
+    nv, ms = 20, 3
+    sim = torch.randn(nv, ms, nv, generator=g)
+    for i in range(nv):
+        sim[i, :, i] += 1.5
+        if i % 3 == 0:
+            sim[i, 2, :] = float("-inf")                    # video i has only two sentences
+        if i % 5 == 0:
+            sim[i, 1, :] = float("nan")
+    ranks = []
+    for s_ in range(ms):
+        for i in range(nv):
+            if torch.isfinite(sim[i, s_, i]):
+                ranks.append(int((sim[i, s_] > sim[i, s_, i]).sum()))
+    ranks = np.array(ranks)
+    res = RetrievalMetrics.tensor_text_to_video_metrics(sim.clone())
+    for k in (1, 5, 10, 50):
+        assert abs(res[f"R{k}"] - 100.0 * np.mean(ranks < k)) < 1e-4
+    assert res["MeanR"] == pytest.approx(np.mean(ranks + 1)) and res["MR"] == float(np.sort(ranks + 1)[(len(ranks) - 1) // 2])
+    v2t = RetrievalMetrics.tensor_video_to_text_sim(sim.clone())
+    ref = torch.where(torch.isnan(sim), torch.full_like(sim, float("-inf")), sim).max(1)[0].t()
+    assert v2t.shape == (nv, nv) and torch.equal(v2t, ref)

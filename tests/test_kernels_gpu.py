@@ -244,6 +244,67 @@ def test_dpc_knn_assign_matches_oracle(B, N, cnum, masked):
         assert torch.equal(got[enough], ref[enough])
 
 
+@pytest.mark.parametrize("M,N,K,bias,res", [(3072, 512, 1536, False, True), (1536, 1024, 512, True, False),
+                                             (200, 130, 64, True, True), (64, 512, 512, False, False)])
+def test_linear_x3_matches_fp64(M, N, K, bias, res):
+    """The split-bf16 linear kernel of the clustering GEMMs against an fp64 product (~fp32 accuracy)."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g) if bias else None
+    r = torch.randn(M, N, generator=g) if res else None
+    xh, xl = ops.split_bf16(x.to(DEV))
+    wh, wl = ops.split_bf16(w.to(DEV))
+    out = torch.empty(M, N, device=DEV)
+    hip.call("nr_linear_x3", hip.ptr(xh), hip.ptr(xl), hip.ptr(wh), hip.ptr(wl), hip.ptr(b.to(DEV) if bias else None, allow_none=True),
+             hip.ptr(r.to(DEV) if res else None, allow_none=True), M, N, K, hip.ptr(out), hip.stream_ptr())
+    ref = x.double() @ w.double().t()
+    if bias:
+        ref = ref + b.double()
+    if res:
+        ref = ref + r.double()
+    assert maxdiff(out, ref) < 3e-5 * float(ref.abs().max())
+
+
+def test_ctm_front_back_equal_the_separate_kernels():
+    """nr_ctm_front / nr_ctm_back (what the step runs) == nr_ctm_norm_score + nr_dpc_knn_assign + nr_merge_ln."""
+    B, N, C, cnum = 16, 24, 512, 4
+    g = torch.Generator().manual_seed(3)
+    y = torch.randn(B, N, C, generator=g).to(DEV)
+    mask = (torch.arange(N)[None] < torch.randint(3, N + 1, (B, 1), generator=g)).float().to(DEV)
+    noise = torch.rand(B, N, generator=g).to(DEV)
+    vec = lambda n, s=1.0: (torch.randn(n, generator=g) * s).to(DEV)
+    ln_w, ln_b, sc_w, sc_b = 1 + vec(C, 0.05), vec(C, 0.01), vec(C, 0.05).reshape(1, C), vec(1, 0.01)
+    n1_w, n1_b, pb = 1 + vec(C, 0.05), vec(C, 0.01), vec(C, 0.01)
+    f = lambda *s: torch.empty(*s, device=DEV)
+    xn, kvn, score, tokw = f(B, N, C), f(B * N, C), f(B, N), f(B, N)
+    hip.call("nr_ctm_norm_score", hip.ptr(y), hip.ptr(mask), B * N, C, hip.ptr(ln_w), hip.ptr(ln_b), hip.ptr(sc_w), hip.ptr(sc_b),
+             hip.ptr(n1_w), hip.ptr(n1_b), 1e-5, hip.ptr(xn), hip.ptr(kvn), hip.ptr(score), hip.ptr(tokw), hip.stream_ptr())
+    assign = ops.dpc_knn_assign(xn, cnum, 3, mask, noise)
+    merged, mpb, qn = f(B * cnum, C), f(B * cnum, C), f(B * cnum, C)
+    hip.call("nr_merge_ln", hip.ptr(xn), hip.ptr(assign), hip.ptr(tokw), B, N, C, cnum, hip.ptr(n1_w), hip.ptr(n1_b), hip.ptr(pb),
+             1e-5, hip.ptr(merged), hip.ptr(mpb), hip.ptr(qn), hip.stream_ptr())
+    xn2, kvn2, score2, tokw2, dist, smax = f(B, N, C), f(B * N, C), f(B, N), f(B, N), f(B, N, N), f(B)
+    hip.call("nr_ctm_front", hip.ptr(y), hip.ptr(mask), B, N, C, hip.ptr(ln_w), hip.ptr(ln_b), hip.ptr(sc_w), hip.ptr(sc_b),
+             hip.ptr(n1_w), hip.ptr(n1_b), 1e-5, hip.ptr(xn2), hip.ptr(kvn2), None, None, hip.ptr(score2), hip.ptr(tokw2),
+             hip.ptr(dist), hip.ptr(smax), hip.stream_ptr())
+    merged2, mpb2, qn2 = f(B * cnum, C), f(B * cnum, C), f(B * cnum, C)
+    assign2 = torch.empty(B, N, dtype=torch.int64, device=DEV)
+    hip.call("nr_ctm_back", hip.ptr(dist), hip.ptr(smax), hip.ptr(mask), hip.ptr(noise), hip.ptr(xn2), hip.ptr(tokw2), B, N, C, 3, cnum,
+             hip.ptr(n1_w), hip.ptr(n1_b), hip.ptr(pb), 1e-5, hip.ptr(merged2), hip.ptr(mpb2), hip.ptr(qn2), hip.ptr(assign2),
+             hip.stream_ptr())
+    assert torch.equal(xn, xn2) and torch.equal(kvn, kvn2) and torch.equal(tokw, tokw2) and torch.equal(assign, assign2)
+    assert torch.equal(merged, merged2) and torch.equal(mpb, mpb2) and torch.equal(qn, qn2)
+    # the split-bf16 form of norm1(xn) carries it to ~2^-16
+    kh = torch.empty(B * N, C, dtype=torch.int16, device=DEV)
+    kl = torch.empty(B * N, C, dtype=torch.int16, device=DEV)
+    hip.call("nr_ctm_front", hip.ptr(y), hip.ptr(mask), B, N, C, hip.ptr(ln_w), hip.ptr(ln_b), hip.ptr(sc_w), hip.ptr(sc_b),
+             hip.ptr(n1_w), hip.ptr(n1_b), 1e-5, hip.ptr(xn2), None, hip.ptr(kh), hip.ptr(kl), hip.ptr(score2), hip.ptr(tokw2),
+             hip.ptr(dist), hip.ptr(smax), hip.stream_ptr())
+    rec = kh.view(torch.bfloat16).float() + kl.view(torch.bfloat16).float()
+    assert maxdiff(rec, kvn) < 3e-5 * float(kvn.abs().max())
+
+
 def test_bank_push_fifo():
     bank = torch.arange(10 * 6, dtype=torch.float32, device=DEV).reshape(10, 2, 3)
     ref = bank.clone()
