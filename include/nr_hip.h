@@ -142,6 +142,39 @@ int nr_ctm_back(const float* dist, const float* smax, const float* mask, const f
                 const float* n1_b, const float* proj_b, float eps, float* merged, float* merged_pb, float* qn,
                 int64_t* assign, void* stream);
 
+/* ---- one whole clustering stage for a group of problems ------------------------------------------------
+ * The step's form of the stage: CTM.forward (cluster.py:689-717) + TCBlock.forward (:938-965) of up to
+ * NR_CTM_MAX_GROUP independent problems -- the text and the video tokens of modeling.py:446-481 -- in
+ * seven launches that each carry the workgroups of every problem (conv GEMM, front, back, q+kv GEMMs,
+ * attention, proj GEMM, preceded by the shift|split).  All GEMMs run split-bf16 (see nr_linear_x3); the
+ * w*_hi/lo operands are the bf16 pairs (nr_split_bf16) of: the conv kernel as a [C, 3C] matrix with the
+ * three taps side by side (tap k multiplies x[n+k-1]), q.weight [C,C], kv.weight [2C,C], proj.weight [C,C].
+ * mask may be NULL (stage 1); conv_bias / q_bias / kv_bias may be NULL; assign (int64 [n_samples,N]) may
+ * be NULL.  workspace: nr_ctm_stage_workspace_bytes(n_samples, N, C, cnum) bytes, 256-byte aligned,
+ * private to the problem.  out [n_samples, cnum, C] f32.  N <= 64, C == 64*heads <= 1024.              */
+#define NR_CTM_MAX_GROUP 4
+typedef struct NrCtmStageDesc {
+    int32_t n_samples, N, C, k, cnum, heads;
+    float eps_ctm, eps_n1;
+    const float* x;
+    const float* mask;
+    const float* noise;
+    const uint16_t *wconv_hi, *wconv_lo;
+    const float* conv_bias;
+    const float *ln_w, *ln_b, *sc_w, *sc_b, *n1_w, *n1_b;
+    const uint16_t *wq_hi, *wq_lo;
+    const float* q_bias;
+    const uint16_t *wkv_hi, *wkv_lo;
+    const float* kv_bias;
+    const uint16_t *wp_hi, *wp_lo;
+    const float* proj_bias;
+    void* workspace;
+    float* out;
+    int64_t* assign;
+} NrCtmStageDesc;
+size_t nr_ctm_stage_workspace_bytes(int n_samples, int N, int C, int cluster_num);
+int nr_ctm_stage_fwd(const NrCtmStageDesc* problems, int n_problems, void* stream);
+
 /* Y[M,N] = X[M,K] W[N,K]^T (+ bias[N]) (+ residual[M,N]) in split-bf16 on the MFMA tile engine: the big
  * fp32 GEMMs of the clustering stage (token convolution cluster.py:664, kv projection :866).
  * x_hi/x_lo [M,K], w_hi/w_lo [N,K] bf16 pairs; out [M,N] f32; K % 64 == 0.

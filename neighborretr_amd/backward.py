@@ -53,7 +53,8 @@ class HeadLossFn(torch.autograd.Function):
         losses, sv = head.head_forward(text_feat.detach(), video_feat.detach(), text_mask, video_mask,
                                        mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v, gt.detach(), gv.detach(),
                                        model.scorer_weights("text_weight_fc"), model.scorer_weights("video_weight_fc"),
-                                       hp, logit_scale.detach(), prec, keep=True, join=model._take_join())
+                                       hp, logit_scale.detach(), prec, keep=True, join=model._take_join(),
+                                       bank_streams=model._bank_streams(text_feat.device))
         ctx.sv, ctx.hp, ctx.exact = sv, dict(hp), prec == hip.PREC_BF16X3
         ctx.masks = (text_mask, video_mask)
         ctx.shapes = (text_feat.shape, video_feat.shape, mb_feat_t.shape, mb_feat_v.shape, gt.shape, gv.shape)

@@ -29,6 +29,8 @@ class _StageWeights:
         # [C_out, 3*C_in] = the conv kernel as the W[N,K] operand of nr_linear_x3, split-bf16
         self.wconv_hi, self.wconv_lo = ops.split_bf16(self.wcat.t().contiguous())
         self.wkv_hi, self.wkv_lo = ops.split_bf16(blk.attn.kv.weight.detach())
+        self.wq_hi, self.wq_lo = ops.split_bf16(blk.attn.q.weight.detach())
+        self.wp_hi, self.wp_lo = ops.split_bf16(blk.attn.proj.weight.detach())
         self.wq_t = blk.attn.q.weight.detach().t().contiguous()
         self.wkv_t = blk.attn.kv.weight.detach().t().contiguous()
         self.wp_t = blk.attn.proj.weight.detach().t().contiguous()
@@ -109,3 +111,52 @@ def ctm_stage_fused(x, mask, ctm, blk, noise, cache, key):
     hip.call("nr_tc_attention", _p(q), _p(kv), _p(score), B, N, C, cnum, attn.num_heads, _p(att), st)
     out = torch.addmm(merged_pb, att, sw.wp_t)          # merged + proj(att) + proj.bias
     return out.view(B, cnum, C)
+
+
+def _addr(t):
+    return None if t is None else t.data_ptr()
+
+
+def ctm_stage_group(problems, cache):
+    """One CTM + TCBlock stage of several independent problems (text and video) in the SAME seven launches
+    (nr_ctm_stage_fwd).  problems: list of (key, x [B,N,C], mask or None, ctm, blk, noise or None).
+    Returns the list of outputs [B,cnum,C]."""
+    import ctypes
+    if not 0 < len(problems) <= hip.CTM_MAX_GROUP:
+        raise hip.NrHipError(f"1..{hip.CTM_MAX_GROUP} problems per grouped stage")
+    descs = (hip.CtmStageDesc * len(problems))()
+    keep, outs = [], []
+    for d, (key, x, mask, ctm, blk, noise) in zip(descs, problems):
+        x = x.detach().float().contiguous()
+        B, N, C = x.shape
+        dev = x.device
+        hip.ptr(x)                                           # device / contiguity check
+        sw = _stage_weights(cache, key, ctm, blk)
+        attn = blk.attn
+        cnum = max(math.ceil(N * ctm.sample_ratio), 1)
+        m = None
+        if mask is not None:
+            m = (mask if mask.dtype == torch.float32 else mask.float()).contiguous()
+        if noise is None:
+            noise = torch.rand((B, N), dtype=torch.float32, device=dev)
+        noise = noise.float().contiguous()
+        nbytes = int(hip.lib().nr_ctm_stage_workspace_bytes(B, N, C, cnum))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((B, cnum, C), dtype=torch.float32, device=dev)
+        conv_bias = getattr(ctm.conv.conv, "bias", None)
+        tensors = dict(x=x, mask=m, noise=noise, wconv_hi=sw.wconv_hi, wconv_lo=sw.wconv_lo, conv_bias=conv_bias,
+                       ln_w=ctm.norm.weight, ln_b=ctm.norm.bias, sc_w=ctm.score.weight, sc_b=ctm.score.bias,
+                       n1_w=blk.norm1.weight, n1_b=blk.norm1.bias, wq_hi=sw.wq_hi, wq_lo=sw.wq_lo, q_bias=attn.q.bias,
+                       wkv_hi=sw.wkv_hi, wkv_lo=sw.wkv_lo, kv_bias=attn.kv.bias, wp_hi=sw.wp_hi, wp_lo=sw.wp_lo,
+                       proj_bias=attn.proj.bias, workspace=ws, out=out, assign=None)
+        d.n_samples, d.N, d.C, d.k, d.cnum, d.heads = B, N, C, int(ctm.k), cnum, int(attn.num_heads)
+        d.eps_ctm, d.eps_n1 = float(ctm.norm.eps), float(blk.norm1.eps)
+        for name, t in tensors.items():
+            if t is not None and (not t.is_cuda or not t.is_contiguous()):
+                raise hip.NrHipError(f"{name}: tensors of the clustering stage must be contiguous GPU tensors")
+            setattr(d, name, _addr(t))
+        keep.append(tensors)
+        outs.append(out)
+    hip.call("nr_ctm_stage_fwd", descs, len(problems), hip.stream_ptr())
+    del keep
+    return outs

@@ -5,7 +5,7 @@
 //   nr_ctm_norm_score      LayerNorm -> token score (+mask -> -inf) -> exp -> the block's norm1
 //   nr_merge_ln            weighted mean of every cluster's tokens (merge_tokens) + norm1 of the result
 //   nr_tc_attention        8-head attention of the merged tokens over the un-merged ones, score-biased
-#include "nr_common.h"
+#include "nr_ctm_bodies.h"
 #include "../../include/nr_hip.h"
 
 // ---- x[n-1] | x[n] | x[n+1] ---------------------------------------------------------------------------
@@ -179,48 +179,15 @@ extern "C" int nr_merge_ln(const float* xn, const int64_t* assign, const float* 
     return NR_OK;
 }
 
-// ---- score-biased multi-head attention: merged tokens (queries) over un-merged tokens ---------------------
-// 16 waves, one per (head, query); lane = key for the logits / softmax, lane = channel for the value sum.
-// head_dim = 64, N <= 64.
-__global__ __launch_bounds__(1024) void nr_tc_attention_kernel(const float* __restrict__ q, const float* __restrict__ kv,
-                                                              const float* __restrict__ score, int N, int C, int cnum, int H,
-                                                              float scale, float* __restrict__ out) {
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* kvb = kv + (size_t)b * N * 2 * C;
-    for (int job = wave; job < H * cnum; job += 16) {
-        const int h = job / cnum, cl = job - h * cnum;
-        const float* qr = q + ((size_t)b * cnum + cl) * C + h * 64;
-        float logit = -INFINITY;
-        if (lane < N) {
-            const float* kr = kvb + (size_t)lane * 2 * C + h * 64;
-            float dot = 0.f;
-#pragma unroll
-            for (int j = 0; j < 64; j += 4) {
-                f32x4_t kk = *reinterpret_cast<const f32x4_t*>(kr + j);
-                f32x4_t qq = *reinterpret_cast<const f32x4_t*>(qr + j);
-                dot += (qq[0] * scale) * kk[0] + (qq[1] * scale) * kk[1] + (qq[2] * scale) * kk[2] + (qq[3] * scale) * kk[3];
-            }
-            logit = dot + score[(size_t)b * N + lane];
-        }
-        const float m = nr_wave_max(logit);
-        float e = lane < N ? expf(logit - m) : 0.f;
-        const float den = nr_wave_sum(e);
-        const float p = e / den;
-        float acc = 0.f;
-        for (int n = 0; n < N; ++n) {
-            float pn = __shfl(p, n);
-            acc += pn * kvb[(size_t)n * 2 * C + C + h * 64 + lane];
-        }
-        out[((size_t)b * cnum + cl) * C + h * 64 + lane] = acc;
-    }
-}
+// ---- score-biased multi-head attention (body in nr_ctm_bodies.h) ---------------------------------------------
+__global__ __launch_bounds__(1024) void nr_tc_attention_kernel(NrAttnArgs a) { nr_tc_attention_body(a, blockIdx.x); }
 
 extern "C" int nr_tc_attention(const float* q, const float* kv, const float* score, int n_samples, int N, int C, int cnum,
                                int H, float* out, void* stream) {
     if (!q || !kv || !score || !out || n_samples <= 0 || N <= 0 || cnum <= 0 || H <= 0) return NR_EINVAL;
     if (N > 64 || C != H * 64) return NR_EUNSUPPORTED;
-    hipLaunchKernelGGL(nr_tc_attention_kernel, dim3(n_samples), dim3(1024), 0, (hipStream_t)stream, q, kv, score, N, C, cnum, H,
-                       1.0f / sqrtf(64.0f), out);
+    NrAttnArgs a{q, kv, score, N, C, cnum, H, 1.0f / sqrtf(64.0f), out, nullptr, nullptr};
+    hipLaunchKernelGGL(nr_tc_attention_kernel, dim3(n_samples), dim3(1024), 0, (hipStream_t)stream, a);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

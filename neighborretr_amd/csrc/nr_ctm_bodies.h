@@ -1,0 +1,351 @@
+// Device bodies of the clustering-stage kernels, shared by the one-problem launches (nr_ctm_fused.hip,
+// nr_ctm.hip) and the grouped launches that run the text and the video problem of a stage in the same
+// grid (nr_ctm_group.hip).  Reference: cluster.py:453-561 (DPC-KNN, merge_tokens), :689-717 (CTM.forward),
+// :834-888 (score-biased attention).
+#pragma once
+#include "nr_common.h"
+
+#define CF_THREADS 1024
+#define CF_MAX_CPL 16      // C <= 1024
+
+struct NrCtmFrontArgs {
+    const float *y, *mask, *ln_w, *ln_b, *sc_w, *sc_b, *n1_w, *n1_b;
+    float eps, inv_sqrt_c;
+    int N, C;
+    float *xn, *kvn, *score, *tokw, *dist, *smax;
+    uint16_t *kvn_hi, *kvn_lo;       // when set, norm1(xn) is written split-bf16 (operand of the kv GEMM) instead of f32
+};
+
+// b = sample index; sx = N*C floats of (dynamic) LDS.  Called by all CF_THREADS threads of the workgroup.
+__device__ __forceinline__ void nr_ctm_front_body(const NrCtmFrontArgs& p, const int b, float* sx) {
+    __shared__ float s_wmax[CF_THREADS / 64];
+    const int N = p.N, C = p.C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = CF_THREADS / 64;
+    const int cpl = C / 64;
+    // ---- phase 1: one wave per token row ------------------------------------------------------------
+    for (int r = wave; r < N; r += NW) {
+        const size_t row = (size_t)b * N + r;
+        const float* yr = p.y + row * C;
+        float v[CF_MAX_CPL];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < CF_MAX_CPL; ++q) {
+            v[q] = q < cpl ? yr[q * 64 + lane] : 0.f;
+            s += v[q];
+        }
+        const float mu = nr_wave_sum(s) / (float)C;
+        float var = 0.f;
+#pragma unroll
+        for (int q = 0; q < CF_MAX_CPL; ++q)
+            if (q < cpl) { float dlt = v[q] - mu; var += dlt * dlt; }
+        const float rstd = rsqrtf(nr_wave_sum(var) / (float)C + p.eps);
+        float dot = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < CF_MAX_CPL; ++q)
+            if (q < cpl) {
+                int c = q * 64 + lane;
+                v[q] = (v[q] - mu) * rstd * p.ln_w[c] + p.ln_b[c];
+                p.xn[row * C + c] = v[q];
+                sx[r * C + c] = v[q];
+                dot += v[q] * p.sc_w[c];
+                s2 += v[q];
+            }
+        float sc = nr_wave_sum(dot) + p.sc_b[0];
+        if (p.mask && p.mask[row] == 0.f) sc = -INFINITY;
+        if (lane == 0) {
+            p.score[row] = sc;
+            p.tokw[row] = expf(sc);
+        }
+        const float mu2 = nr_wave_sum(s2) / (float)C;
+        float var2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < CF_MAX_CPL; ++q)
+            if (q < cpl) { float dlt = v[q] - mu2; var2 += dlt * dlt; }
+        const float rstd2 = rsqrtf(nr_wave_sum(var2) / (float)C + p.eps);
+#pragma unroll
+        for (int q = 0; q < CF_MAX_CPL; ++q)
+            if (q < cpl) {
+                int c = q * 64 + lane;
+                float kv = (v[q] - mu2) * rstd2 * p.n1_w[c] + p.n1_b[c];
+                if (p.kvn_hi) {
+                    uint16_t h = nr_f2bf(kv);
+                    p.kvn_hi[row * C + c] = h;
+                    p.kvn_lo[row * C + c] = nr_f2bf(kv - nr_bf2f(h));
+                } else {
+                    p.kvn[row * C + c] = kv;
+                }
+            }
+    }
+    __syncthreads();
+    // ---- phase 2: pairwise distances, wave per row of the upper triangle -------------------------------
+    float wmax = 0.f;
+    float* db = p.dist + (size_t)b * N * N;
+    for (int i = wave; i < N; i += NW) {
+        float xi[CF_MAX_CPL];
+#pragma unroll
+        for (int q = 0; q < CF_MAX_CPL; ++q) xi[q] = q < cpl ? sx[i * C + q * 64 + lane] : 0.f;
+        if (lane == 0) db[i * N + i] = 0.f;
+        for (int j = i + 1; j < N; j += 2) {
+            const bool two = j + 1 < N;
+            const float* xj0 = sx + j * C;
+            const float* xj1 = sx + (two ? j + 1 : j) * C;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < CF_MAX_CPL; ++q)
+                if (q < cpl) {
+                    int c = q * 64 + lane;
+                    float d0 = xi[q] - xj0[c], d1 = xi[q] - xj1[c];
+                    s0 += d0 * d0;
+                    s1 += d1 * d1;
+                }
+            s0 = nr_wave_sum(s0);
+            s1 = nr_wave_sum(s1);
+            float dv0 = sqrtf(s0) * p.inv_sqrt_c, dv1 = sqrtf(s1) * p.inv_sqrt_c;
+            wmax = fmaxf(wmax, dv0);
+            if (two) wmax = fmaxf(wmax, dv1);
+            if (lane == 0) {
+                db[i * N + j] = dv0;
+                db[j * N + i] = dv0;
+                if (two) {
+                    db[i * N + j + 1] = dv1;
+                    db[(j + 1) * N + i] = dv1;
+                }
+            }
+        }
+    }
+    if (lane == 0) s_wmax[wave] = wmax;
+    __syncthreads();
+    if (tid == 0) {
+        float m = 0.f;
+        for (int w = 0; w < NW; ++w) m = fmaxf(m, s_wmax[w]);
+        p.smax[b] = m;
+    }
+}
+
+
+// ---- assignment + merge -------------------------------------------------------------------------------------
+struct NrCtmBackArgs {
+    const float *dist, *smax, *mask, *noise, *xn, *tokw, *n1_w, *n1_b, *proj_b;
+    int n_samples, N, C, k, cnum;
+    float eps;
+    float *merged, *merged_pb, *qn;
+    int64_t* assign;
+    uint16_t *qn_hi, *qn_lo;         // when set, norm1(merged) is written split-bf16 instead of f32
+};
+
+// b = sample index.  Called by all 256 threads of the workgroup.
+__device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const int b) {
+    __shared__ float sd[64][65];
+    __shared__ float s_density[64], s_score[64], s_share[64], s_tot[64];
+    __shared__ int s_centre[64], s_assign[64];
+    __shared__ float s_red[2][4];
+    const int N = p.N, C = p.C, cnum = p.cnum;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // global maximum over all samples (cluster.py:473-475)
+    float g = 0.f;
+    for (int i = tid; i < p.n_samples; i += 256) g = fmaxf(g, p.smax[i]);
+    g = nr_wave_max(g);
+    if (lane == 0) s_red[0][wave] = g;
+    __syncthreads();
+    const float far = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3])) + 1.0f;
+    const float* db = p.dist + (size_t)b * N * N;
+    const float* mb = p.mask ? p.mask + (size_t)b * N : nullptr;
+    float lmax = 0.f;
+    for (int e = tid; e < N * N; e += 256) {
+        int i = e / N, j = e - i * N;
+        float dv = db[e];
+        if (mb && !(mb[j] > 0.f)) dv = far;
+        sd[i][j] = dv;
+        lmax = fmaxf(lmax, dv);
+    }
+    lmax = nr_wave_max(lmax);
+    if (lane == 0) s_red[1][wave] = lmax;
+    __syncthreads();
+    const float dmax = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
+    for (int i = wave; i < N; i += 4) {               // local density
+        float v = lane < N ? sd[i][lane] : INFINITY;
+        float acc = 0.f;
+        for (int r = 0; r < p.k; ++r) {
+            float m = v;
+            int idx = lane;
+            nr_wave_argmin(m, idx);
+            acc += m * m;
+            if (lane == idx) v = INFINITY;
+        }
+        if (lane == 0) {
+            float dens = expf(-acc / (float)p.k) + p.noise[(size_t)b * N + i] * 1e-6f;
+            if (mb) dens *= (mb[i] > 0.f) ? 1.0f : 0.0f;
+            s_density[i] = dens;
+        }
+    }
+    __syncthreads();
+    for (int i = wave; i < N; i += 4) {               // distance to the nearest denser token; score
+        float di = s_density[i];
+        float v = (lane < N && s_density[lane] > di) ? sd[i][lane] : dmax;
+        v = nr_wave_min(v);
+        if (lane == 0) s_score[i] = v * di;
+    }
+    __syncthreads();
+    if (wave == 0) {                                  // top-cnum centres
+        float v = lane < N ? s_score[lane] : -INFINITY;
+        for (int c = 0; c < cnum; ++c) {
+            float m = v;
+            int idx = lane;
+            nr_wave_argmax(m, idx);
+            if (lane == 0) s_centre[c] = idx;
+            if (lane == idx) v = -INFINITY;
+        }
+    }
+    __syncthreads();
+    if (tid < N) {                                    // nearest centre; centres join themselves
+        float best = INFINITY;
+        int bc = 0;
+        for (int c = 0; c < cnum; ++c) {
+            float dv = sd[s_centre[c]][tid];
+            if (dv < best) { best = dv; bc = c; }
+        }
+        for (int c = 0; c < cnum; ++c)
+            if (s_centre[c] == tid) bc = c;
+        s_assign[tid] = bc;
+        if (p.assign) p.assign[(size_t)b * N + tid] = bc;
+    }
+    __syncthreads();
+    // ---- merge_tokens + norm1 ---------------------------------------------------------------------------
+    if (tid < cnum) {
+        float t = 0.f;
+        for (int n = 0; n < N; ++n)
+            if (s_assign[n] == tid) t += p.tokw[(size_t)b * N + n];
+        s_tot[tid] = t + 1e-6f;
+    }
+    __syncthreads();
+    if (tid < N) s_share[tid] = p.tokw[(size_t)b * N + tid] / s_tot[s_assign[tid]];
+    __syncthreads();
+    const float* xb = p.xn + (size_t)b * N * C;
+    for (int cl = 0; cl < cnum; ++cl) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < N; ++n) {
+            if (s_assign[n] != cl) continue;
+            const float sh = s_share[n];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int c = q * 256 + tid;
+                if (c < C) acc[q] += xb[(size_t)n * C + c] * sh;
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += (q * 256 + tid < C) ? acc[q] : 0.f;
+        s = nr_wave_sum(s);
+        if (lane == 0) s_red[0][wave] = s;
+        __syncthreads();
+        const float mu = (s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3]) / (float)C;
+        float var = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q * 256 + tid < C) { float dlt = acc[q] - mu; var += dlt * dlt; }
+        var = nr_wave_sum(var);
+        if (lane == 0) s_red[1][wave] = var;
+        __syncthreads();
+        const float rstd = rsqrtf((s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]) / (float)C + p.eps);
+        const size_t o = ((size_t)b * cnum + cl) * C;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int c = q * 256 + tid;
+            if (c < C) {
+                if (p.merged) p.merged[o + c] = acc[q];
+                p.merged_pb[o + c] = acc[q] + p.proj_b[c];
+                const float qv = (acc[q] - mu) * rstd * p.n1_w[c] + p.n1_b[c];
+                if (p.qn_hi) {                       // operand of the q GEMM, split-bf16
+                    const uint16_t h = nr_f2bf(qv);
+                    p.qn_hi[o + c] = h;
+                    p.qn_lo[o + c] = nr_f2bf(qv - nr_bf2f(h));
+                } else {
+                    p.qn[o + c] = qv;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
+// ---- score-biased multi-head attention: merged tokens (queries) over un-merged tokens ---------------------
+// 16 waves, one per (head, query); lane = key for the logits / softmax, lane = channel for the value sum.
+// head_dim = 64, N <= 64.
+struct NrAttnArgs {
+    const float *q, *kv, *score;
+    int N, C, cnum, H;
+    float scale;
+    float* out;
+    uint16_t *out_hi, *out_lo;       // when set, the result is written split-bf16 (operand of the proj GEMM)
+};
+
+__device__ __forceinline__ void nr_tc_attention_body(const NrAttnArgs& a, const int b) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int N = a.N, C = a.C, cnum = a.cnum;
+    const float scale = a.scale;
+    const float* kvb = a.kv + (size_t)b * N * 2 * C;
+    for (int job = wave; job < a.H * cnum; job += 16) {
+        const int h = job / cnum, cl = job - h * cnum;
+        const float* qr = a.q + ((size_t)b * cnum + cl) * C + h * 64;
+        float logit = -INFINITY;
+        if (lane < N) {
+            const float* kr = kvb + (size_t)lane * 2 * C + h * 64;
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 64; j += 4) {
+                f32x4_t kk = *reinterpret_cast<const f32x4_t*>(kr + j);
+                f32x4_t qq = *reinterpret_cast<const f32x4_t*>(qr + j);
+                dot += (qq[0] * scale) * kk[0] + (qq[1] * scale) * kk[1] + (qq[2] * scale) * kk[2] + (qq[3] * scale) * kk[3];
+            }
+            logit = dot + a.score[(size_t)b * N + lane];
+        }
+        const float m = nr_wave_max(logit);
+        float e = lane < N ? expf(logit - m) : 0.f;
+        const float den = nr_wave_sum(e);
+        const float p = e / den;
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) {
+            float pn = __shfl(p, n);
+            acc += pn * kvb[(size_t)n * 2 * C + C + h * 64 + lane];
+        }
+        const size_t o = ((size_t)b * cnum + cl) * C + h * 64 + lane;
+        if (a.out_hi) {
+            const uint16_t hh = nr_f2bf(acc);
+            a.out_hi[o] = hh;
+            a.out_lo[o] = nr_f2bf(acc - nr_bf2f(hh));
+        } else {
+            a.out[o] = acc;
+        }
+    }
+}
+
+// ---- x[n-1] | x[n] | x[n+1] of one token row, written as bf16 hi / lo (operand of the conv GEMM) ------------
+struct NrShiftArgs {
+    const float* x;
+    int N, C;
+    uint16_t *hi, *lo;
+};
+
+__device__ __forceinline__ void nr_shift_split_body(const NrShiftArgs& a, const int row) {
+    const int n = row % a.N, C = a.C;
+    for (int k = 0; k < 3; ++k) {
+        const int nn = n + k - 1;
+        const bool ok = nn >= 0 && nn < a.N;
+        const float* src = a.x + (size_t)(row + k - 1) * C;
+        const size_t o = (size_t)row * 3 * C + (size_t)k * C;
+        for (int c = threadIdx.x * 4; c < C; c += 1024) {
+            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4_t*>(src + c);
+            uint16_t h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = nr_f2bf(v[e]);
+                l[e] = nr_f2bf(v[e] - nr_bf2f(h[e]));
+            }
+            *reinterpret_cast<uint2*>(a.hi + o + c) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            *reinterpret_cast<uint2*>(a.lo + o + c) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+        }
+    }
+}

@@ -1,0 +1,209 @@
+// One CTM + TCBlock stage (reference cluster.py:670-717 + :938-965, no-grad forward) for a GROUP of
+// independent problems -- in the training step: the text and the video tokens -- in SEVEN launches:
+//   shift|split -> conv GEMM (+x) -> front (LayerNorm, score, norm1, distances) -> back (DPC-KNN, merge, norm1)
+//   -> q and kv GEMMs (one grouped launch) -> score-biased attention -> proj GEMM (+merged +bias)
+// Every launch carries the workgroups of all problems of the group (workgroup -> problem through a prefix
+// table), so the two modalities advance in lockstep inside the same grids instead of competing from two
+// streams: measured on MI355X, two clustering branches on two streams overlap to only ~0.68 of their
+// summed time, while a grid that holds both costs max(text, video).  All GEMMs run split-bf16 on the MFMA
+// tile engine (nr_linear.hip); their A operands are written hi/lo directly by the producing kernel.
+#include "nr_ctm_bodies.h"
+#include "nr_linear.h"
+#include "../../include/nr_hip.h"
+
+template <typename A>
+struct NrGroupOf {
+    A p[NR_CTM_MAX_GROUP];
+    int start[NR_CTM_MAX_GROUP + 1];     // first workgroup of every problem
+    int n;
+    __device__ __forceinline__ int find(int wg) const {
+        int g = 0;
+#pragma unroll
+        for (int i = 1; i < NR_CTM_MAX_GROUP; ++i)
+            if (i < n && wg >= start[i]) g = i;
+        return g;
+    }
+};
+
+__global__ __launch_bounds__(256) void nr_group_shift_kernel(NrGroupOf<NrShiftArgs> g) {
+    const int gi = g.find(blockIdx.x);
+    nr_shift_split_body(g.p[gi], blockIdx.x - g.start[gi]);
+}
+
+__global__ __launch_bounds__(CF_THREADS) void nr_group_front_kernel(NrGroupOf<NrCtmFrontArgs> g) {
+    extern __shared__ __attribute__((aligned(16))) float sx[];
+    const int gi = g.find(blockIdx.x);
+    nr_ctm_front_body(g.p[gi], blockIdx.x - g.start[gi], sx);
+}
+
+__global__ __launch_bounds__(256) void nr_group_back_kernel(NrGroupOf<NrCtmBackArgs> g) {
+    const int gi = g.find(blockIdx.x);
+    nr_ctm_back_body(g.p[gi], blockIdx.x - g.start[gi]);
+}
+
+__global__ __launch_bounds__(1024) void nr_group_attention_kernel(NrGroupOf<NrAttnArgs> g) {
+    const int gi = g.find(blockIdx.x);
+    nr_tc_attention_body(g.p[gi], blockIdx.x - g.start[gi]);
+}
+
+// ---- workspace carve-up --------------------------------------------------------------------------------------
+namespace {
+struct Carve {
+    char* base;
+    size_t off;
+    template <typename T>
+    T* take(size_t count) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += (count * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+struct StageBuffers {
+    uint16_t *cat_hi, *cat_lo, *kvn_hi, *kvn_lo, *qn_hi, *qn_lo, *att_hi, *att_lo;
+    float *y, *xn, *score, *tokw, *dist, *smax, *merged_pb, *q, *kv;
+    size_t bytes;
+};
+
+StageBuffers carve(void* ws, long B, long N, long C, long cnum) {
+    Carve c{static_cast<char*>(ws), 0};
+    StageBuffers s;
+    s.cat_hi = c.take<uint16_t>(B * N * 3 * C);
+    s.cat_lo = c.take<uint16_t>(B * N * 3 * C);
+    s.y = c.take<float>(B * N * C);
+    s.xn = c.take<float>(B * N * C);
+    s.kvn_hi = c.take<uint16_t>(B * N * C);
+    s.kvn_lo = c.take<uint16_t>(B * N * C);
+    s.score = c.take<float>(B * N);
+    s.tokw = c.take<float>(B * N);
+    s.dist = c.take<float>(B * N * N);
+    s.smax = c.take<float>(B);
+    s.merged_pb = c.take<float>(B * cnum * C);
+    s.qn_hi = c.take<uint16_t>(B * cnum * C);
+    s.qn_lo = c.take<uint16_t>(B * cnum * C);
+    s.q = c.take<float>(B * cnum * C);
+    s.kv = c.take<float>(B * N * 2 * C);
+    s.att_hi = c.take<uint16_t>(B * cnum * C);
+    s.att_lo = c.take<uint16_t>(B * cnum * C);
+    s.bytes = c.off;
+    return s;
+}
+}  // namespace
+
+extern "C" size_t nr_ctm_stage_workspace_bytes(int n_samples, int N, int C, int cluster_num) {
+    if (n_samples <= 0 || N <= 0 || C <= 0 || cluster_num <= 0) return 0;
+    return carve(nullptr, n_samples, N, C, cluster_num).bytes;
+}
+
+extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
+    if (!d || n <= 0 || n > NR_CTM_MAX_GROUP) return NR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    StageBuffers w[NR_CTM_MAX_GROUP];
+    size_t front_lds = 0;
+    for (int i = 0; i < n; ++i) {
+        const NrCtmStageDesc& s = d[i];
+        if (!s.x || !s.noise || !s.wconv_hi || !s.wconv_lo || !s.ln_w || !s.ln_b || !s.sc_w || !s.sc_b || !s.n1_w || !s.n1_b ||
+            !s.wq_hi || !s.wq_lo || !s.wkv_hi || !s.wkv_lo || !s.wp_hi || !s.wp_lo || !s.proj_bias || !s.workspace || !s.out)
+            return NR_EINVAL;
+        if (s.n_samples <= 0 || s.N <= 0 || s.k <= 0 || s.k > s.N || s.cnum <= 0 || s.cnum > s.N || s.heads <= 0) return NR_EINVAL;
+        if (s.N > 64 || s.C <= 0 || (s.C % 64) != 0 || s.C > 1024 || s.C != s.heads * 64) return NR_EUNSUPPORTED;
+        w[i] = carve(s.workspace, s.n_samples, s.N, s.C, s.cnum);
+        size_t lds = (size_t)s.N * s.C * sizeof(float);
+        if (lds > 150 * 1024) return NR_EUNSUPPORTED;
+        front_lds = lds > front_lds ? lds : front_lds;
+    }
+    int rc;
+    // 1. x[n-1] | x[n] | x[n+1] as split-bf16 rows
+    {
+        NrGroupOf<NrShiftArgs> g;
+        g.n = n;
+        int total = 0;
+        for (int i = 0; i < n; ++i) {
+            g.p[i] = NrShiftArgs{d[i].x, d[i].N, d[i].C, w[i].cat_hi, w[i].cat_lo};
+            g.start[i] = total;
+            total += d[i].n_samples * d[i].N;
+        }
+        for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
+        hipLaunchKernelGGL(nr_group_shift_kernel, dim3(total), dim3(256), 0, st, g);
+        NR_LAUNCH_CHECK();
+    }
+    // 2. y = x + conv(x)  (k=3 convolution as a [B*N, 3C] x [3C, C] product)
+    {
+        NrLinearArgs p[NR_CTM_MAX_GROUP];
+        for (int i = 0; i < n; ++i)
+            p[i] = NrLinearArgs{w[i].cat_hi, w[i].cat_lo, d[i].wconv_hi, d[i].wconv_lo, d[i].conv_bias, d[i].x, w[i].y,
+                                d[i].n_samples * d[i].N, d[i].C, 3 * d[i].C};
+        if ((rc = nr_linear_group_launch(p, n, st)) != NR_OK) return rc;
+    }
+    // 3. LayerNorm, score, exp, norm1, pairwise distances
+    {
+        NrGroupOf<NrCtmFrontArgs> g;
+        g.n = n;
+        int total = 0;
+        for (int i = 0; i < n; ++i) {
+            const NrCtmStageDesc& s = d[i];
+            g.p[i] = NrCtmFrontArgs{w[i].y, s.mask, s.ln_w, s.ln_b, s.sc_w, s.sc_b, s.n1_w, s.n1_b, s.eps_ctm, 1.0f / sqrtf((float)s.C),
+                                    s.N, s.C, w[i].xn, nullptr, w[i].score, w[i].tokw, w[i].dist, w[i].smax, w[i].kvn_hi, w[i].kvn_lo};
+            g.start[i] = total;
+            total += s.n_samples;
+        }
+        for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
+        if (front_lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)nr_group_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(nr_group_front_kernel, dim3(total), dim3(CF_THREADS), front_lds, st, g);
+        NR_LAUNCH_CHECK();
+    }
+    // 4. DPC-KNN assignment, weighted cluster means, norm1
+    {
+        NrGroupOf<NrCtmBackArgs> g;
+        g.n = n;
+        int total = 0;
+        for (int i = 0; i < n; ++i) {
+            const NrCtmStageDesc& s = d[i];
+            g.p[i] = NrCtmBackArgs{w[i].dist, w[i].smax, s.mask, s.noise, w[i].xn, w[i].tokw, s.n1_w, s.n1_b, s.proj_bias,
+                                   s.n_samples, s.N, s.C, s.k, s.cnum, s.eps_n1, nullptr, w[i].merged_pb, nullptr, s.assign,
+                                   w[i].qn_hi, w[i].qn_lo};
+            g.start[i] = total;
+            total += s.n_samples;
+        }
+        for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
+        hipLaunchKernelGGL(nr_group_back_kernel, dim3(total), dim3(256), 0, st, g);
+        NR_LAUNCH_CHECK();
+    }
+    // 5. q = norm1(merged) Wq^T (+b), kv = norm1(xn) Wkv^T (+b): 2n problems, one launch
+    {
+        NrLinearArgs p[2 * NR_CTM_MAX_GROUP];
+        for (int i = 0; i < n; ++i) {
+            const NrCtmStageDesc& s = d[i];
+            p[i] = NrLinearArgs{w[i].kvn_hi, w[i].kvn_lo, s.wkv_hi, s.wkv_lo, s.kv_bias, nullptr, w[i].kv, s.n_samples * s.N, 2 * s.C, s.C};
+            p[n + i] = NrLinearArgs{w[i].qn_hi, w[i].qn_lo, s.wq_hi, s.wq_lo, s.q_bias, nullptr, w[i].q, s.n_samples * s.cnum, s.C, s.C};
+        }
+        if ((rc = nr_linear_group_launch(p, 2 * n, st)) != NR_OK) return rc;
+    }
+    // 6. score-biased attention of the merged tokens over the un-merged ones
+    {
+        NrGroupOf<NrAttnArgs> g;
+        g.n = n;
+        int total = 0;
+        for (int i = 0; i < n; ++i) {
+            const NrCtmStageDesc& s = d[i];
+            g.p[i] = NrAttnArgs{w[i].q, w[i].kv, w[i].score, s.N, s.C, s.cnum, s.heads, 1.0f / sqrtf(64.0f), nullptr, w[i].att_hi, w[i].att_lo};
+            g.start[i] = total;
+            total += s.n_samples;
+        }
+        for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
+        hipLaunchKernelGGL(nr_group_attention_kernel, dim3(total), dim3(1024), 0, st, g);
+        NR_LAUNCH_CHECK();
+    }
+    // 7. out = merged + proj(att) + proj.bias
+    {
+        NrLinearArgs p[NR_CTM_MAX_GROUP];
+        for (int i = 0; i < n; ++i)
+            p[i] = NrLinearArgs{w[i].att_hi, w[i].att_lo, d[i].wp_hi, d[i].wp_lo, nullptr, w[i].merged_pb, d[i].out,
+                                d[i].n_samples * d[i].cnum, d[i].C, d[i].C};
+        if ((rc = nr_linear_group_launch(p, n, st)) != NR_OK) return rc;
+    }
+    return NR_OK;
+}

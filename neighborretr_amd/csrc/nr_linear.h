@@ -1,0 +1,17 @@
+// Internal (not exported) interface of the split-bf16 linear kernels: one launch for a GROUP of
+// independent problems Y_g = X_g W_g^T (+bias_g) (+residual_g) -- used by the clustering stage, which
+// runs its text and video problems side by side (nr_ctm_group.hip).
+#pragma once
+#include "nr_common.h"
+
+struct NrLinearArgs {
+    const uint16_t *x_hi, *x_lo, *w_hi, *w_lo;
+    const float *bias, *residual;
+    float* out;
+    int M, N, K;
+};
+
+#define NR_LINEAR_MAX_GROUP 8
+
+// All problems of a group are tiled with the same tile shape; K % 64 == 0 for each.
+int nr_linear_group_launch(const NrLinearArgs* probs, int n_probs, hipStream_t stream);

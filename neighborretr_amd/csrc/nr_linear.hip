@@ -4,23 +4,25 @@
 // hi + lo, products Ah*Bh + Ah*Bl + Al*Bh, fp32 accumulate) and bf16-pipe speed.
 // X arrives already split (nr_shift_concat_split / nr_ctm_front write hi/lo directly), W is split once
 // per parameter version by the host.
+#include <cstdio>
+#include <cstdlib>
 #include "nr_gemm_tile.h"
+#include "nr_linear.h"
+#include "nr_ctm_bodies.h"
 #include "../../include/nr_hip.h"
 
-struct NrLinearArgs {
-    const uint16_t *x_hi, *x_lo, *w_hi, *w_lo;
-    const float *bias, *residual;
-    float* out;
-    int M, N, K;
+struct NrLinearGroup {
+    NrLinearArgs p[NR_LINEAR_MAX_GROUP];
+    int tile_start[NR_LINEAR_MAX_GROUP + 1];    // first workgroup of every problem
+    int n;
 };
 
 template <int MI, int NI, int STAGES>
-__global__ __launch_bounds__(256) void nr_linear_kernel(NrLinearArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void nr_linear_tile(const NrLinearArgs& p, const int tile_row, const int tile_col, char* smem) {
     using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int row0 = blockIdx.y * Tile::BM, col0 = blockIdx.x * Tile::BN;
+    const int row0 = tile_row * Tile::BM, col0 = tile_col * Tile::BN;
     Tile tile;
     tile.zero();
     tile.run(p.x_hi, p.x_lo, row0, p.M, p.w_hi, p.w_lo, col0, p.N, p.K, smem);
@@ -44,6 +46,27 @@ __global__ __launch_bounds__(256) void nr_linear_kernel(NrLinearArgs p) {
 }
 
 template <int MI, int NI, int STAGES>
+__global__ __launch_bounds__(256) void nr_linear_kernel(NrLinearArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    nr_linear_tile<MI, NI, STAGES>(p, blockIdx.y, blockIdx.x, smem);
+}
+
+// grouped: workgroup -> (problem, tile) through the prefix table; tiles of a problem are column-fastest
+template <int MI, int NI, int STAGES>
+__global__ __launch_bounds__(256) void nr_linear_group_kernel(NrLinearGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int gi = 0;
+    const int wg = blockIdx.x;
+#pragma unroll
+    for (int i = 1; i < NR_LINEAR_MAX_GROUP; ++i)
+        if (i < g.n && wg >= g.tile_start[i]) gi = i;
+    const NrLinearArgs& p = g.p[gi];
+    const int t = wg - g.tile_start[gi];
+    const int ncol = (p.N + 32 * NI - 1) / (32 * NI);
+    nr_linear_tile<MI, NI, STAGES>(p, t / ncol, t % ncol, smem);
+}
+
+template <int MI, int NI, int STAGES>
 static int nr_linear_launch_s(NrLinearArgs& a, hipStream_t st) {
     using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES>;
     size_t lds = Tile::RING_BYTES;
@@ -64,6 +87,61 @@ static int nr_linear_launch(NrLinearArgs& a, hipStream_t st) {
     return nr_linear_launch_s<MI, NI, 2>(a, st);
 }
 
+template <int MI, int NI, int STAGES>
+static int nr_linear_group_launch_s(const NrLinearArgs* probs, int n, hipStream_t st) {
+    using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES>;
+    NrLinearGroup g;
+    g.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        g.p[i] = probs[i];
+        g.tile_start[i] = total;
+        total += ((probs[i].M + Tile::BM - 1) / Tile::BM) * ((probs[i].N + Tile::BN - 1) / Tile::BN);
+    }
+    for (int i = n; i <= NR_LINEAR_MAX_GROUP; ++i) g.tile_start[i] = total;
+    size_t lds = Tile::RING_BYTES;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)nr_linear_group_kernel<MI, NI, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((nr_linear_group_kernel<MI, NI, STAGES>), dim3(total), dim3(256), lds, st, g);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// Tile shape / ring depth of a grouped launch.  NR_LINEAR_TILE="MI,NI,STAGES" overrides (tuning only).
+int nr_linear_group_launch(const NrLinearArgs* probs, int n, hipStream_t st) {
+    if (!probs || n <= 0 || n > NR_LINEAR_MAX_GROUP) return NR_EINVAL;
+    long t32x64 = 0, t128 = 0;
+    for (int i = 0; i < n; ++i) {
+        const NrLinearArgs& a = probs[i];
+        if (!a.x_hi || !a.x_lo || !a.w_hi || !a.w_lo || !a.out || a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % 64) != 0) return NR_EINVAL;
+        t32x64 += (long)((a.M + 31) / 32) * ((a.N + 63) / 64);
+        t128 += (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    }
+    // Measured on MI355X over the clustering-stage shapes (tools/cluster_times.py under rocprofv3, us):
+    //   <= 256 tiles of 32x64 (proj, stage-1 conv: one workgroup per CU, latency-bound K loop): 4-deep ring
+    //       <1,2,4> 6.9 / 10.5   vs <1,2,2> 8.2 / 13.6   vs <2,2,2> 11.7 / 17.5
+    //   <= 1536 (stage-1 q+kv, stage-0 conv): <1,2,2> 8.8 / 44.8   vs <2,2,1> 13.0 / 50.8   vs <2,4,1> 18.2 / 53.8
+    //   larger (stage-0 q+kv): <2,4,1> 27.9   vs <2,2,1> 28.2   vs <1,2,2> 31.9;   128x128 once that fills the chip twice
+    int mi, ni, stg;
+    if (t32x64 <= 256) { mi = 1; ni = 2; stg = 4; }
+    else if (t32x64 <= 1536) { mi = 1; ni = 2; stg = 2; }
+    else if (t128 < 1024) { mi = 2; ni = 4; stg = 1; }
+    else { mi = 4; ni = 4; stg = 1; }
+    if (const char* ov = getenv("NR_LINEAR_TILE")) {
+        int a_, b_, c_;
+        if (sscanf(ov, "%d,%d,%d", &a_, &b_, &c_) == 3) { mi = a_; ni = b_; stg = c_; }
+    }
+#define NR_LG_CASE(MI_, NI_, ST_) if (mi == MI_ && ni == NI_ && stg == ST_) return nr_linear_group_launch_s<MI_, NI_, ST_>(probs, n, st)
+    NR_LG_CASE(4, 4, 1);
+    NR_LG_CASE(2, 4, 1); NR_LG_CASE(2, 4, 2);
+    NR_LG_CASE(2, 2, 1); NR_LG_CASE(2, 2, 2);
+    NR_LG_CASE(1, 2, 2); NR_LG_CASE(1, 2, 4);
+#undef NR_LG_CASE
+    return NR_EUNSUPPORTED;
+}
+
 extern "C" int nr_linear_x3(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* w_hi, const uint16_t* w_lo,
                             const float* bias, const float* residual, int M, int N, int K, float* out, void* stream) {
     if (!x_hi || !x_lo || !w_hi || !w_lo || !out || M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0) return NR_EINVAL;
@@ -75,34 +153,13 @@ extern "C" int nr_linear_x3(const uint16_t* x_hi, const uint16_t* x_lo, const ui
     return nr_linear_launch<2, 4>(a, st);
 }
 
-// x[n-1] | x[n] | x[n+1] written directly as bf16 hi / lo (operand of the conv GEMM)
-__global__ __launch_bounds__(256) void nr_shift_concat_split_kernel(const float* __restrict__ x, int N, int C,
-                                                                    uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
-    const int row = blockIdx.x;                 // b*N + n
-    const int n = row % N;
-    for (int k = 0; k < 3; ++k) {
-        const int nn = n + k - 1;
-        const bool ok = nn >= 0 && nn < N;
-        const float* src = x + (size_t)(row + k - 1) * C;
-        const size_t o = (size_t)row * 3 * C + (size_t)k * C;
-        for (int c = threadIdx.x * 4; c < C; c += 1024) {
-            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4_t*>(src + c);
-            uint16_t h[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                h[e] = nr_f2bf(v[e]);
-                l[e] = nr_f2bf(v[e] - nr_bf2f(h[e]));
-            }
-            *reinterpret_cast<uint2*>(hi + o + c) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-            *reinterpret_cast<uint2*>(lo + o + c) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
-        }
-    }
-}
+// x[n-1] | x[n] | x[n+1] written directly as bf16 hi / lo (operand of the conv GEMM); body in nr_ctm_bodies.h
+__global__ __launch_bounds__(256) void nr_shift_concat_split_kernel(NrShiftArgs a) { nr_shift_split_body(a, blockIdx.x); }
 
 extern "C" int nr_shift_concat_split(const float* x, int n_samples, int N, int C, uint16_t* hi, uint16_t* lo, void* stream) {
     if (!x || !hi || !lo || n_samples <= 0 || N <= 0 || C <= 0 || (C % 4) != 0) return NR_EINVAL;
-    hipLaunchKernelGGL(nr_shift_concat_split_kernel, dim3(n_samples * N), dim3(256), 0, (hipStream_t)stream, x, N, C, hi, lo);
+    NrShiftArgs a{x, N, C, hi, lo};
+    hipLaunchKernelGGL(nr_shift_concat_split_kernel, dim3(n_samples * N), dim3(256), 0, (hipStream_t)stream, a);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

@@ -86,12 +86,15 @@ def precision_plan(prec):
 
 
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
-                 gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None):
+                 gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None,
+                 bank_streams=None, local_stream=None, bank_early=0):
     """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None).
 
-    `join`: optional callable run right before the first use of gt / gv -- the caller produces the
-    global tokens on side streams while the local branch (prepare, scorer, three products) runs here,
-    and joins the streams in it."""
+    `join`: optional callable run right before the first use of gt / gv.  Either the caller produces the
+    global tokens on side streams while the local branch runs here and joins those streams in it, or --
+    with gt = gv = None -- `join` itself runs the token clustering on the current stream and returns
+    (gt, gv), while the local branch (prepare, scorer, B x B product) runs on `local_stream`.
+    `bank_streams`: optional pair of side streams for the two memory-bank chains (see below)."""
     B, Nt, d = text_feat.shape
     Nv = video_feat.shape[1]
     M = mb_feat_v.shape[0]
@@ -101,43 +104,92 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
                          "(until_module.py:119-123)")
     if M == 0 or mb_feat_t.shape[0] != M:
         raise ValueError("empty or inconsistent memory bank")
-    if gt.shape[1] != 1 or gv.shape[1] != 1:
-        raise RuntimeError("more than one global token per sample: the reference's centrality term "
-                           "fails to broadcast at this shape (until_module.py:321); parity unpinned")
+    if gt is None and join is None:
+        raise ValueError("gt / gv missing and no join callable to produce them")
     p_bb, p_mlp, p_bank = precision_plan(prec)
     # masks as fp32 once (the loaders hand over int64); the kernels read them as multipliers
     text_mask, video_mask, mb_mask_t, mb_mask_v = (m if m.dtype == torch.float32 else m.float()
                                                    for m in (text_mask, video_mask, mb_mask_t, mb_mask_v))
     lo_b = keep or hip.PREC_BF16X3 in (p_bb, p_mlp, p_bank)
     lo_k = keep or p_bank == hip.PREC_BF16X3
-    pt = ops.prepare_tokens(text_feat, text_mask, want_lo=lo_b, want_colsum=True)
-    pv = ops.prepare_tokens(video_feat, video_mask, want_lo=lo_b, want_colsum=True)
-    pbt = ops.prepare_tokens(mb_feat_t, mb_mask_t, want_lo=lo_k)
-    pbv = ops.prepare_tokens(mb_feat_v, mb_mask_v, want_lo=lo_k)
-    w_t, lg_t = token_weights(pt, text_mask, sw_t, B, Nt, p_mlp, keep)
-    w_v, lg_v = token_weights(pv, video_mask, sw_v, B, Nv, p_mlp, keep)
-    w_bt, lg_bt = token_weights(pbt, mb_mask_t, sw_t, M, Nt, p_bank, keep)
-    w_bv, lg_bv = token_weights(pbv, mb_mask_v, sw_v, M, Nv, p_bank, keep)
+    cur = torch.cuda.current_stream()
+    if local_stream is not None:
+        local_stream.wait_stream(cur)
+        torch.cuda.set_stream(local_stream)
+    try:
+        pt = ops.prepare_tokens(text_feat, text_mask, want_lo=lo_b, want_colsum=True)
+        pv = ops.prepare_tokens(video_feat, video_mask, want_lo=lo_b, want_colsum=True)
+        w_t, lg_t = token_weights(pt, text_mask, sw_t, B, Nt, p_mlp, keep)
+        w_v, lg_v = token_weights(pv, video_mask, sw_v, B, Nv, p_mlp, keep)
+        S, aux0 = ops.local_level(pt, pv, w_t, w_v, B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
+        # mean of the (unmasked) normalised tokens for the centrality weights -- still on the local branch
+        mean_t = ops.reduce_parts(pt.colsum, 1.0 / pt.n_tok)
+        mean_v = ops.reduce_parts(pv.colsum, 1.0 / pv.n_tok)
+    finally:
+        if local_stream is not None:
+            torch.cuda.set_stream(cur)
 
-    S, aux0 = ops.local_level(pt, pv, w_t, w_v, B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
-    # text x bank-video, row mean  -> centrality of text j  (used by the v2t neighbour loss)
-    p1, aux1 = ops.local_level(pt, pbv, w_t, w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM, keep)
-    # bank-text x video, column mean -> centrality of video j (used by the t2v neighbour loss)
-    p0, aux2 = ops.local_level(pbt, pv, w_bt, w_v, M, Nt, B, Nv, p_bank, hip.OUT_COLSUM, keep)
-    c1 = ops.reduce_parts(p1, 1.0 / M)
-    c0 = ops.reduce_parts(p0, 1.0 / M)
-    # mean of the (unmasked) normalised tokens for the centrality weights -- still on the local branch
-    mean_t = ops.reduce_parts(pt.colsum, 1.0 / pt.n_tok)
-    mean_v = ops.reduce_parts(pv.colsum, 1.0 / pv.n_tok)
+    def bank_video():
+        # text x bank-video, row mean  -> centrality of text j  (used by the v2t neighbour loss)
+        pbv = ops.prepare_tokens(mb_feat_v, mb_mask_v, want_lo=lo_k)
+        w_bv, lg_bv = token_weights(pbv, mb_mask_v, sw_v, M, Nv, p_bank, keep)
+        p1, aux1 = ops.local_level(pt, pbv, w_t, w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM, keep)
+        return pbv, w_bv, lg_bv, aux1, ops.reduce_parts(p1, 1.0 / M)
 
+    def bank_text():
+        # bank-text x video, column mean -> centrality of video j (used by the t2v neighbour loss)
+        pbt = ops.prepare_tokens(mb_feat_t, mb_mask_t, want_lo=lo_k)
+        w_bt, lg_bt = token_weights(pbt, mb_mask_t, sw_t, M, Nt, p_bank, keep)
+        p0, aux2 = ops.local_level(pbt, pv, w_bt, w_v, M, Nt, B, Nv, p_bank, hip.OUT_COLSUM, keep)
+        return pbt, w_bt, lg_bt, aux2, ops.reduce_parts(p0, 1.0 / M)
+
+    # `bank_early` chains (0..2) run on the local stream right behind the batch products, i.e. beside the
+    # clustering; the rest is forked after the join (beside the Sinkhorn solve).
+    early = [None, None]
+    if local_stream is not None and bank_early > 0:
+        torch.cuda.set_stream(local_stream)
+        try:
+            early[0] = bank_video()
+            if bank_early > 1:
+                early[1] = bank_text()
+        finally:
+            torch.cuda.set_stream(cur)
     if join is not None:
-        join()
+        produced = join()
+        if produced is not None:
+            gt, gv = produced
+    if local_stream is not None:
+        cur.wait_stream(local_stream)
+        for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi):
+            t_.record_stream(cur)
+    if gt.shape[1] != 1 or gv.shape[1] != 1:
+        raise RuntimeError("more than one global token per sample: the reference's centrality term "
+                           "fails to broadcast at this shape (until_module.py:321); parity unpinned")
+    # The two bank chains feed only the neighbour loss (through c0 / c1), i.e. nothing before the row-loss
+    # kernel.  With `bank_streams` they are forked HERE -- after the clustering branches have joined -- and
+    # run beside the global logits + Sinkhorn, which keep two CUs busy for ~65 us; started earlier they
+    # only fight the (latency-bound) clustering kernels for CUs.
+    if bank_streams is not None:
+        for st_ in bank_streams:
+            st_.wait_stream(cur)
+        with torch.cuda.stream(bank_streams[0]):
+            pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
+        with torch.cuda.stream(bank_streams[1]):
+            pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
+    else:
+        pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
+        pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
     G = global_logits(gt, gv, sw_t1, sw_v1)
     tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
     gt2 = gt.reshape(B, d).float().contiguous()
     gv2 = gv.reshape(B, d).float().contiguous()
     wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
     ls = logit_scale.detach().float().reshape(1).contiguous()
+    if bank_streams is not None:
+        for st_ in bank_streams:
+            cur.wait_stream(st_)
+        for t_ in (c0, c1) + ((pbt.hi, pbv.hi, w_bt, w_bv) if keep else ()):
+            t_.record_stream(cur)
     rowloss = ops.row_losses(S, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"])
     losses = ops.loss_finalize(rowloss, hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
     saved = None

@@ -23,6 +23,17 @@ _I = ctypes.c_int
 _F = ctypes.c_float
 _Z = ctypes.c_size_t
 
+class CtmStageDesc(ctypes.Structure):
+    """NrCtmStageDesc of include/nr_hip.h (field order and types are the ABI)."""
+    _fields_ = ([(n, ctypes.c_int32) for n in ("n_samples", "N", "C", "k", "cnum", "heads")]
+                + [("eps_ctm", _F), ("eps_n1", _F)]
+                + [(n, _P) for n in ("x", "mask", "noise", "wconv_hi", "wconv_lo", "conv_bias", "ln_w", "ln_b", "sc_w", "sc_b",
+                                     "n1_w", "n1_b", "wq_hi", "wq_lo", "q_bias", "wkv_hi", "wkv_lo", "kv_bias", "wp_hi", "wp_lo",
+                                     "proj_bias", "workspace", "out", "assign")])
+
+
+CTM_MAX_GROUP = 4
+
 _SIGNATURES = {
     "nr_version": ([], _I),
     "nr_prepare_parts": ([_I], _I),
@@ -46,6 +57,8 @@ _SIGNATURES = {
     "nr_linear_x3": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
     "nr_shift_concat_split": ([_P, _I, _I, _I, _P, _P, _P], _I),
     "nr_ctm_back": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
+    "nr_ctm_stage_workspace_bytes": ([_I, _I, _I, _I], _Z),
+    "nr_ctm_stage_fwd": ([ctypes.POINTER(CtmStageDesc), _I, _P], _I),
     "nr_sinkhorn_workspace_bytes": ([_I], _Z),
     "nr_sinkhorn_targets": ([_P, _I, _F, _I, _P, _P, _P, _P], _I),
     "nr_row_losses_fwd": ([_P] * 9 + [_I, _I, _F, _P, _P], _I),

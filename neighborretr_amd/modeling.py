@@ -74,6 +74,11 @@ class NeighborRetr(nn.Module):
         self._streams = None
         self._join_global = None
         self.use_side_streams = True
+        self.bank_side_streams = True       # bank chains beside the Sinkhorn solve (head.head_forward)
+        self._bstreams = None
+        self._lstream = None
+        self.bank_early = 1                 # bank chains started beside the clustering instead of the Sinkhorn (0..2)
+        self.group_clustering = True        # text + video clustering in the same launches (no-grad forward)
         self.fuse_clustering = True
         self._ctm_cache = {}
 
@@ -215,7 +220,19 @@ class NeighborRetr(nn.Module):
         from .functional import head_losses
         if noise is None and text_feat.is_cuda:
             noise = self._draw_noise(text_feat.shape[0], text_feat.shape[1], video_feat.shape[1], text_feat.device)
-        if text_feat.is_cuda and self.use_side_streams:
+        mods = tuple(getattr(self, f"{w}_{k}") for w in ("text", "video") for k in ("ctm0", "block0", "ctm1", "block1"))
+        nz = noise or {}
+        if (text_feat.is_cuda and self.use_side_streams and self.group_clustering and not torch.is_grad_enabled()
+                and self._can_fuse_clustering(text_feat, mods) and self._can_fuse_clustering(video_feat, mods)):
+            # loss-only step: the text and video clustering advance together inside grouped launches on THIS
+            # stream (the critical path); the local branch runs beside them on a side stream, the two bank
+            # chains beside the Sinkhorn solve (head.head_forward).
+            gt = gv = None
+
+            def join():
+                return self._merge_grouped(text_feat, video_feat, text_mask, video_mask, nz)
+            self._join_global = join
+        elif text_feat.is_cuda and self.use_side_streams:
             # three independent branches: text clustering | video clustering | local products.
             # The two clustering branches run on side streams (in a captured HIP graph: parallel
             # branches) and are joined right before the global logits need them.
@@ -223,7 +240,6 @@ class NeighborRetr(nn.Module):
             s_t, s_v = self._side_streams(text_feat.device)
             s_t.wait_stream(cur)
             s_v.wait_stream(cur)
-            nz = noise or {}
             with torch.cuda.stream(s_t):
                 gt = self._merge_one("text", text_feat, text_mask, nz.get("t0"), nz.get("t1"))
             with torch.cuda.stream(s_v):
@@ -247,6 +263,17 @@ class NeighborRetr(nn.Module):
         nz = noise or {}
         return (self._merge_one("text", text_feat, text_mask, nz.get("t0"), nz.get("t1")),
                 self._merge_one("video", video_feat, video_mask, nz.get("v0"), nz.get("v1")))
+
+    def _merge_grouped(self, text_feat, video_feat, text_mask, video_mask, nz):
+        """Both modalities through the two clustering stages in grouped launches (no-grad forward)."""
+        from .cluster_fused import ctm_stage_group
+        t, v = ctm_stage_group([("text0", text_feat, text_mask, self.text_ctm0, self.text_block0, nz.get("t0")),
+                                ("video0", video_feat, video_mask, self.video_ctm0, self.video_block0, nz.get("v0"))],
+                               self._ctm_cache)
+        t, v = ctm_stage_group([("text1", t, None, self.text_ctm1, self.text_block1, nz.get("t1")),
+                                ("video1", v, None, self.video_ctm1, self.video_block1, nz.get("v1"))],
+                               self._ctm_cache)
+        return t, v
 
     def _merge_one(self, which, feat, mask, noise0=None, noise1=None):
         """Two CTM + TCBlock stages of one modality: [B,N,d] -> [B,1,d] at the MSR-VTT token counts."""
@@ -284,6 +311,21 @@ class NeighborRetr(nn.Module):
             # default priority: high-priority side streams made the captured graph 1.8x SLOWER on ROCm 7.2
             self._streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
         return self._streams
+
+    def _local_stream(self, device):
+        if not (self.use_side_streams and device.type == "cuda"):
+            return None
+        if self._lstream is None or self._lstream.device != device:
+            self._lstream = torch.cuda.Stream(device=device)
+        return self._lstream
+
+    def _bank_streams(self, device):
+        """Side streams of the two memory-bank chains (head.head_forward), or None when streams are off."""
+        if not (self.use_side_streams and self.bank_side_streams and device.type == "cuda"):
+            return None
+        if self._bstreams is None or self._bstreams[0].device != device:
+            self._bstreams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return self._bstreams
 
     def _take_join(self):
         j, self._join_global = self._join_global, None

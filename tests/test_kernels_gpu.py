@@ -305,6 +305,36 @@ def test_ctm_front_back_equal_the_separate_kernels():
     assert maxdiff(rec, kvn) < 3e-5 * float(kvn.abs().max())
 
 
+def test_grouped_clustering_stage_equals_the_per_modality_path():
+    """nr_ctm_stage_fwd (text and video problems in the same seven launches) against the one-problem fused
+    kernels + library GEMMs: identical cluster assignments, outputs to split-bf16 GEMM accuracy."""
+    from neighborretr_amd import modeling, synth
+    from neighborretr_amd.cluster_fused import ctm_stage_fused, ctm_stage_group
+    B, Nt, Nv = 32, 24, 12
+    m = modeling.NeighborRetr(modeling.default_config())
+    m.load_state_dict(params(), strict=False)
+    m = m.to(DEV).eval()
+    prob = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_problem(77, B, Nt, Nv, 8).items()}
+    nz = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_noise(77, B, Nt, Nv).items()}
+    tm, vm = prob["text_mask"].float(), prob["video_mask"].float()
+    with torch.no_grad():
+        rt0 = ctm_stage_fused(prob["text_feat"], tm, m.text_ctm0, m.text_block0, nz["t0"], {}, "t0")
+        rv0 = ctm_stage_fused(prob["video_feat"], vm, m.video_ctm0, m.video_block0, nz["v0"], {}, "v0")
+        rt1 = ctm_stage_fused(rt0, None, m.text_ctm1, m.text_block1, nz["t1"], {}, "t1")
+        rv1 = ctm_stage_fused(rv0, None, m.video_ctm1, m.video_block1, nz["v1"], {}, "v1")
+        cache = {}
+        gt0, gv0 = ctm_stage_group([("t0", prob["text_feat"], tm, m.text_ctm0, m.text_block0, nz["t0"]),
+                                    ("v0", prob["video_feat"], vm, m.video_ctm0, m.video_block0, nz["v0"])], cache)
+        gt1, gv1 = ctm_stage_group([("t1", gt0, None, m.text_ctm1, m.text_block1, nz["t1"]),
+                                    ("v1", gv0, None, m.video_ctm1, m.video_block1, nz["v1"])], cache)
+        # a single problem goes through the same entry point
+        (st0,) = ctm_stage_group([("t0", prob["text_feat"], tm, m.text_ctm0, m.text_block0, nz["t0"])], cache)
+    assert torch.equal(st0, gt0)
+    for a, b in ((gt0, rt0), (gv0, rv0), (gt1, rt1), (gv1, rv1)):
+        assert a.shape == b.shape
+        assert maxdiff(a, b) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
 def test_bank_push_fifo():
     bank = torch.arange(10 * 6, dtype=torch.float32, device=DEV).reshape(10, 2, 3)
     ref = bank.clone()

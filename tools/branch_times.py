@@ -79,7 +79,18 @@ def main():
         print(f"tail only           : {graph_time(tail_only):8.1f} us")
         print(f"whole step, 1 stream: {graph_time(step_serial):8.1f} us")
         m.use_side_streams = True
-        print(f"whole step, streams : {graph_time(step_serial):8.1f} us")
+        m.group_clustering = False
+        m.bank_side_streams = True
+        print(f"whole step, text | video | local streams, bank beside Sinkhorn: {graph_time(step_serial):8.1f} us")
+        m.group_clustering = True
+        m.bank_side_streams = False
+        print(f"whole step, grouped clustering | local, bank serial : {graph_time(step_serial):8.1f} us")
+        m.bank_side_streams = True
+        print(f"whole step, grouped clustering | local, bank beside Sinkhorn: {graph_time(step_serial):8.1f} us")
+        for e in (1, 2):
+            m.bank_early = e
+            print(f"   ... {e} bank chain(s) beside the clustering instead      : {graph_time(step_serial):8.1f} us")
+        m.bank_early = 0
 
 
 if __name__ == "__main__":
