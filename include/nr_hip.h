@@ -203,6 +203,14 @@ int nr_row_losses_fwd(const float* S, const float* G, const float* tgt_rows, con
                       const float* logit_scale, int B, int K, float temperature, float* rowloss, void* stream);
 int nr_loss_finalize(const float* rowloss, int B, float uniform_weight, float neighbor_weight, float kl_weight,
                      float* losses, void* stream);
+/* nr_row_losses_fwd + nr_loss_finalize in one launch: the workgroup that finishes last reduces the row
+ * terms (same arithmetic, bit-identical losses).  counter: one zero-initialised device word owned by the
+ * caller; the kernel leaves it at zero again.                                                        */
+int nr_row_losses_fwd_final(const float* S, const float* G, const float* tgt_rows, const float* tgt_cols,
+                            const float* bank_c0, const float* bank_c1, const float* wc_text,
+                            const float* wc_video, const float* logit_scale, int B, int K, float temperature,
+                            float* rowloss, uint32_t* counter, float uniform_weight, float neighbor_weight,
+                            float kl_weight, float* losses, void* stream);
 
 /* Backward of nr_row_losses_fwd: recomputes the row statistics, then differentiates all four
  * terms.  g_rowloss [2,4,B] = d(objective)/d(rowloss) (for the fused objective: the constants of
@@ -251,6 +259,16 @@ int nr_token_softmax_bwd(const float* w, const float* dw, int n_samples, int N, 
  *   dg_i = a_i * (mean - ghat_i <ghat_i, mean>) / ||g_i||;   dmean = sum_i a_i ghat_i.           */
 int nr_centrality_weights_bwd(const float* g, const float* gnorm, const float* mean, const float* w, const float* dw,
                               int B, int d, float scale, float* dg, float* dmean, void* stream);
+
+/* Front of the step in one launch (any part may be switched off with n = 0 / NULL):
+ *   out0[i] = (float)mask0[i], out1[i] = (float)mask1[i]   the loader's int64 masks as fp32 multipliers;
+ *   logit_scale_exp[0] = exp(logit_scale[0])                modeling.py:289;
+ *   noise[0..n_noise) uniform in [0,1)                      the torch.rand draws of cluster.py:483, from a
+ *       counter-based generator: rng_state = device uint64[2] {seed, counter}; the kernel advances the
+ *       counter, so replays of a captured graph draw fresh numbers.                                     */
+int nr_step_prologue(const int64_t* mask0, int n0, float* out0, const int64_t* mask1, int n1, float* out1,
+                     const float* logit_scale, float* logit_scale_exp, uint64_t* rng_state, float* noise,
+                     int n_noise, void* stream);
 
 /* Memory-bank FIFO push (modeling.py:237-249): bank <- cat(batch, bank)[:capacity] done as an
  * in-place shift; rows are `row_bytes` wide.  Requires 0 < n_new; if n_new >= capacity the bank

@@ -145,12 +145,23 @@ struct NrRowState {
     }
 };
 
+template <bool COHERENT>
+__device__ __forceinline__ void nr_loss_finalize_body(const float* __restrict__ rowloss, int B, float wu, float wn, float wkl,
+                                                      float* __restrict__ losses);
+
+// Optional tail of the forward launch: the workgroup that finishes LAST reduces the row terms to the five
+// losses (same arithmetic and summation order as nr_loss_finalize, so the result is bit-identical) --
+// one launch less on the step's critical path.  `counter` is a zero-initialised device word that the
+// last workgroup resets, so a captured graph can replay it.
+struct NrRowFinal {
+    unsigned int* counter;
+    float wu, wn, wkl;
+    float* losses;
+};
+
 template <int NE>
-__global__ __launch_bounds__(256) void nr_row_losses_fwd_kernel(NrRowArgs a, float* __restrict__ rowloss) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int dir = blockIdx.y;
-    if (row >= a.B) return;
+__device__ __forceinline__ void nr_row_losses_fwd_rows(const NrRowArgs& a, float* __restrict__ rowloss, const int row, const int dir,
+                                                       const int lane) {
     NrRowState<NE> r;
     r.load(a, row, dir, lane);
     r.stats(a.K, lane);
@@ -180,16 +191,44 @@ __global__ __launch_bounds__(256) void nr_row_losses_fwd_kernel(NrRowArgs a, flo
     }
 }
 
-// losses = (total, centrality, uniform, neighbour, kl)   (modeling.py:329-358)
-__global__ __launch_bounds__(256) void nr_loss_finalize_kernel(const float* __restrict__ rowloss, int B, float wu, float wn,
-                                                               float wkl, float* __restrict__ losses) {
+template <int NE>
+__global__ __launch_bounds__(256) void nr_row_losses_fwd_kernel(NrRowArgs a, float* __restrict__ rowloss, NrRowFinal f) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row < a.B) nr_row_losses_fwd_rows<NE>(a, rowloss, row, blockIdx.y, lane);
+    if (f.counter == nullptr) return;
+    __shared__ int s_last;
+    __threadfence();                               // this workgroup's row terms are visible device-wide
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int total = gridDim.x * gridDim.y;
+        s_last = atomicAdd(f.counter, 1u) == total - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    nr_loss_finalize_body<true>(rowloss, a.B, f.wu, f.wn, f.wkl, f.losses);
+    if (threadIdx.x == 0) *f.counter = 0;
+}
+
+// losses = (total, centrality, uniform, neighbour, kl)   (modeling.py:329-358); 256 threads
+template <bool COHERENT>
+__device__ __forceinline__ void nr_loss_finalize_body(const float* __restrict__ rowloss, int B, float wu, float wn, float wkl,
+                                                      float* __restrict__ losses) {
     __shared__ float red[8][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // wave w handles term w; both directions
     float acc0 = 0.f, acc1 = 0.f;
     for (int j = lane; j < B; j += 64) {
-        acc0 += rowloss[(size_t)(0 * 4 + wave) * B + j];
-        acc1 += rowloss[(size_t)(1 * 4 + wave) * B + j];
+        const float* p0 = rowloss + (size_t)(0 * 4 + wave) * B + j;
+        const float* p1 = rowloss + (size_t)(1 * 4 + wave) * B + j;
+        if constexpr (COHERENT) {      // written by other workgroups of the same launch: read past the L1
+            acc0 += __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc1 += __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            acc0 += *p0;
+            acc1 += *p1;
+        }
     }
     acc0 = nr_wave_sum(acc0);
     acc1 = nr_wave_sum(acc1);
@@ -206,6 +245,11 @@ __global__ __launch_bounds__(256) void nr_loss_finalize_kernel(const float* __re
     }
 }
 
+__global__ __launch_bounds__(256) void nr_loss_finalize_kernel(const float* __restrict__ rowloss, int B, float wu, float wn,
+                                                               float wkl, float* __restrict__ losses) {
+    nr_loss_finalize_body<false>(rowloss, B, wu, wn, wkl, losses);
+}
+
 static int nr_row_ne(int B) {
     int ne = (B + 63) / 64;
     if (ne <= 2) return 2;
@@ -216,6 +260,20 @@ static int nr_row_ne(int B) {
     return 0;
 }
 
+static int nr_row_losses_fwd_launch(const NrRowArgs& a, float* rowloss, const NrRowFinal& f, hipStream_t st) {
+    dim3 grid((a.B + 3) / 4, 2);
+    switch (nr_row_ne(a.B)) {
+        case 2: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<2>, grid, dim3(256), 0, st, a, rowloss, f); break;
+        case 4: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<4>, grid, dim3(256), 0, st, a, rowloss, f); break;
+        case 8: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<8>, grid, dim3(256), 0, st, a, rowloss, f); break;
+        case 16: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<16>, grid, dim3(256), 0, st, a, rowloss, f); break;
+        case 32: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<32>, grid, dim3(256), 0, st, a, rowloss, f); break;
+        default: return NR_EUNSUPPORTED;   // B > 2048
+    }
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
 extern "C" int nr_row_losses_fwd(const float* S, const float* G, const float* tgt_rows, const float* tgt_cols,
                                  const float* bank_c0, const float* bank_c1, const float* wc_text, const float* wc_video,
                                  const float* logit_scale, int B, int K, float temperature, float* rowloss, void* stream) {
@@ -223,18 +281,21 @@ extern "C" int nr_row_losses_fwd(const float* S, const float* G, const float* tg
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;    // the reference raises IndexError for K > B
     NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature};
-    dim3 grid((B + 3) / 4, 2);
-    hipStream_t st = (hipStream_t)stream;
-    switch (nr_row_ne(B)) {
-        case 2: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<2>, grid, dim3(256), 0, st, a, rowloss); break;
-        case 4: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<4>, grid, dim3(256), 0, st, a, rowloss); break;
-        case 8: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<8>, grid, dim3(256), 0, st, a, rowloss); break;
-        case 16: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<16>, grid, dim3(256), 0, st, a, rowloss); break;
-        case 32: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<32>, grid, dim3(256), 0, st, a, rowloss); break;
-        default: return NR_EUNSUPPORTED;   // B > 2048
-    }
-    NR_LAUNCH_CHECK();
-    return NR_OK;
+    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr}, (hipStream_t)stream);
+}
+
+extern "C" int nr_row_losses_fwd_final(const float* S, const float* G, const float* tgt_rows, const float* tgt_cols,
+                                       const float* bank_c0, const float* bank_c1, const float* wc_text,
+                                       const float* wc_video, const float* logit_scale, int B, int K, float temperature,
+                                       float* rowloss, uint32_t* counter, float uniform_weight, float neighbor_weight,
+                                       float kl_weight, float* losses, void* stream) {
+    if (!S || !G || !tgt_rows || !tgt_cols || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale || !rowloss ||
+        !counter || !losses)
+        return NR_EINVAL;
+    if (B <= 0 || K < 0 || K > B) return NR_EINVAL;
+    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature};
+    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{counter, uniform_weight, neighbor_weight, kl_weight, losses},
+                                    (hipStream_t)stream);
 }
 
 extern "C" int nr_loss_finalize(const float* rowloss, int B, float uniform_weight, float neighbor_weight, float kl_weight,

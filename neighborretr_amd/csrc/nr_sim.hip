@@ -188,6 +188,12 @@ __global__ __launch_bounds__(256) void nr_sim_kernel(NrSimArgs p) {
 int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16_t* v_hi, const uint16_t* v_lo,
                         const float* w_t, const float* w_v, int A, int Nt, int Bv, int Nv, int d, int prec, int out_mode,
                         float* out, uint8_t* arg_v, uint8_t* arg_t, float* pmax, float* qmax, hipStream_t st);
+extern "C" int nr_sim_reg_tile(int A, int Nt, int Bv, int Nv, int* TA, int* TB);
+
+static bool nr_sim_force_generic() {
+    const char* e = getenv("NR_SIM_GENERIC");
+    return e && atoi(e);
+}
 
 // ---- host side -------------------------------------------------------------------------------
 // pick the tile extent (64 / 96 / 128 rows) that wastes the fewest MFMA rows on padding
@@ -216,6 +222,7 @@ extern "C" int nr_local_level_tiles(int A, int Nt, int Bv, int Nv, int* n_row_ti
     if (TA == 0 || TB == 0) return NR_EUNSUPPORTED;   // more than 128 tokens per sample
     if (TA > A) TA = A > 0 ? A : 1;
     if (TB > Bv) TB = Bv > 0 ? Bv : 1;
+    if (!nr_sim_force_generic()) nr_sim_reg_tile(A, Nt, Bv, Nv, &TA, &TB);    // the register-epilogue kernel's blocks
     if (n_row_tiles) *n_row_tiles = (A + TA - 1) / TA;
     if (n_col_tiles) *n_col_tiles = (Bv + TB - 1) / TB;
     return NR_OK;
@@ -247,8 +254,7 @@ extern "C" int nr_local_level_fwd(const uint16_t* t_hi, const uint16_t* t_lo, co
     // token counts with a register-level epilogue (nr_sim_reg.hip); NR_SIM_GENERIC=1 forces this file's
     // LDS epilogue (test hook)
     {
-        const char* e = getenv("NR_SIM_GENERIC");
-        if (!(e && atoi(e))) {
+        if (!nr_sim_force_generic()) {
             int rc = nr_sim_reg_dispatch(t_hi, t_lo, v_hi, v_lo, w_t, w_v, A, Nt, Bv, Nv, d, prec, out_mode, out, arg_v, arg_t,
                                          pmax, qmax, (hipStream_t)stream);
             if (rc != NR_EUNSUPPORTED) return rc;

@@ -12,6 +12,15 @@
 // store of the 96x96 block to LDS and three LDS reduction phases.
 // Supported token counts: Nt = MI*TPS, Nv = NI*FPS with (MI,TPS) in {(3,8),(4,16)}, (NI,FPS) in
 // {(3,4),(4,16)}: 24/64 text tokens, 12/64 frames; everything else runs nr_sim.hip.
+//
+// Large products at 24 x 12 tokens (the memory-bank products) run 192 x 192 blocks = 8 texts x 16 videos on
+// 2 x 4 waves (512 threads, (MI,TPS,NI,FPS) = (6,4,3,4)).  The main loop is bound by the operand bytes a CU can
+// pull into LDS by LDS-DMA -- ~25 B/clk/CU measured (60 GB/s), the figure that pins the 96 x 96 blocks
+// (341 B per MFMA) at 27 % and their split-bf16 form (227 B per MFMA) at 42 % of the MFMA peak -- so the
+// way up is fewer bytes per MFMA: doubling both block edges halves them (171 B per MFMA), and eight waves
+// keep two per SIMD so one computes while the other waits on its fragments.
+#include <cstdio>
+#include <cstdlib>
 #include "nr_gemm_tile.h"
 #include "../../include/nr_hip.h"
 
@@ -25,17 +34,17 @@ struct NrSimRegArgs {
     int ntx, nty, PR, PC;      // tile grid and its partition over the 8 XCDs (PR*PC == 8, or PR == 0: none)
 };
 
-template <int W>   // max over W adjacent lanes (W = 4, 8, 16) with the index of the first maximum
+template <int W>   // max over W adjacent lanes (W = 2, 4, 8, 16) with the index of the first maximum
 __device__ __forceinline__ void nr_lanes_argmax(float& v, int& idx) {
     nr_arg_step<true, NR_DPP_XOR1, 0xF>(v, idx);
-    nr_arg_step<true, NR_DPP_XOR2, 0xF>(v, idx);
+    if constexpr (W >= 4) nr_arg_step<true, NR_DPP_XOR2, 0xF>(v, idx);
     if constexpr (W >= 8) nr_arg_step<true, NR_DPP_HALF_MIRROR, 0xF>(v, idx);
     if constexpr (W >= 16) nr_arg_step<true, NR_DPP_MIRROR, 0xF>(v, idx);
 }
 template <int W>
 __device__ __forceinline__ float nr_lanes_max(float v) {
     v = fmaxf(v, nr_dpp<NR_DPP_XOR1>(v, v));
-    v = fmaxf(v, nr_dpp<NR_DPP_XOR2>(v, v));
+    if constexpr (W >= 4) v = fmaxf(v, nr_dpp<NR_DPP_XOR2>(v, v));
     if constexpr (W >= 8) v = fmaxf(v, nr_dpp<NR_DPP_HALF_MIRROR>(v, v));
     if constexpr (W >= 16) v = fmaxf(v, nr_dpp<NR_DPP_MIRROR>(v, v));
     return v;
@@ -43,22 +52,22 @@ __device__ __forceinline__ float nr_lanes_max(float v) {
 template <int W>
 __device__ __forceinline__ float nr_lanes_sum(float v) {
     v += nr_dpp<NR_DPP_XOR1>(v, v);
-    v += nr_dpp<NR_DPP_XOR2>(v, v);
+    if constexpr (W >= 4) v += nr_dpp<NR_DPP_XOR2>(v, v);
     if constexpr (W >= 8) v += nr_dpp<NR_DPP_HALF_MIRROR>(v, v);
     if constexpr (W >= 16) v += nr_dpp<NR_DPP_MIRROR>(v, v);
     return v;
 }
 
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES>
-__global__ __launch_bounds__(256) void nr_sim_reg_kernel(NrSimRegArgs p) {
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC>
+__global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES>;
+    using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES, WC>;
     constexpr int Nt = MI * TPS, Nv = NI * FPS;
     constexpr int TAW = 16 / TPS, TBW = 16 / FPS;     // texts / videos per wave
-    constexpr int TA = 2 * TAW, TB = 2 * TBW;         // per workgroup
+    constexpr int TA = 2 * TAW, TB = WC * TBW;        // per workgroup
     constexpr int GX = TPS / 4;                       // lane groups (of 16) that share a text
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
     // XCD-aware tile order: workgroups b and b+8 land on the same XCD (round-robin dispatch), so XCD x is
     // given one contiguous PR x PC part of the tile grid and its private L2 pulls only that part's
     // operand rows.  Pure speed: any placement computes the same tiles.
@@ -191,23 +200,23 @@ __global__ __launch_bounds__(256) void nr_sim_reg_kernel(NrSimRegArgs p) {
     }
 }
 
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES>
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC>
 static int nr_sim_reg_launch_s(NrSimRegArgs& a, hipStream_t st) {
-    using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES>;
-    auto kern = nr_sim_reg_kernel<MI, NI, TPS, FPS, X3, ARGS, STAGES>;
+    using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES, WC>;
+    auto kern = nr_sim_reg_kernel<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC>;
     size_t lds = Tile::RING_BYTES;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(a.ntx * a.nty), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.ntx * a.nty), dim3(128 * WC), lds, st, a);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }
 
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS>
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int WC = 2>
 static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
-    constexpr int TA = 2 * (16 / TPS), TB = 2 * (16 / FPS);
+    constexpr int TA = 2 * (16 / TPS), TB = WC * (16 / FPS);
     a.ntx = (a.Bv + TB - 1) / TB;
     a.nty = (a.A + TA - 1) / TA;
     // partition of the tile grid over the 8 XCDs that minimises the operand bytes each L2 has to hold
@@ -222,15 +231,34 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
             if (cost < best) { best = cost; a.PR = pr; a.PC = pc; }
         }
     }
-    if (nr_pick_stages((long)a.ntx * a.nty) == 1) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 1>(a, st);
-    return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 2>(a, st);
+    if (const char* e = getenv("NR_SIM_XCD")) {          // tuning hook: "0" = plain row-major order, "RxC" = forced partition
+        int pr = 0, pc = 0;
+        if (sscanf(e, "%dx%d", &pr, &pc) == 2 && pr * pc == 8 && a.nty % pr == 0 && a.ntx % pc == 0) { a.PR = pr; a.PC = pc; }
+        else a.PR = a.PC = 0;
+    }
+    // 192 x 192 blocks (8 waves, one workgroup per CU): nobody else hides their DMA latency, so they run the
+    // 2-deep ring -- except split-bf16, whose two stages (196 KB) exceed the LDS
+    constexpr bool big = WC == 4;
+    const bool one_stage = big ? X3 : nr_pick_stages((long)a.ntx * a.nty) == 1;
+    if (one_stage) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 1, WC>(a, st);
+    if constexpr (big && X3) return NR_EUNSUPPORTED;
+    else return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 2, WC>(a, st);
 }
 
-// tile shape this path would use: texts / videos per workgroup; 0 if the token count is not covered
-extern "C" int nr_sim_reg_tile(int Nt, int Nv, int* TA, int* TB) {
+// tile shape this path uses: texts / videos per workgroup; 0 if the token count is not covered.
+// NR_SIM_BIG=0 keeps the 96 x 96 blocks everywhere (A/B hook).
+static bool nr_sim_reg_big(int A, int Nt, int Bv, int Nv) {
+    if (Nt != 24 || Nv != 12) return false;
+    const char* e = getenv("NR_SIM_BIG");
+    if (e && !atoi(e)) return false;
+    return (long)((A + 7) / 8) * ((Bv + 15) / 16) >= 256;     // at least one 192 x 192 block per CU
+}
+
+extern "C" int nr_sim_reg_tile(int A, int Nt, int Bv, int Nv, int* TA, int* TB) {
     int ta = Nt == 24 ? 4 : (Nt == 64 ? 2 : 0);
     int tb = Nv == 12 ? 8 : (Nv == 64 ? 2 : 0);
     if (!ta || !tb) return 0;
+    if (nr_sim_reg_big(A, Nt, Bv, Nv)) { ta = 8; tb = 16; }
     if (TA) *TA = ta;
     if (TB) *TB = tb;
     return 1;
@@ -240,7 +268,7 @@ extern "C" int nr_sim_reg_tile(int Nt, int Nv, int* TA, int* TB) {
 int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16_t* v_hi, const uint16_t* v_lo,
                         const float* w_t, const float* w_v, int A, int Nt, int Bv, int Nv, int d, int prec, int out_mode,
                         float* out, uint8_t* arg_v, uint8_t* arg_t, float* pmax, float* qmax, hipStream_t st) {
-    if (!nr_sim_reg_tile(Nt, Nv, nullptr, nullptr)) return NR_EUNSUPPORTED;
+    if (!nr_sim_reg_tile(A, Nt, Bv, Nv, nullptr, nullptr)) return NR_EUNSUPPORTED;
     NrSimRegArgs a{t_hi, t_lo, v_hi, v_lo, w_t, w_v, out, arg_v, arg_t, pmax, qmax, A, Bv, d, out_mode};
     const bool x3 = prec == NR_PREC_BF16X3, args = arg_v != nullptr;
 #define NR_REG_CASE(MI_, TPS_, NI_, FPS_)                                                              \
@@ -249,6 +277,10 @@ int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16
                             : nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, true, false>(a, st);             \
         return args ? nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, false, true>(a, st)                      \
                     : nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, false, false>(a, st);                    \
+    }
+    if (nr_sim_reg_big(A, Nt, Bv, Nv)) {     // 24 x 12 tokens, 192 x 192 blocks on 2 x 4 waves
+        if (x3) return args ? nr_sim_reg_launch<6, 3, 4, 4, true, true, 4>(a, st) : nr_sim_reg_launch<6, 3, 4, 4, true, false, 4>(a, st);
+        return args ? nr_sim_reg_launch<6, 3, 4, 4, false, true, 4>(a, st) : nr_sim_reg_launch<6, 3, 4, 4, false, false, 4>(a, st);
     }
     NR_REG_CASE(3, 8, 3, 4)      // 24 text tokens x 12 frames (MSR-VTT)
     NR_REG_CASE(4, 16, 4, 16)    // 64 x 64 (ActivityNet)

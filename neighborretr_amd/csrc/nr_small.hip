@@ -38,36 +38,49 @@ extern "C" int nr_reduce_parts(const float* part, int n_parts, int n, float scal
 }
 
 // ---- C = A * B^T in exact fp32 on v_mfma_f32_16x16x4_f32 (modeling.py:526, one global token) ---
-// One wave per 16x16 output tile; operands straight from global/L2 as float4 along k.  Element s of
-// a lane's float4 feeds MFMA step s, i.e. step s multiplies k = k0 + 4*(lane>>4) + s on both
-// operands -- a permutation of the k order, identical for A and B, so the sum is unchanged.
+// One WORKGROUP per 16x16 output tile, its four waves splitting K (wave w takes the 16-wide k blocks
+// w, w+4, ...) and meeting in LDS: the product is tiny (B x B x d) and sits on the step's critical path,
+// so the K loop is kept short and its loads independent.  Operands come straight from global/L2 as
+// float4 along k; element s of a lane's float4 feeds MFMA step s, i.e. step s multiplies
+// k = k0 + 4*(lane>>4) + s on both operands -- a permutation of the k order, identical for A and B.
 __global__ __launch_bounds__(256) void nr_gemm_nt_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              int M, int N, int K, float* __restrict__ c) {
+    __shared__ f32x4_t s_part[3][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = blockIdx.y * 32 + (wave >> 1) * 16;
-    const int col0 = blockIdx.x * 32 + (wave & 1) * 16;
-    if (row0 >= M || col0 >= N) return;
+    const int row0 = blockIdx.y * 16, col0 = blockIdx.x * 16;
     const int ar = min(row0 + (lane & 15), M - 1);
     const int br = min(col0 + (lane & 15), N - 1);
     const float* pa = a + (size_t)ar * K + 4 * (lane >> 4);
     const float* pb = b + (size_t)br * K + 4 * (lane >> 4);
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        f32x4_t va = *reinterpret_cast<const f32x4_t*>(pa + k0);
-        f32x4_t vb = *reinterpret_cast<const f32x4_t*>(pb + k0);
+    for (int k0 = wave * 16; k0 < K; k0 += 256) {        // 4 k blocks of this wave per trip, loads first
+        f32x4_t va[4], vb[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va[s], vb[s], acc, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * 64;
+            const bool ok = k < K;
+            va[u] = ok ? *reinterpret_cast<const f32x4_t*>(pa + k) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            vb[u] = ok ? *reinterpret_cast<const f32x4_t*>(pb + k) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va[u][s], vb[u][s], acc, 0, 0, 0);
     }
+    if (wave > 0) s_part[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave > 0) return;
+    const f32x4_t p1 = s_part[0][lane], p2 = s_part[1][lane], p3 = s_part[2][lane];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int r = row0 + (lane >> 4) * 4 + j, cc = col0 + (lane & 15);
-        if (r < M && cc < N) c[(size_t)r * N + cc] = acc[j];
+        if (r < M && cc < N) c[(size_t)r * N + cc] = (acc[j] + p1[j]) + (p2[j] + p3[j]);
     }
 }
 
 extern "C" int nr_gemm_nt_f32(const float* a, const float* b, int M, int N, int K, float* c, void* stream) {
     if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || (K % 16) != 0) return NR_EINVAL;
-    dim3 grid((N + 31) / 32, (M + 31) / 32);
+    dim3 grid((N + 15) / 16, (M + 15) / 16);
     hipLaunchKernelGGL(nr_gemm_nt_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, b, M, N, K, c);
     NR_LAUNCH_CHECK();
     return NR_OK;
@@ -281,6 +294,56 @@ __global__ __launch_bounds__(256) void nr_diag_ranks_kernel(const float* __restr
 extern "C" int nr_diag_ranks(const float* S, int N, int32_t* greater, int32_t* equal, void* stream) {
     if (!S || !greater || !equal || N <= 0) return NR_EINVAL;
     hipLaunchKernelGGL(nr_diag_ranks_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, N, greater, equal);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// ---- step prologue -------------------------------------------------------------------------------------------
+// What the step needs before anything else can start, in ONE launch instead of six ATen kernels on the serial
+// front of the critical path: the int64 masks of the loader as fp32 multipliers (modeling.py:283-287 keeps them
+// int64; every kernel here reads fp32), exp(logit_scale) (modeling.py:289), and the uniform tie-break noise of the
+// four DPC-KNN calls (cluster.py:483, torch.rand there).  The noise is a counter-based stream
+// u = splitmix64(splitmix64(seed + counter) + i) >> 40 / 2^24 whose (seed, counter) pair lives on the device and
+// is advanced by the kernel itself, so a captured HIP graph draws fresh numbers at every replay.
+__device__ __forceinline__ unsigned long long nr_splitmix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(1024) void nr_step_prologue_kernel(const int64_t* __restrict__ m0, int n0, float* __restrict__ o0,
+                                                               const int64_t* __restrict__ m1, int n1, float* __restrict__ o1,
+                                                               const float* __restrict__ ls, float* __restrict__ ls_exp,
+                                                               unsigned long long* __restrict__ rng, float* __restrict__ noise,
+                                                               int n_noise) {
+    const int tid = threadIdx.x;
+    unsigned long long key = 0, ctr = 0;
+    if (noise) {
+        ctr = rng[1];
+        key = nr_splitmix64(rng[0] + ctr);
+    }
+    for (int i = tid; i < n0; i += 1024) o0[i] = (float)m0[i];
+    for (int i = tid; i < n1; i += 1024) o1[i] = (float)m1[i];
+    if (ls && tid == 0) ls_exp[0] = expf(ls[0]);
+    for (int i = tid; i < n_noise; i += 1024)
+        noise[i] = (float)(nr_splitmix64(key + (unsigned long long)i) >> 40) * (1.0f / 16777216.0f);
+    if (noise) {
+        __syncthreads();                    // every thread has read the counter
+        if (tid == 0) rng[1] = ctr + 1;
+    }
+}
+
+extern "C" int nr_step_prologue(const int64_t* mask0, int n0, float* out0, const int64_t* mask1, int n1, float* out1,
+                                const float* logit_scale, float* logit_scale_exp, uint64_t* rng_state, float* noise,
+                                int n_noise, void* stream) {
+    if (n0 < 0 || n1 < 0 || n_noise < 0) return NR_EINVAL;
+    if ((n0 > 0 && (!mask0 || !out0)) || (n1 > 0 && (!mask1 || !out1))) return NR_EINVAL;
+    if ((logit_scale != nullptr) != (logit_scale_exp != nullptr)) return NR_EINVAL;
+    if (n_noise > 0 && (!rng_state || !noise)) return NR_EINVAL;
+    hipLaunchKernelGGL(nr_step_prologue_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask0, n0, out0, mask1, n1, out1,
+                       logit_scale, logit_scale_exp, reinterpret_cast<unsigned long long*>(n_noise > 0 ? rng_state : nullptr),
+                       n_noise > 0 ? noise : nullptr, n_noise);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

@@ -113,21 +113,6 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     lo_b = keep or hip.PREC_BF16X3 in (p_bb, p_mlp, p_bank)
     lo_k = keep or p_bank == hip.PREC_BF16X3
     cur = torch.cuda.current_stream()
-    if local_stream is not None:
-        local_stream.wait_stream(cur)
-        torch.cuda.set_stream(local_stream)
-    try:
-        pt = ops.prepare_tokens(text_feat, text_mask, want_lo=lo_b, want_colsum=True)
-        pv = ops.prepare_tokens(video_feat, video_mask, want_lo=lo_b, want_colsum=True)
-        w_t, lg_t = token_weights(pt, text_mask, sw_t, B, Nt, p_mlp, keep)
-        w_v, lg_v = token_weights(pv, video_mask, sw_v, B, Nv, p_mlp, keep)
-        S, aux0 = ops.local_level(pt, pv, w_t, w_v, B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
-        # mean of the (unmasked) normalised tokens for the centrality weights -- still on the local branch
-        mean_t = ops.reduce_parts(pt.colsum, 1.0 / pt.n_tok)
-        mean_v = ops.reduce_parts(pv.colsum, 1.0 / pv.n_tok)
-    finally:
-        if local_stream is not None:
-            torch.cuda.set_stream(cur)
 
     def bank_video():
         # text x bank-video, row mean  -> centrality of text j  (used by the v2t neighbour loss)
@@ -143,16 +128,34 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         p0, aux2 = ops.local_level(pbt, pv, w_bt, w_v, M, Nt, B, Nv, p_bank, hip.OUT_COLSUM, keep)
         return pbt, w_bt, lg_bt, aux2, ops.reduce_parts(p0, 1.0 / M)
 
-    # `bank_early` chains (0..2) run on the local stream right behind the batch products, i.e. beside the
-    # clustering; the rest is forked after the join (beside the Sinkhorn solve).
     early = [None, None]
-    if local_stream is not None and bank_early > 0:
+    if local_stream is not None:
+        # Fork first, then put the CRITICAL path (the clustering that `join` runs on this stream) into the
+        # queue before the local branch: a HIP graph hands its nodes to the hardware queues in capture
+        # order, a microsecond or two apiece, so whatever is captured first starts first.
+        local_stream.wait_stream(cur)
+        produced = join() if join is not None else None
+        if produced is not None:
+            gt, gv = produced
+        join = None
         torch.cuda.set_stream(local_stream)
-        try:
+    try:
+        pt = ops.prepare_tokens(text_feat, text_mask, want_lo=lo_b, want_colsum=True)
+        pv = ops.prepare_tokens(video_feat, video_mask, want_lo=lo_b, want_colsum=True)
+        w_t, lg_t = token_weights(pt, text_mask, sw_t, B, Nt, p_mlp, keep)
+        w_v, lg_v = token_weights(pv, video_mask, sw_v, B, Nv, p_mlp, keep)
+        S, aux0 = ops.local_level(pt, pv, w_t, w_v, B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
+        # mean of the (unmasked) normalised tokens for the centrality weights -- still on the local branch
+        mean_t = ops.reduce_parts(pt.colsum, 1.0 / pt.n_tok)
+        mean_v = ops.reduce_parts(pv.colsum, 1.0 / pv.n_tok)
+        # `bank_early` chains (0..2) run on the local stream right behind the batch products, i.e. beside
+        # the clustering; the rest is forked after the join (beside the Sinkhorn solve).
+        if local_stream is not None and bank_early > 0:
             early[0] = bank_video()
             if bank_early > 1:
                 early[1] = bank_text()
-        finally:
+    finally:
+        if local_stream is not None:
             torch.cuda.set_stream(cur)
     if join is not None:
         produced = join()
@@ -179,19 +182,23 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     else:
         pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
         pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
-    G = global_logits(gt, gv, sw_t1, sw_v1)
-    tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
     gt2 = gt.reshape(B, d).float().contiguous()
     gv2 = gv.reshape(B, d).float().contiguous()
-    wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
+    if bank_streams is not None:       # the centrality weights too run beside the Sinkhorn solve
+        with torch.cuda.stream(bank_streams[0]):
+            wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
+    G = global_logits(gt, gv, sw_t1, sw_v1)
+    tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
+    if bank_streams is None:
+        wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
     ls = logit_scale.detach().float().reshape(1).contiguous()
     if bank_streams is not None:
         for st_ in bank_streams:
             cur.wait_stream(st_)
-        for t_ in (c0, c1) + ((pbt.hi, pbv.hi, w_bt, w_bv) if keep else ()):
+        for t_ in (c0, c1, wc_t, wc_v) + ((pbt.hi, pbv.hi, w_bt, w_bv) if keep else ()):
             t_.record_stream(cur)
-    rowloss = ops.row_losses(S, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"])
-    losses = ops.loss_finalize(rowloss, hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
+    rowloss, losses = ops.row_losses_final(S, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"],
+                                           hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
     saved = None
     if keep:
         saved = dict(pt=pt, pv=pv, pbt=pbt, pbv=pbv, w_t=w_t, w_v=w_v, w_bt=w_bt, w_bv=w_bv,

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "nr_sinkhorn_workspace_bytes": ([_I], _Z),
     "nr_sinkhorn_targets": ([_P, _I, _F, _I, _P, _P, _P, _P], _I),
     "nr_row_losses_fwd": ([_P] * 9 + [_I, _I, _F, _P, _P], _I),
+    "nr_row_losses_fwd_final": ([_P] * 9 + [_I, _I, _F, _P, _P, _F, _F, _F, _P, _P], _I),
     "nr_loss_finalize": ([_P, _I, _F, _F, _F, _P, _P], _I),
     "nr_row_losses_bwd": ([_P] * 9 + [_I, _I, _F, _P, _P, _P, _P, _P, _P, _P], _I),
     "nr_add_transposed": ([_P, _P, _I, _P, _P], _I),
@@ -71,6 +72,7 @@ _SIGNATURES = {
     "nr_normalize_bwd": ([_P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     "nr_token_softmax_bwd": ([_P, _P, _I, _I, _P, _P], _I),
     "nr_centrality_weights_bwd": ([_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P], _I),
+    "nr_step_prologue": ([_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P], _I),
     "nr_bank_push": ([_P, _P, _I, _I, _Z, _P, _P], _I),
     "nr_bank_ring_push": ([_I, _P, _P, _P, _I, _I, _I, _P], _I),
     "nr_diag_ranks": ([_P, _I, _P, _P, _P], _I),

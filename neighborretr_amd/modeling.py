@@ -77,6 +77,7 @@ class NeighborRetr(nn.Module):
         self.bank_side_streams = True       # bank chains beside the Sinkhorn solve (head.head_forward)
         self._bstreams = None
         self._lstream = None
+        self._rng_state = None
         self.bank_early = 1                 # bank chains started beside the clustering instead of the Sinkhorn (0..2)
         self.group_clustering = True        # text + video clustering in the same launches (no-grad forward)
         self.fuse_clustering = True
@@ -191,17 +192,26 @@ class NeighborRetr(nn.Module):
     def loss_step(self, text_feat, video_feat, text_mask, video_mask, idx):
         """Everything after the exchange step: the five losses on the (gathered) global batch and the
         memory-bank push (modeling.py:283-312).  Collective-free, so it captures into a HIP graph."""
-        # masks as fp32 once per step: every kernel reads them as multipliers
-        if text_mask.dtype != torch.float32:
-            text_mask = text_mask.float()
-        if video_mask.dtype != torch.float32:
-            video_mask = video_mask.float()
-        logit_scale = self.clip.logit_scale.exp()
+        noise = None
+        raw_scale = self.clip.logit_scale
+        if text_feat.is_cuda:
+            # masks as fp32 multipliers, exp(logit_scale) and the DPC-KNN tie-break noise in ONE launch
+            scale_in_kernel = not (torch.is_grad_enabled() and raw_scale.requires_grad)
+            sizes = self._noise_sizes(text_feat.shape[1], video_feat.shape[1])
+            B = text_feat.shape[0]
+            text_mask, video_mask, ls_exp, flat = ops.step_prologue(
+                text_mask, video_mask, raw_scale if scale_in_kernel else None,
+                self._rng_state_on(text_feat.device), B * sum(sizes.values()))
+            logit_scale = ls_exp.reshape(()) if scale_in_kernel else raw_scale.exp()
+            noise = self._slice_noise(flat, B, sizes)
+        else:
+            text_mask, video_mask = text_mask.float(), video_mask.float()
+            logit_scale = raw_scale.exp()
         cfg = self.config
         losses = self._compute_losses(text_feat, video_feat, text_mask, video_mask,
                                       self._mb["mb_feat_t"], self._mb["mb_feat_v"], self._mb["mb_mask_t"], self._mb["mb_mask_v"],
                                       cfg.centrality_scale, cfg.beta, cfg.num_neighbors, cfg.temperature,
-                                      logit_scale)
+                                      logit_scale, noise=noise)
         with torch.no_grad():
             self.update_memory_bank(idx, text_feat, video_feat, text_mask, video_mask)
         return losses
@@ -295,16 +305,29 @@ class NeighborRetr(nn.Module):
         return not (feat.requires_grad or any(p.requires_grad for m in mods for p in m.parameters()))
 
     @staticmethod
-    def _draw_noise(B, Nt, Nv, device):
-        """The four DPC-KNN tie-break draws of one step (cluster.py:483) from ONE torch.rand launch."""
+    def _noise_sizes(Nt, Nv):
         t0, v0 = max(math.ceil(Nt / 6), 1), max(math.ceil(Nv / 4), 1)
-        sizes = {"t0": Nt, "t1": t0, "v0": Nv, "v1": v0}
-        flat = torch.rand(B * sum(sizes.values()), device=device, dtype=torch.float32)
+        return {"t0": Nt, "t1": t0, "v0": Nv, "v1": v0}
+
+    @staticmethod
+    def _slice_noise(flat, B, sizes):
         out, off = {}, 0
         for k, n in sizes.items():
             out[k] = flat[off:off + B * n].view(B, n)
             off += B * n
         return out
+
+    @classmethod
+    def _draw_noise(cls, B, Nt, Nv, device):
+        """The four DPC-KNN tie-break draws of one step (cluster.py:483) from ONE torch.rand launch."""
+        sizes = cls._noise_sizes(Nt, Nv)
+        return cls._slice_noise(torch.rand(B * sum(sizes.values()), device=device, dtype=torch.float32), B, sizes)
+
+    def _rng_state_on(self, device):
+        """Device-resident {seed, counter} of the step prologue's noise stream (seeded from torch's seed)."""
+        if self._rng_state is None or self._rng_state.device != device:
+            self._rng_state = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+        return self._rng_state
 
     def _side_streams(self, device):
         if self._streams is None or self._streams[0].device != device:

@@ -169,6 +169,25 @@ def row_losses(S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, lo
     return rowloss
 
 
+_COUNTERS = {}
+
+
+def row_losses_final(S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, K, T, wu, wn, wkl):
+    """Row terms [2,4,B] AND the five losses from one launch (nr_row_losses_fwd_final)."""
+    B = S.shape[0]
+    dev = S.device
+    counter = _COUNTERS.get(dev)
+    if counter is None:
+        counter = _COUNTERS[dev] = torch.zeros((1,), dtype=torch.int32, device=dev)
+    rowloss = torch.empty((2, 4, B), dtype=torch.float32, device=dev)
+    losses = torch.empty((5,), dtype=torch.float32, device=dev)
+    hip.call("nr_row_losses_fwd_final", hip.ptr(S, torch.float32), hip.ptr(G, torch.float32), hip.ptr(tgt_rows), hip.ptr(tgt_cols),
+             hip.ptr(bank_c0, torch.float32), hip.ptr(bank_c1, torch.float32), hip.ptr(wc_text, torch.float32),
+             hip.ptr(wc_video, torch.float32), hip.ptr(logit_scale, torch.float32), B, int(K), float(T),
+             hip.ptr(rowloss), hip.ptr(counter), float(wu), float(wn), float(wkl), hip.ptr(losses), hip.stream_ptr())
+    return rowloss, losses
+
+
 def loss_finalize(rowloss, wu, wn, wkl):
     B = rowloss.shape[-1]
     losses = torch.empty((5,), dtype=torch.float32, device=rowloss.device)
@@ -271,6 +290,37 @@ def bank_push(bank, batch, scratch=None):
     hip.call("nr_bank_push", hip.ptr(bank), hip.ptr(batch.contiguous()), cap, n_new, row_bytes,
              hip.ptr(scratch, allow_none=True), hip.stream_ptr())
     return bank
+
+
+def step_prologue(mask0, mask1, logit_scale, rng_state, n_noise):
+    """nr_step_prologue: (mask0 fp32, mask1 fp32, exp(logit_scale) [1] or None, noise [n_noise] or None).
+    int64 masks are converted by the kernel; fp32 masks pass through untouched."""
+    dev = (mask0 if mask0 is not None else rng_state).device
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    def conv(m):
+        if m is None or m.dtype == torch.float32:
+            return None, m
+        if m.dtype != torch.int64:
+            return None, m.float()
+        m = m.contiguous()
+        return m, torch.empty(m.shape, **f32)
+    i0, o0 = conv(mask0)
+    i1, o1 = conv(mask1)
+    ls_exp = ls = None
+    if logit_scale is not None:
+        ls = logit_scale.detach().float().reshape(1).contiguous()
+        ls_exp = torch.empty((1,), **f32)
+    noise = torch.empty((n_noise,), **f32) if n_noise > 0 else None
+    if i0 is not None or i1 is not None or ls is not None or noise is not None:
+        hip.call("nr_step_prologue", hip.ptr(i0, allow_none=True), i0.numel() if i0 is not None else 0,
+                 hip.ptr(o0 if i0 is not None else None, allow_none=True),
+                 hip.ptr(i1, allow_none=True), i1.numel() if i1 is not None else 0,
+                 hip.ptr(o1 if i1 is not None else None, allow_none=True),
+                 hip.ptr(ls, allow_none=True), hip.ptr(ls_exp, allow_none=True),
+                 hip.ptr(rng_state if noise is not None else None, torch.int64, allow_none=True),
+                 hip.ptr(noise, allow_none=True), int(n_noise), hip.stream_ptr())
+    return o0, o1, ls_exp, noise
 
 
 def bank_ring_push(banks, batches, head_new):

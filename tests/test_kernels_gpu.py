@@ -335,6 +335,59 @@ def test_grouped_clustering_stage_equals_the_per_modality_path():
         assert maxdiff(a, b) < 2e-5 * max(1.0, float(b.abs().max()))
 
 
+def test_step_prologue_masks_scale_and_noise():
+    g = torch.Generator().manual_seed(0)
+    m0 = (torch.rand(128, 24, generator=g) > 0.3).long().to(DEV)
+    m1 = (torch.rand(128, 12, generator=g) > 0.3).long().to(DEV)
+    ls = torch.tensor(2.6593, device=DEV)
+    rng = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+    o0, o1, e, n1 = ops.step_prologue(m0, m1, ls, rng, 5504)
+    assert torch.equal(o0, m0.float()) and torch.equal(o1, m1.float())
+    assert abs(float(e) - float(torch.exp(ls))) < 2e-6 * float(torch.exp(ls))
+    assert int(rng[1]) == 1 and int(rng[0]) == 1234
+    _, _, _, n2 = ops.step_prologue(m0, m1, None, rng, 5504)
+    assert int(rng[1]) == 2
+    for n in (n1, n2):
+        assert float(n.min()) >= 0.0 and float(n.max()) < 1.0 and abs(float(n.mean()) - 0.5) < 0.02
+    assert not torch.equal(n1, n2) and len(torch.unique(n1)) > 5400
+    # the same (seed, counter) reproduces the same stream
+    rng2 = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+    assert torch.equal(ops.step_prologue(None, None, None, rng2, 5504)[3], n1)
+    # fp32 masks pass through; a captured graph draws fresh numbers at every replay
+    f0 = m0.float()
+    assert ops.step_prologue(f0, None, None, rng, 0)[0] is f0
+    gph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ops.step_prologue(m0, m1, ls, rng, 64)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(gph, stream=s):
+            out = ops.step_prologue(m0, m1, ls, rng, 64)[3]
+    gph.replay()
+    torch.cuda.synchronize()
+    a = out.clone()
+    gph.replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(a, out)
+
+
+@pytest.mark.parametrize("B", [16, 128, 300])
+def test_row_losses_final_is_bit_identical_to_two_launches(B):
+    g = torch.Generator().manual_seed(B)
+    S = (torch.rand(B, B, generator=g) * 0.1).to(DEV)
+    G = (torch.randn(B, B, generator=g) * 3).to(DEV)
+    tr, tc = ops.sinkhorn_targets(G, 0.7, 50)
+    v = lambda: (torch.rand(B, generator=g) * 0.1).to(DEV)
+    c0, c1, w0, w1 = v(), v(), 1 + v(), 1 + v()
+    ls = torch.tensor([100.0], device=DEV)
+    K = min(20, B)
+    rl = ops.row_losses(S, G, tr, tc, c0, c1, w0, w1, ls, K, 3.0)
+    ref = ops.loss_finalize(rl, 1.0, 0.5, 2.0)
+    for _ in range(3):                                   # the counter resets itself
+        rl2, fused = ops.row_losses_final(S, G, tr, tc, c0, c1, w0, w1, ls, K, 3.0, 1.0, 0.5, 2.0)
+        assert torch.equal(rl, rl2) and torch.equal(ref, fused)
+
+
 def test_bank_push_fifo():
     bank = torch.arange(10 * 6, dtype=torch.float32, device=DEV).reshape(10, 2, 3)
     ref = bank.clone()
