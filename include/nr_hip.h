@@ -72,8 +72,9 @@ int nr_token_softmax(const float* logit_part, int n_parts, const float* b2, cons
  *   out per out_mode (see NR_OUT_*).  Optional outputs kept for the backward pass (all or none):
  *   arg_v [A,Bv,Nt] / arg_t [A,Bv,Nv] u8 arg-max indices, pmax [A,Bv,Nt] / qmax [A,Bv,Nv] f32 the
  *   pooled maxima themselves.
- * nr_local_level_tiles reports the tile grid the kernel will use (sizes of the partial outputs). */
-int nr_local_level_tiles(int A, int Nt, int Bv, int Nv, int* n_row_tiles, int* n_col_tiles);
+ * nr_local_level_tiles reports the tile grid the kernel will use for that shape and precision (sizes of
+ * the partial outputs).                                                                            */
+int nr_local_level_tiles(int A, int Nt, int Bv, int Nv, int prec, int* n_row_tiles, int* n_col_tiles);
 int nr_local_level_fwd(const uint16_t* t_hi, const uint16_t* t_lo, const uint16_t* v_hi, const uint16_t* v_lo,
                        const float* w_t, const float* w_v, int A, int Nt, int Bv, int Nv, int d,
                        int prec, int out_mode, float* out, uint8_t* arg_v, uint8_t* arg_t,

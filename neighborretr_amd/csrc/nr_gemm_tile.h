@@ -29,6 +29,28 @@ __device__ __forceinline__ void nr_static_for(F&& f) {
     }
 }
 
+#ifdef NR_STAMP
+// In-kernel timing (diagnostic builds only: NR_EXTRA_FLAGS=-DNR_STAMP): every wave keeps cycle sums of the K
+// loop's phases in registers (a global store per stamp would itself sit in vmcnt and be waited for by the
+// loop's own s_waitcnt); wave 0 of workgroup 0 writes them out once at the end.
+static __device__ unsigned long long nr_stamp_buf[256];      // one copy per translation unit
+struct NrPhaseClock {
+    unsigned long long t, wait_dma, barrier, compute, slices;
+    __device__ __forceinline__ void start() { t = __builtin_readcyclecounter(); wait_dma = barrier = compute = slices = 0; }
+    __device__ __forceinline__ unsigned long long lap() {
+        unsigned long long n = __builtin_readcyclecounter(), d = n - t;
+        t = n;
+        return d;
+    }
+    __device__ __forceinline__ void flush(int base) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            nr_stamp_buf[base + 0] = wait_dma; nr_stamp_buf[base + 1] = barrier;
+            nr_stamp_buf[base + 2] = compute;  nr_stamp_buf[base + 3] = slices;
+        }
+    }
+};
+#endif
+
 typedef __attribute__((address_space(3))) void* nr_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* nr_glb_ptr_t;
 
@@ -156,7 +178,15 @@ struct NrGemmTile {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
             if (s < KT) issue(s);
+#ifdef NR_STAMP
+        NrPhaseClock clk;
+        clk.start();
+#endif
         for (int kt = 0; kt < KT; ++kt) {
+#ifdef NR_STAMP
+            clk.compute += clk.lap();
+            clk.slices += 1;
+#endif
             if constexpr (STAGES == 1) {
                 // single stage: refill after everyone is done with the previous slice, no prefetch; the
                 // other resident workgroups of the CU cover the DMA latency (smallest LDS footprint)
@@ -172,7 +202,13 @@ struct NrGemmTile {
                 else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragment reads of slice kt-1 are complete
+#ifdef NR_STAMP
+                clk.wait_dma += clk.lap();
+#endif
                 __builtin_amdgcn_s_barrier();
+#ifdef NR_STAMP
+                clk.barrier += clk.lap();
+#endif
             }
             // The DMA instructions of the slice to prefetch are issued BETWEEN this slice's MFMAs, a few MFMAs
             // apart (an LDS-DMA instruction holds its wave's issue for ~60-180 cycles: in one burst ahead of the
@@ -209,8 +245,11 @@ struct NrGemmTile {
                     }
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[m], fb_h[n], acc[m][n], 0, 0, 0);
                     if constexpr (STAGES > 1) {
-                        // an even spread of the DMA instructions over the slice's 2*MI*NI MFMA groups
-                        constexpr int G = 2 * MI * NI;
+                        // the DMA instructions go out between the MFMA groups of the FIRST HALF of the slice: apart
+                        // enough not to stall the matrix pipe, early enough to have landed when the slice ends
+                        // (spread over the whole slice, the last pieces kept every wave waiting ~640 cycles at
+                        // the next slice's vmcnt -- in-kernel stamps, 192 x 384 blocks)
+                        constexpr int G = (2 * MI * NI + 1) / 2;
                         nr_static_for<0, DMA_PER_STAGE>([&](auto i_c) {
                             constexpr int i = decltype(i_c)::value;
                             // instruction i belongs to group floor(i * G / DMA_PER_STAGE)
@@ -221,6 +260,10 @@ struct NrGemmTile {
                 });
             }
         }
+#ifdef NR_STAMP
+        clk.compute += clk.lap();
+        clk.flush(0);
+#endif
         // every wave is done with the ring before the caller reuses the LDS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();

@@ -6,53 +6,93 @@
 // accumulator row by the token's original norm (W1 x = ||x|| * W1 x_hat), so the features are
 // converted to bf16 only once for both the scorer and the similarity kernel.  Rows of masked
 // tokens are zero vectors; their logits are overwritten with -9e15 by the softmax anyway.
+#include <cstdlib>
 #include "nr_gemm_tile.h"
 #include "../../include/nr_hip.h"
 
-template <bool X3, int STAGES>
-__global__ __launch_bounds__(256) void nr_mlp_kernel(const uint16_t* __restrict__ tok_hi, const uint16_t* __restrict__ tok_lo,
-                                                     const float* __restrict__ norm, int n_tok, int d,
-                                                     const uint16_t* __restrict__ w1_hi, const uint16_t* __restrict__ w1_lo,
-                                                     const float* __restrict__ b1, const float* __restrict__ w2, int H,
-                                                     float* __restrict__ logit_part) {
+// Block shapes: BM = 32*MI token rows x BN = 16*WC*NI hidden units with BN a multiple of 128 (one partial-logit row
+// per 128 hidden units, the granularity nr_token_softmax sums).  The main loop is bound by the operand bytes a CU
+// pulls into LDS (~25 B/clk/CU by LDS-DMA), so the host picks, per launch, the shape that minimises
+//     ceil(workgroups / 256 CUs) * (BM + BN)
+// -- e.g. 96x128 for the 3072 batch text tokens (256 workgroups, one per CU) and 192x256 on 8 waves for the
+// 12288 bank text tokens (again 256) instead of 128x128 everywhere (192 resp. 768 workgroups).
+template <int MI, int NI, int WC, bool X3, int STAGES>
+__global__ __launch_bounds__(128 * WC) void nr_mlp_kernel(const uint16_t* __restrict__ tok_hi, const uint16_t* __restrict__ tok_lo,
+                                                          const float* __restrict__ norm, int n_tok, int d,
+                                                          const uint16_t* __restrict__ w1_hi, const uint16_t* __restrict__ w1_lo,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2, int H,
+                                                          float* __restrict__ logit_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Tile = NrGemmTile<4, 4, X3, 16, 16, STAGES>;
+    using Tile = NrGemmTile<MI, NI, X3, 16, 16, STAGES, WC>;
+    constexpr int BM = Tile::BM, BN = Tile::BN;
+    constexpr int WCOLS = 16 * NI;                 // hidden units per wave
+    constexpr int WPP = 128 / WCOLS;               // waves per 128-unit part
+    static_assert(BN % 128 == 0 && 128 % WCOLS == 0, "a block must hold whole 128-unit parts");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;
+    const int wr = wave / WC, wc = wave % WC;
+    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
 
     Tile tile;
     tile.zero();
     tile.run(tok_hi, tok_lo, row0, n_tok, w1_hi, w1_lo, col0, H, d, smem);
 
-    float bb[4], ww[4];
+    float bb[NI], ww[NI];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        int c = col0 + wc * 64 + n * 16 + (lane & 15);
+    for (int n = 0; n < NI; ++n) {
+        int c = col0 + wc * WCOLS + n * 16 + (lane & 15);
         bb[n] = b1[c];
         ww[n] = w2[c];
     }
-    float* sPart = reinterpret_cast<float*>(smem);   // [2][128]; staging LDS is free after run()
+    float* sPart = reinterpret_cast<float*>(smem);   // [WC][BM]; staging LDS is free after run()
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MI; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int r = wr * 64 + m * 16 + (lane >> 4) * 4 + j;
+            int r = wr * 16 * MI + m * 16 + (lane >> 4) * 4 + j;
             int gr = min(row0 + r, n_tok - 1);
             float sc = norm[gr];
             float v = 0.f;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) v += fmaxf(tile.acc[m][n][j] * sc + bb[n], 0.f) * ww[n];
+            for (int n = 0; n < NI; ++n) v += fmaxf(tile.acc[m][n][j] * sc + bb[n], 0.f) * ww[n];
             v += __shfl_xor(v, 1);
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 8);
-            if ((lane & 15) == 0) sPart[wc * 128 + r] = v;
+            if ((lane & 15) == 0) sPart[wc * BM + r] = v;
         }
     __syncthreads();
-    if (tid < 128 && row0 + tid < n_tok)
-        logit_part[(size_t)blockIdx.x * n_tok + row0 + tid] = sPart[tid] + sPart[128 + tid];
+    // part p of this block = hidden units [col0 + 128p, col0 + 128p + 128) = wave columns [p*WPP, (p+1)*WPP)
+    for (int e = tid; e < (BN / 128) * BM; e += 64 * Tile::NW) {
+        const int part = e / BM, r = e - part * BM;
+        if (row0 + r >= n_tok) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < WPP; ++q) v += sPart[(part * WPP + q) * BM + r];
+        logit_part[(size_t)(blockIdx.x * (BN / 128) + part) * n_tok + row0 + r] = v;
+    }
 }
+
+namespace {
+struct MlpShape { int mi, ni, wc; };
+
+template <int MI, int NI, int WC, bool X3, int STAGES>
+int mlp_launch(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d, const uint16_t* w1_hi,
+               const uint16_t* w1_lo, const float* b1, const float* w2, int H, float* logit_part, hipStream_t st) {
+    using Tile = NrGemmTile<MI, NI, X3, 16, 16, STAGES, WC>;
+    size_t lds = Tile::RING_BYTES;
+    const size_t epi = (size_t)WC * Tile::BM * sizeof(float);
+    if (lds < epi) lds = epi;
+    auto kern = nr_mlp_kernel<MI, NI, WC, X3, STAGES>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(H / Tile::BN, (n_tok + Tile::BM - 1) / Tile::BM);
+    hipLaunchKernelGGL(kern, grid, dim3(128 * WC), lds, st, tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+}  // namespace
 
 extern "C" int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d,
                                    const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2,
@@ -61,26 +101,46 @@ extern "C" int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_l
     if (n_tok <= 0 || d <= 0 || (d % 64) != 0 || H <= 0 || (H % 128) != 0) return NR_EINVAL;
     if (prec != NR_PREC_BF16 && prec != NR_PREC_BF16X3) return NR_EINVAL;
     if (prec == NR_PREC_BF16X3 && (!tok_lo || !w1_lo)) return NR_EINVAL;
-    dim3 grid(H / 128, (n_tok + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
     const bool x3 = prec == NR_PREC_BF16X3;
-    const int stages = nr_pick_stages((long)grid.x * grid.y);
-#define NR_MLP_CASE(X3_, ST_)                                                                                          \
-    if (x3 == X3_ && stages == ST_) {                                                                                  \
-        size_t lds = NrGemmTile<4, 4, X3_, 16, 16, ST_>::RING_BYTES;                                                   \
-        if (lds < 1024) lds = 1024;                                                                                    \
-        if (lds > 64 * 1024) {                                                                                         \
-            hipError_t e = hipFuncSetAttribute((const void*)nr_mlp_kernel<X3_, ST_>,                                   \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
-            if (e != hipSuccess) return (int)e;                                                                        \
-        }                                                                                                              \
-        hipLaunchKernelGGL((nr_mlp_kernel<X3_, ST_>), grid, dim3(256), lds, st, tok_hi, tok_lo, norm, n_tok, d, w1_hi, \
-                           w1_lo, b1, w2, H, logit_part);                                                              \
+    // candidate block shapes (MI, NI, WC): 64/96/128 x 128 on 4 waves, 128/192 x 256 on 8 waves (one-pass bf16
+    // only: the split operands of a 256-wide block do not fit the LDS twice)
+    static const MlpShape cand[] = {{2, 4, 2}, {3, 4, 2}, {4, 4, 2}, {4, 4, 4}, {6, 4, 4}};
+    int best = -1;
+    long best_cost = 0, best_wg = 0;
+    for (int c = 0; c < 5; ++c) {
+        const int bm = 32 * cand[c].mi, bn = 16 * cand[c].wc * cand[c].ni;
+        if (H % bn) continue;
+        if (x3 && cand[c].wc == 4) continue;
+        const long wg = (long)((n_tok + bm - 1) / bm) * (H / bn);
+        const long cost = ((wg + 255) / 256) * (bm + bn);
+        if (best < 0 || cost < best_cost || (cost == best_cost && wg > best_wg)) { best = c; best_cost = cost; best_wg = wg; }
     }
-    NR_MLP_CASE(true, 1) NR_MLP_CASE(true, 2) NR_MLP_CASE(false, 1) NR_MLP_CASE(false, 2)
-#undef NR_MLP_CASE
-    NR_LAUNCH_CHECK();
-    return NR_OK;
+    if (const char* e = getenv("NR_MLP_SHAPE")) {          // tuning hook: index into the candidate list
+        int c = atoi(e);
+        if (c >= 0 && c < 5 && H % (16 * cand[c].wc * cand[c].ni) == 0 && !(x3 && cand[c].wc == 4)) {
+            best = c;
+            best_wg = (long)((n_tok + 32 * cand[c].mi - 1) / (32 * cand[c].mi)) * (H / (16 * cand[c].wc * cand[c].ni));
+        }
+    }
+    if (best < 0) return NR_EUNSUPPORTED;
+    // ring depth: workgroups that sit alone on their CU prefetch for themselves (2 stages); crowded grids run 1
+    const bool two = best_wg < 3 * 256;
+#define NR_MLP_GO(MI_, NI_, WC_)                                                                                              \
+    if (cand[best].mi == MI_ && cand[best].ni == NI_ && cand[best].wc == WC_) {                                               \
+        if (x3) {                                                                                                             \
+            if constexpr (WC_ == 2) {                                                                                         \
+                return two ? mlp_launch<MI_, NI_, WC_, true, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st) \
+                           : mlp_launch<MI_, NI_, WC_, true, 1>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st); \
+            }                                                                                                                 \
+        } else {                                                                                                              \
+            return two ? mlp_launch<MI_, NI_, WC_, false, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st)    \
+                       : mlp_launch<MI_, NI_, WC_, false, 1>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st);   \
+        }                                                                                                                     \
+    }
+    NR_MLP_GO(2, 4, 2) NR_MLP_GO(3, 4, 2) NR_MLP_GO(4, 4, 2) NR_MLP_GO(4, 4, 4) NR_MLP_GO(6, 4, 4)
+#undef NR_MLP_GO
+    return NR_EUNSUPPORTED;
 }
 
 // one wave per sample; N <= 256 tokens

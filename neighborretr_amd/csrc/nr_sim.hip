@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void nr_sim_kernel(NrSimArgs p) {
 int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16_t* v_hi, const uint16_t* v_lo,
                         const float* w_t, const float* w_v, int A, int Nt, int Bv, int Nv, int d, int prec, int out_mode,
                         float* out, uint8_t* arg_v, uint8_t* arg_t, float* pmax, float* qmax, hipStream_t st);
-extern "C" int nr_sim_reg_tile(int A, int Nt, int Bv, int Nv, int* TA, int* TB);
+extern "C" int nr_sim_reg_tile(int A, int Nt, int Bv, int Nv, int prec, int* TA, int* TB);
 
 static bool nr_sim_force_generic() {
     const char* e = getenv("NR_SIM_GENERIC");
@@ -215,14 +215,14 @@ static int nr_pick_extent(int n_tok, int* mi_out) {
     return (32 * best_mi) / n_tok;
 }
 
-extern "C" int nr_local_level_tiles(int A, int Nt, int Bv, int Nv, int* n_row_tiles, int* n_col_tiles) {
+extern "C" int nr_local_level_tiles(int A, int Nt, int Bv, int Nv, int prec, int* n_row_tiles, int* n_col_tiles) {
     int mi, ni;
     if (A <= 0 || Bv <= 0 || Nt <= 0 || Nv <= 0) return NR_EINVAL;
     int TA = nr_pick_extent(Nt, &mi), TB = nr_pick_extent(Nv, &ni);
     if (TA == 0 || TB == 0) return NR_EUNSUPPORTED;   // more than 128 tokens per sample
     if (TA > A) TA = A > 0 ? A : 1;
     if (TB > Bv) TB = Bv > 0 ? Bv : 1;
-    if (!nr_sim_force_generic()) nr_sim_reg_tile(A, Nt, Bv, Nv, &TA, &TB);    // the register-epilogue kernel's blocks
+    if (!nr_sim_force_generic()) nr_sim_reg_tile(A, Nt, Bv, Nv, prec, &TA, &TB);    // the register-epilogue kernel's blocks
     if (n_row_tiles) *n_row_tiles = (A + TA - 1) / TA;
     if (n_col_tiles) *n_col_tiles = (Bv + TB - 1) / TB;
     return NR_OK;

@@ -19,10 +19,20 @@
 // (341 B per MFMA) at 27 % and their split-bf16 form (227 B per MFMA) at 42 % of the MFMA peak -- so the
 // way up is fewer bytes per MFMA: doubling both block edges halves them (171 B per MFMA), and eight waves
 // keep two per SIMD so one computes while the other waits on its fragments.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include "nr_gemm_tile.h"
 #include "../../include/nr_hip.h"
+
+#ifdef NR_STAMP
+extern "C" int nr_debug_stamps(unsigned long long* host, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(nr_stamp_buf), sizeof(unsigned long long) * 256);
+    (void)reset;
+    return 16;
+}
+#endif
 
 struct NrSimRegArgs {
     const uint16_t *t_hi, *t_lo, *v_hi, *v_lo;
@@ -68,6 +78,9 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     constexpr int GX = TPS / 4;                       // lane groups (of 16) that share a text
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
+#ifdef NR_STAMP
+    const unsigned long long t_start = __builtin_readcyclecounter();
+#endif
     // XCD-aware tile order: workgroups b and b+8 land on the same XCD (round-robin dispatch), so XCD x is
     // given one contiguous PR x PC part of the tile grid and its private L2 pulls only that part's
     // operand rows.  Pure speed: any placement computes the same tiles.
@@ -94,19 +107,25 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     const int bg = bx * TB + wc * TBW + bl;
     const bool ok = ag < p.A && bg < p.Bv;
     const int agc = min(ag, p.A - 1), bgc = min(bg, p.Bv - 1);
-    // this lane's token weights, fetched before the main loop so their latency hides under it
+    // this lane's token weights: fetched before the main loop so their latency hides under it -- except in the
+    // largest blocks, whose accumulators leave no registers to park them in
+    constexpr bool LATE_W = MI * NI >= 36;
     float wt[MI][4], wv[NI];
+    auto load_weights = [&]() {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        f32x4_t q = *reinterpret_cast<const f32x4_t*>(p.w_t + (size_t)agc * Nt + TPS * i + tau0);
-        wt[i][0] = q[0]; wt[i][1] = q[1]; wt[i][2] = q[2]; wt[i][3] = q[3];
-    }
+        for (int i = 0; i < MI; ++i) {
+            f32x4_t q = *reinterpret_cast<const f32x4_t*>(p.w_t + (size_t)agc * Nt + TPS * i + tau0);
+            wt[i][0] = q[0]; wt[i][1] = q[1]; wt[i][2] = q[2]; wt[i][3] = q[3];
+        }
 #pragma unroll
-    for (int n = 0; n < NI; ++n) wv[n] = p.w_v[(size_t)bgc * Nv + FPS * n + phi];
+        for (int n = 0; n < NI; ++n) wv[n] = p.w_v[(size_t)bgc * Nv + FPS * n + phi];
+    };
+    if constexpr (!LATE_W) load_weights();
 
     Tile tile;
     tile.zero();
     tile.run(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
+    if constexpr (LATE_W) load_weights();
 
     // ---- t2v: P[t] = max over the video's frames; sum_t w_t[t] * P[t] -------------------------------
     float t2v = 0.f;
@@ -174,6 +193,9 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     v2t = nr_lanes_sum<FPS>(v2t);
 
     const float S = 0.5f * (t2v + v2t);
+#ifdef NR_STAMP
+    if (blockIdx.x == 0 && threadIdx.x == 0) nr_stamp_buf[4] = __builtin_readcyclecounter() - t_start;
+#endif
     const bool writer = (phi == 0) && ((g % GX) == 0);
     if (p.out_mode == NR_OUT_FULL) {
         if (writer && ok) p.out[(size_t)ag * p.Bv + bg] = S;
@@ -239,26 +261,46 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
     // 192 x 192 blocks (8 waves, one workgroup per CU): nobody else hides their DMA latency, so they run the
     // 2-deep ring -- except split-bf16, whose two stages (196 KB) exceed the LDS
     constexpr bool big = WC == 4;
-    const bool one_stage = big ? X3 : nr_pick_stages((long)a.ntx * a.nty) == 1;
+    constexpr bool mid = WC == 2 && MI * NI >= 18;          // 96 x 192 split-bf16: 144 KB for two stages, one workgroup per CU
+    const bool one_stage = big ? X3 : (mid ? false : nr_pick_stages((long)a.ntx * a.nty) == 1);
     if (one_stage) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 1, WC>(a, st);
     if constexpr (big && X3) return NR_EUNSUPPORTED;
-    else return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 2, WC>(a, st);
+    else {
+        if constexpr (big && NI == 3) {          // 192 x 192: three stages fit (144 KB)
+            const char* e = getenv("NR_SIM_STAGES");
+            if (e && atoi(e) == 3) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 3, WC>(a, st);
+        }
+        return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 2, WC>(a, st);
+    }
 }
 
 // tile shape this path uses: texts / videos per workgroup; 0 if the token count is not covered.
 // NR_SIM_BIG=0 keeps the 96 x 96 blocks everywhere (A/B hook).
-static bool nr_sim_reg_big(int A, int Nt, int Bv, int Nv) {
-    if (Nt != 24 || Nv != 12) return false;
+// 0: 96 x 96 blocks; 1: 192 x 192 (8 texts x 16 videos); 2: 192 x 384 (8 x 32); 3: 96 x 192 (4 x 16, split-bf16
+// only).  The largest block that still gives every CU a workgroup: the main loop is bound by the LDS-DMA bytes
+// per CU.  NR_SIM_BIG=0/1/2 caps it, NR_SIM_BIG=3 forces level 3 for split-bf16 (A/B hooks).
+static int nr_sim_reg_big(int A, int Nt, int Bv, int Nv, int prec) {
+    if (Nt != 24 || Nv != 12) return 0;
+    const bool x3 = prec == NR_PREC_BF16X3;
+    int cap = x3 ? 1 : 2;       // split-bf16 fragments do not fit beside 144 accumulators
     const char* e = getenv("NR_SIM_BIG");
-    if (e && !atoi(e)) return false;
-    return (long)((A + 7) / 8) * ((Bv + 15) / 16) >= 256;     // at least one 192 x 192 block per CU
+    const int env = e ? atoi(e) : -1;
+    if (env >= 0 && env <= 2) cap = std::min(cap, env);
+    const long wg3 = (long)((A + 3) / 4) * ((Bv + 15) / 16);
+    if (x3 && env == 3 && wg3 >= 256) return 3;
+    if (x3 && env < 0 && wg3 >= 256 && (long)((A + 7) / 8) * ((Bv + 15) / 16) < 256) return 3;
+    if (cap >= 2 && (long)((A + 7) / 8) * ((Bv + 31) / 32) >= 256) return 2;
+    if (cap >= 1 && (long)((A + 7) / 8) * ((Bv + 15) / 16) >= 256) return 1;
+    return 0;
 }
 
-extern "C" int nr_sim_reg_tile(int A, int Nt, int Bv, int Nv, int* TA, int* TB) {
+extern "C" int nr_sim_reg_tile(int A, int Nt, int Bv, int Nv, int prec, int* TA, int* TB) {
     int ta = Nt == 24 ? 4 : (Nt == 64 ? 2 : 0);
     int tb = Nv == 12 ? 8 : (Nv == 64 ? 2 : 0);
     if (!ta || !tb) return 0;
-    if (nr_sim_reg_big(A, Nt, Bv, Nv)) { ta = 8; tb = 16; }
+    const int big = nr_sim_reg_big(A, Nt, Bv, Nv, prec);
+    if (big == 3) { ta = 4; tb = 16; }
+    else if (big) { ta = 8; tb = big == 2 ? 32 : 16; }
     if (TA) *TA = ta;
     if (TB) *TB = tb;
     return 1;
@@ -268,7 +310,7 @@ extern "C" int nr_sim_reg_tile(int A, int Nt, int Bv, int Nv, int* TA, int* TB) 
 int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16_t* v_hi, const uint16_t* v_lo,
                         const float* w_t, const float* w_v, int A, int Nt, int Bv, int Nv, int d, int prec, int out_mode,
                         float* out, uint8_t* arg_v, uint8_t* arg_t, float* pmax, float* qmax, hipStream_t st) {
-    if (!nr_sim_reg_tile(A, Nt, Bv, Nv, nullptr, nullptr)) return NR_EUNSUPPORTED;
+    if (!nr_sim_reg_tile(A, Nt, Bv, Nv, prec, nullptr, nullptr)) return NR_EUNSUPPORTED;
     NrSimRegArgs a{t_hi, t_lo, v_hi, v_lo, w_t, w_v, out, arg_v, arg_t, pmax, qmax, A, Bv, d, out_mode};
     const bool x3 = prec == NR_PREC_BF16X3, args = arg_v != nullptr;
 #define NR_REG_CASE(MI_, TPS_, NI_, FPS_)                                                              \
@@ -278,7 +320,13 @@ int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16
         return args ? nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, false, true>(a, st)                      \
                     : nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, false, false>(a, st);                    \
     }
-    if (nr_sim_reg_big(A, Nt, Bv, Nv)) {     // 24 x 12 tokens, 192 x 192 blocks on 2 x 4 waves
+    if (nr_sim_reg_big(A, Nt, Bv, Nv, prec) == 3) {     // split-bf16, 96 x 192 blocks (4 texts x 16 videos), 2-deep ring
+        return args ? nr_sim_reg_launch<3, 6, 8, 2, true, true, 2>(a, st) : nr_sim_reg_launch<3, 6, 8, 2, true, false, 2>(a, st);
+    }
+    if (nr_sim_reg_big(A, Nt, Bv, Nv, prec) == 2) {     // 24 x 12 tokens, 192 x 384 blocks on 2 x 4 waves
+        return args ? nr_sim_reg_launch<6, 6, 4, 2, false, true, 4>(a, st) : nr_sim_reg_launch<6, 6, 4, 2, false, false, 4>(a, st);
+    }
+    if (nr_sim_reg_big(A, Nt, Bv, Nv, prec)) {     // 24 x 12 tokens, 192 x 192 blocks on 2 x 4 waves
         if (x3) return args ? nr_sim_reg_launch<6, 3, 4, 4, true, true, 4>(a, st) : nr_sim_reg_launch<6, 3, 4, 4, true, false, 4>(a, st);
         return args ? nr_sim_reg_launch<6, 3, 4, 4, false, true, 4>(a, st) : nr_sim_reg_launch<6, 3, 4, 4, false, false, 4>(a, st);
     }

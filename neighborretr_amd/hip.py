@@ -41,7 +41,7 @@ _SIGNATURES = {
     "nr_split_bf16": ([_P, _Z, _P, _P, _P], _I),
     "nr_token_logits_fwd": ([_P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     "nr_token_softmax": ([_P, _I, _P, _P, _I, _I, _P, _P, _P], _I),
-    "nr_local_level_tiles": ([_I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)], _I),
+    "nr_local_level_tiles": ([_I, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)], _I),
     "nr_local_level_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),
     "nr_reduce_parts": ([_P, _I, _I, _F, _P, _P], _I),
     "nr_gemm_nt_f32": ([_P, _P, _I, _I, _I, _P, _P], _I),
@@ -146,9 +146,9 @@ def prepare_parts(n_tok):
     return lib().nr_prepare_parts(int(n_tok))
 
 
-def local_level_tiles(A, Nt, Bv, Nv):
+def local_level_tiles(A, Nt, Bv, Nv, prec=PREC_BF16):
     r, c = _I(0), _I(0)
-    _check("nr_local_level_tiles", lib().nr_local_level_tiles(A, Nt, Bv, Nv, ctypes.byref(r), ctypes.byref(c)))
+    _check("nr_local_level_tiles", lib().nr_local_level_tiles(A, Nt, Bv, Nv, int(prec), ctypes.byref(r), ctypes.byref(c)))
     return r.value, c.value
 
 

@@ -76,7 +76,7 @@ def local_level(prep_t, prep_v, w_t, w_v, A, Nt, Bv, Nv, prec=hip.PREC_BF16, out
     if out_mode == hip.OUT_FULL:
         out = torch.empty((A, Bv), dtype=torch.float32, device=dev)
     else:
-        nr, nc = hip.local_level_tiles(A, Nt, Bv, Nv)
+        nr, nc = hip.local_level_tiles(A, Nt, Bv, Nv, prec)
         out = torch.empty((nc, A) if out_mode == hip.OUT_ROWSUM else (nr, Bv), dtype=torch.float32, device=dev)
     arg_v = arg_t = pmax = qmax = None
     if want_arg:

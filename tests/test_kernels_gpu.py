@@ -120,7 +120,7 @@ def test_local_level_matches_oracle(A, Nt, Bv, Nv, prec, tol, sim_variant):
         assert maxdiff(got_q, qm) < 1e-5
         assert maxdiff(pmax, pm) < 2e-6 and maxdiff(qmax, qm) < 2e-6
     # bank modes: row / column sums of the same matrix
-    nr, nc = hip.local_level_tiles(A, Nt, Bv, Nv)
+    nr, nc = hip.local_level_tiles(A, Nt, Bv, Nv, prec)
     rs, _ = ops.local_level(pt, pv, w_t.to(DEV), w_v.to(DEV), A, Nt, Bv, Nv, prec, hip.OUT_ROWSUM)
     cs, _ = ops.local_level(pt, pv, w_t.to(DEV), w_v.to(DEV), A, Nt, Bv, Nv, prec, hip.OUT_COLSUM)
     assert rs.shape == (nc, A) and cs.shape == (nr, Bv)
