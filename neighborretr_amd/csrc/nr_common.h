@@ -129,3 +129,15 @@ __device__ __forceinline__ void nr_wave_arg(float& v, int& idx) {
 }
 __device__ __forceinline__ void nr_wave_argmax(float& v, int& idx) { nr_wave_arg<true>(v, idx); }
 __device__ __forceinline__ void nr_wave_argmin(float& v, int& idx) { nr_wave_arg<false>(v, idx); }
+
+// XCD-aware tile order for 1-D grids.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD
+// b % 8), each with its own 4 MiB L2.  Tiles that share operand rows should therefore sit on ONE XCD: XCD x takes
+// the contiguous tile range [x*chunk, (x+1)*chunk) in the caller's (operand-sharing) order.  The grid must be
+// launched with 8*chunk workgroups, chunk = ceil(n_tiles / 8); returns -1 for the padding workgroups.
+__device__ __forceinline__ int nr_xcd_chunk_tile(int wg, int n_tiles) {
+    const int chunk = (n_tiles + 7) >> 3;
+    const int t = (wg & 7) * chunk + (wg >> 3);
+    return t < n_tiles && (wg >> 3) < chunk ? t : -1;
+}
+static inline int nr_xcd_chunk_grid(int n_tiles) { return 8 * ((n_tiles + 7) / 8); }
+

@@ -17,11 +17,11 @@ struct NrLinearGroup {
     int n;
 };
 
-template <int MI, int NI, int STAGES>
+template <int MI, int NI, int STAGES, int WC>
 __device__ __forceinline__ void nr_linear_tile(const NrLinearArgs& p, const int tile_row, const int tile_col, char* smem) {
-    using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES>;
+    using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES, WC>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
     const int row0 = tile_row * Tile::BM, col0 = tile_col * Tile::BN;
     Tile tile;
     tile.zero();
@@ -48,22 +48,25 @@ __device__ __forceinline__ void nr_linear_tile(const NrLinearArgs& p, const int 
 template <int MI, int NI, int STAGES>
 __global__ __launch_bounds__(256) void nr_linear_kernel(NrLinearArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    nr_linear_tile<MI, NI, STAGES>(p, blockIdx.y, blockIdx.x, smem);
+    nr_linear_tile<MI, NI, STAGES, 2>(p, blockIdx.y, blockIdx.x, smem);
 }
 
 // grouped: workgroup -> (problem, tile) through the prefix table; tiles of a problem are column-fastest
-template <int MI, int NI, int STAGES>
-__global__ __launch_bounds__(256) void nr_linear_group_kernel(NrLinearGroup g) {
+template <int MI, int NI, int STAGES, int WC>
+__global__ __launch_bounds__(128 * WC) void nr_linear_group_kernel(NrLinearGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int gi = 0;
-    const int wg = blockIdx.x;
+    // tiles are numbered problem by problem, column-fastest: the column tiles of one row tile (same X rows) are
+    // neighbours, and nr_xcd_chunk_tile keeps neighbours on one XCD so that its L2 fetches those rows once
+    const int wg = nr_xcd_chunk_tile(blockIdx.x, g.tile_start[NR_LINEAR_MAX_GROUP]);
+    if (wg < 0) return;
 #pragma unroll
     for (int i = 1; i < NR_LINEAR_MAX_GROUP; ++i)
         if (i < g.n && wg >= g.tile_start[i]) gi = i;
     const NrLinearArgs& p = g.p[gi];
     const int t = wg - g.tile_start[gi];
-    const int ncol = (p.N + 32 * NI - 1) / (32 * NI);
-    nr_linear_tile<MI, NI, STAGES>(p, t / ncol, t % ncol, smem);
+    const int ncol = (p.N + 16 * WC * NI - 1) / (16 * WC * NI);
+    nr_linear_tile<MI, NI, STAGES, WC>(p, t / ncol, t % ncol, smem);
 }
 
 template <int MI, int NI, int STAGES>
@@ -87,9 +90,9 @@ static int nr_linear_launch(NrLinearArgs& a, hipStream_t st) {
     return nr_linear_launch_s<MI, NI, 2>(a, st);
 }
 
-template <int MI, int NI, int STAGES>
+template <int MI, int NI, int STAGES, int WC = 2>
 static int nr_linear_group_launch_s(const NrLinearArgs* probs, int n, hipStream_t st) {
-    using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES>;
+    using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES, WC>;
     NrLinearGroup g;
     g.n = n;
     int total = 0;
@@ -101,10 +104,10 @@ static int nr_linear_group_launch_s(const NrLinearArgs* probs, int n, hipStream_
     for (int i = n; i <= NR_LINEAR_MAX_GROUP; ++i) g.tile_start[i] = total;
     size_t lds = Tile::RING_BYTES;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)nr_linear_group_kernel<MI, NI, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)nr_linear_group_kernel<MI, NI, STAGES, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((nr_linear_group_kernel<MI, NI, STAGES>), dim3(total), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((nr_linear_group_kernel<MI, NI, STAGES, WC>), dim3(nr_xcd_chunk_grid(total)), dim3(128 * WC), lds, st, g);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }
@@ -119,19 +122,31 @@ int nr_linear_group_launch(const NrLinearArgs* probs, int n, hipStream_t st) {
         t32x64 += (long)((a.M + 31) / 32) * ((a.N + 63) / 64);
         t128 += (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     }
-    // Measured on MI355X over the clustering-stage shapes (tools/cluster_times.py under rocprofv3, us):
+    // Measured on MI355X over the clustering-stage shapes (tools/cluster_times.py under rocprofv3, us; XCD-aware
+    // tile order):
     //   <= 256 tiles of 32x64 (proj, stage-1 conv: one workgroup per CU, latency-bound K loop): 4-deep ring
-    //       <1,2,4> 6.9 / 10.5   vs <1,2,2> 8.2 / 13.6   vs <2,2,2> 11.7 / 17.5
-    //   <= 1536 (stage-1 q+kv, stage-0 conv): <1,2,2> 8.8 / 44.8   vs <2,2,1> 13.0 / 50.8   vs <2,4,1> 18.2 / 53.8
-    //   larger (stage-0 q+kv): <2,4,1> 27.9   vs <2,2,1> 28.2   vs <1,2,2> 31.9;   128x128 once that fills the chip twice
-    int mi, ni, stg;
+    //       <1,2,4> 7.1 / 10.3   vs <1,2,2> 8.9 / 14.0   vs <2,2,2> 12.1 / 18.1
+    //   <= 640 (stage-1 q+kv):       <1,2,2> 9.2    vs <2,2,2> 10.7   vs <1,2,4> 11.9
+    //   <= 1536 (stage-0 conv):      <2,2,1> 34.5   vs 64x128 on 8 waves 38.9   vs <1,2,2> 41.7   vs <2,4,1> 47.7
+    //   larger (stage-0 q+kv):       64x128 on 8 waves, 1 stage 22.6   vs <2,4,1> 25.7   vs <2,2,1> 26.5   vs <1,2,2> 30.7
+    int mi, ni, stg, wcols = 2;
     if (t32x64 <= 256) { mi = 1; ni = 2; stg = 4; }
-    else if (t32x64 <= 1536) { mi = 1; ni = 2; stg = 2; }
-    else if (t128 < 1024) { mi = 2; ni = 4; stg = 1; }
+    else if (t32x64 <= 640) { mi = 1; ni = 2; stg = 2; }
+    else if (t32x64 <= 1536) { mi = 2; ni = 2; stg = 1; }
+    else if (t128 < 1024) { mi = 2; ni = 2; stg = 1; wcols = 4; }
     else { mi = 4; ni = 4; stg = 1; }
     if (const char* ov = getenv("NR_LINEAR_TILE")) {
-        int a_, b_, c_;
-        if (sscanf(ov, "%d,%d,%d", &a_, &b_, &c_) == 3) { mi = a_; ni = b_; stg = c_; }
+        int a_, b_, c_, d_ = 2;
+        if (sscanf(ov, "%d,%d,%d,%d", &a_, &b_, &c_, &d_) >= 3) { mi = a_; ni = b_; stg = c_; wcols = d_; }
+    }
+    if (wcols == 4) {
+#define NR_LG8_CASE(MI_, NI_, ST_) if (mi == MI_ && ni == NI_ && stg == ST_) return nr_linear_group_launch_s<MI_, NI_, ST_, 4>(probs, n, st)
+        NR_LG8_CASE(4, 2, 1); NR_LG8_CASE(4, 2, 2);       // 128 x 128 on 8 waves
+        NR_LG8_CASE(2, 2, 1); NR_LG8_CASE(2, 2, 2);       // 64 x 128
+        NR_LG8_CASE(4, 4, 1);                             // 128 x 256
+        NR_LG8_CASE(2, 4, 1); NR_LG8_CASE(2, 4, 2);       // 64 x 256
+#undef NR_LG8_CASE
+        return NR_EUNSUPPORTED;
     }
 #define NR_LG_CASE(MI_, NI_, ST_) if (mi == MI_ && ni == NI_ && stg == ST_) return nr_linear_group_launch_s<MI_, NI_, ST_>(probs, n, st)
     NR_LG_CASE(4, 4, 1);

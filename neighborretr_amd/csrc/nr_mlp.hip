@@ -30,7 +30,13 @@ __global__ __launch_bounds__(128 * WC) void nr_mlp_kernel(const uint16_t* __rest
     static_assert(BN % 128 == 0 && 128 % WCOLS == 0, "a block must hold whole 128-unit parts");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
-    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+    // 1-D grid, tiles numbered column-fastest: the H/BN column tiles of one token-row tile are neighbours and
+    // nr_xcd_chunk_tile keeps neighbours on one XCD, whose L2 then fetches those token rows once
+    const int n_col = H / BN;
+    const int tile_id = nr_xcd_chunk_tile(blockIdx.x, n_col * ((n_tok + BM - 1) / BM));
+    if (tile_id < 0) return;
+    const int bx = tile_id % n_col, by = tile_id / n_col;
+    const int row0 = by * BM, col0 = bx * BN;
 
     Tile tile;
     tile.zero();
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(128 * WC) void nr_mlp_kernel(const uint16_t* __rest
         float v = 0.f;
 #pragma unroll
         for (int q = 0; q < WPP; ++q) v += sPart[(part * WPP + q) * BM + r];
-        logit_part[(size_t)(blockIdx.x * (BN / 128) + part) * n_tok + row0 + r] = v;
+        logit_part[(size_t)(bx * (BN / 128) + part) * n_tok + row0 + r] = v;
     }
 }
 
@@ -87,7 +93,7 @@ int mlp_launch(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid(H / Tile::BN, (n_tok + Tile::BM - 1) / Tile::BM);
+    dim3 grid(nr_xcd_chunk_grid((H / Tile::BN) * ((n_tok + Tile::BM - 1) / Tile::BM)));
     hipLaunchKernelGGL(kern, grid, dim3(128 * WC), lds, st, tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part);
     NR_LAUNCH_CHECK();
     return NR_OK;
