@@ -180,14 +180,24 @@ extern "C" int nr_merge_ln(const float* xn, const int64_t* assign, const float* 
 }
 
 // ---- score-biased multi-head attention (body in nr_ctm_bodies.h) ---------------------------------------------
-__global__ __launch_bounds__(1024) void nr_tc_attention_kernel(NrAttnArgs a) { nr_tc_attention_body(a, blockIdx.x); }
+__global__ __launch_bounds__(1024) void nr_tc_attention_kernel(NrAttnArgs a, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) float skv[];
+    nr_tc_attention_body(a, blockIdx.x, use_lds ? skv : nullptr);
+}
 
 extern "C" int nr_tc_attention(const float* q, const float* kv, const float* score, int n_samples, int N, int C, int cnum,
                                int H, float* out, void* stream) {
     if (!q || !kv || !score || !out || n_samples <= 0 || N <= 0 || cnum <= 0 || H <= 0) return NR_EINVAL;
     if (N > 64 || C != H * 64) return NR_EUNSUPPORTED;
     NrAttnArgs a{q, kv, score, N, C, cnum, H, 1.0f / sqrtf(64.0f), out, nullptr, nullptr};
-    hipLaunchKernelGGL(nr_tc_attention_kernel, dim3(n_samples), dim3(1024), 0, (hipStream_t)stream, a);
+    size_t lds = (size_t)N * (2 * C + 4) * sizeof(float);
+    const int use_lds = lds <= 128 * 1024;
+    if (!use_lds) lds = 0;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)nr_tc_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(nr_tc_attention_kernel, dim3(n_samples), dim3(1024), lds, (hipStream_t)stream, a, use_lds);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

@@ -222,17 +222,48 @@ __device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const i
     if (tid < N) s_share[tid] = p.tokw[(size_t)b * N + tid] / s_tot[s_assign[tid]];
     __syncthreads();
     const float* xb = p.xn + (size_t)b * N * C;
-    for (int cl = 0; cl < cnum; ++cl) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int n = 0; n < N; ++n) {
-            if (s_assign[n] != cl) continue;
-            const float sh = s_share[n];
+    // Clusters are merged four at a time: the token rows are read ONCE per group with eight rows of loads in
+    // flight (a row-by-row loop that skips foreign rows serialises one L2 round trip per row), and every row is
+    // added to each of the four accumulators with weight (its share, or exactly 0 when it belongs elsewhere) --
+    // the same fma chain in the same token order as a loop that skips, hence bit-identical sums.
+    constexpr int CG = 4, RB = 8;
+    for (int cl0 = 0; cl0 < cnum; cl0 += CG) {
+        float accg[CG][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int c = q * 256 + tid;
-                if (c < C) acc[q] += xb[(size_t)n * C + c] * sh;
+        for (int g = 0; g < CG; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) accg[g][q] = 0.f;
+        for (int n0 = 0; n0 < N; n0 += RB) {
+            float xv[RB][4];
+#pragma unroll
+            for (int u = 0; u < RB; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = q * 256 + tid, n = min(n0 + u, N - 1);
+                    xv[u][q] = c < C ? xb[(size_t)n * C + c] : 0.f;
+                }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int n = n0 + u;
+                if (n < N) {
+                    const int a_n = s_assign[n];
+                    const float sh = s_share[n];
+#pragma unroll
+                    for (int g = 0; g < CG; ++g) {
+                        const float w = a_n == cl0 + g ? sh : 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) accg[g][q] = fmaf(xv[u][q], w, accg[g][q]);
+                    }
+                }
             }
         }
+#pragma unroll
+      for (int g = 0; g < CG; ++g) {
+        const int cl = cl0 + g;
+        if (cl >= cnum) break;
+        float acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = accg[g][q];
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) s += (q * 256 + tid < C) ? acc[q] : 0.f;
@@ -266,6 +297,7 @@ __device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const i
             }
         }
         __syncthreads();
+      }
     }
 }
 
@@ -281,17 +313,33 @@ struct NrAttnArgs {
     uint16_t *out_hi, *out_lo;       // when set, the result is written split-bf16 (operand of the proj GEMM)
 };
 
-__device__ __forceinline__ void nr_tc_attention_body(const NrAttnArgs& a, const int b) {
+// skv: N * (2C + 4) floats of LDS for the sample's k|v rows (row stride padded by 4 floats so that the 16 lanes
+// of a ds_read_b128 group, one key row each, fall on different banks), or nullptr to read k and v from global
+// memory (samples whose rows do not fit).  With the rows in LDS the kernel makes ONE global round trip for
+// them instead of a dependent chain per (head, query) job.
+__device__ __forceinline__ int nr_tc_attention_lds_floats(int N, int C) { return N * (2 * C + 4); }
+
+__device__ __forceinline__ void nr_tc_attention_body(const NrAttnArgs& a, const int b, float* skv) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int N = a.N, C = a.C, cnum = a.cnum;
     const float scale = a.scale;
     const float* kvb = a.kv + (size_t)b * N * 2 * C;
+    const int ld = skv ? 2 * C + 4 : 2 * C;
+    if (skv) {
+        const int per_row = 2 * C / 4;                       // float4 per row
+        for (int e = threadIdx.x; e < N * per_row; e += 1024) {
+            const int n = e / per_row, c4 = e - n * per_row;
+            *reinterpret_cast<f32x4_t*>(skv + n * ld + c4 * 4) = *reinterpret_cast<const f32x4_t*>(kvb + (size_t)n * 2 * C + c4 * 4);
+        }
+        __syncthreads();
+    }
+    const float* kvs = skv ? skv : kvb;
     for (int job = wave; job < a.H * cnum; job += 16) {
         const int h = job / cnum, cl = job - h * cnum;
         const float* qr = a.q + ((size_t)b * cnum + cl) * C + h * 64;
         float logit = -INFINITY;
         if (lane < N) {
-            const float* kr = kvb + (size_t)lane * 2 * C + h * 64;
+            const float* kr = kvs + (size_t)lane * ld + h * 64;
             float dot = 0.f;
 #pragma unroll
             for (int j = 0; j < 64; j += 4) {
@@ -308,7 +356,7 @@ __device__ __forceinline__ void nr_tc_attention_body(const NrAttnArgs& a, const 
         float acc = 0.f;
         for (int n = 0; n < N; ++n) {
             float pn = __shfl(p, n);
-            acc += pn * kvb[(size_t)n * 2 * C + C + h * 64 + lane];
+            acc += pn * kvs[(size_t)n * ld + C + h * 64 + lane];
         }
         const size_t o = ((size_t)b * cnum + cl) * C + h * 64 + lane;
         if (a.out_hi) {

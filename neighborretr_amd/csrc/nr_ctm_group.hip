@@ -41,9 +41,10 @@ __global__ __launch_bounds__(256) void nr_group_back_kernel(NrGroupOf<NrCtmBackA
     nr_ctm_back_body(g.p[gi], blockIdx.x - g.start[gi]);
 }
 
-__global__ __launch_bounds__(1024) void nr_group_attention_kernel(NrGroupOf<NrAttnArgs> g) {
+__global__ __launch_bounds__(1024) void nr_group_attention_kernel(NrGroupOf<NrAttnArgs> g, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) float skv[];
     const int gi = g.find(blockIdx.x);
-    nr_tc_attention_body(g.p[gi], blockIdx.x - g.start[gi]);
+    nr_tc_attention_body(g.p[gi], blockIdx.x - g.start[gi], use_lds ? skv : nullptr);
 }
 
 // ---- workspace carve-up --------------------------------------------------------------------------------------
@@ -194,7 +195,18 @@ extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
             total += s.n_samples;
         }
         for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
-        hipLaunchKernelGGL(nr_group_attention_kernel, dim3(total), dim3(1024), 0, st, g);
+        size_t lds = 0;                      // k|v rows of the largest problem, if every problem's rows fit
+        for (int i = 0; i < n; ++i) {
+            size_t need = (size_t)d[i].N * (2 * d[i].C + 4) * sizeof(float);
+            lds = need > lds ? need : lds;
+        }
+        const int use_lds = lds <= 128 * 1024;
+        if (!use_lds) lds = 0;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)nr_group_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(nr_group_attention_kernel, dim3(total), dim3(1024), lds, st, g, use_lds);
         NR_LAUNCH_CHECK();
     }
     // 7. out = merged + proj(att) + proj.bias
