@@ -17,42 +17,64 @@ struct NrCtmFrontArgs {
 };
 
 // b = sample index; sx = N*C floats of (dynamic) LDS.  Called by all CF_THREADS threads of the workgroup.
+// CPL = channels per lane the registers are sized for (C <= 64*CPL).
+// Phase 1 is one global round trip per row: the five per-channel parameter vectors are loaded once up front,
+// and the NEXT row of a wave is loaded before the current row's results are stored (vmcnt retires in order:
+// a load issued after stores waits for their acknowledgement -- with the loads placed between the LayerNorm
+// and norm1 halves of a row that was three dependent round trips per row).
+template <int CPL>
 __device__ __forceinline__ void nr_ctm_front_body(const NrCtmFrontArgs& p, const int b, float* sx) {
     __shared__ float s_wmax[CF_THREADS / 64];
     const int N = p.N, C = p.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = CF_THREADS / 64;
     const int cpl = C / 64;
+    const float* __restrict__ g_y = p.y;
+    float* __restrict__ g_xn = p.xn;
     // ---- phase 1: one wave per token row ------------------------------------------------------------
+    float lnw[CPL], lnb[CPL], scw[CPL], n1w[CPL], n1b[CPL], v[CPL], vnext[CPL];
+    if (wave < N) {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int c = q * 64 + lane;
+            const bool on = q < cpl;
+            v[q] = on ? g_y[((size_t)b * N + wave) * C + c] : 0.f;
+            lnw[q] = on ? p.ln_w[c] : 0.f;
+            lnb[q] = on ? p.ln_b[c] : 0.f;
+            scw[q] = on ? p.sc_w[c] : 0.f;
+            n1w[q] = on ? p.n1_w[c] : 0.f;
+            n1b[q] = on ? p.n1_b[c] : 0.f;
+        }
+    }
+    const float scb = p.sc_b[0];
     for (int r = wave; r < N; r += NW) {
         const size_t row = (size_t)b * N + r;
-        const float* yr = p.y + row * C;
-        float v[CF_MAX_CPL];
+        const bool more = r + NW < N;
+        const float mk = p.mask ? p.mask[row] : 1.f;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) vnext[q] = (more && q < cpl) ? g_y[(row + NW) * C + q * 64 + lane] : 0.f;
         float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < CF_MAX_CPL; ++q) {
-            v[q] = q < cpl ? yr[q * 64 + lane] : 0.f;
-            s += v[q];
-        }
+        for (int q = 0; q < CPL; ++q) s += v[q];
         const float mu = nr_wave_sum(s) / (float)C;
         float var = 0.f;
 #pragma unroll
-        for (int q = 0; q < CF_MAX_CPL; ++q)
+        for (int q = 0; q < CPL; ++q)
             if (q < cpl) { float dlt = v[q] - mu; var += dlt * dlt; }
         const float rstd = rsqrtf(nr_wave_sum(var) / (float)C + p.eps);
         float dot = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < CF_MAX_CPL; ++q)
+        for (int q = 0; q < CPL; ++q)
             if (q < cpl) {
                 int c = q * 64 + lane;
-                v[q] = (v[q] - mu) * rstd * p.ln_w[c] + p.ln_b[c];
-                p.xn[row * C + c] = v[q];
+                v[q] = (v[q] - mu) * rstd * lnw[q] + lnb[q];
+                g_xn[row * C + c] = v[q];
                 sx[r * C + c] = v[q];
-                dot += v[q] * p.sc_w[c];
+                dot += v[q] * scw[q];
                 s2 += v[q];
             }
-        float sc = nr_wave_sum(dot) + p.sc_b[0];
-        if (p.mask && p.mask[row] == 0.f) sc = -INFINITY;
+        float sc = nr_wave_sum(dot) + scb;
+        if (p.mask && mk == 0.f) sc = -INFINITY;
         if (lane == 0) {
             p.score[row] = sc;
             p.tokw[row] = expf(sc);
@@ -60,14 +82,14 @@ __device__ __forceinline__ void nr_ctm_front_body(const NrCtmFrontArgs& p, const
         const float mu2 = nr_wave_sum(s2) / (float)C;
         float var2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < CF_MAX_CPL; ++q)
+        for (int q = 0; q < CPL; ++q)
             if (q < cpl) { float dlt = v[q] - mu2; var2 += dlt * dlt; }
         const float rstd2 = rsqrtf(nr_wave_sum(var2) / (float)C + p.eps);
 #pragma unroll
-        for (int q = 0; q < CF_MAX_CPL; ++q)
+        for (int q = 0; q < CPL; ++q)
             if (q < cpl) {
                 int c = q * 64 + lane;
-                float kv = (v[q] - mu2) * rstd2 * p.n1_w[c] + p.n1_b[c];
+                float kv = (v[q] - mu2) * rstd2 * n1w[q] + n1b[q];
                 if (p.kvn_hi) {
                     uint16_t h = nr_f2bf(kv);
                     p.kvn_hi[row * C + c] = h;
@@ -76,15 +98,17 @@ __device__ __forceinline__ void nr_ctm_front_body(const NrCtmFrontArgs& p, const
                     p.kvn[row * C + c] = kv;
                 }
             }
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) v[q] = vnext[q];
     }
     __syncthreads();
     // ---- phase 2: pairwise distances, wave per row of the upper triangle -------------------------------
     float wmax = 0.f;
     float* db = p.dist + (size_t)b * N * N;
     for (int i = wave; i < N; i += NW) {
-        float xi[CF_MAX_CPL];
+        float xi[CPL];
 #pragma unroll
-        for (int q = 0; q < CF_MAX_CPL; ++q) xi[q] = q < cpl ? sx[i * C + q * 64 + lane] : 0.f;
+        for (int q = 0; q < CPL; ++q) xi[q] = q < cpl ? sx[i * C + q * 64 + lane] : 0.f;
         if (lane == 0) db[i * N + i] = 0.f;
         for (int j = i + 1; j < N; j += 2) {
             const bool two = j + 1 < N;
@@ -92,7 +116,7 @@ __device__ __forceinline__ void nr_ctm_front_body(const NrCtmFrontArgs& p, const
             const float* xj1 = sx + (two ? j + 1 : j) * C;
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int q = 0; q < CF_MAX_CPL; ++q)
+            for (int q = 0; q < CPL; ++q)
                 if (q < cpl) {
                     int c = q * 64 + lane;
                     float d0 = xi[q] - xj0[c], d1 = xi[q] - xj1[c];

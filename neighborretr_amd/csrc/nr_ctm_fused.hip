@@ -12,9 +12,10 @@
 #include "nr_ctm_bodies.h"
 #include "../../include/nr_hip.h"
 
+template <int CPL>
 __global__ __launch_bounds__(CF_THREADS) void nr_ctm_front_kernel(NrCtmFrontArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sx[];      // [N][C] normalised tokens
-    nr_ctm_front_body(p, blockIdx.x, sx);
+    nr_ctm_front_body<CPL>(p, blockIdx.x, sx);
 }
 
 extern "C" int nr_ctm_front(const float* y, const float* mask, int n_samples, int N, int C, const float* ln_w,
@@ -26,13 +27,16 @@ extern "C" int nr_ctm_front(const float* y, const float* mask, int n_samples, in
     if (n_samples <= 0 || N <= 0 || N > 64 || C <= 0 || (C % 64) != 0 || C > 64 * CF_MAX_CPL) return NR_EUNSUPPORTED;
     size_t lds = (size_t)N * C * sizeof(float);
     if (lds > 150 * 1024) return NR_EUNSUPPORTED;
+    const bool small = C <= 512;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)nr_ctm_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(small ? (const void*)nr_ctm_front_kernel<8> : (const void*)nr_ctm_front_kernel<CF_MAX_CPL>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     NrCtmFrontArgs p{y, mask, ln_w, ln_b, sc_w, sc_b, n1_w, n1_b, eps, 1.0f / sqrtf((float)C), N, C, xn, kvn, score, tokw, dist, smax,
                      kvn_hi, kvn_lo};
-    hipLaunchKernelGGL(nr_ctm_front_kernel, dim3(n_samples), dim3(CF_THREADS), lds, (hipStream_t)stream, p);
+    if (small) hipLaunchKernelGGL(nr_ctm_front_kernel<8>, dim3(n_samples), dim3(CF_THREADS), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(nr_ctm_front_kernel<CF_MAX_CPL>, dim3(n_samples), dim3(CF_THREADS), lds, (hipStream_t)stream, p);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

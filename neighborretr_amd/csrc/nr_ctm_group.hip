@@ -30,10 +30,11 @@ __global__ __launch_bounds__(256) void nr_group_shift_kernel(NrGroupOf<NrShiftAr
     nr_shift_split_body(g.p[gi], blockIdx.x - g.start[gi]);
 }
 
+template <int CPL>
 __global__ __launch_bounds__(CF_THREADS) void nr_group_front_kernel(NrGroupOf<NrCtmFrontArgs> g) {
     extern __shared__ __attribute__((aligned(16))) float sx[];
     const int gi = g.find(blockIdx.x);
-    nr_ctm_front_body(g.p[gi], blockIdx.x - g.start[gi], sx);
+    nr_ctm_front_body<CPL>(g.p[gi], blockIdx.x - g.start[gi], sx);
 }
 
 __global__ __launch_bounds__(256) void nr_group_back_kernel(NrGroupOf<NrCtmBackArgs> g) {
@@ -149,11 +150,15 @@ extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
             total += s.n_samples;
         }
         for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
+        bool small = true;                   // registers sized for C <= 512 unless a problem is wider
+        for (int i = 0; i < n; ++i) small = small && d[i].C <= 512;
         if (front_lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)nr_group_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds);
+            hipError_t e = hipFuncSetAttribute(small ? (const void*)nr_group_front_kernel<8> : (const void*)nr_group_front_kernel<CF_MAX_CPL>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(nr_group_front_kernel, dim3(total), dim3(CF_THREADS), front_lds, st, g);
+        if (small) hipLaunchKernelGGL(nr_group_front_kernel<8>, dim3(total), dim3(CF_THREADS), front_lds, st, g);
+        else hipLaunchKernelGGL(nr_group_front_kernel<CF_MAX_CPL>, dim3(total), dim3(CF_THREADS), front_lds, st, g);
         NR_LAUNCH_CHECK();
     }
     // 4. DPC-KNN assignment, weighted cluster means, norm1
