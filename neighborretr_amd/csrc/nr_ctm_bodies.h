@@ -3,6 +3,7 @@
 // grid (nr_ctm_group.hip).  Reference: cluster.py:453-561 (DPC-KNN, merge_tokens), :689-717 (CTM.forward),
 // :834-888 (score-biased attention).
 #pragma once
+#include <type_traits>
 #include "nr_common.h"
 
 #define CF_THREADS 1024
@@ -159,35 +160,105 @@ struct NrCtmBackArgs {
 };
 
 // b = sample index.  Called by all 256 threads of the workgroup.
-__device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const int b) {
+// sxn: N*C floats of dynamic LDS for the sample's normalised tokens, or nullptr (rows that do not fit are read
+// from global memory in the merge).  With sxn the rows are fetched by LDS-DMA at the very start and land while
+// the DPC-KNN phases run; every other global operand (distances, token weights, noise, mask, the per-sample
+// maxima) is also requested before the first barrier, so the kernel pays ONE global round trip, not a chain.
+// 16 waves per sample: the density / score rows are spread over them, and the merge runs all clusters at once --
+// job j = (cluster, 128-channel chunk) goes to wave j mod 16, the LayerNorm statistics of a cluster meet in LDS.
+// (In-kernel stamps of the 4-wave version at N=24, 4 clusters: 19.6k cycles in the density loop, 22k in the
+// cluster-by-cluster merge, of 61k.)
+#ifdef NR_STAMP
+static __device__ unsigned long long nr_back_stamps[16];
+#endif
+typedef __attribute__((address_space(3))) void* nr_bk_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* nr_bk_glb_ptr_t;
+
+#define BK_THREADS 1024
+#define BK_MAXJ 12          // merge jobs per wave: cnum * C/128 <= 16 * BK_MAXJ
+
+__device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const int b, float* sxn) {
+    constexpr int NW = BK_THREADS / 64;
     __shared__ float sd[64][65];
-    __shared__ float s_density[64], s_score[64], s_share[64], s_tot[64];
+    __shared__ float s_density[64], s_score[64], s_share[64], s_tot[64], s_tokw[64], s_noise[64], s_mask[64];
     __shared__ int s_centre[64], s_assign[64];
-    __shared__ float s_red[2][4];
+    __shared__ float s_red[2][NW];
+    __shared__ float s_psum[NW * BK_MAXJ], s_pvar[NW * BK_MAXJ];
     const int N = p.N, C = p.C, cnum = p.cnum;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef NR_STAMP
+    unsigned long long tk[10];
+    int tn = 0;
+    tk[tn++] = __builtin_readcyclecounter();
+#define BK_LAP() tk[tn++] = __builtin_readcyclecounter()
+#else
+#define BK_LAP() ((void)0)
+#endif
+    const float* xb = p.xn + (size_t)b * N * C;
+    if (sxn) {                                        // 1 KiB per wave-instruction, linear copy
+        const int chunks = N * C / 256;
+        for (int k = wave; k < chunks; k += NW)
+            __builtin_amdgcn_global_load_lds((nr_bk_glb_ptr_t)(xb + (size_t)k * 256 + lane * 4),
+                                             (nr_bk_lds_ptr_t)(sxn + (size_t)k * 256), 16, 0, 0);
+    }
+    const float* db = p.dist + (size_t)b * N * N;
+    constexpr int DPT = 4;                            // distances per thread: N*N <= 4096 = 4 * 1024
+    float dreg[DPT];
+#pragma unroll
+    for (int u = 0; u < DPT; ++u) {
+        const int e = tid + BK_THREADS * u;
+        dreg[u] = e < N * N ? db[e] : 0.f;
+    }
+    if (tid < N) {
+        s_tokw[tid] = p.tokw[(size_t)b * N + tid];
+        s_noise[tid] = p.noise[(size_t)b * N + tid];
+        s_mask[tid] = p.mask ? p.mask[(size_t)b * N + tid] : 1.f;
+    }
+    // per-channel parameters of this wave's first merge job (the only one at the usual sizes), requested now so
+    // that the merge's stores do not wait for another round trip
+    const int CH = C / 128, jobs = cnum * CH;
+    float pb0[2] = {0.f, 0.f}, nw0[2] = {0.f, 0.f}, nb0[2] = {0.f, 0.f};
+    if (wave < jobs) {
+        const int c0 = (wave % CH) * 128 + lane;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            pb0[h] = p.proj_b[c0 + 64 * h];
+            nw0[h] = p.n1_w[c0 + 64 * h];
+            nb0[h] = p.n1_b[c0 + 64 * h];
+        }
+    }
     // global maximum over all samples (cluster.py:473-475)
     float g = 0.f;
-    for (int i = tid; i < p.n_samples; i += 256) g = fmaxf(g, p.smax[i]);
+    for (int i = tid; i < p.n_samples; i += BK_THREADS) g = fmaxf(g, p.smax[i]);
     g = nr_wave_max(g);
     if (lane == 0) s_red[0][wave] = g;
     __syncthreads();
-    const float far = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3])) + 1.0f;
-    const float* db = p.dist + (size_t)b * N * N;
-    const float* mb = p.mask ? p.mask + (size_t)b * N : nullptr;
+    BK_LAP();      // 1: operands requested and arrived (first barrier)
+    float far = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) far = fmaxf(far, s_red[0][w]);
+    far += 1.0f;
+    const bool masked = p.mask != nullptr;
     float lmax = 0.f;
-    for (int e = tid; e < N * N; e += 256) {
-        int i = e / N, j = e - i * N;
-        float dv = db[e];
-        if (mb && !(mb[j] > 0.f)) dv = far;
-        sd[i][j] = dv;
-        lmax = fmaxf(lmax, dv);
+#pragma unroll
+    for (int u = 0; u < DPT; ++u) {
+        const int e = tid + BK_THREADS * u;
+        if (e < N * N) {
+            int i = e / N, j = e - i * N;
+            float dv = dreg[u];
+            if (masked && !(s_mask[j] > 0.f)) dv = far;
+            sd[i][j] = dv;
+            lmax = fmaxf(lmax, dv);
+        }
     }
     lmax = nr_wave_max(lmax);
     if (lane == 0) s_red[1][wave] = lmax;
     __syncthreads();
-    const float dmax = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
-    for (int i = wave; i < N; i += 4) {               // local density
+    float dmax = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dmax = fmaxf(dmax, s_red[1][w]);
+    BK_LAP();      // 2: distances in LDS
+    for (int i = wave; i < N; i += NW) {              // local density
         float v = lane < N ? sd[i][lane] : INFINITY;
         float acc = 0.f;
         for (int r = 0; r < p.k; ++r) {
@@ -198,13 +269,14 @@ __device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const i
             if (lane == idx) v = INFINITY;
         }
         if (lane == 0) {
-            float dens = expf(-acc / (float)p.k) + p.noise[(size_t)b * N + i] * 1e-6f;
-            if (mb) dens *= (mb[i] > 0.f) ? 1.0f : 0.0f;
+            float dens = expf(-acc / (float)p.k) + s_noise[i] * 1e-6f;
+            if (masked) dens *= (s_mask[i] > 0.f) ? 1.0f : 0.0f;
             s_density[i] = dens;
         }
     }
     __syncthreads();
-    for (int i = wave; i < N; i += 4) {               // distance to the nearest denser token; score
+    BK_LAP();      // 3: densities
+    for (int i = wave; i < N; i += NW) {              // distance to the nearest denser token; score
         float di = s_density[i];
         float v = (lane < N && s_density[lane] > di) ? sd[i][lane] : dmax;
         v = nr_wave_min(v);
@@ -235,96 +307,112 @@ __device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const i
         if (p.assign) p.assign[(size_t)b * N + tid] = bc;
     }
     __syncthreads();
+    BK_LAP();      // 4: centres + assignment
     // ---- merge_tokens + norm1 ---------------------------------------------------------------------------
-    if (tid < cnum) {
-        float t = 0.f;
-        for (int n = 0; n < N; ++n)
-            if (s_assign[n] == tid) t += p.tokw[(size_t)b * N + n];
-        s_tot[tid] = t + 1e-6f;
+    for (int c = wave; c < cnum; c += NW) {           // all_weight of cluster c (cluster.py:536-540), one wave each
+        const float t = nr_wave_sum((lane < N && s_assign[lane] == c) ? s_tokw[lane] : 0.f);
+        if (lane == 0) s_tot[c] = t + 1e-6f;
     }
     __syncthreads();
-    if (tid < N) s_share[tid] = p.tokw[(size_t)b * N + tid] / s_tot[s_assign[tid]];
+    if (tid < N) s_share[tid] = s_tokw[tid] / s_tot[s_assign[tid]];
+    if (sxn) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the token rows has landed
     __syncthreads();
-    const float* xb = p.xn + (size_t)b * N * C;
-    // Clusters are merged four at a time: the token rows are read ONCE per group with eight rows of loads in
-    // flight (a row-by-row loop that skips foreign rows serialises one L2 round trip per row), and every row is
-    // added to each of the four accumulators with weight (its share, or exactly 0 when it belongs elsewhere) --
-    // the same fma chain in the same token order as a loop that skips, hence bit-identical sums.
-    constexpr int CG = 4, RB = 8;
-    for (int cl0 = 0; cl0 < cnum; cl0 += CG) {
-        float accg[CG][4];
+    BK_LAP();      // 5: shares, token rows landed
+    // job j = cl * CH + ch: cluster cl, channels [128 ch, 128 ch + 128); lane owns channels 128 ch + lane and + 64.
+    // Every token row is added with weight (its share, or exactly 0 when it belongs to another cluster): the same
+    // fma chain in token order as a loop that skips foreign rows.
+    float acc[BK_MAXJ][2];
 #pragma unroll
-        for (int g = 0; g < CG; ++g)
+    for (int jj = 0; jj < BK_MAXJ; ++jj) {
+        acc[jj][0] = acc[jj][1] = 0.f;
+        const int j = wave + NW * jj;
+        if (j < jobs) {
+            const int cl = j / CH, c0 = (j - cl * CH) * 128 + lane;
+            // (two separate loops: a per-element "LDS or global" select makes the compiler issue BOTH loads)
+            auto accumulate = [&](auto from_lds) {
+                constexpr int RB = 8;
+                for (int n0 = 0; n0 < N; n0 += RB) {
+                    float x0[RB], x1[RB];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) accg[g][q] = 0.f;
-        for (int n0 = 0; n0 < N; n0 += RB) {
-            float xv[RB][4];
+                    for (int u = 0; u < RB; ++u) {
+                        const int n = min(n0 + u, N - 1);
+                        if constexpr (decltype(from_lds)::value) {
+                            x0[u] = sxn[n * C + c0];
+                            x1[u] = sxn[n * C + c0 + 64];
+                        } else {
+                            x0[u] = xb[(size_t)n * C + c0];
+                            x1[u] = xb[(size_t)n * C + c0 + 64];
+                        }
+                    }
 #pragma unroll
-            for (int u = 0; u < RB; ++u)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = q * 256 + tid, n = min(n0 + u, N - 1);
-                    xv[u][q] = c < C ? xb[(size_t)n * C + c] : 0.f;
-                }
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                const int n = n0 + u;
-                if (n < N) {
-                    const int a_n = s_assign[n];
-                    const float sh = s_share[n];
-#pragma unroll
-                    for (int g = 0; g < CG; ++g) {
-                        const float w = a_n == cl0 + g ? sh : 0.f;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) accg[g][q] = fmaf(xv[u][q], w, accg[g][q]);
+                    for (int u = 0; u < RB; ++u) {
+                        const int n = n0 + u;
+                        if (n < N) {
+                            const float w = s_assign[n] == cl ? s_share[n] : 0.f;
+                            acc[jj][0] = fmaf(x0[u], w, acc[jj][0]);
+                            acc[jj][1] = fmaf(x1[u], w, acc[jj][1]);
+                        }
                     }
                 }
-            }
+            };
+            if (sxn) accumulate(std::true_type{});
+            else accumulate(std::false_type{});
+            const float s = nr_wave_sum(acc[jj][0] + acc[jj][1]);
+            if (lane == 0) s_psum[j] = s;
         }
+    }
+    __syncthreads();
+    float mu[BK_MAXJ];
 #pragma unroll
-      for (int g = 0; g < CG; ++g) {
-        const int cl = cl0 + g;
-        if (cl >= cnum) break;
-        float acc[4];
+    for (int jj = 0; jj < BK_MAXJ; ++jj) {
+        mu[jj] = 0.f;
+        const int j = wave + NW * jj;
+        if (j < jobs) {
+            const int cl = j / CH;
+            float t = 0.f;
+            for (int ch = 0; ch < CH; ++ch) t += s_psum[cl * CH + ch];
+            mu[jj] = t / (float)C;
+            const float d0 = acc[jj][0] - mu[jj], d1 = acc[jj][1] - mu[jj];
+            const float v = nr_wave_sum(d0 * d0 + d1 * d1);
+            if (lane == 0) s_pvar[j] = v;
+        }
+    }
+    __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = accg[g][q];
-        float s = 0.f;
+    for (int jj = 0; jj < BK_MAXJ; ++jj) {
+        const int j = wave + NW * jj;
+        if (j < jobs) {
+            const int cl = j / CH, c0 = (j - cl * CH) * 128 + lane;
+            float t = 0.f;
+            for (int ch = 0; ch < CH; ++ch) t += s_pvar[cl * CH + ch];
+            const float rstd = rsqrtf(t / (float)C + p.eps);
+            const size_t o = ((size_t)b * cnum + cl) * C;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s += (q * 256 + tid < C) ? acc[q] : 0.f;
-        s = nr_wave_sum(s);
-        if (lane == 0) s_red[0][wave] = s;
-        __syncthreads();
-        const float mu = (s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3]) / (float)C;
-        float var = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q * 256 + tid < C) { float dlt = acc[q] - mu; var += dlt * dlt; }
-        var = nr_wave_sum(var);
-        if (lane == 0) s_red[1][wave] = var;
-        __syncthreads();
-        const float rstd = rsqrtf((s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]) / (float)C + p.eps);
-        const size_t o = ((size_t)b * cnum + cl) * C;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int c = q * 256 + tid;
-            if (c < C) {
-                if (p.merged) p.merged[o + c] = acc[q];
-                p.merged_pb[o + c] = acc[q] + p.proj_b[c];
-                const float qv = (acc[q] - mu) * rstd * p.n1_w[c] + p.n1_b[c];
+            for (int h = 0; h < 2; ++h) {
+                const int c = c0 + 64 * h;
+                const float a = acc[jj][h];
+                const float pbv = jj == 0 ? pb0[h] : p.proj_b[c];
+                const float nwv = jj == 0 ? nw0[h] : p.n1_w[c];
+                const float nbv = jj == 0 ? nb0[h] : p.n1_b[c];
+                if (p.merged) p.merged[o + c] = a;
+                p.merged_pb[o + c] = a + pbv;
+                const float qv = (a - mu[jj]) * rstd * nwv + nbv;
                 if (p.qn_hi) {                       // operand of the q GEMM, split-bf16
-                    const uint16_t h = nr_f2bf(qv);
-                    p.qn_hi[o + c] = h;
-                    p.qn_lo[o + c] = nr_f2bf(qv - nr_bf2f(h));
+                    const uint16_t hh = nr_f2bf(qv);
+                    p.qn_hi[o + c] = hh;
+                    p.qn_lo[o + c] = nr_f2bf(qv - nr_bf2f(hh));
                 } else {
                     p.qn[o + c] = qv;
                 }
             }
         }
-        __syncthreads();
-      }
     }
+    BK_LAP();      // 6: merged
+#ifdef NR_STAMP
+    if (b == 0 && tid == 0 && p.n_samples > 1)
+        for (int i = 0; i < tn; ++i) nr_back_stamps[i] = tk[i] - tk[0];
+#endif
 }
-
 
 // ---- score-biased multi-head attention: merged tokens (queries) over un-merged tokens ---------------------
 // 16 waves, one per (head, query); lane = key for the logits / softmax, lane = channel for the value sum.

@@ -41,7 +41,10 @@ extern "C" int nr_ctm_front(const float* y, const float* mask, int n_samples, in
     return NR_OK;
 }
 
-__global__ __launch_bounds__(256) void nr_ctm_back_kernel(NrCtmBackArgs p) { nr_ctm_back_body(p, blockIdx.x); }
+__global__ __launch_bounds__(BK_THREADS) void nr_ctm_back_kernel(NrCtmBackArgs p, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) float sxn[];
+    nr_ctm_back_body(p, blockIdx.x, use_lds ? sxn : nullptr);
+}
 
 extern "C" int nr_ctm_back(const float* dist, const float* smax, const float* mask, const float* noise, const float* xn,
                            const float* tokw, int n_samples, int N, int C, int k, int cluster_num, const float* n1_w,
@@ -49,10 +52,17 @@ extern "C" int nr_ctm_back(const float* dist, const float* smax, const float* ma
                            int64_t* assign, void* stream) {
     if (!dist || !smax || !noise || !xn || !tokw || !n1_w || !n1_b || !proj_b || !merged || !merged_pb || !qn) return NR_EINVAL;
     if (n_samples <= 0 || N <= 0 || k <= 0 || k > N || cluster_num <= 0 || cluster_num > N) return NR_EINVAL;
-    if (N > 64 || C <= 0 || C > 1024) return NR_EUNSUPPORTED;
+    if (N > 64 || C <= 0 || C > 1024 || (C % 128) != 0 || cluster_num * (C / 128) > 16 * BK_MAXJ) return NR_EUNSUPPORTED;
     NrCtmBackArgs p{dist, smax, mask, noise, xn, tokw, n1_w, n1_b, proj_b, n_samples, N, C, k, cluster_num, eps,
                     merged, merged_pb, qn, assign, nullptr, nullptr};
-    hipLaunchKernelGGL(nr_ctm_back_kernel, dim3(n_samples), dim3(256), 0, (hipStream_t)stream, p);
+    size_t lds = (size_t)N * C * sizeof(float);
+    const int use_lds = lds <= 96 * 1024 && (N * C) % 256 == 0;
+    if (!use_lds) lds = 0;
+    if (lds > 40 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)nr_ctm_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(nr_ctm_back_kernel, dim3(n_samples), dim3(BK_THREADS), lds, (hipStream_t)stream, p, use_lds);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

@@ -37,9 +37,10 @@ __global__ __launch_bounds__(CF_THREADS) void nr_group_front_kernel(NrGroupOf<Nr
     nr_ctm_front_body<CPL>(g.p[gi], blockIdx.x - g.start[gi], sx);
 }
 
-__global__ __launch_bounds__(256) void nr_group_back_kernel(NrGroupOf<NrCtmBackArgs> g) {
+__global__ __launch_bounds__(BK_THREADS) void nr_group_back_kernel(NrGroupOf<NrCtmBackArgs> g, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) float sxn[];
     const int gi = g.find(blockIdx.x);
-    nr_ctm_back_body(g.p[gi], blockIdx.x - g.start[gi]);
+    nr_ctm_back_body(g.p[gi], blockIdx.x - g.start[gi], use_lds ? sxn : nullptr);
 }
 
 __global__ __launch_bounds__(1024) void nr_group_attention_kernel(NrGroupOf<NrAttnArgs> g, int use_lds) {
@@ -47,6 +48,14 @@ __global__ __launch_bounds__(1024) void nr_group_attention_kernel(NrGroupOf<NrAt
     const int gi = g.find(blockIdx.x);
     nr_tc_attention_body(g.p[gi], blockIdx.x - g.start[gi], use_lds ? skv : nullptr);
 }
+
+#ifdef NR_STAMP
+extern "C" int nr_debug_back_stamps(unsigned long long* host) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(nr_back_stamps), sizeof(unsigned long long) * 16);
+    return 7;
+}
+#endif
 
 // ---- workspace carve-up --------------------------------------------------------------------------------------
 namespace {
@@ -108,7 +117,8 @@ extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
             !s.wq_hi || !s.wq_lo || !s.wkv_hi || !s.wkv_lo || !s.wp_hi || !s.wp_lo || !s.proj_bias || !s.workspace || !s.out)
             return NR_EINVAL;
         if (s.n_samples <= 0 || s.N <= 0 || s.k <= 0 || s.k > s.N || s.cnum <= 0 || s.cnum > s.N || s.heads <= 0) return NR_EINVAL;
-        if (s.N > 64 || s.C <= 0 || (s.C % 64) != 0 || s.C > 1024 || s.C != s.heads * 64) return NR_EUNSUPPORTED;
+        if (s.N > 64 || s.C <= 0 || (s.C % 128) != 0 || s.C > 1024 || s.C != s.heads * 64) return NR_EUNSUPPORTED;
+        if (s.cnum * (s.C / 128) > 16 * BK_MAXJ) return NR_EUNSUPPORTED;
         w[i] = carve(s.workspace, s.n_samples, s.N, s.C, s.cnum);
         size_t lds = (size_t)s.N * s.C * sizeof(float);
         if (lds > 150 * 1024) return NR_EUNSUPPORTED;
@@ -175,7 +185,20 @@ extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
             total += s.n_samples;
         }
         for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
-        hipLaunchKernelGGL(nr_group_back_kernel, dim3(total), dim3(256), 0, st, g);
+        size_t lds = 0;                      // token rows of the largest problem, if every problem's rows fit
+        bool fits = true;
+        for (int i = 0; i < n; ++i) {
+            size_t need = (size_t)d[i].N * d[i].C * sizeof(float);
+            lds = need > lds ? need : lds;
+            fits = fits && (d[i].N * d[i].C) % 256 == 0;
+        }
+        const int use_lds = fits && lds <= 96 * 1024;
+        if (!use_lds) lds = 0;
+        if (lds > 40 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)nr_group_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(nr_group_back_kernel, dim3(total), dim3(BK_THREADS), lds, st, g, use_lds);
         NR_LAUNCH_CHECK();
     }
     // 5. q = norm1(merged) Wq^T (+b), kv = norm1(xn) Wkv^T (+b): 2n problems, one launch

@@ -294,7 +294,9 @@ def test_ctm_front_back_equal_the_separate_kernels():
              hip.ptr(n1_w), hip.ptr(n1_b), hip.ptr(pb), 1e-5, hip.ptr(merged2), hip.ptr(mpb2), hip.ptr(qn2), hip.ptr(assign2),
              hip.stream_ptr())
     assert torch.equal(xn, xn2) and torch.equal(kvn, kvn2) and torch.equal(tokw, tokw2) and torch.equal(assign, assign2)
-    assert torch.equal(merged, merged2) and torch.equal(mpb, mpb2) and torch.equal(qn, qn2)
+    # cluster weight totals and LayerNorm statistics are tree-summed in the fused kernel: equal to rounding
+    assert maxdiff(merged, merged2) < 2e-6 * float(merged.abs().max()) and maxdiff(mpb, mpb2) < 2e-6 * float(mpb.abs().max())
+    assert maxdiff(qn, qn2) < 4e-6 * float(qn.abs().max())
     # the split-bf16 form of norm1(xn) carries it to ~2^-16
     kh = torch.empty(B * N, C, dtype=torch.int16, device=DEV)
     kl = torch.empty(B * N, C, dtype=torch.int16, device=DEV)
