@@ -214,6 +214,34 @@ def main():
             fb()
         torch.cuda.synchronize()
         extra["fwd_bwd_ms_per_step"] = (time.perf_counter() - t1) / nfb * 1e3
+        # the same training step (forward + backward, grads left in .grad) captured as ONE HIP graph: the eager
+        # step is bound by the host issuing the autograd-traced clustering ops, the replay is not
+        if not args.no_graph:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        fb()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                gfb = torch.cuda.CUDAGraph()
+                model.zero_grad(set_to_none=True)
+                tf.grad = vf.grad = None
+                with torch.cuda.graph(gfb):
+                    ls = model(tf, shard["text_mask"], vf, shard["video_mask"], shard["idx"], 0)
+                    ls[0].backward()
+                for _ in range(5):
+                    gfb.replay()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(nfb):
+                    gfb.replay()
+                torch.cuda.synchronize()
+                extra["fwd_bwd_graph_ms_per_step"] = (time.perf_counter() - t1) / nfb * 1e3
+            except Exception as e:
+                print(f"[bench] fwd+bwd graph capture unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+                torch.cuda.synchronize()
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------------
     roofline = None

@@ -246,6 +246,20 @@ int nr_local_level_bwd(int side, const float* dS, int ds_mode, float ds_scale,
                        int A, int Nt, int Bv, int Nv, int d, float* d_x, float* d_w, int accumulate,
                        void* workspace, void* stream);
 
+/* The d_x half of nr_local_level_bwd as an MFMA GEMM: 96 x 96 blocks of the (sparse) routing matrix
+ *   P[(s,n),(o,m)] = 0.5 dS(s,o) ( w_other[o,m] [scat(s,o,m) == n] + w_self[s,n] [gath(s,o,n) == m] )
+ * are generated in LDS from the stored arg-max bytes and multiplied with the other operand's tokens.
+ *   oT_hi / oT_lo: the other operand's prepared tokens TRANSPOSED, [d][ldk] bf16 (ldk >= its token count,
+ *   multiple of 8, zero padded); oT_lo may be NULL (one pass).  Token counts must divide 96 (12 / 24),
+ *   d % 256 == 0 (nr_local_level_bwd_mfma_supported); d_w is not produced -- call nr_local_level_bwd with
+ *   d_x == NULL for it.  workspace: nr_local_level_bwd_mfma_workspace_bytes(...).                    */
+int nr_local_level_bwd_mfma_supported(int Nt, int Nv, int d);
+size_t nr_local_level_bwd_mfma_workspace_bytes(int side, int A, int Nt, int Bv, int Nv, int d);
+int nr_local_level_bwd_mfma(int side, const float* dS, int ds_mode, float ds_scale, const uint16_t* oT_hi,
+                            const uint16_t* oT_lo, int ldk, const float* w_self, const float* w_other,
+                            const uint8_t* arg_v, const uint8_t* arg_t, int A, int Nt, int Bv, int Nv, int d,
+                            float* d_x, int accumulate, void* workspace, void* stream);
+
 /* Backward of F.normalize + mask + the centrality mean (nr_prepare_tokens):
  *   g = mask*d_xn + dmean/n_tok;  dx = (g - xhat <xhat,g>) / ||x||,  xhat = x/||x||.
  *   x [n_tok,d] original features, norm [n_tok], mask [n_tok] or NULL, d_xn [n_tok,d] or NULL,

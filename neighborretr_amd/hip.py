@@ -69,6 +69,9 @@ _SIGNATURES = {
     "nr_colsum": ([_P, _I, _I, _P, _P], _I),
     "nr_local_level_bwd_workspace_bytes": ([_I, _I, _I, _I, _I, _I], _Z),
     "nr_local_level_bwd": ([_I, _P, _I, _F] + [_P] * 8 + [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P], _I),
+    "nr_local_level_bwd_mfma_supported": ([_I, _I, _I], _I),
+    "nr_local_level_bwd_mfma_workspace_bytes": ([_I, _I, _I, _I, _I, _I], _Z),
+    "nr_local_level_bwd_mfma": ([_I, _P, _I, _F, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P], _I),
     "nr_normalize_bwd": ([_P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     "nr_token_softmax_bwd": ([_P, _P, _I, _I, _P, _P], _I),
     "nr_centrality_weights_bwd": ([_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P], _I),

@@ -227,6 +227,9 @@ def colsum(a):
     return out
 
 
+USE_MFMA_BACKWARD = True        # False: the scalar arg-max walk for d_x too (reference for the MFMA path in the tests)
+
+
 def local_level_bwd(side, dS, ds_mode, ds_scale, other, w_self, w_other, aux, A, Nt, Bv, Nv, d_x=None, d_w=None,
                     want_dx=True, accumulate=False, use_lo=True):
     """Arg-max-routed gradient for one operand (nr_local_level_bwd).  `other` is the Prepared
@@ -241,12 +244,33 @@ def local_level_bwd(side, dS, ds_mode, ds_scale, other, w_self, w_other, aux, A,
         d_x = torch.empty((n_self, d), dtype=torch.float32, device=dev)
     if d_w is None:
         d_w = torch.empty((n_self,), dtype=torch.float32, device=dev)
+    mfma = want_dx and USE_MFMA_BACKWARD and bool(hip.lib().nr_local_level_bwd_mfma_supported(Nt, Nv, d))
+    if mfma:
+        # d_x on the matrix cores (routing-matrix blocks generated in LDS x the other operand's tokens, which the
+        # kernel wants k-contiguous: transposed here); d_w from the scalar kernel in its weights-only mode
+        def transposed(t):
+            n_tok = t.shape[0]
+            ldk = (n_tok + 7) // 8 * 8
+            if ldk == n_tok:
+                return t.t().contiguous(), ldk
+            out = torch.zeros((d, ldk), dtype=t.dtype, device=dev)
+            out[:, :n_tok] = t.t()
+            return out, ldk
+        o_hi_t, ldk = transposed(other.hi.view(-1, d))
+        o_lo_t = transposed(other.lo.view(-1, d))[0] if (use_lo and other.lo is not None) else None
+        ws = torch.empty((int(hip.lib().nr_local_level_bwd_mfma_workspace_bytes(int(side), A, Nt, Bv, Nv, d)),),
+                         dtype=torch.uint8, device=dev)
+        hip.call("nr_local_level_bwd_mfma", int(side), hip.ptr(dS, torch.float32), int(ds_mode), float(ds_scale),
+                 hip.ptr(o_hi_t), hip.ptr(o_lo_t, allow_none=True), int(ldk), hip.ptr(w_self, torch.float32),
+                 hip.ptr(w_other, torch.float32), hip.ptr(arg_v), hip.ptr(arg_t), A, Nt, Bv, Nv, d, hip.ptr(d_x),
+                 1 if accumulate else 0, hip.ptr(ws), hip.stream_ptr())
     ws = torch.empty((int(hip.lib().nr_local_level_bwd_workspace_bytes(int(side), A, Nt, Bv, Nv, d)),), dtype=torch.uint8,
                      device=dev)
+    scalar_dx = want_dx and not mfma
     hip.call("nr_local_level_bwd", int(side), hip.ptr(dS, torch.float32), int(ds_mode), float(ds_scale),
              hip.ptr(other.hi), hip.ptr(other.lo if use_lo else None, allow_none=True), hip.ptr(w_self, torch.float32),
              hip.ptr(w_other, torch.float32), hip.ptr(arg_v), hip.ptr(arg_t), hip.ptr(pmax), hip.ptr(qmax),
-             A, Nt, Bv, Nv, d, hip.ptr(d_x if want_dx else None, allow_none=True), hip.ptr(d_w),
+             A, Nt, Bv, Nv, d, hip.ptr(d_x if scalar_dx else None, allow_none=True), hip.ptr(d_w),
              1 if accumulate else 0, hip.ptr(ws), hip.stream_ptr())
     return (d_x if want_dx else None), d_w
 

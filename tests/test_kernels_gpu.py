@@ -390,6 +390,40 @@ def test_row_losses_final_is_bit_identical_to_two_launches(B):
         assert torch.equal(rl, rl2) and torch.equal(ref, fused)
 
 
+@pytest.mark.parametrize("side,mode,A,Bv,use_lo", [(0, 0, 40, 56, True), (1, 0, 40, 56, False), (0, 1, 16, 200, False),
+                                                    (1, 2, 200, 16, True), (0, 0, 3, 5, False)])
+def test_mfma_backward_matches_the_scalar_walk(side, mode, A, Bv, use_lo):
+    """nr_local_level_bwd_mfma (routing-matrix blocks on the matrix cores) against nr_sim_bwd_kernel's
+    entry-by-entry walk: same d_x to bf16-coefficient accuracy, d_w identical (same kernel)."""
+    Nt, Nv, d = 24, 12, 512
+    g = torch.Generator().manual_seed(A * 7 + Bv + side)
+    t = torch.randn(A, Nt, d, generator=g).to(DEV)
+    v = torch.randn(Bv, Nv, d, generator=g).to(DEV)
+    tm = (torch.arange(Nt)[None] < torch.randint(2, Nt + 1, (A, 1), generator=g)).float().to(DEV)
+    vm = (torch.arange(Nv)[None] < torch.randint(2, Nv + 1, (Bv, 1), generator=g)).float().to(DEV)
+    pt, pv = ops.prepare_tokens(t, tm), ops.prepare_tokens(v, vm)
+    w_t = torch.softmax(torch.randn(A, Nt, generator=g), -1).to(DEV)
+    w_v = torch.softmax(torch.randn(Bv, Nv, generator=g), -1).to(DEV)
+    _, aux = ops.local_level(pt, pv, w_t, w_v, A, Nt, Bv, Nv, hip.PREC_BF16X3, hip.OUT_FULL, want_arg=True)
+    dS = (torch.randn(A, Bv, generator=g) if mode == 0 else torch.randn(A if mode == 1 else Bv, generator=g)).to(DEV)
+    other, ws_, wo_ = (pv, w_t, w_v) if side == 0 else (pt, w_v, w_t)
+    try:
+        ops.USE_MFMA_BACKWARD = False
+        dx_ref, dw_ref = ops.local_level_bwd(side, dS, mode, 0.37, other, ws_, wo_, aux, A, Nt, Bv, Nv, use_lo=use_lo)
+        ops.USE_MFMA_BACKWARD = True
+        dx, dw = ops.local_level_bwd(side, dS, mode, 0.37, other, ws_, wo_, aux, A, Nt, Bv, Nv, use_lo=use_lo)
+        base = dx.clone()
+        dx2, _ = ops.local_level_bwd(side, dS, mode, 0.37, other, ws_, wo_, aux, A, Nt, Bv, Nv, d_x=base, d_w=dw.clone(),
+                                     accumulate=True, use_lo=use_lo)
+    finally:
+        ops.USE_MFMA_BACKWARD = True
+    assert torch.equal(dw, dw_ref)
+    scale = float(dx_ref.abs().max())
+    assert maxdiff(dx, dx_ref) < 4e-3 * scale                 # coefficients rounded to bf16
+    assert float((dx - dx_ref).abs().mean()) < 4e-4 * scale
+    assert maxdiff(dx2, 2 * dx) < 1e-5 * scale
+
+
 def test_bank_push_fifo():
     bank = torch.arange(10 * 6, dtype=torch.float32, device=DEV).reshape(10, 2, 3)
     ref = bank.clone()
