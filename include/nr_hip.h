@@ -175,6 +175,11 @@ typedef struct NrCtmStageDesc {
 } NrCtmStageDesc;
 size_t nr_ctm_stage_workspace_bytes(int n_samples, int N, int C, int cluster_num);
 int nr_ctm_stage_fwd(const NrCtmStageDesc* problems, int n_problems, void* stream);
+/* Launches [first, last) of the stage's NR_CTM_STAGE_LAUNCHES only (0 shift|split, 1 conv GEMM, 2 front, 3 back,
+ * 4 q+kv GEMMs, 5 attention, 6 proj GEMM): a host that captures the step into a HIP graph interleaves them with
+ * the launches of an independent branch, because the graph starts its nodes in capture order.            */
+#define NR_CTM_STAGE_LAUNCHES 7
+int nr_ctm_stage_fwd_range(const NrCtmStageDesc* problems, int n_problems, int first, int last, void* stream);
 
 /* Y[M,N] = X[M,K] W[N,K]^T (+ bias[N]) (+ residual[M,N]) in split-bf16 on the MFMA tile engine: the big
  * fp32 GEMMs of the clustering stage (token convolution cluster.py:664, kv projection :866).

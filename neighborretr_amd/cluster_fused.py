@@ -117,10 +117,11 @@ def _addr(t):
     return None if t is None else t.data_ptr()
 
 
-def ctm_stage_group(problems, cache):
+def ctm_stage_group(problems, cache, stepwise=False):
     """One CTM + TCBlock stage of several independent problems (text and video) in the SAME seven launches
     (nr_ctm_stage_fwd).  problems: list of (key, x [B,N,C], mask or None, ctm, blk, noise or None).
-    Returns the list of outputs [B,cnum,C]."""
+    Returns the list of outputs [B,cnum,C]; with stepwise=True returns (outputs, generator) where every
+    next() of the generator issues ONE of the seven launches on the then-current stream."""
     import ctypes
     if not 0 < len(problems) <= hip.CTM_MAX_GROUP:
         raise hip.NrHipError(f"1..{hip.CTM_MAX_GROUP} problems per grouped stage")
@@ -157,6 +158,13 @@ def ctm_stage_group(problems, cache):
             setattr(d, name, _addr(t))
         keep.append(tensors)
         outs.append(out)
+    if stepwise:
+        def launches(alive=keep):
+            for i in range(hip.CTM_STAGE_LAUNCHES):
+                hip.call("nr_ctm_stage_fwd_range", descs, len(problems), i, i + 1, hip.stream_ptr())
+                yield
+            del alive                            # the tensors behind the descriptors stay alive until here
+        return outs, launches()
     hip.call("nr_ctm_stage_fwd", descs, len(problems), hip.stream_ptr())
     del keep
     return outs

@@ -107,7 +107,12 @@ extern "C" size_t nr_ctm_stage_workspace_bytes(int n_samples, int N, int C, int 
 }
 
 extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
-    if (!d || n <= 0 || n > NR_CTM_MAX_GROUP) return NR_EINVAL;
+    return nr_ctm_stage_fwd_range(d, n, 0, NR_CTM_STAGE_LAUNCHES, stream);
+}
+
+// launches [first, last) of the stage's seven: lets the host interleave them with other work in capture order
+extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first, int last, void* stream) {
+    if (!d || n <= 0 || n > NR_CTM_MAX_GROUP || first < 0 || last > NR_CTM_STAGE_LAUNCHES || first >= last) return NR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     StageBuffers w[NR_CTM_MAX_GROUP];
     size_t front_lds = 0;
@@ -126,7 +131,7 @@ extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
     }
     int rc;
     // 1. x[n-1] | x[n] | x[n+1] as split-bf16 rows
-    {
+    if (first <= 0 && 0 < last) {
         NrGroupOf<NrShiftArgs> g;
         g.n = n;
         int total = 0;
@@ -140,7 +145,7 @@ extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
         NR_LAUNCH_CHECK();
     }
     // 2. y = x + conv(x)  (k=3 convolution as a [B*N, 3C] x [3C, C] product)
-    {
+    if (first <= 1 && 1 < last) {
         NrLinearArgs p[NR_CTM_MAX_GROUP];
         for (int i = 0; i < n; ++i)
             p[i] = NrLinearArgs{w[i].cat_hi, w[i].cat_lo, d[i].wconv_hi, d[i].wconv_lo, d[i].conv_bias, d[i].x, w[i].y,
@@ -148,7 +153,7 @@ extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
         if ((rc = nr_linear_group_launch(p, n, st)) != NR_OK) return rc;
     }
     // 3. LayerNorm, score, exp, norm1, pairwise distances
-    {
+    if (first <= 2 && 2 < last) {
         NrGroupOf<NrCtmFrontArgs> g;
         g.n = n;
         int total = 0;
@@ -172,7 +177,7 @@ extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
         NR_LAUNCH_CHECK();
     }
     // 4. DPC-KNN assignment, weighted cluster means, norm1
-    {
+    if (first <= 3 && 3 < last) {
         NrGroupOf<NrCtmBackArgs> g;
         g.n = n;
         int total = 0;
@@ -202,7 +207,7 @@ extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
         NR_LAUNCH_CHECK();
     }
     // 5. q = norm1(merged) Wq^T (+b), kv = norm1(xn) Wkv^T (+b): 2n problems, one launch
-    {
+    if (first <= 4 && 4 < last) {
         NrLinearArgs p[2 * NR_CTM_MAX_GROUP];
         for (int i = 0; i < n; ++i) {
             const NrCtmStageDesc& s = d[i];
@@ -212,7 +217,7 @@ extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
         if ((rc = nr_linear_group_launch(p, 2 * n, st)) != NR_OK) return rc;
     }
     // 6. score-biased attention of the merged tokens over the un-merged ones
-    {
+    if (first <= 5 && 5 < last) {
         NrGroupOf<NrAttnArgs> g;
         g.n = n;
         int total = 0;
@@ -238,7 +243,7 @@ extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
         NR_LAUNCH_CHECK();
     }
     // 7. out = merged + proj(att) + proj.bias
-    {
+    if (first <= 6 && 6 < last) {
         NrLinearArgs p[NR_CTM_MAX_GROUP];
         for (int i = 0; i < n; ++i)
             p[i] = NrLinearArgs{w[i].att_hi, w[i].att_lo, d[i].wp_hi, d[i].wp_lo, nullptr, w[i].merged_pb, d[i].out,

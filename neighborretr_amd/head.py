@@ -87,13 +87,15 @@ def precision_plan(prec):
 
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                  gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None,
-                 bank_streams=None, local_stream=None, bank_early=0):
+                 bank_streams=None, local_stream=None, bank_early=0,
+                 capture_order=((7, 9), (7, 1 << 30))):
     """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None).
 
     `join`: optional callable run right before the first use of gt / gv.  Either the caller produces the
     global tokens on side streams while the local branch runs here and joins those streams in it, or --
-    with gt = gv = None -- `join` itself runs the token clustering on the current stream and returns
-    (gt, gv), while the local branch (prepare, scorer, B x B product) runs on `local_stream`.
+    with gt = gv = None -- `join` runs the token clustering on the current stream and returns (gt, gv), while
+    the local branch (prepare, scorer, B x B product) runs on `local_stream`; if `join` is a GENERATOR that
+    issues one launch per next() and returns (gt, gv), its launches are interleaved with the local branch's.
     `bank_streams`: optional pair of side streams for the two memory-bank chains (see below)."""
     B, Nt, d = text_feat.shape
     Nv = video_feat.shape[1]
@@ -114,53 +116,129 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     lo_k = keep or p_bank == hip.PREC_BF16X3
     cur = torch.cuda.current_stream()
 
-    def bank_video():
+    # The local branch, one kernel launch per step (a generator, so that it can be interleaved launch by launch
+    # with the clustering -- see below); its results land in `L`.
+    L = {}
+    early = [None, None]
+
+    def local_steps():
+        L["pt"] = pt_ = ops.prepare_tokens(text_feat, text_mask, want_lo=lo_b, want_colsum=True)
+        yield
+        L["pv"] = pv_ = ops.prepare_tokens(video_feat, video_mask, want_lo=lo_b, want_colsum=True)
+        yield
+        parts = ops.token_logit_parts(pt_, sw_t.w1_hi, sw_t.w1_lo, sw_t.b1, sw_t.w2, p_mlp)
+        yield
+        L["w_t"], L["lg_t"] = ops.token_softmax(parts, sw_t.b2, text_mask, B, Nt, keep)
+        yield
+        parts = ops.token_logit_parts(pv_, sw_v.w1_hi, sw_v.w1_lo, sw_v.b1, sw_v.w2, p_mlp)
+        yield
+        L["w_v"], L["lg_v"] = ops.token_softmax(parts, sw_v.b2, video_mask, B, Nv, keep)
+        yield
+        L["S"], L["aux0"] = ops.local_level(pt_, pv_, L["w_t"], L["w_v"], B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
+        yield
+        # mean of the (unmasked) normalised tokens for the centrality weights -- still on the local branch
+        L["mean_t"] = ops.reduce_parts(pt_.colsum, 1.0 / pt_.n_tok)
+        yield
+        L["mean_v"] = ops.reduce_parts(pv_.colsum, 1.0 / pv_.n_tok)
+        yield
+        # `bank_early` chains (0..2) run right behind the batch products, i.e. beside the clustering; the rest is
+        # forked after the join (beside the Sinkhorn solve)
+        if local_stream is not None and bank_early > 0:
+            early[0] = yield from bank_video_steps()
+            if bank_early > 1:
+                early[1] = yield from bank_text_steps()
+
+    def bank_video_steps():
         # text x bank-video, row mean  -> centrality of text j  (used by the v2t neighbour loss)
         pbv = ops.prepare_tokens(mb_feat_v, mb_mask_v, want_lo=lo_k)
-        w_bv, lg_bv = token_weights(pbv, mb_mask_v, sw_v, M, Nv, p_bank, keep)
-        p1, aux1 = ops.local_level(pt, pbv, w_t, w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM, keep)
-        return pbv, w_bv, lg_bv, aux1, ops.reduce_parts(p1, 1.0 / M)
+        yield
+        parts = ops.token_logit_parts(pbv, sw_v.w1_hi, sw_v.w1_lo, sw_v.b1, sw_v.w2, p_bank)
+        yield
+        w_bv, lg_bv = ops.token_softmax(parts, sw_v.b2, mb_mask_v, M, Nv, keep)
+        yield
+        p1, aux1 = ops.local_level(L["pt"], pbv, L["w_t"], w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM, keep)
+        yield
+        c1 = ops.reduce_parts(p1, 1.0 / M)
+        yield
+        return pbv, w_bv, lg_bv, aux1, c1
 
-    def bank_text():
+    def bank_text_steps():
         # bank-text x video, column mean -> centrality of video j (used by the t2v neighbour loss)
         pbt = ops.prepare_tokens(mb_feat_t, mb_mask_t, want_lo=lo_k)
-        w_bt, lg_bt = token_weights(pbt, mb_mask_t, sw_t, M, Nt, p_bank, keep)
-        p0, aux2 = ops.local_level(pbt, pv, w_bt, w_v, M, Nt, B, Nv, p_bank, hip.OUT_COLSUM, keep)
-        return pbt, w_bt, lg_bt, aux2, ops.reduce_parts(p0, 1.0 / M)
+        yield
+        parts = ops.token_logit_parts(pbt, sw_t.w1_hi, sw_t.w1_lo, sw_t.b1, sw_t.w2, p_bank)
+        yield
+        w_bt, lg_bt = ops.token_softmax(parts, sw_t.b2, mb_mask_t, M, Nt, keep)
+        yield
+        p0, aux2 = ops.local_level(pbt, L["pv"], w_bt, L["w_v"], M, Nt, B, Nv, p_bank, hip.OUT_COLSUM, keep)
+        yield
+        c0 = ops.reduce_parts(p0, 1.0 / M)
+        yield
+        return pbt, w_bt, lg_bt, aux2, c0
 
-    early = [None, None]
-    if local_stream is not None:
-        # Fork first, then put the CRITICAL path (the clustering that `join` runs on this stream) into the
-        # queue before the local branch: a HIP graph hands its nodes to the hardware queues in capture
-        # order, a microsecond or two apiece, so whatever is captured first starts first.
+    def exhaust(gen):
+        """Runs a step generator to its end; returns its return value."""
+        while True:
+            try:
+                next(gen)
+            except StopIteration as stop:
+                return stop.value
+
+    bank_video = lambda: exhaust(bank_video_steps())     # noqa: E731
+    bank_text = lambda: exhaust(bank_text_steps())       # noqa: E731
+
+    stepwise_join = join is not None and hasattr(join, "__next__")
+    if local_stream is not None and stepwise_join:
+        # A captured HIP graph starts its nodes in CAPTURE ORDER: a node on another queue does not start before
+        # the nodes captured ahead of it have started (profiled step: a branch captured after 7 clustering nodes
+        # began 120 us late and ended up the critical path).  So the two branches are captured interleaved:
+        # `capture_order` = [(clustering launches, local launches), ...] per turn, the last pair repeating.
         local_stream.wait_stream(cur)
-        produced = join() if join is not None else None
+        loc = local_steps()
+        loc_alive, clu_alive = True, True
+        produced = None
+        turn = 0
+        while loc_alive or clu_alive:
+            n_clu, n_loc = capture_order[min(turn, len(capture_order) - 1)]
+            turn += 1
+            if clu_alive:
+                try:
+                    for _ in range(n_clu if loc_alive else 1 << 30):
+                        next(join)
+                except StopIteration as stop:
+                    produced, clu_alive = stop.value, False
+            if loc_alive:
+                torch.cuda.set_stream(local_stream)
+                try:
+                    for _ in range(n_loc if clu_alive else 1 << 30):
+                        next(loc)
+                except StopIteration:
+                    loc_alive = False
+                finally:
+                    torch.cuda.set_stream(cur)
         if produced is not None:
             gt, gv = produced
-        join = None
-        torch.cuda.set_stream(local_stream)
-    try:
-        pt = ops.prepare_tokens(text_feat, text_mask, want_lo=lo_b, want_colsum=True)
-        pv = ops.prepare_tokens(video_feat, video_mask, want_lo=lo_b, want_colsum=True)
-        w_t, lg_t = token_weights(pt, text_mask, sw_t, B, Nt, p_mlp, keep)
-        w_v, lg_v = token_weights(pv, video_mask, sw_v, B, Nv, p_mlp, keep)
-        S, aux0 = ops.local_level(pt, pv, w_t, w_v, B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
-        # mean of the (unmasked) normalised tokens for the centrality weights -- still on the local branch
-        mean_t = ops.reduce_parts(pt.colsum, 1.0 / pt.n_tok)
-        mean_v = ops.reduce_parts(pv.colsum, 1.0 / pv.n_tok)
-        # `bank_early` chains (0..2) run on the local stream right behind the batch products, i.e. beside
-        # the clustering; the rest is forked after the join (beside the Sinkhorn solve).
-        if local_stream is not None and bank_early > 0:
-            early[0] = bank_video()
-            if bank_early > 1:
-                early[1] = bank_text()
-    finally:
+    else:
+        # `join`: one callable run right before gt / gv are needed (may return them); generators are run through
         if local_stream is not None:
-            torch.cuda.set_stream(cur)
-    if join is not None:
-        produced = join()
-        if produced is not None:
-            gt, gv = produced
+            local_stream.wait_stream(cur)
+            if join is not None:
+                produced = exhaust(join) if stepwise_join else join()
+                if produced is not None:
+                    gt, gv = produced
+                join = None
+            torch.cuda.set_stream(local_stream)
+        try:
+            exhaust(local_steps())
+        finally:
+            if local_stream is not None:
+                torch.cuda.set_stream(cur)
+        if join is not None:
+            produced = exhaust(join) if stepwise_join else join()
+            if produced is not None:
+                gt, gv = produced
+    pt, pv, w_t, w_v, lg_t, lg_v = L["pt"], L["pv"], L["w_t"], L["w_v"], L["lg_t"], L["lg_v"]
+    S, aux0, mean_t, mean_v = L["S"], L["aux0"], L["mean_t"], L["mean_v"]
     if local_stream is not None:
         cur.wait_stream(local_stream)
         for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi):
@@ -168,28 +246,29 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     if gt.shape[1] != 1 or gv.shape[1] != 1:
         raise RuntimeError("more than one global token per sample: the reference's centrality term "
                            "fails to broadcast at this shape (until_module.py:321); parity unpinned")
-    # The two bank chains feed only the neighbour loss (through c0 / c1), i.e. nothing before the row-loss
-    # kernel.  With `bank_streams` they are forked HERE -- after the clustering branches have joined -- and
-    # run beside the global logits + Sinkhorn, which keep two CUs busy for ~65 us; started earlier they
-    # only fight the (latency-bound) clustering kernels for CUs.
+    # After the join the critical path is global logits -> Sinkhorn -> row losses: those are captured FIRST.  What
+    # is left of the bank chains and the centrality weights feed only the row-loss kernel; with `bank_streams`
+    # they are forked from the join point (an event recorded before the Sinkhorn launch) and run beside the
+    # solve, which keeps two CUs busy for ~55 us.
+    fork = None
+    if bank_streams is not None:
+        fork = torch.cuda.Event()
+        fork.record(cur)
+    gt2 = gt.reshape(B, d).float().contiguous()
+    gv2 = gv.reshape(B, d).float().contiguous()
+    G = global_logits(gt, gv, sw_t1, sw_v1)
+    tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
     if bank_streams is not None:
         for st_ in bank_streams:
-            st_.wait_stream(cur)
-        with torch.cuda.stream(bank_streams[0]):
-            pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
+            st_.wait_event(fork)
         with torch.cuda.stream(bank_streams[1]):
             pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
+        with torch.cuda.stream(bank_streams[0]):
+            pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
+            wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
     else:
         pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
         pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
-    gt2 = gt.reshape(B, d).float().contiguous()
-    gv2 = gv.reshape(B, d).float().contiguous()
-    if bank_streams is not None:       # the centrality weights too run beside the Sinkhorn solve
-        with torch.cuda.stream(bank_streams[0]):
-            wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
-    G = global_logits(gt, gv, sw_t1, sw_v1)
-    tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
-    if bank_streams is None:
         wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
     ls = logit_scale.detach().float().reshape(1).contiguous()
     if bank_streams is not None:

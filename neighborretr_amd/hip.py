@@ -33,6 +33,7 @@ class CtmStageDesc(ctypes.Structure):
 
 
 CTM_MAX_GROUP = 4
+CTM_STAGE_LAUNCHES = 7
 
 _SIGNATURES = {
     "nr_version": ([], _I),
@@ -59,6 +60,7 @@ _SIGNATURES = {
     "nr_ctm_back": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
     "nr_ctm_stage_workspace_bytes": ([_I, _I, _I, _I], _Z),
     "nr_ctm_stage_fwd": ([ctypes.POINTER(CtmStageDesc), _I, _P], _I),
+    "nr_ctm_stage_fwd_range": ([ctypes.POINTER(CtmStageDesc), _I, _I, _I, _P], _I),
     "nr_sinkhorn_workspace_bytes": ([_I], _Z),
     "nr_sinkhorn_targets": ([_P, _I, _F, _I, _P, _P, _P, _P], _I),
     "nr_row_losses_fwd": ([_P] * 9 + [_I, _I, _F, _P, _P], _I),

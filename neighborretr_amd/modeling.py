@@ -78,7 +78,9 @@ class NeighborRetr(nn.Module):
         self._bstreams = None
         self._lstream = None
         self._rng_state = None
-        self.bank_early = 1                 # bank chains started beside the clustering instead of the Sinkhorn (0..2)
+        # capture order of the loss-only step: (clustering launches, local-branch launches) per turn, last repeats
+        self.capture_order = ((7, 9), (7, 1 << 30))
+        self.bank_early = 2                 # bank chains started beside the clustering instead of the Sinkhorn (0..2)
         self.group_clustering = True        # text + video clustering in the same launches (no-grad forward)
         self.fuse_clustering = True
         self._ctm_cache = {}
@@ -239,9 +241,7 @@ class NeighborRetr(nn.Module):
             # chains beside the Sinkhorn solve (head.head_forward).
             gt = gv = None
 
-            def join():
-                return self._merge_grouped(text_feat, video_feat, text_mask, video_mask, nz)
-            self._join_global = join
+            self._join_global = self._merge_grouped_steps(text_feat, video_feat, text_mask, video_mask, nz)
         elif text_feat.is_cuda and self.use_side_streams:
             # three independent branches: text clustering | video clustering | local products.
             # The two clustering branches run on side streams (in a captured HIP graph: parallel
@@ -273,6 +273,21 @@ class NeighborRetr(nn.Module):
         nz = noise or {}
         return (self._merge_one("text", text_feat, text_mask, nz.get("t0"), nz.get("t1")),
                 self._merge_one("video", video_feat, video_mask, nz.get("v0"), nz.get("v1")))
+
+    def _merge_grouped_steps(self, text_feat, video_feat, text_mask, video_mask, nz):
+        """The two grouped clustering stages as a generator that issues ONE kernel launch per next() (on the
+        then-current stream) and returns (gt, gv): head.head_forward interleaves these launches with the local
+        branch's, because a captured HIP graph starts its nodes in capture order."""
+        from .cluster_fused import ctm_stage_group
+        (t, v), steps = ctm_stage_group(
+            [("text0", text_feat, text_mask, self.text_ctm0, self.text_block0, nz.get("t0")),
+             ("video0", video_feat, video_mask, self.video_ctm0, self.video_block0, nz.get("v0"))], self._ctm_cache, stepwise=True)
+        yield from steps
+        (t, v), steps = ctm_stage_group(
+            [("text1", t, None, self.text_ctm1, self.text_block1, nz.get("t1")),
+             ("video1", v, None, self.video_ctm1, self.video_block1, nz.get("v1"))], self._ctm_cache, stepwise=True)
+        yield from steps
+        return t, v
 
     def _merge_grouped(self, text_feat, video_feat, text_mask, video_mask, nz):
         """Both modalities through the two clustering stages in grouped launches (no-grad forward)."""

@@ -90,6 +90,11 @@ def main():
         for e in (1, 2):
             m.bank_early = e
             print(f"   ... {e} bank chain(s) beside the clustering instead      : {graph_time(step_serial):8.1f} us")
+        m.bank_early = 2
+        for name, order in (("7|9|7|rest", ((7, 9), (7, 1 << 30))), ("1:1", ((1, 1),)), ("1:2", ((1, 2),)), ("2:3", ((2, 3),)),
+                            ("3|4 then 1:2", ((3, 4), (1, 2))), ("7|all", ((7, 1 << 30),)), ("all|all", ((1 << 30, 1 << 30),))):
+            m.capture_order = order
+            print(f"   capture order {name:14s}: {graph_time(step_serial):8.1f} us")
         m.bank_early = 0
 
 
