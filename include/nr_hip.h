@@ -280,6 +280,15 @@ int nr_token_softmax_bwd(const float* w, const float* dw, int n_samples, int N, 
 int nr_centrality_weights_bwd(const float* g, const float* gnorm, const float* mean, const float* w, const float* dw,
                               int B, int d, float scale, float* dg, float* dmean, void* stream);
 
+/* The exchange step's packing (modeling.py:274-280: five all_gathers -> one).  nr_pack_shard copies n <= 8
+ * device buffers (srcs / bytes / offsets are HOST arrays) to their offsets inside one packed record;
+ * nr_unpack_gathered scatters the [world, record_bytes] all-gather result into n rank-major outputs
+ * (dst_k[w*bytes_k + i] = rec_w[offset_k + i]); where u8_to_f32[k] != 0 the piece is bytes_k uint8 values per
+ * rank written as fp32 (the masks become the multipliers the kernels read).  One launch each.        */
+int nr_pack_shard(int n, const void* const* srcs, const size_t* bytes, const size_t* offsets, void* packed, void* stream);
+int nr_unpack_gathered(int n, const void* gathered, int world, size_t record_bytes, const size_t* bytes,
+                       const size_t* offsets, void* const* dsts, const int* u8_to_f32, void* stream);
+
 /* Front of the step in one launch (any part may be switched off with n = 0 / NULL):
  *   out0[i] = (float)mask0[i], out1[i] = (float)mask1[i]   the loader's int64 masks as fp32 multipliers;
  *   logit_scale_exp[0] = exp(logit_scale[0])                modeling.py:289;

@@ -347,3 +347,96 @@ extern "C" int nr_step_prologue(const int64_t* mask0, int n0, float* out0, const
     NR_LAUNCH_CHECK();
     return NR_OK;
 }
+
+// ---- exchange step: pack a rank's shard / unpack the gathered buffer -------------------------------------------
+// The five tensors of the exchange (modeling.py:274-280) travel as ONE byte buffer per rank.  nr_pack_shard
+// concatenates them in one launch; nr_unpack_gathered scatters the [W, stride] result of the all-gather into the
+// five rank-major outputs in one launch, converting the u8 masks to the fp32 multipliers the kernels read.
+struct NrPackArgs {
+    const char* src[8];
+    char* dst[8];
+    unsigned long long bytes[8], off[8];     // per piece: size per rank, offset inside a rank's packed record
+    int convert[8];                          // unpack only: 1 = u8 -> f32
+    int n, W;
+    unsigned long long stride;               // packed record size
+};
+
+__global__ __launch_bounds__(256) void nr_pack_kernel(NrPackArgs a, char* __restrict__ out) {
+    const int k = blockIdx.y;
+    if (k >= a.n) return;
+    const unsigned long long nb = a.bytes[k];
+    const char* s = a.src[k];
+    char* d = out + a.off[k];
+    const bool vec = ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d) | nb) & 15) == 0;
+    if (vec) {
+        for (unsigned long long i = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16; i < nb; i += (unsigned long long)gridDim.x * 4096)
+            *reinterpret_cast<uint4*>(d + i) = *reinterpret_cast<const uint4*>(s + i);
+    } else {
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (unsigned long long)gridDim.x * 256) d[i] = s[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void nr_unpack_kernel(NrPackArgs a, const char* __restrict__ recv) {
+    const int k = blockIdx.y, w = blockIdx.z;
+    if (k >= a.n) return;
+    const unsigned long long nb = a.bytes[k];
+    const char* s = recv + (unsigned long long)w * a.stride + a.off[k];
+    if (a.convert[k]) {
+        float* d = reinterpret_cast<float*>(a.dst[k]) + (unsigned long long)w * nb;
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (unsigned long long)gridDim.x * 256)
+            d[i] = (float)(unsigned char)s[i];
+        return;
+    }
+    char* d = a.dst[k] + (unsigned long long)w * nb;
+    const bool vec = ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d) | nb) & 15) == 0;
+    if (vec) {
+        for (unsigned long long i = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16; i < nb; i += (unsigned long long)gridDim.x * 4096)
+            *reinterpret_cast<uint4*>(d + i) = *reinterpret_cast<const uint4*>(s + i);
+    } else {
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (unsigned long long)gridDim.x * 256) d[i] = s[i];
+    }
+}
+
+extern "C" int nr_pack_shard(int n, const void* const* srcs, const size_t* bytes, const size_t* offsets, void* packed, void* stream) {
+    if (n <= 0 || n > 8 || !srcs || !bytes || !offsets || !packed) return NR_EINVAL;
+    NrPackArgs a{};
+    a.n = n;
+    size_t mx = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!srcs[k]) return NR_EINVAL;
+        a.src[k] = static_cast<const char*>(srcs[k]);
+        a.bytes[k] = bytes[k];
+        a.off[k] = offsets[k];
+        mx = bytes[k] > mx ? bytes[k] : mx;
+    }
+    unsigned gx = (unsigned)((mx + 4095) / 4096);
+    if (gx < 1) gx = 1;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(nr_pack_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a, static_cast<char*>(packed));
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+extern "C" int nr_unpack_gathered(int n, const void* gathered, int world, size_t record_bytes, const size_t* bytes,
+                                  const size_t* offsets, void* const* dsts, const int* u8_to_f32, void* stream) {
+    if (n <= 0 || n > 8 || !gathered || world <= 0 || !bytes || !offsets || !dsts || !u8_to_f32) return NR_EINVAL;
+    NrPackArgs a{};
+    a.n = n;
+    a.W = world;
+    a.stride = record_bytes;
+    size_t mx = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!dsts[k]) return NR_EINVAL;
+        a.dst[k] = static_cast<char*>(dsts[k]);
+        a.bytes[k] = bytes[k];
+        a.off[k] = offsets[k];
+        a.convert[k] = u8_to_f32[k];
+        mx = bytes[k] > mx ? bytes[k] : mx;
+    }
+    unsigned gx = (unsigned)((mx + 4095) / 4096);
+    if (gx < 1) gx = 1;
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(nr_unpack_kernel, dim3(gx, n, world), dim3(256), 0, (hipStream_t)stream, a, static_cast<const char*>(gathered));
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}

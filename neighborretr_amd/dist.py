@@ -37,21 +37,37 @@ class PackedAllGather(torch.autograd.Function):
         ix = idx.to(torch.int64).contiguous()
         tm = text_mask.to(torch.uint8).contiguous()
         vm = video_mask.to(torch.uint8).contiguous()
-        parts = [tf.view(-1).view(torch.uint8), vf.view(-1).view(torch.uint8), ix.view(-1).view(torch.uint8),
-                 tm.view(-1), vm.view(-1)]
-        sizes = [p.numel() for p in parts]
+        pieces = [tf, vf, ix, tm, vm]
+        sizes = [p.numel() * p.element_size() for p in pieces]
+        offs = [sum(sizes[:k]) for k in range(5)]
         total = (sum(sizes) + 15) // 16 * 16
         send = torch.empty(total, dtype=torch.uint8, device=dev)
-        off = 0
-        for p, n in zip(parts, sizes):
-            send[off:off + n] = p
-            off += n
         recv = torch.empty(W * total, dtype=torch.uint8, device=dev)
+        if dev.type == "cuda":
+            # one launch packs, one collective moves, one launch unpacks -- straight into `out` when the caller
+            # supplied static destinations (a captured graph reads them), the masks already as fp32 multipliers
+            from . import ops
+            ops.pack_shard(pieces, send, offs)
+            dist.all_gather_into_tensor(recv, send)
+            out = getattr(args, "_gather_out", None)
+            if out is None:
+                out = (torch.empty((W * b,) + tuple(tf.shape[1:]), dtype=torch.float32, device=dev),
+                       torch.empty((W * b,) + tuple(vf.shape[1:]), dtype=torch.float32, device=dev),
+                       torch.empty((W * b,) + tuple(ix.shape[1:]), dtype=torch.int64, device=dev),
+                       torch.empty((W * b,) + tuple(tm.shape[1:]), dtype=torch.float32, device=dev),
+                       torch.empty((W * b,) + tuple(vm.shape[1:]), dtype=torch.float32, device=dev))
+            ops.unpack_gathered(recv, W, total, sizes, offs, list(out), [False, False, False, True, True])
+            g_tf, g_vf, g_ix, g_tm, g_vm = out
+            ctx.mark_non_differentiable(g_ix, g_tm, g_vm)
+            return g_tf, g_vf, g_ix, g_tm, g_vm
+        parts = [p.view(-1).view(torch.uint8) for p in pieces]
+        for p, n, o in zip(parts, sizes, offs):
+            send[o:o + n] = p
         dist.all_gather_into_tensor(recv, send)
         recv = recv.view(W, total)
 
         def take(k, dtype, shape):
-            o = sum(sizes[:k])
+            o = offs[k]
             return recv[:, o:o + sizes[k]].contiguous().view(-1).view(dtype).view((W * b,) + tuple(shape))
         g_tf = take(0, torch.float32, tf.shape[1:])
         g_vf = take(1, torch.float32, vf.shape[1:])

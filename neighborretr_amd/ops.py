@@ -316,6 +316,29 @@ def bank_push(bank, batch, scratch=None):
     return bank
 
 
+def pack_shard(tensors, packed, offsets):
+    """nr_pack_shard: the (contiguous GPU) tensors' bytes at `offsets` inside the uint8 buffer `packed`."""
+    import ctypes
+    n = len(tensors)
+    for t in tensors:
+        hip.ptr(t)
+    srcs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    nbytes = (ctypes.c_size_t * n)(*[t.numel() * t.element_size() for t in tensors])
+    offs = (ctypes.c_size_t * n)(*offsets)
+    hip.call("nr_pack_shard", n, srcs, nbytes, offs, hip.ptr(packed, torch.uint8), hip.stream_ptr())
+
+
+def unpack_gathered(gathered, world, record_bytes, nbytes, offsets, outs, u8_to_f32):
+    """nr_unpack_gathered: [world, record_bytes] uint8 -> the rank-major output tensors `outs`."""
+    import ctypes
+    n = len(outs)
+    for t in outs:
+        hip.ptr(t)
+    hip.call("nr_unpack_gathered", n, hip.ptr(gathered, torch.uint8), int(world), int(record_bytes),
+             (ctypes.c_size_t * n)(*nbytes), (ctypes.c_size_t * n)(*offsets), (ctypes.c_void_p * n)(*[t.data_ptr() for t in outs]),
+             (ctypes.c_int * n)(*[1 if c else 0 for c in u8_to_f32]), hip.stream_ptr())
+
+
 def step_prologue(mask0, mask1, logit_scale, rng_state, n_noise):
     """nr_step_prologue: (mask0 fp32, mask1 fp32, exp(logit_scale) [1] or None, noise [n_noise] or None).
     int64 masks are converted by the kernel; fp32 masks pass through untouched."""

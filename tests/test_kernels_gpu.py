@@ -424,6 +424,31 @@ def test_mfma_backward_matches_the_scalar_walk(side, mode, A, Bv, use_lo):
     assert maxdiff(dx2, 2 * dx) < 1e-5 * scale
 
 
+def test_pack_and_unpack_of_the_exchange_step():
+    """nr_pack_shard / nr_unpack_gathered: two ranks' shards packed, concatenated as the all-gather would, unpacked
+    rank-major with the u8 masks turned into fp32 multipliers."""
+    g = torch.Generator().manual_seed(5)
+    W, b, Nt, Nv, d = 2, 5, 24, 12, 512
+    shards = []
+    for r in range(W):
+        shards.append([torch.randn(b, Nt, d, generator=g).to(DEV), torch.randn(b, Nv, d, generator=g).to(DEV),
+                       torch.randint(0, 10 ** 6, (b,), generator=g).to(DEV),
+                       (torch.rand(b, Nt, generator=g) > 0.3).to(torch.uint8).to(DEV),
+                       (torch.rand(b, Nv, generator=g) > 0.3).to(torch.uint8).to(DEV)])
+    sizes = [t.numel() * t.element_size() for t in shards[0]]
+    offs = [sum(sizes[:k]) for k in range(5)]
+    total = (sum(sizes) + 15) // 16 * 16
+    recv = torch.zeros(W * total, dtype=torch.uint8, device=DEV)
+    for r in range(W):
+        ops.pack_shard(shards[r], recv[r * total:(r + 1) * total], offs)
+    outs = [torch.empty(W * b, Nt, d, device=DEV), torch.empty(W * b, Nv, d, device=DEV),
+            torch.empty(W * b, dtype=torch.int64, device=DEV), torch.empty(W * b, Nt, device=DEV), torch.empty(W * b, Nv, device=DEV)]
+    ops.unpack_gathered(recv, W, total, sizes, offs, outs, [False, False, False, True, True])
+    for k in range(5):
+        ref = torch.cat([shards[r][k] for r in range(W)], 0)
+        assert torch.equal(outs[k], ref.float() if k >= 3 else ref)
+
+
 def test_bank_push_fifo():
     bank = torch.arange(10 * 6, dtype=torch.float32, device=DEV).reshape(10, 2, 3)
     ref = bank.clone()
