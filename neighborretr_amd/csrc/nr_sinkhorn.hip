@@ -18,35 +18,66 @@
 // and a = b = 1, so nothing can overflow.
 // B > 128: the matrix stays in L2/MALL; one launch per half-iteration (wave per row, coalesced),
 // the column pass running on a transposed copy held in the workspace (log domain throughout).
+#include <cstdlib>
 #include "nr_common.h"
 #include "../../include/nr_hip.h"
 
-#define SK_EPT 16
+// sum / max over the 128/EPT adjacent lanes that share a line (8, 4 or 2 lanes)
+template <int LPL>
+__device__ __forceinline__ float sk_group_sum(float v) {
+    v += nr_dpp<NR_DPP_XOR1>(v, v);
+    if constexpr (LPL >= 4) v += nr_dpp<NR_DPP_XOR2>(v, v);
+    if constexpr (LPL >= 8) v += nr_dpp<NR_DPP_HALF_MIRROR>(v, v);
+    return v;
+}
+template <int LPL>
+__device__ __forceinline__ float sk_group_max(float v) {
+    v = fmaxf(v, nr_dpp<NR_DPP_XOR1>(v, v));
+    if constexpr (LPL >= 4) v = fmaxf(v, nr_dpp<NR_DPP_XOR2>(v, v));
+    if constexpr (LPL >= 8) v = fmaxf(v, nr_dpp<NR_DPP_HALF_MIRROR>(v, v));
+    return v;
+}
 
-__global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __restrict__ G, int B, float beta, int iters,
-                                                                 float* __restrict__ tgt_rows, float* __restrict__ tgt_cols) {
+// SK_EPT entries of a line per thread, LPL = 128 / SK_EPT lanes per line, 128 * LPL threads.  Measured (MI355X,
+// B = 128, 50 iterations): see the launcher.
+template <int SK_EPT>
+__global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel(const float* __restrict__ G, int B, float beta, int iters,
+                                                                              float* __restrict__ tgt_rows, float* __restrict__ tgt_cols) {
+    constexpr int LPL = 128 / SK_EPT;
     __shared__ __attribute__((aligned(16))) float s_a[128];
     __shared__ __attribute__((aligned(16))) float s_b[128];
     const int dir = blockIdx.x;                 // 0: problem on G, 1: problem on G^T
     float* tgt = dir == 0 ? tgt_rows : tgt_cols;
     const int tid = threadIdx.x;
-    const int line = tid >> 3, sub = tid & 7;   // `line` = row in the row pass, column in the column pass
+    const int line = tid / LPL, sub = tid % LPL;   // `line` = row in the row pass, column in the column pass
     const float norm = -logf((float)(2 * B));
     const float mass = 1.0f / (float)(2 * B);   // e^mu = e^nu
     const bool live = line < B;
 
-    // X[i][j] = G[i][j] (dir 0) or G[j][i] (dir 1);  pr[k] = X[line][16 sub + k],  pc[k] = X[16 sub + k][line]
-    // (unconditional loads at clamped indices + select: a load under a per-element branch would cost
-    // one dependent L2 round trip each)
+    // X[i][j] = G[i][j] (dir 0) or G[j][i] (dir 1);  pr[k] = X[line][EPT sub + k],  pc[k] = X[EPT sub + k][line].
+    // G is staged through LDS once: coalesced 16-byte global loads (one round trip), then the row segment and
+    // the (strided) column segment of every thread come out of LDS -- 2*EPT scalar global loads per thread, half
+    // of them a different cache line per lane, cost ~10 us of the kernel's fixed 20.
+    extern __shared__ __attribute__((aligned(16))) float sG[];     // [B][SG_LD]
+    constexpr int SG_LD = 129;
+    {
+        const int n4 = B * B / 4;                                   // B % 4 == 0 is checked by the launcher
+        for (int e = tid; e < n4; e += 128 * LPL) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(G + (size_t)e * 4);
+            const int i = (e * 4) / B, j = (e * 4) - i * B;
+            float* d = sG + i * SG_LD + j;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+    }
+    __syncthreads();
     float pr[SK_EPT], pc[SK_EPT];
     const int lc = min(line, B - 1);
 #pragma unroll
     for (int k = 0; k < SK_EPT; ++k) {
         int o = sub * SK_EPT + k;
         int oc = min(o, B - 1);
-        size_t ir = dir == 0 ? (size_t)lc * B + oc : (size_t)oc * B + lc;
-        size_t ic = dir == 0 ? (size_t)oc * B + lc : (size_t)lc * B + oc;
-        float xr = G[ir], xc = G[ic];
+        float xr = dir == 0 ? sG[lc * SG_LD + oc] : sG[oc * SG_LD + lc];
+        float xc = dir == 0 ? sG[oc * SG_LD + lc] : sG[lc * SG_LD + oc];
         bool ok = live && o < B;
         pr[k] = ok ? xr : -INFINITY;
         pc[k] = ok ? xc : -INFINITY;
@@ -60,11 +91,11 @@ __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __
             float m = -INFINITY;
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) m = fmaxf(m, pr[k]);                 // v = 0
-            m = nr_group8_max(m);
+            m = sk_group_max<LPL>(m);
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) s += __expf(pr[k] - m);
-            s = nr_group8_sum(s);
+            s = sk_group_sum<LPL>(s);
             if (live && sub == 0) s_a[line] = norm - (m + __logf(s));
         }
         __syncthreads();
@@ -75,11 +106,11 @@ __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __
                 x[k] = pc[k] + s_a[sub * SK_EPT + k];
                 m = fmaxf(m, x[k]);
             }
-            m = nr_group8_max(m);
+            m = sk_group_max<LPL>(m);
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) s += __expf(x[k] - m);
-            s = nr_group8_sum(s);
+            s = sk_group_sum<LPL>(s);
             if (live && sub == 0) s_b[line] = norm - (m + __logf(s));
         }
         __syncthreads();
@@ -108,7 +139,7 @@ __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __
                 f32x4_t f = *reinterpret_cast<const f32x4_t*>(&s_b[sub * SK_EPT + k]);
                 r0 += pr[k] * f[0]; r1 += pr[k + 1] * f[1]; r2 += pr[k + 2] * f[2]; r3 += pr[k + 3] * f[3];
             }
-            float r = nr_group8_sum((r0 + r1) + (r2 + r3));
+            float r = sk_group_sum<LPL>((r0 + r1) + (r2 + r3));
             a_own = live ? mass * __builtin_amdgcn_rcpf(r) : 0.f;
             if (sub == 0) s_a[line] = a_own;
         }
@@ -120,7 +151,7 @@ __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __
                 f32x4_t f = *reinterpret_cast<const f32x4_t*>(&s_a[sub * SK_EPT + k]);
                 c0 += pc[k] * f[0]; c1 += pc[k + 1] * f[1]; c2 += pc[k + 2] * f[2]; c3 += pc[k + 3] * f[3];
             }
-            float c = nr_group8_sum((c0 + c1) + (c2 + c3));
+            float c = sk_group_sum<LPL>((c0 + c1) + (c2 + c3));
             b_own = live ? mass * __builtin_amdgcn_rcpf(c) : 0.f;
             if (sub == 0) s_b[line] = b_own;
         }
@@ -130,9 +161,14 @@ __global__ __launch_bounds__(1024) void nr_sinkhorn_small_kernel(const float* __
     if (live) {
         const float sc = beta * (float)(2 * B) * a_own;
 #pragma unroll
-        for (int k = 0; k < SK_EPT; ++k) {
-            int o = sub * SK_EPT + k;
-            if (o < B) tgt[(size_t)line * B + o] = sc * pr[k] * s_b[o] + (o == line ? 1.0f - beta : 0.f);
+        for (int k = 0; k < SK_EPT; k += 4) {             // 16-byte stores (B % 4 == 0)
+            const int o = sub * SK_EPT + k;
+            if (o < B) {
+                f32x4_t q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = sc * pr[k + e] * s_b[o + e] + (o + e == line ? 1.0f - beta : 0.f);
+                *reinterpret_cast<f32x4_t*>(tgt + (size_t)line * B + o) = q;
+            }
         }
     }
 }
@@ -189,7 +225,7 @@ __global__ __launch_bounds__(256) void nr_sinkhorn_plan_kernel(const float* __re
 }
 
 extern "C" size_t nr_sinkhorn_workspace_bytes(int B) {
-    if (B <= 128) return 16;
+    if (B <= 128 && (B % 4) == 0) return 16;
     return ((size_t)B * B + 4 * (size_t)B) * sizeof(float) + 64;
 }
 
@@ -197,8 +233,20 @@ extern "C" int nr_sinkhorn_targets(const float* G, int B, float beta, int iters,
                                    void* workspace, void* stream) {
     if (!G || !tgt_rows || !tgt_cols || B <= 0 || iters < 0) return NR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (B <= 128) {
-        hipLaunchKernelGGL(nr_sinkhorn_small_kernel, dim3(2), dim3(1024), 0, st, G, B, beta, iters, tgt_rows, tgt_cols);
+    if (B <= 128 && (B % 4) == 0) {
+        const size_t lds = (size_t)B * 129 * sizeof(float);
+        // entries per thread: 16 (1024 threads) / 32 (512) / 64 (256); NR_SINKHORN_EPT overrides (tuning hook)
+        int ept = 32;
+        if (const char* e = getenv("NR_SINKHORN_EPT")) ept = atoi(e);
+        if (lds > 64 * 1024) {
+            const void* k = ept == 16 ? (const void*)nr_sinkhorn_small_kernel<16> : ept == 64 ? (const void*)nr_sinkhorn_small_kernel<64>
+                                                                                             : (const void*)nr_sinkhorn_small_kernel<32>;
+            hipError_t er = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (er != hipSuccess) return (int)er;
+        }
+        if (ept == 16) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<16>, dim3(2), dim3(1024), lds, st, G, B, beta, iters, tgt_rows, tgt_cols);
+        else if (ept == 64) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<64>, dim3(2), dim3(256), lds, st, G, B, beta, iters, tgt_rows, tgt_cols);
+        else hipLaunchKernelGGL(nr_sinkhorn_small_kernel<32>, dim3(2), dim3(512), lds, st, G, B, beta, iters, tgt_rows, tgt_cols);
         NR_LAUNCH_CHECK();
         return NR_OK;
     }
