@@ -280,6 +280,12 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
 // only).  The largest block that still gives every CU a workgroup: the main loop is bound by the LDS-DMA bytes
 // per CU.  NR_SIM_BIG=0/1/2 caps it, NR_SIM_BIG=3 forces level 3 for split-bf16 (A/B hooks).
 static int nr_sim_reg_big(int A, int Nt, int Bv, int Nv, int prec) {
+    if (Nt == 64 && Nv == 64) {       // 4: 128 x 256 blocks (2 texts x 4 videos) on 8 waves, once they fill the chip
+        const char* e64 = getenv("NR_SIM_BIG");
+        if (e64 && atoi(e64) == 0) return 0;
+        if (prec == NR_PREC_BF16X3) return 0;             // split-bf16 would run a 1-stage ring there: measured slower
+        return (long)((A + 1) / 2) * ((Bv + 3) / 4) >= 256 ? 4 : 0;
+    }
     if (Nt != 24 || Nv != 12) return 0;
     const bool x3 = prec == NR_PREC_BF16X3;
     int cap = x3 ? 1 : 2;       // split-bf16 fragments do not fit beside 144 accumulators
@@ -299,7 +305,8 @@ extern "C" int nr_sim_reg_tile(int A, int Nt, int Bv, int Nv, int prec, int* TA,
     int tb = Nv == 12 ? 8 : (Nv == 64 ? 2 : 0);
     if (!ta || !tb) return 0;
     const int big = nr_sim_reg_big(A, Nt, Bv, Nv, prec);
-    if (big == 3) { ta = 4; tb = 16; }
+    if (big == 4) { ta = 2; tb = 4; }
+    else if (big == 3) { ta = 4; tb = 16; }
     else if (big) { ta = 8; tb = big == 2 ? 32 : 16; }
     if (TA) *TA = ta;
     if (TB) *TB = tb;
@@ -319,6 +326,10 @@ int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16
                             : nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, true, false>(a, st);             \
         return args ? nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, false, true>(a, st)                      \
                     : nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, false, false>(a, st);                    \
+    }
+    if (nr_sim_reg_big(A, Nt, Bv, Nv, prec) == 4) {     // 64 x 64 tokens, 128 x 256 blocks on 2 x 4 waves
+        if (x3) return args ? nr_sim_reg_launch<4, 4, 16, 16, true, true, 4>(a, st) : nr_sim_reg_launch<4, 4, 16, 16, true, false, 4>(a, st);
+        return args ? nr_sim_reg_launch<4, 4, 16, 16, false, true, 4>(a, st) : nr_sim_reg_launch<4, 4, 16, 16, false, false, 4>(a, st);
     }
     if (nr_sim_reg_big(A, Nt, Bv, Nv, prec) == 3) {     // split-bf16, 96 x 192 blocks (4 texts x 16 videos), 2-deep ring
         return args ? nr_sim_reg_launch<3, 6, 8, 2, true, true, 2>(a, st) : nr_sim_reg_launch<3, 6, 8, 2, true, false, 2>(a, st);

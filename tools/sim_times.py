@@ -42,6 +42,8 @@ def main():
             (512, 24, 128, 12, hip.PREC_BF16, hip.OUT_COLSUM, "bank-text x batch, bf16"),
             (1000, 24, 1000, 12, hip.PREC_BF16X3, hip.OUT_FULL, "eval 1k x 1k, split-bf16"),
             (1024, 24, 512, 12, hip.PREC_BF16, hip.OUT_ROWSUM, "B=1024 x bank, bf16"),
+            (128, 64, 1024, 64, hip.PREC_BF16, hip.OUT_ROWSUM, "ActivityNet 128 x 1024 bank, bf16"),
+            (128, 64, 128, 64, hip.PREC_BF16X3, hip.OUT_FULL, "ActivityNet batch x batch, split-bf16"),
             (128, 24, 512, 12, hip.PREC_BF16, hip.OUT_COLSUM, "128 x 512 colsum"),
             (512, 24, 128, 12, hip.PREC_BF16, hip.OUT_ROWSUM, "512 x 128 rowsum"),
             (128, 24, 512, 12, hip.PREC_BF16, hip.OUT_FULL, "128 x 512 full"),
