@@ -60,7 +60,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_tile_query_no_gpu_needed():
     assert hip.local_level_tiles(128, 24, 128, 12) == (32, 16)      # 4 texts x 8 videos per 96x96 block
-    assert hip.local_level_tiles(128, 64, 1024, 64) == (64, 512)    # 2 x 2 per 128x128 block
+    assert hip.local_level_tiles(128, 64, 1024, 64) == (64, 256)    # one pass: 2 x 4 per 128x256 block on 8 waves
+    assert hip.local_level_tiles(128, 64, 1024, 64, hip.PREC_BF16X3) == (64, 512)    # split-bf16: 2 x 2 per 128x128 block
     assert hip.local_level_tiles(128, 24, 512, 12, hip.PREC_BF16) == (16, 16)      # bank product: 8 x 32 per 192x384 block
     assert hip.local_level_tiles(128, 24, 512, 12, hip.PREC_BF16X3) == (16, 32)    # split-bf16: 8 x 16 per 192x192 block
     with pytest.raises(hip.NrHipError):
