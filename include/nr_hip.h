@@ -294,10 +294,12 @@ int nr_unpack_gathered(int n, const void* gathered, int world, size_t record_byt
  *   logit_scale_exp[0] = exp(logit_scale[0])                modeling.py:289;
  *   noise[0..n_noise) uniform in [0,1)                      the torch.rand draws of cluster.py:483, from a
  *       counter-based generator: rng_state = device uint64[2] {seed, counter}; the kernel advances the
- *       counter, so replays of a captured graph draw fresh numbers.                                     */
+ *       counter, so replays of a captured graph draw fresh numbers;
+ *   ring_head (device int32, optional): *ring_head = (*ring_head - ring_advance) mod ring_capacity -- the
+ *       memory bank's ring head moves back by the batch this step will push (nr_bank_ring_push reads it).  */
 int nr_step_prologue(const int64_t* mask0, int n0, float* out0, const int64_t* mask1, int n1, float* out1,
                      const float* logit_scale, float* logit_scale_exp, uint64_t* rng_state, float* noise,
-                     int n_noise, void* stream);
+                     int n_noise, int32_t* ring_head, int ring_advance, int ring_capacity, void* stream);
 
 /* Memory-bank FIFO push (modeling.py:237-249): bank <- cat(batch, bank)[:capacity] done as an
  * in-place shift; rows are `row_bytes` wide.  Requires 0 < n_new; if n_new >= capacity the bank
@@ -307,9 +309,11 @@ int nr_bank_push(void* bank, const void* batch, int capacity, int n_new, size_t 
 
 /* The same FIFO kept as a ring (logical order L[i] = S[(head+i) mod capacity]): writes the n_new batch
  * rows of up to 8 tensors at rows [head_new, head_new+n_new) mod capacity in one launch.
- * banks / batches / row_bytes are HOST arrays of n_tensors device pointers / row sizes.          */
+ * banks / batches / row_bytes are HOST arrays of n_tensors device pointers / row sizes.  head_dev (device
+ * int32, optional) overrides head_new: the head then lives on the device, advanced by nr_step_prologue, so that
+ * a captured HIP graph pushes to a new place at every replay.                                      */
 int nr_bank_ring_push(int n_tensors, void* const* banks, const void* const* batches, const size_t* row_bytes,
-                      int capacity, int head_new, int n_new, void* stream);
+                      int capacity, int head_new, const int32_t* head_dev, int n_new, void* stream);
 
 /* Rank of the diagonal in every row under the reference's tie rule (metrics.py:58-66):
  *   greater[i] = #{j : S[i,j] > S[i,i]},  equal[i] = #{j : S[i,j] == S[i,i]} (includes j=i). */

@@ -231,12 +231,13 @@ struct NrRingArgs {
     const void* batch[NR_RING_MAX];
     unsigned long long row_bytes[NR_RING_MAX];
     int capacity, head_new, n_new;
+    const int* head_dev;       // when set: the ring head lives on the device (a captured graph must not bake it in)
 };
 
 __global__ __launch_bounds__(256) void nr_bank_ring_kernel(NrRingArgs a) {
     const int t = blockIdx.y, r = blockIdx.x;
     const size_t rb = a.row_bytes[t];
-    int dr = a.head_new + r;
+    int dr = (a.head_dev ? *a.head_dev : a.head_new) + r;
     if (dr >= a.capacity) dr -= a.capacity;
     const char* src = (const char*)a.batch[t] + (size_t)r * rb;
     char* dst = (char*)a.bank[t] + (size_t)dr * rb;
@@ -250,9 +251,10 @@ __global__ __launch_bounds__(256) void nr_bank_ring_kernel(NrRingArgs a) {
 }
 
 extern "C" int nr_bank_ring_push(int n_tensors, void* const* banks, const void* const* batches, const size_t* row_bytes,
-                                 int capacity, int head_new, int n_new, void* stream) {
+                                 int capacity, int head_new, const int32_t* head_dev, int n_new, void* stream) {
     if (n_tensors <= 0 || n_tensors > NR_RING_MAX || !banks || !batches || !row_bytes) return NR_EINVAL;
-    if (capacity <= 0 || n_new <= 0 || n_new > capacity || head_new < 0 || head_new >= capacity) return NR_EINVAL;
+    if (capacity <= 0 || n_new <= 0 || n_new > capacity) return NR_EINVAL;
+    if (!head_dev && (head_new < 0 || head_new >= capacity)) return NR_EINVAL;
     NrRingArgs a;
     for (int i = 0; i < n_tensors; ++i) {
         if (!banks[i] || !batches[i] || row_bytes[i] == 0) return NR_EINVAL;
@@ -260,7 +262,7 @@ extern "C" int nr_bank_ring_push(int n_tensors, void* const* banks, const void* 
         a.batch[i] = batches[i];
         a.row_bytes[i] = row_bytes[i];
     }
-    a.capacity = capacity; a.head_new = head_new; a.n_new = n_new;
+    a.capacity = capacity; a.head_new = head_new; a.n_new = n_new; a.head_dev = head_dev;
     hipLaunchKernelGGL(nr_bank_ring_kernel, dim3(n_new, n_tensors), dim3(256), 0, (hipStream_t)stream, a);
     NR_LAUNCH_CHECK();
     return NR_OK;
@@ -316,8 +318,14 @@ __global__ __launch_bounds__(1024) void nr_step_prologue_kernel(const int64_t* _
                                                                const int64_t* __restrict__ m1, int n1, float* __restrict__ o1,
                                                                const float* __restrict__ ls, float* __restrict__ ls_exp,
                                                                unsigned long long* __restrict__ rng, float* __restrict__ noise,
-                                                               int n_noise) {
+                                                               int n_noise, int* __restrict__ ring_head, int ring_advance,
+                                                               int ring_capacity) {
     const int tid = threadIdx.x;
+    // the memory bank's ring head moves back by the batch that this step will push (modeling.py:237-249 as a ring)
+    if (ring_head && tid == 0) {
+        int h = (*ring_head - ring_advance) % ring_capacity;
+        *ring_head = h < 0 ? h + ring_capacity : h;
+    }
     unsigned long long key = 0, ctr = 0;
     if (noise) {
         ctr = rng[1];
@@ -336,14 +344,15 @@ __global__ __launch_bounds__(1024) void nr_step_prologue_kernel(const int64_t* _
 
 extern "C" int nr_step_prologue(const int64_t* mask0, int n0, float* out0, const int64_t* mask1, int n1, float* out1,
                                 const float* logit_scale, float* logit_scale_exp, uint64_t* rng_state, float* noise,
-                                int n_noise, void* stream) {
+                                int n_noise, int32_t* ring_head, int ring_advance, int ring_capacity, void* stream) {
     if (n0 < 0 || n1 < 0 || n_noise < 0) return NR_EINVAL;
+    if (ring_head && (ring_capacity <= 0 || ring_advance < 0)) return NR_EINVAL;
     if ((n0 > 0 && (!mask0 || !out0)) || (n1 > 0 && (!mask1 || !out1))) return NR_EINVAL;
     if ((logit_scale != nullptr) != (logit_scale_exp != nullptr)) return NR_EINVAL;
     if (n_noise > 0 && (!rng_state || !noise)) return NR_EINVAL;
     hipLaunchKernelGGL(nr_step_prologue_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask0, n0, out0, mask1, n1, out1,
                        logit_scale, logit_scale_exp, reinterpret_cast<unsigned long long*>(n_noise > 0 ? rng_state : nullptr),
-                       n_noise > 0 ? noise : nullptr, n_noise);
+                       n_noise > 0 ? noise : nullptr, n_noise, ring_head, ring_advance, ring_capacity);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

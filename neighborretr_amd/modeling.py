@@ -106,7 +106,12 @@ class NeighborRetr(nn.Module):
             "mb_mask_t": torch.empty((0, 0), dtype=torch.float, device=cpu),
             "mb_mask_v": torch.empty((0, 0), dtype=torch.float, device=cpu),
         }
+        # ring head: a host integer for CPU banks; for GPU banks a device int32 (`_mb_head_dev`) that the step
+        # prologue moves and nr_bank_ring_push reads, so that a captured HIP graph pushes to a new place at every
+        # replay.  `_ring_advanced`: this step's prologue has already moved the head.
         self._mb_head = 0
+        self._mb_head_dev = None
+        self._ring_advanced = False
         self.mb_batch = 0
 
     # The bank attributes keep the reference's names and FIFO meaning (newest sample first; written
@@ -115,10 +120,24 @@ class NeighborRetr(nn.Module):
     # attribute from outside materialises the FIFO order first; the forward pass reads the raw ring,
     # whose order is irrelevant (the bank is only consumed through means over its samples).
     def _bank_fifo(self):
+        if self._mb_head_dev is not None:
+            self._mb_head = int(self._mb_head_dev.item())          # (a sync: only when the bank is read from outside)
+            self._mb_head_dev = None
         if self._mb_head:
             h = self._mb_head
             self._mb = {k: torch.roll(v, shifts=-h, dims=0) for k, v in self._mb.items()}
             self._mb_head = 0
+
+    def _ring_ready(self, b):
+        """(head tensor, advance, capacity) for the step prologue when the coming push takes the ring path, else None."""
+        mb = self._mb
+        cap = mb["mb_feat_v"].size(0)
+        if cap == 0 or b >= cap or not all(t.is_cuda and t.is_contiguous() for t in mb.values()):
+            return None
+        if self._mb_head_dev is None or self._mb_head_dev.device != mb["mb_feat_v"].device:
+            self._mb_head_dev = torch.tensor([self._mb_head], dtype=torch.int32, device=mb["mb_feat_v"].device)
+            self._mb_head = 0
+        return self._mb_head_dev, b, cap
 
     def _bank_get(self, name):
         self._bank_fifo()
@@ -162,7 +181,7 @@ class NeighborRetr(nn.Module):
         mb = self._mb
         if mb["mb_feat_v"].size(0) == 0:                       # empty bank adopts the batch (:224-231)
             self._mb = {k: (v.float() if k.startswith("mb_mask") else v.clone()) for k, v in new.items()}
-            self._mb_head = 0
+            self._mb_head, self._mb_head_dev = 0, None
             self.mb_batch = idx.size(0)
             return
         cap, b = mb["mb_feat_v"].size(0), idx.size(0)
@@ -172,10 +191,12 @@ class NeighborRetr(nn.Module):
             self._bank_fifo()
             self._mb = {k: torch.cat((new[k].to(v.dtype), v), 0)[:cap].contiguous() for k, v in self._mb.items()}
             return
-        head = (self._mb_head - b) % cap
+        ring = self._ring_ready(b)
+        if not self._ring_advanced:                            # called outside loss_step: move the head here
+            ring[0].sub_(b).remainder_(cap)
+        self._ring_advanced = False
         names = list(mb)
-        ops.bank_ring_push([mb[k] for k in names], [new[k].to(mb[k].dtype) for k in names], head)
-        self._mb_head = head
+        ops.bank_ring_push([mb[k] for k in names], [new[k].to(mb[k].dtype) for k in names], 0, head_dev=ring[0])
 
     # ------------------------------------------------------------------ forward (modeling.py:251-312)
     def forward(self, text_ids, text_mask, video, video_mask=None, idx=None, global_step=0, logger=None):
@@ -201,9 +222,11 @@ class NeighborRetr(nn.Module):
             scale_in_kernel = not (torch.is_grad_enabled() and raw_scale.requires_grad)
             sizes = self._noise_sizes(text_feat.shape[1], video_feat.shape[1])
             B = text_feat.shape[0]
+            ring = self._ring_ready(B)
             text_mask, video_mask, ls_exp, flat = ops.step_prologue(
                 text_mask, video_mask, raw_scale if scale_in_kernel else None,
-                self._rng_state_on(text_feat.device), B * sum(sizes.values()))
+                self._rng_state_on(text_feat.device), B * sum(sizes.values()), ring=ring)
+            self._ring_advanced = ring is not None
             logit_scale = ls_exp.reshape(()) if scale_in_kernel else raw_scale.exp()
             noise = self._slice_noise(flat, B, sizes)
         else:

@@ -339,9 +339,10 @@ def unpack_gathered(gathered, world, record_bytes, nbytes, offsets, outs, u8_to_
              (ctypes.c_int * n)(*[1 if c else 0 for c in u8_to_f32]), hip.stream_ptr())
 
 
-def step_prologue(mask0, mask1, logit_scale, rng_state, n_noise):
+def step_prologue(mask0, mask1, logit_scale, rng_state, n_noise, ring=None):
     """nr_step_prologue: (mask0 fp32, mask1 fp32, exp(logit_scale) [1] or None, noise [n_noise] or None).
-    int64 masks are converted by the kernel; fp32 masks pass through untouched."""
+    int64 masks are converted by the kernel; fp32 masks pass through untouched.
+    ring = (head int32[1] device tensor, advance, capacity): the bank's ring head is moved back by `advance`."""
     dev = (mask0 if mask0 is not None else rng_state).device
     f32 = dict(dtype=torch.float32, device=dev)
 
@@ -359,19 +360,22 @@ def step_prologue(mask0, mask1, logit_scale, rng_state, n_noise):
         ls = logit_scale.detach().float().reshape(1).contiguous()
         ls_exp = torch.empty((1,), **f32)
     noise = torch.empty((n_noise,), **f32) if n_noise > 0 else None
-    if i0 is not None or i1 is not None or ls is not None or noise is not None:
+    if i0 is not None or i1 is not None or ls is not None or noise is not None or ring is not None:
         hip.call("nr_step_prologue", hip.ptr(i0, allow_none=True), i0.numel() if i0 is not None else 0,
                  hip.ptr(o0 if i0 is not None else None, allow_none=True),
                  hip.ptr(i1, allow_none=True), i1.numel() if i1 is not None else 0,
                  hip.ptr(o1 if i1 is not None else None, allow_none=True),
                  hip.ptr(ls, allow_none=True), hip.ptr(ls_exp, allow_none=True),
                  hip.ptr(rng_state if noise is not None else None, torch.int64, allow_none=True),
-                 hip.ptr(noise, allow_none=True), int(n_noise), hip.stream_ptr())
+                 hip.ptr(noise, allow_none=True), int(n_noise),
+                 hip.ptr(ring[0] if ring else None, torch.int32, allow_none=True), int(ring[1]) if ring else 0,
+                 int(ring[2]) if ring else 0, hip.stream_ptr())
     return o0, o1, ls_exp, noise
 
 
-def bank_ring_push(banks, batches, head_new):
-    """Ring-buffer push of several bank tensors in one launch (nr_bank_ring_push)."""
+def bank_ring_push(banks, batches, head_new, head_dev=None):
+    """Ring-buffer push of several bank tensors in one launch (nr_bank_ring_push).  head_dev: int32 [1] device
+    tensor holding the head (overrides head_new)."""
     import ctypes
     n = len(banks)
     cap, n_new = banks[0].shape[0], batches[0].shape[0]
@@ -385,7 +389,8 @@ def bank_ring_push(banks, batches, head_new):
     rb = (ctypes.c_size_t * n)(*[b[0].numel() * b.element_size() for b in banks])
     for b in list(banks) + bs:
         hip.ptr(b)                      # device / contiguity check
-    hip.call("nr_bank_ring_push", n, pb, pn, rb, cap, int(head_new), n_new, hip.stream_ptr())
+    hip.call("nr_bank_ring_push", n, pb, pn, rb, cap, int(head_new), hip.ptr(head_dev, torch.int32, allow_none=True), n_new,
+             hip.stream_ptr())
 
 
 def diag_ranks(S):

@@ -176,6 +176,52 @@ def test_until_module_classes_forward_and_backward():
         NeighborAdjustingLoss()(S.to(DEV), bank.to(DEV), B + 1, 3.0)
 
 
+def test_graph_replays_keep_pushing_the_bank_forward():
+    """The ring head lives on the device (moved by the step prologue): every replay of a captured step pushes its
+    batch to a NEW place, and the FIFO read back afterwards is cat(newest ... oldest, old bank)[:M]."""
+    B, Nt, Nv, M = 8, 24, 12, 40
+    x = problem(1003, B, Nt, Nv, M, device=DEV)
+    m = _model("bf16", K=4)
+    m.mb_feat_t, m.mb_feat_v = x["mb_feat_t"].clone(), x["mb_feat_v"].clone()
+    m.mb_mask_t, m.mb_mask_v = x["mb_mask_t"].clone(), x["mb_mask_v"].clone()
+    old_ind = torch.arange(1000, 1000 + M, device=DEV)
+    m.mb_ind = old_ind.clone()
+    idx = x["idx"].clone()
+    vid = x["video_feat"].clone()
+    pushed = []
+
+    def step():
+        with torch.no_grad():
+            m(x["text_feat"], x["text_mask"], vid, x["video_mask"], idx, 0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for r in range(2):                                   # eager steps first (also warms the allocator)
+            idx.copy_(torch.arange(B, device=DEV) + 10 * r)
+            vid.copy_(x["video_feat"] + r)
+            pushed.append((idx.clone(), vid.clone()))
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    pushed.append((idx.clone(), vid.clone()))                # the capture itself does not execute: first replay below
+    for r in range(2, 5):
+        idx.copy_(torch.arange(B, device=DEV) + 10 * r)
+        vid.copy_(x["video_feat"] + r)
+        if r > 2:
+            pushed.append((idx.clone(), vid.clone()))
+        else:
+            pushed[-1] = (idx.clone(), vid.clone())
+        g.replay()
+    torch.cuda.synchronize()
+    ref_ind = torch.cat([p[0] for p in reversed(pushed)] + [old_ind])[:M]
+    ref_vid = torch.cat([p[1] for p in reversed(pushed)] + [x["mb_feat_v"]])[:M]
+    assert torch.equal(m.mb_ind, ref_ind)
+    assert torch.equal(m.mb_feat_v, ref_vid)
+
+
 def test_forward_updates_memory_bank_fifo_and_eval_returns_none():
     B, Nt, Nv, M = 16, 24, 12, 40
     x = problem(1001, B, Nt, Nv, M, device=DEV)
