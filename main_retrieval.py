@@ -79,6 +79,9 @@ def get_args():
     p.add_argument("--synthetic_train", type=int, default=2048, help="synthetic training pairs")
     p.add_argument("--synthetic_test", type=int, default=1000, help="synthetic test pairs (MSR-VTT 1k-A size)")
     p.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "bf16_all"])
+    p.add_argument("--hip_graph", type=int, default=0,
+                   help="1: forward + backward of the training step replayed from ONE captured HIP graph "
+                        "(single rank; the eager step is bound by the host issuing ~560 launches)")
     args = p.parse_args()
     if args.batch_size % max(1, int(os.environ.get("WORLD_SIZE", "1"))):
         raise ValueError("--batch_size must divide over the ranks (args_parser.py:149-165)")
@@ -146,16 +149,73 @@ def clear_memory_bank(model):
     model._init_memory_bank()
 
 
+class GraphedStep:
+    """Forward + backward of one training step as a captured HIP graph with static input buffers: replay()
+    leaves the losses in .losses and the gradients in the parameters' .grad (the optimizer step stays eager)."""
+
+    def __init__(self, model, example, params):
+        self.static = [t.clone() for t in example]
+        self.params = params
+        self.model = model
+        self.capture()
+
+    def bank_key(self):
+        """Identity of the memory-bank tensors the captured graph reads (MemoryBankManager swaps them per epoch)."""
+        return tuple(v.data_ptr() for v in self.model._mb.values())
+
+    def capture(self):
+        model, params = self.model, self.params
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):                       # warm-up on a side stream, as graph capture requires
+                for p in params:
+                    p.grad = None
+                model(*self.static, 0)[0].backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for p in params:
+            p.grad = None
+        # derived weights (bf16 hi/lo splits) are cached per parameter version: drop the caches so that the splits are
+        # captured too and every replay re-derives them from the fp32 parameters the optimizer has just updated
+        model._scorer_cache.clear()
+        model._ctm_cache.clear()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.losses = model(*self.static, 0)
+            self.losses[0].backward()
+        self.grads = [p.grad for p in params]        # static gradient buffers of the graph
+        self.key = self.bank_key()
+
+    def run(self, batch):
+        if self.bank_key() != self.key:              # the bank was replaced from outside: the graph reads stale memory
+            self.capture()
+        for dst, src in zip(self.static, batch):
+            dst.copy_(src)
+        self.graph.replay()
+        for p, g in zip(self.params, self.grads):    # optimizer.zero_grad(set_to_none=True) drops them: put them back
+            p.grad = g
+        return self.losses
+
+
 def train_epoch(args, model, ddp, data, optimizer, epoch, global_step):
     from neighborretr_amd.dist import reduce_losses
     model.train()
     t0 = time.time()
+    graphed = getattr(args, "_graphed_step", None)
     for i in range(len(data)):
         global_step += 1
         text, text_mask, video, video_mask, idx = data.batch(i, args.device)
-        losses = ddp(text, text_mask, video, video_mask, idx, global_step)
-        loss = losses[0]
-        loss.backward()
+        if args.hip_graph and args.world_size == 1:
+            if graphed is None:
+                graphed = args._graphed_step = GraphedStep(model, (text, text_mask, video, video_mask, idx),
+                                                           [p for p in model.parameters() if p.requires_grad])
+            losses = graphed.run((text, text_mask, video, video_mask, idx))
+            loss = None
+        else:
+            losses = ddp(text, text_mask, video, video_mask, idx, global_step)
+            loss = losses[0]
+            loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
         optimizer.step()
         optimizer.zero_grad(set_to_none=True)

@@ -9,10 +9,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_main_retrieval_synthetic_trains_and_evaluates(tmp_path):
+@pytest.mark.parametrize("hip_graph", [0, 1])
+def test_main_retrieval_synthetic_trains_and_evaluates(tmp_path, hip_graph):
     cmd = [sys.executable, os.path.join(ROOT, "main_retrieval.py"), "--do_train", "1", "--synthetic", "--batch_size", "32",
            "--num_neighbors", "8", "--mb_batch", "2", "--epochs", "1", "--synthetic_train", "256", "--synthetic_test", "200",
-           "--n_display", "4", "--save_model", "--output_dir", str(tmp_path)]
+           "--n_display", "4", "--save_model", "--output_dir", str(tmp_path), "--hip_graph", str(hip_graph)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "memory bank: 64 samples" in r.stdout
