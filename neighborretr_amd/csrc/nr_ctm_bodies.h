@@ -177,6 +177,10 @@ typedef const __attribute__((address_space(1))) void* nr_bk_glb_ptr_t;
 #define BK_THREADS 1024
 #define BK_MAXJ 12          // merge jobs per wave: cnum * C/128 <= 16 * BK_MAXJ
 
+// FUSED = called right behind nr_ctm_front_body by the same workgroup (unmasked stages only: without a mask the
+// global maximum of the distances is never used, so nothing has to come from other workgroups): sxn already holds
+// the rows (the front body's sx), p.smax is not read.
+template <bool FUSED = false>
 __device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const int b, float* sxn) {
     constexpr int NW = BK_THREADS / 64;
     __shared__ float sd[64][65];
@@ -195,7 +199,7 @@ __device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const i
 #define BK_LAP() ((void)0)
 #endif
     const float* xb = p.xn + (size_t)b * N * C;
-    if (sxn) {                                        // 1 KiB per wave-instruction, linear copy
+    if (sxn && !FUSED) {                              // 1 KiB per wave-instruction, linear copy
         const int chunks = N * C / 256;
         for (int k = wave; k < chunks; k += NW)
             __builtin_amdgcn_global_load_lds((nr_bk_glb_ptr_t)(xb + (size_t)k * 256 + lane * 4),
@@ -229,7 +233,8 @@ __device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const i
     }
     // global maximum over all samples (cluster.py:473-475)
     float g = 0.f;
-    for (int i = tid; i < p.n_samples; i += BK_THREADS) g = fmaxf(g, p.smax[i]);
+    if constexpr (!FUSED)
+        for (int i = tid; i < p.n_samples; i += BK_THREADS) g = fmaxf(g, p.smax[i]);
     g = nr_wave_max(g);
     if (lane == 0) s_red[0][wave] = g;
     __syncthreads();
@@ -315,7 +320,7 @@ __device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const i
     }
     __syncthreads();
     if (tid < N) s_share[tid] = s_tokw[tid] / s_tot[s_assign[tid]];
-    if (sxn) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the token rows has landed
+    if (sxn && !FUSED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the token rows has landed
     __syncthreads();
     BK_LAP();      // 5: shares, token rows landed
     // job j = cl * CH + ch: cluster cl, channels [128 ch, 128 ch + 128); lane owns channels 128 ch + lane and + 64.

@@ -37,6 +37,19 @@ __global__ __launch_bounds__(CF_THREADS) void nr_group_front_kernel(NrGroupOf<Nr
     nr_ctm_front_body<CPL>(g.p[gi], blockIdx.x - g.start[gi], sx);
 }
 
+// front + back in one launch for stages without a mask (stage 1 of the step): the back half needs nothing from
+// other workgroups then, and the normalised rows it merges are the ones the front half left in LDS
+template <int CPL>
+__global__ __launch_bounds__(CF_THREADS) void nr_group_front_back_kernel(NrGroupOf<NrCtmFrontArgs> gf, NrGroupOf<NrCtmBackArgs> gb) {
+    extern __shared__ __attribute__((aligned(16))) float sx[];
+    const int gi = gf.find(blockIdx.x);
+    const int b = blockIdx.x - gf.start[gi];
+    nr_ctm_front_body<CPL>(gf.p[gi], b, sx);
+    __threadfence_block();                 // the distances / token weights this workgroup just stored are read back
+    __syncthreads();
+    nr_ctm_back_body<true>(gb.p[gi], b, sx);
+}
+
 __global__ __launch_bounds__(BK_THREADS) void nr_group_back_kernel(NrGroupOf<NrCtmBackArgs> g, int use_lds) {
     extern __shared__ __attribute__((aligned(16))) float sxn[];
     const int gi = g.find(blockIdx.x);
@@ -152,59 +165,67 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
                                 d[i].n_samples * d[i].N, d[i].C, 3 * d[i].C};
         if ((rc = nr_linear_group_launch(p, n, st)) != NR_OK) return rc;
     }
-    // 3. LayerNorm, score, exp, norm1, pairwise distances
-    if (first <= 2 && 2 < last) {
-        NrGroupOf<NrCtmFrontArgs> g;
-        g.n = n;
+    // 3 + 4. front (LayerNorm, score, exp, norm1, pairwise distances) and back (DPC-KNN assignment, weighted cluster
+    //        means, norm1).  Two launches when a problem carries a mask (the back half then needs the maximum
+    //        distance over ALL samples); ONE when none does (stage 1 of the step): launch index 2 runs both, index 3
+    //        is empty.
+    bool fusable = true;
+    for (int i = 0; i < n; ++i) fusable = fusable && d[i].mask == nullptr;
+    if ((first <= 2 && 2 < last) || (first <= 3 && 3 < last)) {
+        NrGroupOf<NrCtmFrontArgs> gf;
+        NrGroupOf<NrCtmBackArgs> gb;
+        gf.n = gb.n = n;
         int total = 0;
         for (int i = 0; i < n; ++i) {
             const NrCtmStageDesc& s = d[i];
-            g.p[i] = NrCtmFrontArgs{w[i].y, s.mask, s.ln_w, s.ln_b, s.sc_w, s.sc_b, s.n1_w, s.n1_b, s.eps_ctm, 1.0f / sqrtf((float)s.C),
-                                    s.N, s.C, w[i].xn, nullptr, w[i].score, w[i].tokw, w[i].dist, w[i].smax, w[i].kvn_hi, w[i].kvn_lo};
-            g.start[i] = total;
+            gf.p[i] = NrCtmFrontArgs{w[i].y, s.mask, s.ln_w, s.ln_b, s.sc_w, s.sc_b, s.n1_w, s.n1_b, s.eps_ctm, 1.0f / sqrtf((float)s.C),
+                                     s.N, s.C, w[i].xn, nullptr, w[i].score, w[i].tokw, w[i].dist, w[i].smax, w[i].kvn_hi, w[i].kvn_lo};
+            gb.p[i] = NrCtmBackArgs{w[i].dist, w[i].smax, s.mask, s.noise, w[i].xn, w[i].tokw, s.n1_w, s.n1_b, s.proj_bias,
+                                    s.n_samples, s.N, s.C, s.k, s.cnum, s.eps_n1, nullptr, w[i].merged_pb, nullptr, s.assign,
+                                    w[i].qn_hi, w[i].qn_lo};
+            gf.start[i] = gb.start[i] = total;
             total += s.n_samples;
         }
-        for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
+        for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) gf.start[i] = gb.start[i] = total;
         bool small = true;                   // registers sized for C <= 512 unless a problem is wider
         for (int i = 0; i < n; ++i) small = small && d[i].C <= 512;
-        if (front_lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(small ? (const void*)nr_group_front_kernel<8> : (const void*)nr_group_front_kernel<CF_MAX_CPL>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds);
-            if (e != hipSuccess) return (int)e;
+        if (first <= 2 && 2 < last) {
+            if (fusable) {
+                const void* k = small ? (const void*)nr_group_front_back_kernel<8> : (const void*)nr_group_front_back_kernel<CF_MAX_CPL>;
+                if (front_lds > 64 * 1024) {
+                    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds);
+                    if (e != hipSuccess) return (int)e;
+                }
+                if (small) hipLaunchKernelGGL(nr_group_front_back_kernel<8>, dim3(total), dim3(CF_THREADS), front_lds, st, gf, gb);
+                else hipLaunchKernelGGL(nr_group_front_back_kernel<CF_MAX_CPL>, dim3(total), dim3(CF_THREADS), front_lds, st, gf, gb);
+            } else {
+                if (front_lds > 64 * 1024) {
+                    hipError_t e = hipFuncSetAttribute(small ? (const void*)nr_group_front_kernel<8> : (const void*)nr_group_front_kernel<CF_MAX_CPL>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds);
+                    if (e != hipSuccess) return (int)e;
+                }
+                if (small) hipLaunchKernelGGL(nr_group_front_kernel<8>, dim3(total), dim3(CF_THREADS), front_lds, st, gf);
+                else hipLaunchKernelGGL(nr_group_front_kernel<CF_MAX_CPL>, dim3(total), dim3(CF_THREADS), front_lds, st, gf);
+            }
+            NR_LAUNCH_CHECK();
         }
-        if (small) hipLaunchKernelGGL(nr_group_front_kernel<8>, dim3(total), dim3(CF_THREADS), front_lds, st, g);
-        else hipLaunchKernelGGL(nr_group_front_kernel<CF_MAX_CPL>, dim3(total), dim3(CF_THREADS), front_lds, st, g);
-        NR_LAUNCH_CHECK();
-    }
-    // 4. DPC-KNN assignment, weighted cluster means, norm1
-    if (first <= 3 && 3 < last) {
-        NrGroupOf<NrCtmBackArgs> g;
-        g.n = n;
-        int total = 0;
-        for (int i = 0; i < n; ++i) {
-            const NrCtmStageDesc& s = d[i];
-            g.p[i] = NrCtmBackArgs{w[i].dist, w[i].smax, s.mask, s.noise, w[i].xn, w[i].tokw, s.n1_w, s.n1_b, s.proj_bias,
-                                   s.n_samples, s.N, s.C, s.k, s.cnum, s.eps_n1, nullptr, w[i].merged_pb, nullptr, s.assign,
-                                   w[i].qn_hi, w[i].qn_lo};
-            g.start[i] = total;
-            total += s.n_samples;
+        if (first <= 3 && 3 < last && !fusable) {
+            size_t lds = 0;                      // token rows of the largest problem, if every problem's rows fit
+            bool fits = true;
+            for (int i = 0; i < n; ++i) {
+                size_t need = (size_t)d[i].N * d[i].C * sizeof(float);
+                lds = need > lds ? need : lds;
+                fits = fits && (d[i].N * d[i].C) % 256 == 0;
+            }
+            const int use_lds = fits && lds <= 96 * 1024;
+            if (!use_lds) lds = 0;
+            if (lds > 40 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)nr_group_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipLaunchKernelGGL(nr_group_back_kernel, dim3(total), dim3(BK_THREADS), lds, st, gb, use_lds);
+            NR_LAUNCH_CHECK();
         }
-        for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
-        size_t lds = 0;                      // token rows of the largest problem, if every problem's rows fit
-        bool fits = true;
-        for (int i = 0; i < n; ++i) {
-            size_t need = (size_t)d[i].N * d[i].C * sizeof(float);
-            lds = need > lds ? need : lds;
-            fits = fits && (d[i].N * d[i].C) % 256 == 0;
-        }
-        const int use_lds = fits && lds <= 96 * 1024;
-        if (!use_lds) lds = 0;
-        if (lds > 40 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)nr_group_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(nr_group_back_kernel, dim3(total), dim3(BK_THREADS), lds, st, g, use_lds);
-        NR_LAUNCH_CHECK();
     }
     // 5. q = norm1(merged) Wq^T (+b), kv = norm1(xn) Wkv^T (+b): 2n problems, one launch
     if (first <= 4 && 4 < last) {
