@@ -176,9 +176,10 @@ def row_losses_final(S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_vid
     """Row terms [2,4,B] AND the five losses from one launch (nr_row_losses_fwd_final)."""
     B = S.shape[0]
     dev = S.device
-    counter = _COUNTERS.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)     # one counter per stream: launches on one stream are ordered
+    counter = _COUNTERS.get(key)
     if counter is None:
-        counter = _COUNTERS[dev] = torch.zeros((1,), dtype=torch.int32, device=dev)
+        counter = _COUNTERS[key] = torch.zeros((1,), dtype=torch.int32, device=dev)
     rowloss = torch.empty((2, 4, B), dtype=torch.float32, device=dev)
     losses = torch.empty((5,), dtype=torch.float32, device=dev)
     hip.call("nr_row_losses_fwd_final", hip.ptr(S, torch.float32), hip.ptr(G, torch.float32), hip.ptr(tgt_rows), hip.ptr(tgt_cols),
