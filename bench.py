@@ -311,7 +311,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: B=128 d=512 Nt=24 Nv=12 M=512 K=20 (MSR-VTT shape), "
                                    "loss-only forward incl. token clustering and bank push",
                        "global_batch": c["B"], "per_rank_batch": b, "precision_plan": args.precision,
-                       "hip_graph": graph is not None, "parallelism": f"dp{world} (all-gather + replicated loss)"},
+                       "hip_graph": graph is not None, "parallelism": f"dp{world} (all-gather + replicated loss)",
+                       "memory_bank": "ring (device head) + persistent prepared bf16 shadow, extended by the batch rows at every push"},
             "losses": [round(float(x), 5) for x in losses],
             "roofline": roofline,
         }

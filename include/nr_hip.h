@@ -308,7 +308,7 @@ int nr_bank_push(void* bank, const void* batch, int capacity, int n_new, size_t 
                  void* stream);
 
 /* The same FIFO kept as a ring (logical order L[i] = S[(head+i) mod capacity]): writes the n_new batch
- * rows of up to 8 tensors at rows [head_new, head_new+n_new) mod capacity in one launch.
+ * rows of up to 12 tensors at rows [head_new, head_new+n_new) mod capacity in one launch.
  * banks / batches / row_bytes are HOST arrays of n_tensors device pointers / row sizes.  head_dev (device
  * int32, optional) overrides head_new: the head then lives on the device, advanced by nr_step_prologue, so that
  * a captured HIP graph pushes to a new place at every replay.                                      */

@@ -225,7 +225,7 @@ extern "C" int nr_bank_push(void* bank, const void* batch, int capacity, int n_n
 // Logical FIFO order (newest first, modeling.py:237-249) is L[i] = S[(head + i) mod capacity]; a push
 // moves head back by n_new and writes the batch there.  All tensors of the bank (ids, features,
 // masks) go in ONE launch: blockIdx.y = tensor, blockIdx.x = batch row.
-#define NR_RING_MAX 8
+#define NR_RING_MAX 12
 struct NrRingArgs {
     void* bank[NR_RING_MAX];
     const void* batch[NR_RING_MAX];

@@ -88,7 +88,7 @@ def precision_plan(prec):
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                  gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None,
                  bank_streams=None, local_stream=None, bank_early=0,
-                 capture_order=((7, 9), (7, 1 << 30))):
+                 capture_order=((7, 9), (7, 1 << 30)), bank_prepared=None, prepared_out=None):
     """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None).
 
     `join`: optional callable run right before the first use of gt / gv.  Either the caller produces the
@@ -96,7 +96,10 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     with gt = gv = None -- `join` runs the token clustering on the current stream and returns (gt, gv), while
     the local branch (prepare, scorer, B x B product) runs on `local_stream`; if `join` is a GENERATOR that
     issues one launch per next() and returns (gt, gv), its launches are interleaved with the local branch's.
-    `bank_streams`: optional pair of side streams for the two memory-bank chains (see below)."""
+    `bank_streams`: optional pair of side streams for the two memory-bank chains (see below).
+    `bank_prepared`: optional (text, video) ops.Prepared of the bank (its persistent normalised bf16 shadow): the
+    two bank prepare launches are skipped.  `prepared_out`: optional dict that receives the batch's prepared
+    tokens ("pt", "pv") -- what the bank shadow is extended with at the push."""
     B, Nt, d = text_feat.shape
     Nv = video_feat.shape[1]
     M = mb_feat_v.shape[0]
@@ -150,8 +153,11 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
 
     def bank_video_steps():
         # text x bank-video, row mean  -> centrality of text j  (used by the v2t neighbour loss)
-        pbv = ops.prepare_tokens(mb_feat_v, mb_mask_v, want_lo=lo_k)
-        yield
+        if bank_prepared is not None:
+            pbv = bank_prepared[1]
+        else:
+            pbv = ops.prepare_tokens(mb_feat_v, mb_mask_v, want_lo=lo_k)
+            yield
         parts = ops.token_logit_parts(pbv, sw_v.w1_hi, sw_v.w1_lo, sw_v.b1, sw_v.w2, p_bank)
         yield
         w_bv, lg_bv = ops.token_softmax(parts, sw_v.b2, mb_mask_v, M, Nv, keep)
@@ -164,8 +170,11 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
 
     def bank_text_steps():
         # bank-text x video, column mean -> centrality of video j (used by the t2v neighbour loss)
-        pbt = ops.prepare_tokens(mb_feat_t, mb_mask_t, want_lo=lo_k)
-        yield
+        if bank_prepared is not None:
+            pbt = bank_prepared[0]
+        else:
+            pbt = ops.prepare_tokens(mb_feat_t, mb_mask_t, want_lo=lo_k)
+            yield
         parts = ops.token_logit_parts(pbt, sw_t.w1_hi, sw_t.w1_lo, sw_t.b1, sw_t.w2, p_bank)
         yield
         w_bt, lg_bt = ops.token_softmax(parts, sw_t.b2, mb_mask_t, M, Nt, keep)
@@ -238,6 +247,8 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
             if produced is not None:
                 gt, gv = produced
     pt, pv, w_t, w_v, lg_t, lg_v = L["pt"], L["pv"], L["w_t"], L["w_v"], L["lg_t"], L["lg_v"]
+    if prepared_out is not None:
+        prepared_out["pt"], prepared_out["pv"] = pt, pv
     S, aux0, mean_t, mean_v = L["S"], L["aux0"], L["mean_t"], L["mean_v"]
     if local_stream is not None:
         cur.wait_stream(local_stream)

@@ -113,13 +113,32 @@ class NeighborRetr(nn.Module):
         self._mb_head_dev = None
         self._ring_advanced = False
         self.mb_batch = 0
+        # persistent prepared form of the bank (normalised * mask as bf16 hi/lo + norms), kept in step with the ring:
+        # built lazily from the fp32 bank, extended at every push with the batch's own prepared rows, dropped whenever
+        # the bank is touched from outside.  `_last_prepared`: the batch's prepared tokens of the running step.
+        self._mb_shadow = None
+        self._last_prepared = {}
+        self.use_bank_shadow = True
 
     # The bank attributes keep the reference's names and FIFO meaning (newest sample first; written
     # wholesale by MemoryBankManager, memory_bank.py:206-211).  Internally the bank is a RING: a push
     # rewrites only the batch rows (nr_bank_ring_push) instead of shifting the whole bank.  Reading an
     # attribute from outside materialises the FIFO order first; the forward pass reads the raw ring,
     # whose order is irrelevant (the bank is only consumed through means over its samples).
+    def _bank_shadow(self):
+        """(text, video) ops.Prepared of the bank for the loss-only step, or None (CPU bank, shadow disabled, grad
+        mode: the training path keeps its own prepare launches, whose outputs the backward saves)."""
+        mb = self._mb
+        if not self.use_bank_shadow or torch.is_grad_enabled() or mb["mb_feat_v"].numel() == 0 or not mb["mb_feat_v"].is_cuda:
+            return None
+        if self._mb_shadow is None:
+            self._mb_shadow = (ops.prepare_tokens(mb["mb_feat_t"], mb["mb_mask_t"], want_lo=True),
+                               ops.prepare_tokens(mb["mb_feat_v"], mb["mb_mask_v"], want_lo=True))
+        return self._mb_shadow
+
     def _bank_fifo(self):
+        if self._mb_head_dev is not None or self._mb_head:
+            self._mb_shadow = None                 # the roll below re-orders the rows: rebuild on next use
         if self._mb_head_dev is not None:
             self._mb_head = int(self._mb_head_dev.item())          # (a sync: only when the bank is read from outside)
             self._mb_head_dev = None
@@ -148,6 +167,7 @@ class NeighborRetr(nn.Module):
         if name.startswith("mb_mask") and torch.is_tensor(value) and value.dtype != torch.float32:
             value = value.float()        # masks live as fp32 (the reference's own initial dtype, :182-183)
         self._mb[name] = value
+        self._mb_shadow = None
 
     mb_ind = property(lambda self: self._bank_get("mb_ind"), lambda self, v: self._bank_set("mb_ind", v))
     mb_feat_t = property(lambda self: self._bank_get("mb_feat_t"), lambda self, v: self._bank_set("mb_feat_t", v))
@@ -181,6 +201,7 @@ class NeighborRetr(nn.Module):
         mb = self._mb
         if mb["mb_feat_v"].size(0) == 0:                       # empty bank adopts the batch (:224-231)
             self._mb = {k: (v.float() if k.startswith("mb_mask") else v.clone()) for k, v in new.items()}
+            self._mb_shadow = None
             self._mb_head, self._mb_head_dev = 0, None
             self.mb_batch = idx.size(0)
             return
@@ -190,13 +211,27 @@ class NeighborRetr(nn.Module):
             # B >= capacity: the bank becomes the first rows of the batch (:244-249); CPU banks: plain cat
             self._bank_fifo()
             self._mb = {k: torch.cat((new[k].to(v.dtype), v), 0)[:cap].contiguous() for k, v in self._mb.items()}
+            self._mb_shadow = None
             return
         ring = self._ring_ready(b)
         if not self._ring_advanced:                            # called outside loss_step: move the head here
             ring[0].sub_(b).remainder_(cap)
         self._ring_advanced = False
         names = list(mb)
-        ops.bank_ring_push([mb[k] for k in names], [new[k].to(mb[k].dtype) for k in names], 0, head_dev=ring[0])
+        banks, rows = [mb[k] for k in names], [new[k].to(mb[k].dtype) for k in names]
+        sh, lp = self._mb_shadow, self._last_prepared
+        if sh is not None:
+            if lp.get("pt") is not None and lp["pt"].lo is not None and lp["pv"].lo is not None:
+                # the batch's prepared rows (computed by this step's local branch) extend the shadow in the same launch
+                Nt, Nv = text_feat.shape[1], video_feat.shape[1]
+                for prep_b, prep_n, N in ((sh[0], lp["pt"], Nt), (sh[1], lp["pv"], Nv)):
+                    d = prep_b.d
+                    banks += [prep_b.hi.view(cap, N * d), prep_b.lo.view(cap, N * d), prep_b.norm.view(cap, N)]
+                    rows += [prep_n.hi.view(b, N * d), prep_n.lo.view(b, N * d), prep_n.norm.view(b, N)]
+            else:
+                self._mb_shadow = None             # pushed without prepared rows (direct call): rebuild on next use
+        self._last_prepared = {}
+        ops.bank_ring_push(banks, rows, 0, head_dev=ring[0])
 
     # ------------------------------------------------------------------ forward (modeling.py:251-312)
     def forward(self, text_ids, text_mask, video, video_mask=None, idx=None, global_step=0, logger=None):

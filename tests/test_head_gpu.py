@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import nr_oracle as O
-from neighborretr_amd import modeling, synth
+from neighborretr_amd import ops, modeling, synth
 from util import golden, maxdiff, noise, params, problem
 
 pytestmark = pytest.mark.gpu
@@ -216,6 +216,12 @@ def test_graph_replays_keep_pushing_the_bank_forward():
             pushed[-1] = (idx.clone(), vid.clone())
         g.replay()
     torch.cuda.synchronize()
+    # the persistent prepared shadow of the bank followed every push: it equals a fresh prepare of the raw ring
+    assert m._mb_shadow is not None
+    for k, (feat, mask) in enumerate((("mb_feat_t", "mb_mask_t"), ("mb_feat_v", "mb_mask_v"))):
+        fresh = ops.prepare_tokens(m._mb[feat], m._mb[mask], want_lo=True)
+        assert torch.equal(fresh.hi, m._mb_shadow[k].hi) and torch.equal(fresh.lo, m._mb_shadow[k].lo)
+        assert torch.equal(fresh.norm, m._mb_shadow[k].norm)
     ref_ind = torch.cat([p[0] for p in reversed(pushed)] + [old_ind])[:M]
     ref_vid = torch.cat([p[1] for p in reversed(pushed)] + [x["mb_feat_v"]])[:M]
     assert torch.equal(m.mb_ind, ref_ind)
