@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL; gloo only to rehearse ranks that share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard_loss", action="store_true",
+                    help="N>1 only: similarity / bank work sharded over the ranks (head.head_forward_sharded) instead of "
+                         "the reference's replicated loss; runs eagerly (its collectives are not graph-captured)")
     ap.add_argument("--backward", action="store_true", help="also time forward+backward (reported as extra fields)")
     return ap.parse_args()
 
@@ -121,6 +124,9 @@ def main():
     b = c["B"] // world
     model = build_model(args.precision, dev)
     model.config.world_size, model.config.local_rank = world, rank
+    if args.shard_loss and world > 1:
+        model.shard_loss = True
+        args.no_graph = True
     full = synth.make_problem(1002, c["B"], c["Nt"], c["Nv"], c["M"])
     sl = slice(rank * b, (rank + 1) * b)
     shard = {k: torch.from_numpy(full[k][sl]).to(dev) for k in ("text_feat", "video_feat", "text_mask", "video_mask", "idx")}
@@ -311,7 +317,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: B=128 d=512 Nt=24 Nv=12 M=512 K=20 (MSR-VTT shape), "
                                    "loss-only forward incl. token clustering and bank push",
                        "global_batch": c["B"], "per_rank_batch": b, "precision_plan": args.precision,
-                       "hip_graph": graph is not None, "parallelism": f"dp{world} (all-gather + replicated loss)",
+                       "hip_graph": graph is not None, "parallelism": f"dp{world} (all-gather + " + ("sharded loss)" if (args.shard_loss and world > 1) else "replicated loss)"),
                        "memory_bank": "ring (device head) + persistent prepared bf16 shadow, extended by the batch rows at every push"},
             "losses": [round(float(x), 5) for x in losses],
             "roofline": roofline,

@@ -209,6 +209,16 @@ int nr_row_losses_fwd(const float* S, const float* G, const float* tgt_rows, con
                       const float* logit_scale, int B, int K, float temperature, float* rowloss, void* stream);
 int nr_loss_finalize(const float* rowloss, int B, float uniform_weight, float neighbor_weight, float kl_weight,
                      float* losses, void* stream);
+/* Row-slab form of nr_row_losses_fwd for a loss sharded over ranks: the caller owns samples
+ * [row0, row0 + n_rows) and holds S_rows = S[row0 : row0+n_rows, :] ([n_rows, B]) and S_cols = S[:, row0 : row0+n_rows]
+ * ([B, n_rows]); G, the Sinkhorn targets, the bank centralities and the centrality weights are the full (replicated)
+ * ones.  Only the owned rows of rowloss [2,4,B] are written: zero the buffer first, sum it over the ranks
+ * (all-reduce), then nr_loss_finalize -- every rank then holds the same five losses.                    */
+int nr_row_losses_fwd_slab(const float* S_rows, const float* S_cols, int row0, int n_rows, const float* G,
+                           const float* tgt_rows, const float* tgt_cols, const float* bank_c0, const float* bank_c1,
+                           const float* wc_text, const float* wc_video, const float* logit_scale, int B, int K,
+                           float temperature, float* rowloss, void* stream);
+
 /* nr_row_losses_fwd + nr_loss_finalize in one launch: the workgroup that finishes last reduces the row
  * terms (same arithmetic, bit-identical losses).  counter: one zero-initialised device word owned by the
  * caller; the kernel leaves it at zero again.                                                        */

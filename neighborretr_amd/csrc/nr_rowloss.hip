@@ -18,6 +18,12 @@ struct NrRowArgs {
     const float *S, *G, *tgt_rows, *tgt_cols, *bank_c0, *bank_c1, *wc_text, *wc_video, *logit_scale;
     int B, K;
     float T;
+    // Row-slab form (nr_row_losses_fwd_slab): only rows [row0, row0 + n_rows) of either direction are computed,
+    // and S is given as the two slabs a rank owns -- S_cols = S[:, row0 : row0 + n_rows] as a [B, n_rows] matrix
+    // (direction 1 reads its row i as column i - row0 of it), S itself = S[row0 : row0 + n_rows, :] as [n_rows, B].
+    // Zero / nullptr in the full form.
+    const float* S_cols;
+    int row0, n_rows;
 };
 
 // Everything the forward and the backward need about one row, recomputed identically in both.
@@ -49,7 +55,8 @@ struct NrRowState {
             valid[e] = j < B;
             int jj = valid[e] ? j : 0;
             size_t idx = dir == 0 ? (size_t)row * B + jj : (size_t)jj * B + row;
-            s[e] = a.S[idx];
+            if (a.S_cols) s[e] = dir == 0 ? a.S[(size_t)(row - a.row0) * B + jj] : a.S_cols[(size_t)jj * a.n_rows + (row - a.row0)];
+            else s[e] = a.S[idx];
             g[e] = a.G[idx];
             c[e] = cvec[jj];
             tg[e] = tgt[(size_t)row * B + jj];
@@ -194,8 +201,9 @@ __device__ __forceinline__ void nr_row_losses_fwd_rows(const NrRowArgs& a, float
 template <int NE>
 __global__ __launch_bounds__(256) void nr_row_losses_fwd_kernel(NrRowArgs a, float* __restrict__ rowloss, NrRowFinal f) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row < a.B) nr_row_losses_fwd_rows<NE>(a, rowloss, row, blockIdx.y, lane);
+    const int local = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = a.row0 + local;
+    if (local < (a.S_cols ? a.n_rows : a.B)) nr_row_losses_fwd_rows<NE>(a, rowloss, row, blockIdx.y, lane);
     if (f.counter == nullptr) return;
     __shared__ int s_last;
     __threadfence();                               // this workgroup's row terms are visible device-wide
@@ -261,7 +269,7 @@ static int nr_row_ne(int B) {
 }
 
 static int nr_row_losses_fwd_launch(const NrRowArgs& a, float* rowloss, const NrRowFinal& f, hipStream_t st) {
-    dim3 grid((a.B + 3) / 4, 2);
+    dim3 grid(((a.S_cols ? a.n_rows : a.B) + 3) / 4, 2);
     switch (nr_row_ne(a.B)) {
         case 2: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<2>, grid, dim3(256), 0, st, a, rowloss, f); break;
         case 4: hipLaunchKernelGGL(nr_row_losses_fwd_kernel<4>, grid, dim3(256), 0, st, a, rowloss, f); break;
@@ -280,7 +288,18 @@ extern "C" int nr_row_losses_fwd(const float* S, const float* G, const float* tg
     if (!S || !G || !tgt_rows || !tgt_cols || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale || !rowloss)
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;    // the reference raises IndexError for K > B
-    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature};
+    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0};
+    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr}, (hipStream_t)stream);
+}
+
+extern "C" int nr_row_losses_fwd_slab(const float* S_rows, const float* S_cols, int row0, int n_rows, const float* G,
+                                      const float* tgt_rows, const float* tgt_cols, const float* bank_c0, const float* bank_c1,
+                                      const float* wc_text, const float* wc_video, const float* logit_scale, int B, int K,
+                                      float temperature, float* rowloss, void* stream) {
+    if (!S_rows || !S_cols || !G || !tgt_rows || !tgt_cols || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale || !rowloss)
+        return NR_EINVAL;
+    if (B <= 0 || K < 0 || K > B || row0 < 0 || n_rows <= 0 || row0 + n_rows > B) return NR_EINVAL;
+    NrRowArgs a{S_rows, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, S_cols, row0, n_rows};
     return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr}, (hipStream_t)stream);
 }
 
@@ -293,7 +312,7 @@ extern "C" int nr_row_losses_fwd_final(const float* S, const float* G, const flo
         !counter || !losses)
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;
-    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature};
+    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0};
     return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{counter, uniform_weight, neighbor_weight, kl_weight, losses},
                                     (hipStream_t)stream);
 }
@@ -433,7 +452,7 @@ extern "C" int nr_row_losses_bwd(const float* S, const float* G, const float* tg
         !dS_dir || !dG_dir || !d_c_rows || !d_wc || !d_ls_rows)
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;
-    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature};
+    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0};
     dim3 grid((B + 3) / 4, 2);
     hipStream_t st = (hipStream_t)stream;
 #define NR_BWD_CASE(N_) \

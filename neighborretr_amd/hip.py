@@ -64,6 +64,7 @@ _SIGNATURES = {
     "nr_sinkhorn_workspace_bytes": ([_I], _Z),
     "nr_sinkhorn_targets": ([_P, _I, _F, _I, _P, _P, _P, _P], _I),
     "nr_row_losses_fwd": ([_P] * 9 + [_I, _I, _F, _P, _P], _I),
+    "nr_row_losses_fwd_slab": ([_P, _P, _I, _I] + [_P] * 8 + [_I, _I, _F, _P, _P], _I),
     "nr_row_losses_fwd_final": ([_P] * 9 + [_I, _I, _F, _P, _P, _F, _F, _F, _P, _P], _I),
     "nr_loss_finalize": ([_P, _I, _F, _F, _F, _P, _P], _I),
     "nr_row_losses_bwd": ([_P] * 9 + [_I, _I, _F, _P, _P, _P, _P, _P, _P, _P], _I),

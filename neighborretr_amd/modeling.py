@@ -119,6 +119,9 @@ class NeighborRetr(nn.Module):
         self._mb_shadow = None
         self._last_prepared = {}
         self.use_bank_shadow = True
+        # loss-only step with the similarity / bank work sharded over the ranks (head.head_forward_sharded) instead
+        # of the reference's replicated loss; off by default (the collectives are not graph-captured)
+        self.shard_loss = False
 
     # The bank attributes keep the reference's names and FIFO meaning (newest sample first; written
     # wholesale by MemoryBankManager, memory_bank.py:206-211).  Internally the bank is a RING: a push
@@ -292,6 +295,17 @@ class NeighborRetr(nn.Module):
             noise = self._draw_noise(text_feat.shape[0], text_feat.shape[1], video_feat.shape[1], text_feat.device)
         mods = tuple(getattr(self, f"{w}_{k}") for w in ("text", "video") for k in ("ctm0", "block0", "ctm1", "block1"))
         nz = noise or {}
+        world = int(getattr(self.config, "world_size", 1))
+        if (self.shard_loss and world > 1 and text_feat.is_cuda and not torch.is_grad_enabled()
+                and self._can_fuse_clustering(text_feat, mods) and self._can_fuse_clustering(video_feat, mods)):
+            import torch.distributed as dist
+            gt, gv = self._merge_grouped(text_feat, video_feat, text_mask, video_mask, nz)
+            losses = head.head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v,
+                                               mb_mask_t, mb_mask_v, gt, gv, self.scorer_weights("text_weight_fc"),
+                                               self.scorer_weights("video_weight_fc"), hp, logit_scale, self._prec(),
+                                               dist.get_rank(), world, bank_prepared=self._bank_shadow(),
+                                               prepared_out=self._last_prepared)
+            return losses[0], losses[1], losses[2], losses[3], losses[4]
         if (text_feat.is_cuda and self.use_side_streams and self.group_clustering and not torch.is_grad_enabled()
                 and self._can_fuse_clustering(text_feat, mods) and self._can_fuse_clustering(video_feat, mods)):
             # loss-only step: the text and video clustering advance together inside grouped launches on THIS

@@ -169,6 +169,17 @@ def row_losses(S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, lo
     return rowloss
 
 
+def row_losses_slab(S_rows, S_cols, row0, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, K, T):
+    """Row terms [2,4,B] of the rows [row0, row0 + n) only (zero elsewhere) from the two slabs of S a rank owns."""
+    n, B = S_rows.shape
+    rowloss = torch.zeros((2, 4, B), dtype=torch.float32, device=S_rows.device)
+    hip.call("nr_row_losses_fwd_slab", hip.ptr(S_rows, torch.float32), hip.ptr(S_cols, torch.float32), int(row0), int(n),
+             hip.ptr(G, torch.float32), hip.ptr(tgt_rows), hip.ptr(tgt_cols), hip.ptr(bank_c0, torch.float32),
+             hip.ptr(bank_c1, torch.float32), hip.ptr(wc_text, torch.float32), hip.ptr(wc_video, torch.float32),
+             hip.ptr(logit_scale, torch.float32), B, int(K), float(T), hip.ptr(rowloss), hip.stream_ptr())
+    return rowloss
+
+
 _COUNTERS = {}
 
 
