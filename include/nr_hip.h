@@ -195,6 +195,14 @@ int nr_shift_concat_split(const float* x, int n_samples, int N, int C, uint16_t*
 size_t nr_sinkhorn_workspace_bytes(int B);
 int nr_sinkhorn_targets(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols,
                         void* workspace, void* stream);
+/* The same solve emitting the uniform-regularisation ROW TERMS directly (until_module.py:285-289 on those targets):
+ *   uniform_rows[dir][i] = -sum_j tgt_ij (T X_ij - LSE_j(T X_ij)),  X = G (dir 0) / G^T (dir 1)   (direction dir at
+ * uniform_rows + dir * uniform_dir_stride);
+ * write them as rows 1 of rowloss [2,4,B] (uniform_rows = rowloss + B, uniform_dir_stride = 4B) and run
+ * nr_row_losses_fwd_no_uniform for the other terms BESIDE this launch.  tgt_rows / tgt_cols may both be NULL.
+ * B <= 128, B % 4 == 0 (NR_EUNSUPPORTED otherwise: use nr_sinkhorn_targets + nr_row_losses_fwd).            */
+int nr_sinkhorn_uniform_rows(const float* G, int B, float beta, int iters, float temperature, float* uniform_rows,
+                             int uniform_dir_stride, float* tgt_rows, float* tgt_cols, void* workspace, void* stream);
 
 /* Row-wise fused losses, both directions (until_module.py:303-328 centrality, :161-211 neighbour,
  * :285-289 uniform CE, :351-357 KL; orchestration modeling.py:329-401).  One wave per
@@ -209,6 +217,11 @@ int nr_row_losses_fwd(const float* S, const float* G, const float* tgt_rows, con
                       const float* logit_scale, int B, int K, float temperature, float* rowloss, void* stream);
 int nr_loss_finalize(const float* rowloss, int B, float uniform_weight, float neighbor_weight, float kl_weight,
                      float* losses, void* stream);
+/* nr_row_losses_fwd without the uniform term: rowloss[dir][0,2,3][i] only, no dependence on the Sinkhorn targets. */
+int nr_row_losses_fwd_no_uniform(const float* S, const float* G, const float* bank_c0, const float* bank_c1,
+                                 const float* wc_text, const float* wc_video, const float* logit_scale, int B, int K,
+                                 float temperature, float* rowloss, void* stream);
+
 /* Row-slab form of nr_row_losses_fwd for a loss sharded over ranks: the caller owns samples
  * [row0, row0 + n_rows) and holds S_rows = S[row0 : row0+n_rows, :] ([n_rows, B]) and S_cols = S[:, row0 : row0+n_rows]
  * ([B, n_rows]); G, the Sinkhorn targets, the bank centralities and the centrality weights are the full (replicated)

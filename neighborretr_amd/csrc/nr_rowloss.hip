@@ -59,7 +59,7 @@ struct NrRowState {
             else s[e] = a.S[idx];
             g[e] = a.G[idx];
             c[e] = cvec[jj];
-            tg[e] = tgt[(size_t)row * B + jj];
+            tg[e] = tgt ? tgt[(size_t)row * B + jj] : 0.f;      // no targets: the uniform term comes from the Sinkhorn kernel
         }
     }
 
@@ -192,7 +192,7 @@ __device__ __forceinline__ void nr_row_losses_fwd_rows(const NrRowArgs& a, float
         const int B = a.B;
         float* o = rowloss + (size_t)dir * 4 * B;
         o[0 * B + row] = -(r.s_ii * r.ls - r.lse_c) * r.wci;
-        o[1 * B + row] = l_u;
+        if (a.tgt_rows) o[1 * B + row] = l_u;
         o[2 * B + row] = -num / ps;
         o[3 * B + row] = l_kl;
     }
@@ -289,6 +289,17 @@ extern "C" int nr_row_losses_fwd(const float* S, const float* G, const float* tg
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;    // the reference raises IndexError for K > B
     NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0};
+    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr}, (hipStream_t)stream);
+}
+
+// centrality, neighbour and KL terms only (rowloss[dir][0,2,3][i]); the uniform term rowloss[dir][1][i] is left to
+// nr_sinkhorn_uniform_rows, so that this launch does not wait for the Sinkhorn solve
+extern "C" int nr_row_losses_fwd_no_uniform(const float* S, const float* G, const float* bank_c0, const float* bank_c1,
+                                            const float* wc_text, const float* wc_video, const float* logit_scale, int B, int K,
+                                            float temperature, float* rowloss, void* stream) {
+    if (!S || !G || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale || !rowloss) return NR_EINVAL;
+    if (B <= 0 || K < 0 || K > B) return NR_EINVAL;
+    NrRowArgs a{S, G, nullptr, nullptr, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0};
     return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr}, (hipStream_t)stream);
 }
 

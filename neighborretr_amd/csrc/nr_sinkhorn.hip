@@ -42,7 +42,8 @@ __device__ __forceinline__ float sk_group_max(float v) {
 // B = 128, 50 iterations): see the launcher.
 template <int SK_EPT>
 __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel(const float* __restrict__ G, int B, float beta, int iters,
-                                                                              float* __restrict__ tgt_rows, float* __restrict__ tgt_cols) {
+                                                                              float* __restrict__ tgt_rows, float* __restrict__ tgt_cols,
+                                                                              float temperature, float* __restrict__ uniform_rows, int uniform_stride) {
     constexpr int LPL = 128 / SK_EPT;
     __shared__ __attribute__((aligned(16))) float s_a[128];
     __shared__ __attribute__((aligned(16))) float s_b[128];
@@ -158,7 +159,39 @@ __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel
         __syncthreads();
     }
     // ---- Q = P / e^norm = 2B * a_i K_ij b_j;  target = beta*Q + (1-beta)*I ----------------------------
-    if (live) {
+    // Optionally also the uniform-regularisation row term itself (until_module.py:285-289 on these targets):
+    //   u_i = -sum_j tgt_ij * (T * X_ij - LSE_j(T * X_ij)),   X = G (direction 0) or G^T (direction 1),
+    // written to uniform_rows[dir][i] -- the row-loss kernel then does not depend on the Sinkhorn solve at all
+    // and runs beside it.  (tgt may then be NULL: nobody else reads the targets in the loss-only step.)
+    if (uniform_rows) {
+        float xg[SK_EPT], m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < SK_EPT; ++k) {
+            const int o = min(sub * SK_EPT + k, B - 1);
+            xg[k] = (dir == 0 ? sG[lc * SG_LD + o] : sG[o * SG_LD + lc]) * temperature;
+            if (live && sub * SK_EPT + k < B) m = fmaxf(m, xg[k]);
+        }
+        m = sk_group_max<LPL>(m);
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < SK_EPT; ++k)
+            if (live && sub * SK_EPT + k < B) se += __expf(xg[k] - m);
+        se = sk_group_sum<LPL>(se);
+        const float lse_u = m + __logf(se);
+        const float sc = beta * (float)(2 * B) * a_own;
+        float u = 0.f;
+#pragma unroll
+        for (int k = 0; k < SK_EPT; ++k) {
+            const int o = sub * SK_EPT + k;
+            if (live && o < B) {
+                const float t = sc * pr[k] * s_b[o] + (o == line ? 1.0f - beta : 0.f);
+                u -= t * (xg[k] - lse_u);
+            }
+        }
+        u = sk_group_sum<LPL>(u);
+        if (live && sub == 0) uniform_rows[(size_t)dir * uniform_stride + line] = u;
+    }
+    if (live && tgt) {
         const float sc = beta * (float)(2 * B) * a_own;
 #pragma unroll
         for (int k = 0; k < SK_EPT; k += 4) {             // 16-byte stores (B % 4 == 0)
@@ -229,9 +262,25 @@ extern "C" size_t nr_sinkhorn_workspace_bytes(int B) {
     return ((size_t)B * B + 4 * (size_t)B) * sizeof(float) + 64;
 }
 
+static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols, float temperature,
+                           float* uniform_rows, int uniform_stride, void* workspace, void* stream);
+
 extern "C" int nr_sinkhorn_targets(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols,
                                    void* workspace, void* stream) {
-    if (!G || !tgt_rows || !tgt_cols || B <= 0 || iters < 0) return NR_EINVAL;
+    if (!tgt_rows || !tgt_cols) return NR_EINVAL;
+    return nr_sinkhorn_run(G, B, beta, iters, tgt_rows, tgt_cols, 0.f, nullptr, 0, workspace, stream);
+}
+
+extern "C" int nr_sinkhorn_uniform_rows(const float* G, int B, float beta, int iters, float temperature, float* uniform_rows,
+                                        int uniform_dir_stride, float* tgt_rows, float* tgt_cols, void* workspace, void* stream) {
+    if (!uniform_rows || B > 128 || (B % 4) != 0) return uniform_rows ? NR_EUNSUPPORTED : NR_EINVAL;
+    if ((tgt_rows == nullptr) != (tgt_cols == nullptr) || uniform_dir_stride < B) return NR_EINVAL;
+    return nr_sinkhorn_run(G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_dir_stride, workspace, stream);
+}
+
+static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols, float temperature,
+                           float* uniform_rows, int uniform_stride, void* workspace, void* stream) {
+    if (!G || B <= 0 || iters < 0) return NR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (B <= 128 && (B % 4) == 0) {
         const size_t lds = (size_t)B * 129 * sizeof(float);
@@ -244,13 +293,13 @@ extern "C" int nr_sinkhorn_targets(const float* G, int B, float beta, int iters,
             hipError_t er = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (er != hipSuccess) return (int)er;
         }
-        if (ept == 16) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<16>, dim3(2), dim3(1024), lds, st, G, B, beta, iters, tgt_rows, tgt_cols);
-        else if (ept == 64) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<64>, dim3(2), dim3(256), lds, st, G, B, beta, iters, tgt_rows, tgt_cols);
-        else hipLaunchKernelGGL(nr_sinkhorn_small_kernel<32>, dim3(2), dim3(512), lds, st, G, B, beta, iters, tgt_rows, tgt_cols);
+        if (ept == 16) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<16>, dim3(2), dim3(1024), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride);
+        else if (ept == 64) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<64>, dim3(2), dim3(256), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride);
+        else hipLaunchKernelGGL(nr_sinkhorn_small_kernel<32>, dim3(2), dim3(512), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride);
         NR_LAUNCH_CHECK();
         return NR_OK;
     }
-    if (!workspace) return NR_EINVAL;
+    if (!workspace || !tgt_rows || !tgt_cols || uniform_rows) return NR_EINVAL;
     float* GT = reinterpret_cast<float*>(workspace);
     float* u = GT + (size_t)B * B;     // [2][B]
     float* v = u + 2 * (size_t)B;      // [2][B]

@@ -267,8 +267,20 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         fork.record(cur)
     gt2 = gt.reshape(B, d).float().contiguous()
     gv2 = gv.reshape(B, d).float().contiguous()
+    ls = logit_scale.detach().float().reshape(1).contiguous()
     G = global_logits(gt, gv, sw_t1, sw_v1)
-    tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
+    # Loss-only step at B <= 128: the Sinkhorn kernel emits the uniform-CE row terms itself, so the row-loss kernel
+    # (top-K neighbours, centrality, KL: the expensive terms) does not wait for the solve -- it runs BESIDE it on a
+    # side stream, and only the 5-number finalize follows both.
+    split_tail = (not keep) and bank_streams is not None and B <= 128 and B % 4 == 0
+    if split_tail:
+        rowloss = torch.empty((2, 4, B), dtype=torch.float32, device=G.device)
+        g_ready = torch.cuda.Event()
+        g_ready.record(cur)
+        ops.sinkhorn_uniform_rows(G, hp["beta"], hp["temperature"], rowloss, 50)
+        tgt_r = tgt_c = None
+    else:
+        tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
     if bank_streams is not None:
         for st_ in bank_streams:
             st_.wait_event(fork)
@@ -277,18 +289,24 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         with torch.cuda.stream(bank_streams[0]):
             pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
             wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
+            if split_tail:
+                bank_streams[0].wait_stream(bank_streams[1])
+                bank_streams[0].wait_event(g_ready)
+                ops.row_losses_no_uniform(S, G, c0, c1, wc_t, wc_v, ls, K, hp["temperature"], rowloss)
     else:
         pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
         pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
         wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
-    ls = logit_scale.detach().float().reshape(1).contiguous()
     if bank_streams is not None:
         for st_ in bank_streams:
             cur.wait_stream(st_)
         for t_ in (c0, c1, wc_t, wc_v) + ((pbt.hi, pbv.hi, w_bt, w_bv) if keep else ()):
             t_.record_stream(cur)
-    rowloss, losses = ops.row_losses_final(S, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"],
-                                           hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
+    if split_tail:
+        losses = ops.loss_finalize(rowloss, hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
+    else:
+        rowloss, losses = ops.row_losses_final(S, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"],
+                                               hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
     saved = None
     if keep:
         saved = dict(pt=pt, pv=pv, pbt=pbt, pbv=pbv, w_t=w_t, w_v=w_v, w_bt=w_bt, w_bv=w_bv,

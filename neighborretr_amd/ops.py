@@ -159,6 +159,28 @@ def sinkhorn_targets(G, beta, iters=50):
     return tr, tc
 
 
+def sinkhorn_uniform_rows(G, beta, T, rowloss, iters=50):
+    """Sinkhorn solve writing the uniform-CE row terms straight into rowloss[:, 1, :] (nr_sinkhorn_uniform_rows);
+    the targets themselves are not materialised.  False if the shape is not covered (B > 128 or B % 4)."""
+    G = _f32(G).contiguous()
+    B = G.shape[0]
+    if B > 128 or B % 4:
+        return False
+    ws = torch.empty((hip.sinkhorn_workspace_bytes(B),), dtype=torch.uint8, device=G.device)
+    base = rowloss.view(-1)[B:]                    # rowloss [2,4,B]: term 1 of direction d starts at (4 d + 1) B
+    hip.call("nr_sinkhorn_uniform_rows", hip.ptr(G), B, float(beta), int(iters), float(T), hip.ptr(base, torch.float32), 4 * B,
+             None, None, hip.ptr(ws), hip.stream_ptr())
+    return True
+
+
+def row_losses_no_uniform(S, G, bank_c0, bank_c1, wc_text, wc_video, logit_scale, K, T, rowloss):
+    """Centrality / neighbour / KL row terms into rowloss[:, (0, 2, 3), :] (nr_row_losses_fwd_no_uniform)."""
+    B = S.shape[0]
+    hip.call("nr_row_losses_fwd_no_uniform", hip.ptr(S, torch.float32), hip.ptr(G, torch.float32), hip.ptr(bank_c0, torch.float32),
+             hip.ptr(bank_c1, torch.float32), hip.ptr(wc_text, torch.float32), hip.ptr(wc_video, torch.float32),
+             hip.ptr(logit_scale, torch.float32), B, int(K), float(T), hip.ptr(rowloss, torch.float32), hip.stream_ptr())
+
+
 def row_losses(S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, K, T):
     B = S.shape[0]
     rowloss = torch.empty((2, 4, B), dtype=torch.float32, device=S.device)

@@ -449,6 +449,28 @@ def test_pack_and_unpack_of_the_exchange_step():
         assert torch.equal(outs[k], ref.float() if k >= 3 else ref)
 
 
+@pytest.mark.parametrize("B", [16, 128])
+def test_split_tail_matches_the_single_launch(B):
+    """Uniform-CE row terms from the Sinkhorn kernel + the other terms from nr_row_losses_fwd_no_uniform == the
+    one-launch path (targets materialised, nr_row_losses_fwd_final)."""
+    g = torch.Generator().manual_seed(B + 3)
+    S = (torch.rand(B, B, generator=g) * 0.1).to(DEV)
+    G = (torch.randn(B, B, generator=g) * 6 + torch.eye(B) * 5).to(DEV)
+    v = lambda: (torch.rand(B, generator=g) * 0.1).to(DEV)
+    c0, c1, w0, w1 = v(), v(), 1 + v(), 1 + v()
+    ls = torch.tensor([100.0], device=DEV)
+    K = min(20, B)
+    tr, tc = ops.sinkhorn_targets(G, 0.7, 50)
+    rl_ref, ref = ops.row_losses_final(S, G, tr, tc, c0, c1, w0, w1, ls, K, 3.0, 1.0, 1.0, 1.0)
+    rl = torch.full((2, 4, B), float("nan"), device=DEV)
+    assert ops.sinkhorn_uniform_rows(G, 0.7, 3.0, rl, 50)
+    ops.row_losses_no_uniform(S, G, c0, c1, w0, w1, ls, K, 3.0, rl)
+    got = ops.loss_finalize(rl, 1.0, 1.0, 1.0)
+    assert torch.equal(rl[:, [0, 2, 3]], rl_ref[:, [0, 2, 3]])
+    assert maxdiff(rl[:, 1], rl_ref[:, 1]) < 2e-5 * float(rl_ref[:, 1].abs().max())
+    assert maxdiff(got, ref) < 2e-5 * float(ref.abs().max())
+
+
 def test_bank_push_fifo():
     bank = torch.arange(10 * 6, dtype=torch.float32, device=DEV).reshape(10, 2, 3)
     ref = bank.clone()
