@@ -250,61 +250,76 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     if prepared_out is not None:
         prepared_out["pt"], prepared_out["pv"] = pt, pv
     S, aux0, mean_t, mean_v = L["S"], L["aux0"], L["mean_t"], L["mean_v"]
-    if local_stream is not None:
-        cur.wait_stream(local_stream)
-        for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi):
-            t_.record_stream(cur)
     if gt.shape[1] != 1 or gv.shape[1] != 1:
         raise RuntimeError("more than one global token per sample: the reference's centrality term "
                            "fails to broadcast at this shape (until_module.py:321); parity unpinned")
-    # After the join the critical path is global logits -> Sinkhorn -> row losses: those are captured FIRST.  What
-    # is left of the bank chains and the centrality weights feed only the row-loss kernel; with `bank_streams`
-    # they are forked from the join point (an event recorded before the Sinkhorn launch) and run beside the
-    # solve, which keeps two CUs busy for ~55 us.
-    fork = None
-    if bank_streams is not None:
-        fork = torch.cuda.Event()
-        fork.record(cur)
     gt2 = gt.reshape(B, d).float().contiguous()
     gv2 = gv.reshape(B, d).float().contiguous()
     ls = logit_scale.detach().float().reshape(1).contiguous()
-    G = global_logits(gt, gv, sw_t1, sw_v1)
-    # Loss-only step at B <= 128: the Sinkhorn kernel emits the uniform-CE row terms itself, so the row-loss kernel
-    # (top-K neighbours, centrality, KL: the expensive terms) does not wait for the solve -- it runs BESIDE it on a
-    # side stream, and only the 5-number finalize follows both.
-    split_tail = (not keep) and bank_streams is not None and B <= 128 and B % 4 == 0
+    # Loss-only step at B <= 128 ("split tail"): the global logits and the Sinkhorn solve depend on the clustering
+    # alone, so they follow it on THIS stream without waiting for the local branch; the Sinkhorn kernel emits the
+    # uniform-CE row terms itself, and everything that needs the local branch (leftover bank chains, centrality
+    # weights, the row-loss kernel with its top-K) gathers on a side stream that joins only for the 5-number
+    # finalize.  Critical path: prologue -> clustering -> logits -> Sinkhorn -> finalize -> push.
+    split_tail = (not keep) and bank_streams is not None and local_stream is not None and B <= 128 and B % 4 == 0
     if split_tail:
-        rowloss = torch.empty((2, 4, B), dtype=torch.float32, device=G.device)
+        G = global_logits(gt, gv, sw_t1, sw_v1)
         g_ready = torch.cuda.Event()
         g_ready.record(cur)
+        rowloss = torch.empty((2, 4, B), dtype=torch.float32, device=G.device)
         ops.sinkhorn_uniform_rows(G, hp["beta"], hp["temperature"], rowloss, 50)
         tgt_r = tgt_c = None
-    else:
-        tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
-    if bank_streams is not None:
-        for st_ in bank_streams:
-            st_.wait_event(fork)
-        with torch.cuda.stream(bank_streams[1]):
+        side, side2 = bank_streams
+        side.wait_stream(local_stream)
+        side2.wait_stream(local_stream)
+        with torch.cuda.stream(side2):
             pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
-        with torch.cuda.stream(bank_streams[0]):
+        with torch.cuda.stream(side):
             pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
+            side.wait_event(g_ready)
             wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
-            if split_tail:
-                bank_streams[0].wait_stream(bank_streams[1])
-                bank_streams[0].wait_event(g_ready)
-                ops.row_losses_no_uniform(S, G, c0, c1, wc_t, wc_v, ls, K, hp["temperature"], rowloss)
-    else:
-        pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
-        pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
-        wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
-    if bank_streams is not None:
-        for st_ in bank_streams:
-            cur.wait_stream(st_)
-        for t_ in (c0, c1, wc_t, wc_v) + ((pbt.hi, pbv.hi, w_bt, w_bv) if keep else ()):
+            side.wait_stream(side2)
+            ops.row_losses_no_uniform(S, G, c0, c1, wc_t, wc_v, ls, K, hp["temperature"], rowloss)
+        cur.wait_stream(side)
+        for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi, c0, c1, wc_t, wc_v):
             t_.record_stream(cur)
-    if split_tail:
+            t_.record_stream(side)
+        if pt.lo is not None:
+            pt.lo.record_stream(cur)
+            pv.lo.record_stream(cur)
+        pt.norm.record_stream(cur)
+        pv.norm.record_stream(cur)
         losses = ops.loss_finalize(rowloss, hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
     else:
+        if local_stream is not None:
+            cur.wait_stream(local_stream)
+            for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi):
+                t_.record_stream(cur)
+        # The critical path after the join is global logits -> Sinkhorn -> row losses: captured FIRST.  What is left
+        # of the bank chains and the centrality weights feed only the row-loss kernel; with `bank_streams` they are
+        # forked from the join point (an event recorded before the Sinkhorn launch) and run beside the solve.
+        fork = None
+        if bank_streams is not None:
+            fork = torch.cuda.Event()
+            fork.record(cur)
+        G = global_logits(gt, gv, sw_t1, sw_v1)
+        tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
+        if bank_streams is not None:
+            for st_ in bank_streams:
+                st_.wait_event(fork)
+            with torch.cuda.stream(bank_streams[1]):
+                pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
+            with torch.cuda.stream(bank_streams[0]):
+                pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
+                wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
+            for st_ in bank_streams:
+                cur.wait_stream(st_)
+            for t_ in (c0, c1, wc_t, wc_v) + ((pbt.hi, pbv.hi, w_bt, w_bv) if keep else ()):
+                t_.record_stream(cur)
+        else:
+            pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
+            pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
+            wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
         rowloss, losses = ops.row_losses_final(S, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"],
                                                hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
     saved = None
