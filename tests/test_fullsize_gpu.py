@@ -37,6 +37,9 @@ def _tokens(seed, n, N, d=512):
     (1024, 24, 512, 12, hip.PREC_BF16X3),     # configs[2]: batch x bank
     (128, 64, 1024, 64, hip.PREC_BF16),       # configs[3]: ActivityNet token counts, batch x bank (M=1024)
     (1024, 64, 128, 64, hip.PREC_BF16X3),     # configs[3]: bank x batch
+    (130, 24, 520, 12, hip.PREC_BF16),        # 192 x 384 blocks with ragged edges (130 = 16*8+2 texts, 520 = 16*32+8 videos)
+    (1000, 24, 1000, 12, hip.PREC_BF16X3),    # MSR-VTT 1k-A evaluation size: 192 x 192 split-bf16 blocks, ragged edges
+    (250, 24, 90, 12, hip.PREC_BF16X3),       # 96 x 192 split-bf16 blocks, ragged edges
 ])
 def test_local_level_properties_at_full_size(A, Nt, Bv, Nv, prec):
     t, tm, wt = _tokens(11, A, Nt)
@@ -66,7 +69,9 @@ def test_local_level_properties_at_full_size(A, Nt, Bv, Nv, prec):
     assert maxdiff(ops.reduce_parts(rs, 1.0 / Bv), S.double().mean(1)) < 1e-6
     assert maxdiff(ops.reduce_parts(cs, 1.0 / A), S.double().mean(0)) < 1e-6
     # spot check of 6 x 5 pairs against the oracle arithmetic in fp64
-    ia, ib = torch.arange(0, A, A // 6)[:6], torch.arange(1, Bv, Bv // 5)[:5]
+    ia, ib = torch.arange(0, A, max(A // 6, 1))[:6], torch.arange(1, Bv, max(Bv // 5, 1))[:5]
+    ia = torch.cat((ia, torch.tensor([A - 1])))              # the ragged last block too
+    ib = torch.cat((ib, torch.tensor([Bv - 1])))
     tn = torch.nn.functional.normalize(t[ia].cpu().double(), dim=-1) * tm[ia].cpu().double()[..., None]
     vn = torch.nn.functional.normalize(v[ib].cpu().double(), dim=-1) * vm[ib].cpu().double()[..., None]
     R = torch.einsum("atd,bvd->abtv", tn, vn)
