@@ -307,12 +307,12 @@ def test_ctm_front_back_equal_the_separate_kernels():
     assert maxdiff(rec, kvn) < 3e-5 * float(kvn.abs().max())
 
 
-def test_grouped_clustering_stage_equals_the_per_modality_path():
+@pytest.mark.parametrize("B,Nt,Nv", [(32, 24, 12), (8, 64, 64), (6, 20, 9)])
+def test_grouped_clustering_stage_equals_the_per_modality_path(B, Nt, Nv):
     """nr_ctm_stage_fwd (text and video problems in the same seven launches) against the one-problem fused
     kernels + library GEMMs: identical cluster assignments, outputs to split-bf16 GEMM accuracy."""
     from neighborretr_amd import modeling, synth
     from neighborretr_amd.cluster_fused import ctm_stage_fused, ctm_stage_group
-    B, Nt, Nv = 32, 24, 12
     m = modeling.NeighborRetr(modeling.default_config())
     m.load_state_dict(params(), strict=False)
     m = m.to(DEV).eval()
