@@ -67,35 +67,138 @@ def build_model(precision, device):
     return m
 
 
-def cpu_baseline(steps=5):
-    """The CPU port of the reference algorithm on the same workload; forward only."""
+def host_cores():
+    """(logical CPUs this process may run on, physical cores among them) from the affinity mask and /proc/cpuinfo."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    phys = set()
+    try:
+        cpu = pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                cpu, pid, cid = int(v), None, None
+            elif k == "physical id":
+                pid = int(v)
+            elif k == "core id":
+                cid = int(v)
+            elif not k and cpu is not None:
+                if cpu in allowed and pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                cpu = None
+        if cpu is not None and cpu in allowed and pid is not None and cid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    return len(allowed), (len(phys) or len(allowed))
+
+
+def cpu_baseline(samples=7):
+    """The CPU port of the reference algorithm (oracle/nr_oracle.py, pinned against the reference's own outputs) on the
+    same workload, timed on this host: forward at 1 thread and at one thread per physical core (median of `samples`
+    after 2 warm-ups each), forward+backward at all cores (median of 3).  `value` = the all-core forward rate."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nr_oracle as O
     from neighborretr_amd import synth
-    cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
-    torch.set_num_threads(threads)
+    logical, physical = host_cores()
     c = CFG
     prob = {k: torch.from_numpy(v) for k, v in synth.make_problem(1002, c["B"], c["Nt"], c["Nv"], c["M"]).items()}
     P = {k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}
     nz = {k: torch.from_numpy(v) for k, v in synth.make_noise(1002, c["B"], c["Nt"], c["Nv"]).items()}
     hp = dict(synth.DEFAULT_HP, num_neighbors=c["K"])
-    ls = torch.tensor(100.0)
 
-    def one():
-        with torch.no_grad():
-            return O.compute_losses(prob["text_feat"], prob["video_feat"], prob["text_mask"], prob["video_mask"],
-                                    prob["mb_feat_t"], prob["mb_feat_v"], prob["mb_mask_t"], prob["mb_mask_v"], P, hp, ls, nz)
-    one(); one()
-    ts = []
-    for _ in range(steps):
-        t0 = time.perf_counter()
-        one()
-        ts.append(time.perf_counter() - t0)
-    med = float(np.median(ts))
-    return {"value": 1.0 / med, "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} forward steps of configs[1] (B=128,Nt=24,Nv=12,M=512,K=20) after 2 warm-ups, median; "
-                      f"torch CPU ops, {threads} threads", "ms_per_step": med * 1e3}
+    def one(grad=False):
+        ls = torch.tensor(100.0, requires_grad=grad)
+        tf, vf = prob["text_feat"].clone().requires_grad_(grad), prob["video_feat"].clone().requires_grad_(grad)
+        Pg = {k: v.clone().requires_grad_(grad) for k, v in P.items()} if grad else P
+        with torch.set_grad_enabled(grad):
+            out = O.compute_losses(tf, vf, prob["text_mask"], prob["video_mask"], prob["mb_feat_t"], prob["mb_feat_v"],
+                                   prob["mb_mask_t"], prob["mb_mask_v"], Pg, hp, ls, nz)
+            if grad:
+                out[0].backward()
+        return out
+
+    def timed(threads, n, grad=False, warm=2):
+        torch.set_num_threads(threads)
+        for _ in range(warm):
+            one(grad)
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            one(grad)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+    t_all = timed(physical, samples)
+    t_one = timed(1, samples)
+    t_fb = timed(physical, 3, grad=True, warm=1)
+    return {"value": round(1.0 / t_all, 3), "unit": "steps/s", "cores": physical, "kind": "port",
+            "physical_cores": physical, "logical_cpus": logical,
+            "sample": f"configs[1] (B=128,Nt=24,Nv=12,M=512,K=20), torch CPU ops: forward x{samples} at {physical} threads "
+                      f"(one per physical core) and x{samples} at 1 thread, forward+backward x3 at {physical} threads; "
+                      "medians after warm-ups",
+            "ms_per_step": round(t_all * 1e3, 2),
+            "one_thread": {"value": round(1.0 / t_one, 3), "ms_per_step": round(t_one * 1e3, 2), "cores": 1},
+            "fwd_bwd": {"value": round(1.0 / t_fb, 3), "ms_per_step": round(t_fb * 1e3, 2), "cores": physical}}
+
+
+def parity_gates(model, dev):
+    """the gates reported beside every timing.  One extra UN-TIMED step on the inputs and the DPC-KNN noise
+    of the reference fixture tests/golden/c2_b128.npz (outputs of the unmodified reference on exactly this workload):
+    max|dS| of the batch x batch similarity in the step's precision plan, |dL| of the five losses, and whether the
+    retrieval ranks (`cols` of RetrievalMetrics.compute_metrics, metrics.py:58-66) are identical on the rank-exact
+    path.  The reference's cols are recomputed here from ITS similarity matrix with its own three numpy lines."""
+    from neighborretr_amd import head, synth
+    from neighborretr_amd.metrics import RetrievalMetrics
+    path = os.path.join(ROOT, "tests", "golden", "c2_b128.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    c = CFG
+    assert (int(g["B"]), int(g["Nt"]), int(g["Nv"]), int(g["M"]), int(g["K"])) == (c["B"], c["Nt"], c["Nv"], c["M"], c["K"])
+    prob = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_problem(int(g["seed"]), c["B"], c["Nt"], c["Nv"], c["M"]).items()}
+    nz = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_noise(int(g["seed"]), c["B"], c["Nt"], c["Nv"]).items()}
+    cfg = model.config
+    with torch.no_grad():
+        losses = torch.stack(model._compute_losses(
+            prob["text_feat"], prob["video_feat"], prob["text_mask"], prob["video_mask"], prob["mb_feat_t"], prob["mb_feat_v"],
+            prob["mb_mask_t"], prob["mb_mask_v"], cfg.centrality_scale, cfg.beta, c["K"], cfg.temperature,
+            torch.tensor(100.0, device=dev), noise=nz)).cpu().numpy()
+        sw_t, sw_v = model.scorer_weights("text_weight_fc"), model.scorer_weights("video_weight_fc")
+        p_bb = head.precision_plan(model._prec())[0]
+        S_plan = head.similarity_matrix(prob["text_feat"], prob["video_feat"], prob["text_mask"].float(),
+                                        prob["video_mask"].float(), sw_t, sw_v, p_bb)
+        S_exact, _ = model.get_similarity_logits(prob["text_feat"], prob["video_feat"], prob["text_mask"], prob["video_mask"])
+        mine = RetrievalMetrics.compute_metrics(S_exact)
+    ref_S = g["S"]
+    sx = np.sort(-ref_S, axis=1)
+    ref_cols = np.where(sx - np.diag(-ref_S)[:, None] == 0)[1]
+    dL = np.abs(losses - g["losses"])
+    return {"fixture": "tests/golden/c2_b128.npz (reference outputs on this workload)",
+            "max_dS": float(np.abs(S_plan.cpu().numpy() - ref_S).max()),
+            "max_dS_rank_exact_path": float(np.abs(S_exact.cpu().numpy() - ref_S).max()),
+            "dL": [float(f"{x:.3e}") for x in dL], "dL_order": ["total", "centrality", "uniform", "neighbor", "kl"],
+            "losses": [round(float(x), 5) for x in losses], "ref_losses": [round(float(x), 5) for x in g["losses"]],
+            "cols_identical": bool(np.array_equal(np.asarray(mine["cols"]), ref_cols)),
+            "R1": mine["R1"], "tol_losses": 1e-3, "pass": bool(dL.max() < 1e-3 and np.array_equal(np.asarray(mine["cols"]), ref_cols))}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` typed without a launcher: start N fresh rank processes (one per GPU) through
+    torch.distributed.run and relay their output.  This parent has made no GPU call (it only parsed arguments), and it
+    does not exec: the ranks are children, their exit code becomes ours."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -106,7 +209,7 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N")
+        raise SystemExit(launch_ranks(args.gpus))
     import torch.distributed as dist
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
@@ -323,6 +426,7 @@ def main():
             "roofline": roofline,
         }
         line.update(extra)
+        line["parity"] = parity_gates(model, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -95,10 +95,16 @@ int nr_centrality_weights(const float* g, int B, int d, const float* colsum_part
                           float scale, float* w, float* gnorm, float* mean_out, void* stream);
 
 /* Same weights for both modalities in one launch, from the finished token means
- * (mean = nr_reduce_parts(colsum_part, 1/n_tok)): w = exp(scale * <g/||g||, mean>).            */
-int nr_centrality_weights_pair(const float* g_text, const float* g_video, int B, int d, const float* mean_text,
-                               const float* mean_video, float scale, float* w_text, float* w_video,
-                               float* gnorm_text, float* gnorm_video, void* stream);
+ * (mean = nr_reduce_parts(colsum_part, 1/n_tok)).  g_text [B, n_g_text, d], g_video [B, n_g_video, d]:
+ *   w[i] = mean_g exp(scale * <g_ig/||g_ig||, mean>).
+ * n_g = 1 is the reference's expression (modeling.py:403-430).  n_g > 1 (ActivityNet token counts) has no reference
+ * answer -- its loss fails to broadcast [B] * [B,n_g] (until_module.py:321); the mean over the global tokens is this
+ * build's documented reduction (config.centrality_multi_token = "mean").
+ * gnorm_* [B*n_g] and wtok_* [B*n_g] (per-token norms / weights, kept for backward) out or NULL.     */
+int nr_centrality_weights_pair(const float* g_text, const float* g_video, int B, int n_g_text, int n_g_video, int d,
+                               const float* mean_text, const float* mean_video, float scale, float* w_text,
+                               float* w_video, float* gnorm_text, float* gnorm_video, float* wtok_text,
+                               float* wtok_video, void* stream);
 
 /* DPC-KNN cluster assignment of every token (cluster.py:453-509; index-only, no gradient):
  *   x [n_samples,N,C] f32 tokens; mask [n_samples,N] f32 (>0 = valid) or NULL; noise [n_samples,N]

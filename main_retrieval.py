@@ -79,6 +79,12 @@ def get_args():
     p.add_argument("--synthetic_train", type=int, default=2048, help="synthetic training pairs")
     p.add_argument("--synthetic_test", type=int, default=1000, help="synthetic test pairs (MSR-VTT 1k-A size)")
     p.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "bf16_all"])
+    p.add_argument("--dist_backend", default="nccl", choices=["nccl", "gloo"],
+                   help="collective backend: nccl = RCCL over xGMI (one GPU per rank); gloo only to rehearse several "
+                        "ranks on ONE GPU (tests)")
+    p.add_argument("--centrality_multi_token", default="raise", choices=["raise", "mean"],
+                   help="several global tokens per sample (ActivityNet token counts): 'raise' like the reference "
+                        "(until_module.py:321), 'mean' = centrality weight averaged over the sample's global tokens")
     p.add_argument("--hip_graph", type=int, default=0,
                    help="1: forward + backward of the training step replayed from ONE captured HIP graph "
                         "(single rank; the eager step is bound by the host issuing ~560 launches)")
@@ -95,10 +101,17 @@ def setup_distributed(args):
     args.local_rank = int(os.environ.get("LOCAL_RANK", str(args.local_rank)))
     if not torch.cuda.is_available():
         raise RuntimeError("the HIP path needs an MI355X; there is no CPU fallback")
-    torch.cuda.set_device(args.local_rank)
-    args.device = torch.device("cuda", args.local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and args.local_rank >= n_dev:
+        raise RuntimeError(f"LOCAL_RANK {args.local_rank} but {n_dev} GPU(s) visible: RCCL needs one GPU per rank")
+    args.device_index = args.local_rank % n_dev                     # gloo rehearsal: ranks share the card
+    torch.cuda.set_device(args.device_index)
+    args.device = torch.device("cuda", args.device_index)
     if args.world_size > 1:
-        dist.init_process_group("nccl", device_id=args.device)      # "nccl" is RCCL on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=args.device)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
     # AllGather / packed_allgather slice gradients by GLOBAL rank
     args.local_rank = args.rank
     return args
@@ -159,20 +172,26 @@ class GraphedStep:
         self.model = model
         self.capture()
 
-    def bank_key(self):
-        """Identity of the memory-bank tensors the captured graph reads (MemoryBankManager swaps them per epoch)."""
-        return tuple(v.data_ptr() for v in self.model._mb.values())
-
     def capture(self):
         model, params = self.model, self.params
+        B = self.static[0].shape[0]
+        # Warm-up on a side stream, as graph capture requires -- with the bank FROZEN: a warm-up step that pushed its
+        # batch would leave the static batch in the bank three times (and three more times after every re-capture),
+        # which is not the reference's FIFO (modeling.py:222-249).
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):                       # warm-up on a side stream, as graph capture requires
-                for p in params:
-                    p.grad = None
-                model(*self.static, 0)[0].backward()
+        model.bank_frozen = True
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    for p in params:
+                        p.grad = None
+                    model(*self.static, 0)[0].backward()
+        finally:
+            model.bank_frozen = False
         torch.cuda.current_stream().wait_stream(side)
+        # the device-resident ring head must exist before the capture (creating it is a host-to-device copy)
+        model._ring_ready(B)
         torch.cuda.synchronize()
         for p in params:
             p.grad = None
@@ -185,10 +204,14 @@ class GraphedStep:
             self.losses = model(*self.static, 0)
             self.losses[0].backward()
         self.grads = [p.grad for p in params]        # static gradient buffers of the graph
-        self.key = self.bank_key()
+        # What the graph has baked in: the addresses of the five bank tensors and of the device ring head.  Hold
+        # strong references (a bank replaced from outside must not hand its blocks to somebody else while this graph
+        # can still replay) and remember the bank's storage generation; run() re-captures when it has moved on.
+        self.bank_refs = (dict(model._mb), model._mb_head_dev)
+        self.generation = model._mb_gen
 
     def run(self, batch):
-        if self.bank_key() != self.key:              # the bank was replaced from outside: the graph reads stale memory
+        if self.model._mb_gen != self.generation:    # the bank's tensors / ring head were replaced: the graph is stale
             self.capture()
         for dst, src in zip(self.static, batch):
             dst.copy_(src)
@@ -268,7 +291,7 @@ def main():
     model = model.to(args.device)
     ddp = model
     if args.world_size > 1:
-        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[args.local_rank % torch.cuda.device_count()],
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[args.device_index],
                                                         find_unused_parameters=True)   # optimizer.py:79-84
     train = SyntheticFeatures(args, args.synthetic_train, "train", args.seed)
     test = SyntheticFeatures(args, args.synthetic_test, "test", args.seed + 1)

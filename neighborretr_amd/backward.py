@@ -58,6 +58,9 @@ class HeadLossFn(torch.autograd.Function):
         ctx.sv, ctx.hp, ctx.exact = sv, dict(hp), prec == hip.PREC_BF16X3
         ctx.masks = (text_mask, video_mask)
         ctx.shapes = (text_feat.shape, video_feat.shape, mb_feat_t.shape, mb_feat_v.shape, gt.shape, gv.shape)
+        if gt.shape[1] != 1 or gv.shape[1] != 1:
+            raise NotImplementedError("gradient of the head with several global tokens per sample is not implemented")
+        sv["gt2"], sv["gv2"] = sv["gt2"].reshape(-1, sv["gt2"].shape[-1]), sv["gv2"].reshape(-1, sv["gv2"].shape[-1])
         ctx.save_for_backward(text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v)
         return losses
 
@@ -82,8 +85,9 @@ class HeadLossFn(torch.autograd.Function):
         d_gv = dG.t() @ sv["gt2"]
         # centrality weights
         cs = hp["centrality_scale"]
-        dg_t, dmean_t = ops.centrality_weights_bwd(sv["gt2"], sv["gn_t"], sv["mean_t"], sv["wc_t"], dwc[0], cs)
-        dg_v, dmean_v = ops.centrality_weights_bwd(sv["gv2"], sv["gn_v"], sv["mean_v"], sv["wc_v"], dwc[1], cs)
+        gn_t, gn_v = sv["cw_aux"][0], sv["cw_aux"][1]
+        dg_t, dmean_t = ops.centrality_weights_bwd(sv["gt2"], gn_t, sv["mean_t"], sv["wc_t"], dwc[0], cs)
+        dg_v, dmean_v = ops.centrality_weights_bwd(sv["gv2"], gn_v, sv["mean_v"], sv["wc_v"], dwc[1], cs)
         d_gt = (d_gt + dg_t).reshape(gt_shape)
         d_gv = (d_gv + dg_v).reshape(gv_shape)
         # similarity kernels: batch x batch, text x bank-video (row mean), bank-text x video (col mean)

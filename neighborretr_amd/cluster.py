@@ -44,7 +44,10 @@ def dpc_knn_assign(x, cluster_num, k, mask=None, noise=None):
         denser = density[:, None, :] > density[:, :, None]
         dmax = dist.flatten(1).max(-1).values[:, None, None]
         parent = torch.where(denser, dist, dmax.expand_as(dist)).min(-1).values
-        centres = (parent * density).topk(cluster_num, dim=-1).indices          # [B,c]
+        # centres: top `cluster_num` scores, exact ties (zero-score padding tokens, equal densities) -> LOWER index,
+        # the rule of the HIP kernels (nr_cluster.hip) and of oracle.dpc_knn(centre_ties="lowest_index");
+        # torch.topk (cluster.py:498 in the reference) leaves the tie order to the backend
+        centres = (parent * density).sort(dim=-1, descending=True, stable=True).indices[:, :cluster_num]   # [B,c]
         to_centre = dist.gather(1, centres[:, :, None].expand(B, cluster_num, N))
         assign = to_centre.argmin(1)
         ids = torch.arange(cluster_num, device=x.device)[None, :].expand(B, cluster_num)
@@ -139,6 +142,18 @@ class TCBlock(nn.Module):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim)
         self.attn = TCAttention(dim, num_heads, qkv_bias)
+        self.apply(self._init_weights)            # cluster.py:918: the block initialises itself on construction
+
+    @staticmethod
+    def _init_weights(m):
+        """cluster.py:920-932: q / kv / proj weights trunc_normal(std 0.02, cut at +-2), zero biases, LayerNorm 1 / 0."""
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02, a=-2.0, b=2.0)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
 
     def forward(self, inputs):
         down, full = inputs

@@ -12,6 +12,16 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #define NR_NEG_BIG (-9e15f)   // the reference's "-inf" (modeling.py:486, until_module.py:111)
 #define NR_POS_BIG (9e15f)
 
+// Tuning hooks (block shapes, ring depths, tile orders forced from the environment for A/B measurements) exist only in
+// -DNR_TUNE builds (NR_EXTRA_FLAGS=-DNR_TUNE python -m neighborretr_amd.build --force).  A release build never reads
+// the environment: the behaviour of the shipped ABI does not depend on stray variables.
+#ifdef NR_TUNE
+#include <stdlib.h>
+static inline const char* nr_tune_env(const char* name) { return getenv(name); }
+#else
+static inline const char* nr_tune_env(const char*) { return nullptr; }
+#endif
+
 // status codes returned by every extern "C" entry point
 #define NR_OK 0
 #define NR_EINVAL (-1)

@@ -135,7 +135,7 @@ int nr_linear_group_launch(const NrLinearArgs* probs, int n, hipStream_t st) {
     else if (t32x64 <= 1536) { mi = 2; ni = 2; stg = 1; }
     else if (t128 < 1024) { mi = 2; ni = 2; stg = 1; wcols = 4; }
     else { mi = 4; ni = 4; stg = 1; }
-    if (const char* ov = getenv("NR_LINEAR_TILE")) {
+    if (const char* ov = nr_tune_env("NR_LINEAR_TILE")) {
         int a_, b_, c_, d_ = 2;
         if (sscanf(ov, "%d,%d,%d,%d", &a_, &b_, &c_, &d_) >= 3) { mi = a_; ni = b_; stg = c_; wcols = d_; }
     }

@@ -122,7 +122,7 @@ extern "C" int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_l
         const long cost = ((wg + 255) / 256) * (bm + bn);
         if (best < 0 || cost < best_cost || (cost == best_cost && wg > best_wg)) { best = c; best_cost = cost; best_wg = wg; }
     }
-    if (const char* e = getenv("NR_MLP_SHAPE")) {          // tuning hook: index into the candidate list
+    if (const char* e = nr_tune_env("NR_MLP_SHAPE")) {          // tuning hook: index into the candidate list
         int c = atoi(e);
         if (c >= 0 && c < 5 && H % (16 * cand[c].wc * cand[c].ni) == 0 && !(x3 && cand[c].wc == 4)) {
             best = c;

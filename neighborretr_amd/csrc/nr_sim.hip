@@ -191,7 +191,7 @@ int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16
 extern "C" int nr_sim_reg_tile(int A, int Nt, int Bv, int Nv, int prec, int* TA, int* TB);
 
 static bool nr_sim_force_generic() {
-    const char* e = getenv("NR_SIM_GENERIC");
+    const char* e = nr_tune_env("NR_SIM_GENERIC");
     return e && atoi(e);
 }
 

@@ -253,7 +253,7 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
             if (cost < best) { best = cost; a.PR = pr; a.PC = pc; }
         }
     }
-    if (const char* e = getenv("NR_SIM_XCD")) {          // tuning hook: "0" = plain row-major order, "RxC" = forced partition
+    if (const char* e = nr_tune_env("NR_SIM_XCD")) {          // tuning hook: "0" = plain row-major order, "RxC" = forced partition
         int pr = 0, pc = 0;
         if (sscanf(e, "%dx%d", &pr, &pc) == 2 && pr * pc == 8 && a.nty % pr == 0 && a.ntx % pc == 0) { a.PR = pr; a.PC = pc; }
         else a.PR = a.PC = 0;
@@ -267,7 +267,7 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
     if constexpr (big && X3) return NR_EUNSUPPORTED;
     else {
         if constexpr (big && NI == 3) {          // 192 x 192: three stages fit (144 KB)
-            const char* e = getenv("NR_SIM_STAGES");
+            const char* e = nr_tune_env("NR_SIM_STAGES");
             if (e && atoi(e) == 3) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 3, WC>(a, st);
         }
         return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 2, WC>(a, st);
@@ -281,7 +281,7 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
 // per CU.  NR_SIM_BIG=0/1/2 caps it, NR_SIM_BIG=3 forces level 3 for split-bf16 (A/B hooks).
 static int nr_sim_reg_big(int A, int Nt, int Bv, int Nv, int prec) {
     if (Nt == 64 && Nv == 64) {       // 4: 128 x 256 blocks (2 texts x 4 videos) on 8 waves, once they fill the chip
-        const char* e64 = getenv("NR_SIM_BIG");
+        const char* e64 = nr_tune_env("NR_SIM_BIG");
         if (e64 && atoi(e64) == 0) return 0;
         if (prec == NR_PREC_BF16X3) return 0;             // split-bf16 would run a 1-stage ring there: measured slower
         return (long)((A + 1) / 2) * ((Bv + 3) / 4) >= 256 ? 4 : 0;
@@ -289,7 +289,7 @@ static int nr_sim_reg_big(int A, int Nt, int Bv, int Nv, int prec) {
     if (Nt != 24 || Nv != 12) return 0;
     const bool x3 = prec == NR_PREC_BF16X3;
     int cap = x3 ? 1 : 2;       // split-bf16 fragments do not fit beside 144 accumulators
-    const char* e = getenv("NR_SIM_BIG");
+    const char* e = nr_tune_env("NR_SIM_BIG");
     const int env = e ? atoi(e) : -1;
     if (env >= 0 && env <= 2) cap = std::min(cap, env);
     const long wg3 = (long)((A + 3) / 4) * ((Bv + 15) / 16);

@@ -286,7 +286,7 @@ static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* 
         const size_t lds = (size_t)B * 129 * sizeof(float);
         // entries per thread: 16 (1024 threads) / 32 (512) / 64 (256); NR_SINKHORN_EPT overrides (tuning hook)
         int ept = 32;
-        if (const char* e = getenv("NR_SINKHORN_EPT")) ept = atoi(e);
+        if (const char* e = nr_tune_env("NR_SINKHORN_EPT")) ept = atoi(e);
         if (lds > 64 * 1024) {
             const void* k = ept == 16 ? (const void*)nr_sinkhorn_small_kernel<16> : ept == 64 ? (const void*)nr_sinkhorn_small_kernel<64>
                                                                                              : (const void*)nr_sinkhorn_small_kernel<32>;

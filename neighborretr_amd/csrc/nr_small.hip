@@ -161,42 +161,58 @@ extern "C" int nr_centrality_weights(const float* g, int B, int d, const float* 
 
 // Both modalities in one launch from FINISHED token means (mean = nr_reduce_parts over the prepared
 // column sums, issued on the local branch long before the global tokens exist): one wave per
-// (sample, modality), blockIdx.y = modality.
+// (sample, modality), blockIdx.y = modality.  A sample may carry several global tokens (ActivityNet token
+// counts leave 3 text / 6 video tokens): the wave walks its sample's n_g tokens, w = mean_g exp(scale * cos_g)
+// -- the documented "mean" reduction of config.centrality_multi_token (the reference has no answer there,
+// until_module.py:321); with n_g = 1 this is the reference's expression.  Per-token weights / norms are kept for
+// the backward pass when asked for.
 __global__ __launch_bounds__(256) void nr_centrality_pair_kernel(const float* __restrict__ g0, const float* __restrict__ g1,
-                                                                 int B, int d, const float* __restrict__ mean0,
+                                                                 int B, int ng0, int ng1, int d, const float* __restrict__ mean0,
                                                                  const float* __restrict__ mean1, float scale,
                                                                  float* __restrict__ w0, float* __restrict__ w1,
-                                                                 float* __restrict__ gn0, float* __restrict__ gn1) {
+                                                                 float* __restrict__ gn0, float* __restrict__ gn1,
+                                                                 float* __restrict__ wtok0, float* __restrict__ wtok1) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
     const bool second = blockIdx.y == 1;
-    const float* gi = (second ? g1 : g0) + (size_t)i * d;
+    const int ng = second ? ng1 : ng0;
     const float* mean = second ? mean1 : mean0;
-    float dot = 0.f, ss = 0.f;
-    for (int k = lane * 4; k < d; k += 256) {
-        f32x4_t x = *reinterpret_cast<const f32x4_t*>(gi + k);
-        f32x4_t m = *reinterpret_cast<const f32x4_t*>(mean + k);
-        dot += x[0] * m[0] + x[1] * m[1] + x[2] * m[2] + x[3] * m[3];
-        ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    float* gn = second ? gn1 : gn0;
+    float* wtok = second ? wtok1 : wtok0;
+    float acc = 0.f;
+    for (int t = 0; t < ng; ++t) {
+        const float* gi = (second ? g1 : g0) + ((size_t)i * ng + t) * d;
+        float dot = 0.f, ss = 0.f;
+        for (int k = lane * 4; k < d; k += 256) {
+            f32x4_t x = *reinterpret_cast<const f32x4_t*>(gi + k);
+            f32x4_t m = *reinterpret_cast<const f32x4_t*>(mean + k);
+            dot += x[0] * m[0] + x[1] * m[1] + x[2] * m[2] + x[3] * m[3];
+            ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+        }
+        dot = nr_wave_sum(dot);
+        ss = nr_wave_sum(ss);
+        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+        const float wt = expf(dot / nrm * scale);
+        acc += wt;
+        if (lane == 0) {
+            if (gn) gn[(size_t)i * ng + t] = nrm;
+            if (wtok) wtok[(size_t)i * ng + t] = wt;
+        }
     }
-    dot = nr_wave_sum(dot);
-    ss = nr_wave_sum(ss);
-    float nrm = fmaxf(sqrtf(ss), 1e-12f);
-    if (lane == 0) {
-        (second ? w1 : w0)[i] = expf(dot / nrm * scale);
-        float* gn = second ? gn1 : gn0;
-        if (gn) gn[i] = nrm;
-    }
+    if (lane == 0) (second ? w1 : w0)[i] = ng == 1 ? acc : acc / (float)ng;
 }
 
-extern "C" int nr_centrality_weights_pair(const float* g_text, const float* g_video, int B, int d, const float* mean_text,
-                                          const float* mean_video, float scale, float* w_text, float* w_video,
-                                          float* gnorm_text, float* gnorm_video, void* stream) {
+extern "C" int nr_centrality_weights_pair(const float* g_text, const float* g_video, int B, int n_g_text, int n_g_video, int d,
+                                          const float* mean_text, const float* mean_video, float scale, float* w_text,
+                                          float* w_video, float* gnorm_text, float* gnorm_video, float* wtok_text,
+                                          float* wtok_video, void* stream) {
     if (!g_text || !g_video || !mean_text || !mean_video || !w_text || !w_video || B <= 0 || d <= 0 || (d % 4) != 0)
         return NR_EINVAL;
+    if (n_g_text <= 0 || n_g_video <= 0) return NR_EINVAL;
     hipLaunchKernelGGL(nr_centrality_pair_kernel, dim3((B + 3) / 4, 2), dim3(256), 0, (hipStream_t)stream, g_text, g_video, B,
-                       d, mean_text, mean_video, scale, w_text, w_video, gnorm_text, gnorm_video);
+                       n_g_text, n_g_video, d, mean_text, mean_video, scale, w_text, w_video, gnorm_text, gnorm_video, wtok_text,
+                       wtok_video);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

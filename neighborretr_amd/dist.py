@@ -9,6 +9,9 @@ one all_gather_into_tensor (RCCL over xGMI on the GPU box; gloo in the CPU tests
 the step is latency-bound, so one launch instead of five (plus the reference's barrier, which is
 dropped: the collective already orders the data) is what matters.
 
+Returned dtypes are the same on every device: features fp32, idx int64, masks fp32 (the multipliers
+every kernel of the head reads; the reference hands int64 masks on and converts later).
+
 Backward keeps the reference's semantics (AllGather.backward): every rank differentiates the
 full replicated loss, so the gradient of the gathered features is just this rank's slice -- no
 reduction.
@@ -72,8 +75,8 @@ class PackedAllGather(torch.autograd.Function):
         g_tf = take(0, torch.float32, tf.shape[1:])
         g_vf = take(1, torch.float32, vf.shape[1:])
         g_ix = take(2, torch.int64, ix.shape[1:])
-        g_tm = take(3, torch.uint8, tm.shape[1:]).to(text_mask.dtype)
-        g_vm = take(4, torch.uint8, vm.shape[1:]).to(video_mask.dtype)
+        g_tm = take(3, torch.uint8, tm.shape[1:]).float()
+        g_vm = take(4, torch.uint8, vm.shape[1:]).float()
         ctx.mark_non_differentiable(g_ix, g_tm, g_vm)
         return g_tf, g_vf, g_ix, g_tm, g_vm
 

@@ -39,7 +39,8 @@ def head_losses(model, text_feat, video_feat, text_mask, video_mask, mb_feat_t, 
                                   join=model._take_join(), bank_streams=model._bank_streams(text_feat.device),
                                   local_stream=model._local_stream(text_feat.device) if gt is None else None,
                                   bank_early=model.bank_early, capture_order=model.capture_order,
-                                  bank_prepared=model._bank_shadow(), prepared_out=model._last_prepared)
+                                  bank_prepared=model._bank_shadow(mb_feat_t, mb_feat_v), prepared_out=model._last_prepared,
+                                  **model._global_scorers(text_feat, video_feat))
     return losses
 
 

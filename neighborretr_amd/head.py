@@ -69,6 +69,23 @@ def global_logits(gt, gv, sw_t1=None, sw_v1=None):
     return G
 
 
+def _check_global_tokens(gt, gv, hp):
+    """More than one global token per sample (ActivityNet token counts: 64 -> 11 -> 3 text, 64 -> 16 -> 6 video
+    tokens): the reference's centrality term multiplies [B] by [B,G] and raises (until_module.py:321), so there is
+    no reference answer.  config.centrality_multi_token = "raise" (default) mirrors that; "mean" runs the step with
+    w_i = mean over the sample's global tokens of the reference's per-token weight."""
+    if gt.shape[1] == 1 and gv.shape[1] == 1:
+        return
+    mode = hp.get("centrality_multi_token", "raise")
+    if mode == "mean":
+        return
+    if mode != "raise":
+        raise ValueError(f"centrality_multi_token={mode!r}: expected 'raise' or 'mean'")
+    raise RuntimeError(f"{gt.shape[1]} / {gv.shape[1]} global tokens per sample: the reference's centrality term fails to "
+                       "broadcast at this shape (until_module.py:321); set config.centrality_multi_token='mean' to run "
+                       "with the documented reduction (parity unpinned for that one term)")
+
+
 PREC_MIXED = 2   # host-level plan: split-bf16 where logit_scale amplifies the error, bf16 elsewhere
 
 
@@ -250,11 +267,9 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     if prepared_out is not None:
         prepared_out["pt"], prepared_out["pv"] = pt, pv
     S, aux0, mean_t, mean_v = L["S"], L["aux0"], L["mean_t"], L["mean_v"]
-    if gt.shape[1] != 1 or gv.shape[1] != 1:
-        raise RuntimeError("more than one global token per sample: the reference's centrality term "
-                           "fails to broadcast at this shape (until_module.py:321); parity unpinned")
-    gt2 = gt.reshape(B, d).float().contiguous()
-    gv2 = gv.reshape(B, d).float().contiguous()
+    _check_global_tokens(gt, gv, hp)
+    gt2 = gt.float().contiguous()                  # [B, G, d]: G = 1 at the MSR-VTT token counts
+    gv2 = gv.float().contiguous()
     ls = logit_scale.detach().float().reshape(1).contiguous()
     # Loss-only step at B <= 128 ("split tail"): the global logits and the Sinkhorn solve depend on the clustering
     # alone, so they follow it on THIS stream without waiting for the local branch; the Sinkhorn kernel emits the
@@ -277,7 +292,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         with torch.cuda.stream(side):
             pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
             side.wait_event(g_ready)
-            wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
+            wc_t, wc_v, cw_aux = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
             side.wait_stream(side2)
             ops.row_losses_no_uniform(S, G, c0, c1, wc_t, wc_v, ls, K, hp["temperature"], rowloss)
         cur.wait_stream(side)
@@ -311,7 +326,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
                 pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
             with torch.cuda.stream(bank_streams[0]):
                 pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
-                wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
+                wc_t, wc_v, cw_aux = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
             for st_ in bank_streams:
                 cur.wait_stream(st_)
             for t_ in (c0, c1, wc_t, wc_v) + ((pbt.hi, pbv.hi, w_bt, w_bv) if keep else ()):
@@ -319,7 +334,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         else:
             pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
             pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
-            wc_t, wc_v, gn_t, gn_v = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
+            wc_t, wc_v, cw_aux = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
         rowloss, losses = ops.row_losses_final(S, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"],
                                                hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
     saved = None
@@ -327,7 +342,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         saved = dict(pt=pt, pv=pv, pbt=pbt, pbv=pbv, w_t=w_t, w_v=w_v, w_bt=w_bt, w_bv=w_bv,
                      lg_t=lg_t, lg_v=lg_v, lg_bt=lg_bt, lg_bv=lg_bv,
                      aux=(aux0, aux1, aux2), S=S, G=G, tgt_r=tgt_r, tgt_c=tgt_c,
-                     c0=c0, c1=c1, wc_t=wc_t, wc_v=wc_v, gn_t=gn_t, gn_v=gn_v, mean_t=mean_t, mean_v=mean_v,
+                     c0=c0, c1=c1, wc_t=wc_t, wc_v=wc_v, cw_aux=cw_aux, mean_t=mean_t, mean_v=mean_v,
                      ls=ls, gt2=gt2, gv2=gv2)
     return losses, saved
 
@@ -339,7 +354,8 @@ def _rows(prep, first, count):
 
 
 def head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
-                         gt, gv, sw_t, sw_v, hp, logit_scale, prec, rank, world, bank_prepared=None, prepared_out=None):
+                         gt, gv, sw_t, sw_v, hp, logit_scale, prec, rank, world, bank_prepared=None, prepared_out=None,
+                         sw_t1=None, sw_v1=None):
     """Loss-only forward with the similarity and bank work SHARDED over `world` ranks: rank r owns the
     samples [r*b, (r+1)*b) of the gathered batch and computes the two slabs of S it needs for its rows of either
     direction (2/W of the batch x batch product), its slice of both bank centrality vectors (1/W of the bank
@@ -355,8 +371,7 @@ def head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t
         raise ValueError("the gathered batch must divide over the ranks")
     if K > B:
         raise ValueError(f"num_neighbors={K} > batch={B}")
-    if gt.shape[1] != 1 or gv.shape[1] != 1:
-        raise RuntimeError("more than one global token per sample (until_module.py:321)")
+    _check_global_tokens(gt, gv, hp)
     b, r0 = B // world, rank * (B // world)
     p_bb, p_mlp, p_bank = precision_plan(prec)
     text_mask, video_mask, mb_mask_t, mb_mask_v = (m if m.dtype == torch.float32 else m.float()
@@ -389,11 +404,11 @@ def head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t
     c1 = everyone[:, 1, :].reshape(B).contiguous()
     mean_t = ops.reduce_parts(pt.colsum, 1.0 / pt.n_tok)
     mean_v = ops.reduce_parts(pv.colsum, 1.0 / pv.n_tok)
-    gt2 = gt.reshape(B, d).float().contiguous()
-    gv2 = gv.reshape(B, d).float().contiguous()
-    G = global_logits(gt, gv)
+    gt2 = gt.float().contiguous()
+    gv2 = gv.float().contiguous()
+    G = global_logits(gt, gv, sw_t1, sw_v1)
     tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
-    wc_t, wc_v, _, _ = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], False)
+    wc_t, wc_v, _ = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], False)
     ls = logit_scale.detach().float().reshape(1).contiguous()
     rowloss = ops.row_losses_slab(S_rows, S_cols, r0, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"])
     dist.all_reduce(rowloss)                       # every row was written by exactly one rank, zeros elsewhere

@@ -47,7 +47,7 @@ _SIGNATURES = {
     "nr_reduce_parts": ([_P, _I, _I, _F, _P, _P], _I),
     "nr_gemm_nt_f32": ([_P, _P, _I, _I, _I, _P, _P], _I),
     "nr_centrality_weights": ([_P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P], _I),
-    "nr_centrality_weights_pair": ([_P, _P, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P], _I),
+    "nr_centrality_weights_pair": ([_P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P], _I),
     "nr_dpc_workspace_bytes": ([_I, _I], _Z),
     "nr_dpc_knn_assign": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     "nr_shift_concat": ([_P, _I, _I, _I, _P, _P], _I),

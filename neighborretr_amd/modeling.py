@@ -25,7 +25,11 @@ from .until_module import (AllGather, CentralityWeightingLoss, KLDivergenceLoss,
 allgather = AllGather.apply
 
 DEFAULTS = dict(centrality_scale=0.3, beta=0.7, num_neighbors=20, temperature=3.0, uniform_weight=1.0,
-                neighbor_weight=1.0, kl_weight=1.0, world_size=1, local_rank=0)   # args_parser.py:26-41
+                neighbor_weight=1.0, kl_weight=1.0, world_size=1, local_rank=0,   # args_parser.py:26-41
+                # this build: what the centrality term does when a sample keeps SEVERAL global tokens (ActivityNet token
+                # counts).  "raise" = the reference's behaviour (until_module.py:321 fails to broadcast); "mean" = weight
+                # averaged over the sample's global tokens (head._check_global_tokens)
+                centrality_multi_token="raise")
 
 
 class FeatureModeCLIP(nn.Module):
@@ -99,6 +103,11 @@ class NeighborRetr(nn.Module):
 
     def _init_memory_bank(self):
         cpu = torch.device("cpu")
+        # generation of the bank's STORAGE: bumped whenever the tensors a captured graph may have baked in (the five
+        # bank tensors, the device ring head) are replaced -- main_retrieval.GraphedStep re-captures on a change
+        self._mb_gen = getattr(self, "_mb_gen", 0) + 1
+        # True: the step neither moves the ring head nor pushes (graph-capture warm-up must leave the bank alone)
+        self.bank_frozen = getattr(self, "bank_frozen", False)
         self._mb = {
             "mb_ind": torch.tensor([], dtype=torch.long, device=cpu),
             "mb_feat_t": torch.empty((0, 0, 0), dtype=torch.float, device=cpu),
@@ -128,10 +137,13 @@ class NeighborRetr(nn.Module):
     # rewrites only the batch rows (nr_bank_ring_push) instead of shifting the whole bank.  Reading an
     # attribute from outside materialises the FIFO order first; the forward pass reads the raw ring,
     # whose order is irrelevant (the bank is only consumed through means over its samples).
-    def _bank_shadow(self):
+    def _bank_shadow(self, mb_feat_t=None, mb_feat_v=None):
         """(text, video) ops.Prepared of the bank for the loss-only step, or None (CPU bank, shadow disabled, grad
-        mode: the training path keeps its own prepare launches, whose outputs the backward saves)."""
+        mode: the training path keeps its own prepare launches, whose outputs the backward saves -- or the bank
+        features handed to _compute_losses are not this model's own ring tensors)."""
         mb = self._mb
+        if (mb_feat_t is not None and mb_feat_t is not mb["mb_feat_t"]) or (mb_feat_v is not None and mb_feat_v is not mb["mb_feat_v"]):
+            return None
         if not self.use_bank_shadow or torch.is_grad_enabled() or mb["mb_feat_v"].numel() == 0 or not mb["mb_feat_v"].is_cuda:
             return None
         if self._mb_shadow is None:
@@ -145,10 +157,12 @@ class NeighborRetr(nn.Module):
         if self._mb_head_dev is not None:
             self._mb_head = int(self._mb_head_dev.item())          # (a sync: only when the bank is read from outside)
             self._mb_head_dev = None
+            self._mb_gen += 1                                      # a captured graph holds the old head tensor
         if self._mb_head:
             h = self._mb_head
             self._mb = {k: torch.roll(v, shifts=-h, dims=0) for k, v in self._mb.items()}
             self._mb_head = 0
+            self._mb_gen += 1
 
     def _ring_ready(self, b):
         """(head tensor, advance, capacity) for the step prologue when the coming push takes the ring path, else None."""
@@ -159,6 +173,7 @@ class NeighborRetr(nn.Module):
         if self._mb_head_dev is None or self._mb_head_dev.device != mb["mb_feat_v"].device:
             self._mb_head_dev = torch.tensor([self._mb_head], dtype=torch.int32, device=mb["mb_feat_v"].device)
             self._mb_head = 0
+            self._mb_gen += 1
         return self._mb_head_dev, b, cap
 
     def _bank_get(self, name):
@@ -171,6 +186,7 @@ class NeighborRetr(nn.Module):
             value = value.float()        # masks live as fp32 (the reference's own initial dtype, :182-183)
         self._mb[name] = value
         self._mb_shadow = None
+        self._mb_gen += 1
 
     mb_ind = property(lambda self: self._bank_get("mb_ind"), lambda self, v: self._bank_set("mb_ind", v))
     mb_feat_t = property(lambda self: self._bank_get("mb_feat_t"), lambda self, v: self._bank_set("mb_feat_t", v))
@@ -197,6 +213,14 @@ class NeighborRetr(nn.Module):
             return sw
         return hit[1]
 
+    def _global_scorers(self, text_feat, video_feat):
+        """sw_t1 / sw_v1 keyword arguments of the head: the *_weight_fc1 scorers, needed by global_level only when a
+        sample keeps more than one global token (modeling.py:518-523; one token => softmax weight 1)."""
+        (_, t1), (_, v1) = self._token_counts(text_feat.shape[1], video_feat.shape[1])
+        if t1 == 1 and v1 == 1:
+            return {}
+        return dict(sw_t1=self.scorer_weights("text_weight_fc1"), sw_v1=self.scorer_weights("video_weight_fc1"))
+
     # ------------------------------------------------------------------ memory bank (modeling.py:222-249)
     def update_memory_bank(self, idx, text_feat, video_feat, text_mask, video_mask):
         new = {"mb_ind": idx, "mb_feat_v": video_feat.detach(), "mb_feat_t": text_feat.detach(),
@@ -206,6 +230,7 @@ class NeighborRetr(nn.Module):
             self._mb = {k: (v.float() if k.startswith("mb_mask") else v.clone()) for k, v in new.items()}
             self._mb_shadow = None
             self._mb_head, self._mb_head_dev = 0, None
+            self._mb_gen += 1
             self.mb_batch = idx.size(0)
             return
         cap, b = mb["mb_feat_v"].size(0), idx.size(0)
@@ -215,6 +240,7 @@ class NeighborRetr(nn.Module):
             self._bank_fifo()
             self._mb = {k: torch.cat((new[k].to(v.dtype), v), 0)[:cap].contiguous() for k, v in self._mb.items()}
             self._mb_shadow = None
+            self._mb_gen += 1
             return
         ring = self._ring_ready(b)
         if not self._ring_advanced:                            # called outside loss_step: move the head here
@@ -260,7 +286,7 @@ class NeighborRetr(nn.Module):
             scale_in_kernel = not (torch.is_grad_enabled() and raw_scale.requires_grad)
             sizes = self._noise_sizes(text_feat.shape[1], video_feat.shape[1])
             B = text_feat.shape[0]
-            ring = self._ring_ready(B)
+            ring = None if self.bank_frozen else self._ring_ready(B)
             text_mask, video_mask, ls_exp, flat = ops.step_prologue(
                 text_mask, video_mask, raw_scale if scale_in_kernel else None,
                 self._rng_state_on(text_feat.device), B * sum(sizes.values()), ring=ring)
@@ -275,8 +301,9 @@ class NeighborRetr(nn.Module):
                                       self._mb["mb_feat_t"], self._mb["mb_feat_v"], self._mb["mb_mask_t"], self._mb["mb_mask_v"],
                                       cfg.centrality_scale, cfg.beta, cfg.num_neighbors, cfg.temperature,
                                       logit_scale, noise=noise)
-        with torch.no_grad():
-            self.update_memory_bank(idx, text_feat, video_feat, text_mask, video_mask)
+        if not self.bank_frozen:
+            with torch.no_grad():
+                self.update_memory_bank(idx, text_feat, video_feat, text_mask, video_mask)
         return losses
 
     # ------------------------------------------------------------------ losses (modeling.py:314-360)
@@ -284,7 +311,7 @@ class NeighborRetr(nn.Module):
         c = self.config
         return dict(centrality_scale=centrality_scale, beta=beta, num_neighbors=num_neighbors,
                     temperature=temperature, uniform_weight=c.uniform_weight, neighbor_weight=c.neighbor_weight,
-                    kl_weight=c.kl_weight)
+                    kl_weight=c.kl_weight, centrality_multi_token=getattr(c, "centrality_multi_token", "raise"))
 
     def _compute_losses(self, text_feat, video_feat, text_mask, video_mask,
                         mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
@@ -303,8 +330,8 @@ class NeighborRetr(nn.Module):
             losses = head.head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v,
                                                mb_mask_t, mb_mask_v, gt, gv, self.scorer_weights("text_weight_fc"),
                                                self.scorer_weights("video_weight_fc"), hp, logit_scale, self._prec(),
-                                               dist.get_rank(), world, bank_prepared=self._bank_shadow(),
-                                               prepared_out=self._last_prepared)
+                                               dist.get_rank(), world, bank_prepared=self._bank_shadow(mb_feat_t, mb_feat_v),
+                                               prepared_out=self._last_prepared, **self._global_scorers(text_feat, video_feat))
             return losses[0], losses[1], losses[2], losses[3], losses[4]
         if (text_feat.is_cuda and self.use_side_streams and self.group_clustering and not torch.is_grad_enabled()
                 and self._can_fuse_clustering(text_feat, mods) and self._can_fuse_clustering(video_feat, mods)):
@@ -392,8 +419,16 @@ class NeighborRetr(nn.Module):
         return not (feat.requires_grad or any(p.requires_grad for m in mods for p in m.parameters()))
 
     @staticmethod
-    def _noise_sizes(Nt, Nv):
-        t0, v0 = max(math.ceil(Nt / 6), 1), max(math.ceil(Nv / 4), 1)
+    def _token_counts(Nt, Nv):
+        """((text tokens after stage 0, after stage 1), (video ...)): cluster.py:712 with the ratios of
+        modeling.py:188-196 (the same float products as the CTM modules evaluate)."""
+        t0 = max(math.ceil(Nt * (1 / 6)), 1)
+        v0 = max(math.ceil(Nv * (1 / 4)), 1)
+        return (t0, max(math.ceil(t0 * (1 / 4)), 1)), (v0, max(math.ceil(v0 * (1 / 3)), 1))
+
+    @classmethod
+    def _noise_sizes(cls, Nt, Nv):
+        (t0, _), (v0, _) = cls._token_counts(Nt, Nv)
         return {"t0": Nt, "t1": t0, "v0": Nv, "v1": v0}
 
     @staticmethod

@@ -120,17 +120,25 @@ def centrality_weights(g, colsum, n_tok, scale, want_aux=False):
 
 
 def centrality_weights_pair(gt, gv, mean_t, mean_v, scale, want_aux=False):
-    """(w_text, w_video, gnorm_text, gnorm_video) from finished token means (nr_centrality_weights_pair)."""
-    B, d = gt.shape
+    """(w_text [B], w_video [B], aux) from finished token means (nr_centrality_weights_pair).
+    gt [B,d] or [B,Gt,d], gv likewise: with several global tokens per sample the weight is the mean over them
+    (config.centrality_multi_token = "mean").  aux = None or (gnorm_t, gnorm_v, wtok_t, wtok_v), per global token."""
+    if gt.dim() == 2:
+        gt, gv = gt[:, None, :], gv[:, None, :]
+    B, n_gt, d = gt.shape
+    n_gv = gv.shape[1]
     dev = gt.device
     w_t = torch.empty((B,), dtype=torch.float32, device=dev)
     w_v = torch.empty((B,), dtype=torch.float32, device=dev)
-    gn_t = torch.empty((B,), dtype=torch.float32, device=dev) if want_aux else None
-    gn_v = torch.empty((B,), dtype=torch.float32, device=dev) if want_aux else None
-    hip.call("nr_centrality_weights_pair", hip.ptr(gt, torch.float32), hip.ptr(gv, torch.float32), B, d,
+    aux = None
+    if want_aux:
+        aux = tuple(torch.empty((B * n,), dtype=torch.float32, device=dev) for n in (n_gt, n_gv, n_gt, n_gv))
+    a = aux or (None,) * 4
+    hip.call("nr_centrality_weights_pair", hip.ptr(gt, torch.float32), hip.ptr(gv, torch.float32), B, n_gt, n_gv, d,
              hip.ptr(mean_t, torch.float32), hip.ptr(mean_v, torch.float32), float(scale), hip.ptr(w_t), hip.ptr(w_v),
-             hip.ptr(gn_t, allow_none=True), hip.ptr(gn_v, allow_none=True), hip.stream_ptr())
-    return w_t, w_v, gn_t, gn_v
+             hip.ptr(a[0], allow_none=True), hip.ptr(a[1], allow_none=True), hip.ptr(a[2], allow_none=True),
+             hip.ptr(a[3], allow_none=True), hip.stream_ptr())
+    return w_t, w_v, aux
 
 
 def dpc_knn_assign(x, cluster_num, k, mask=None, noise=None):

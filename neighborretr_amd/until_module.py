@@ -33,6 +33,11 @@ class CentralityWeightingLoss(_RowLossModule):
         S = similarity_matrix.float().contiguous()
         z, v, one = self._neutral(S)
         w = centrality_weights.float().contiguous()
+        if w.dim() != 1 or w.shape[0] != S.shape[0]:
+            # the reference multiplies diag_log_probs [B] by the weights and fails to broadcast (until_module.py:321)
+            raise RuntimeError(f"The size of tensor a ({S.shape[0]}) must match the size of tensor b ({w.shape[-1]}) at "
+                               "non-singleton dimension 1: one centrality weight per sample expected (several global "
+                               "tokens per sample: see config.centrality_multi_token)")
         rl = row_loss_terms(S, z, z, z, v, v, w, w, one, 0, 1.0)
         return rl[0, 0].mean()
 

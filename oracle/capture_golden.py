@@ -172,9 +172,14 @@ def capture_case(name, NeighborRetr, seed, B, Nt, Nv, M, K, full=True, blank_vid
         with FeedRand(noise_queue(noise)):
             gt_ref, gv_ref = m.merge_global_features(tf, vf, tm, vm)
         nt = {k: torch.from_numpy(v) for k, v in noise.items()}
-        gt_o, gv_o = O.merge_global_features(tf, vf, tm, vm, Pt, nt)
+        # the oracle under the tie rule the reference executes (torch.topk on this host) ...
+        gt_o, gv_o = O.merge_global_features(tf, vf, tm, vm, Pt, nt, centre_ties="torch_topk")
         rec("gt", gt_ref, gt_o)
         rec("gv", gv_ref, gv_o)
+        # ... and under the build's documented rule (ties -> lower index): not stored, only reported
+        gt_l, gv_l = O.merge_global_features(tf, vf, tm, vm, Pt, nt, centre_ties="lowest_index")
+        rec("gt[lowest_index]", gt_ref, gt_l, store=False)
+        rec("gv[lowest_index]", gv_ref, gv_l, store=False)
         G_ref, _ = m.global_level(gt_ref, gv_ref)
         G_o, _ = O.global_level(gt_o, gv_o, Pt)
         rec("G", G_ref, G_o)

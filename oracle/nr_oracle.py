@@ -86,16 +86,31 @@ def global_level(gt, gv, P):
 # ---------------------------------------------------------------------------
 # a-5  centrality weights                             (modeling.py:403-430)
 # ---------------------------------------------------------------------------
-def centrality_weights(text_feat, video_feat, gt, gv, centrality_scale):
-    """exp(c * mean_j <g_i, x_j>) over ALL B*N tokens, padding included (:423-428)."""
+def centrality_weights(text_feat, video_feat, gt, gv, centrality_scale, multi_token="raise"):
+    """exp(c * mean_j <g_i, x_j>) over ALL B*N tokens, padding included (:423-428).
+
+    One global token per sample (MSR-VTT token counts): [B] weights, as the reference.  With G > 1 global tokens
+    (ActivityNet token counts: 3 text / 6 video tokens) the reference's expression yields [B,G] weights and its
+    loss then fails to broadcast (until_module.py:321) -- there is NO reference answer.  `multi_token`:
+      "raise"  (default) keep the [B,G] weights the reference computes; centrality_weighting_loss raises like it;
+      "mean"   the build's documented reduction: w_i = mean_g exp(c * <g_ig, mean_j x_j>), i.e. what
+               `diag_log_probs[:, None] * weights` followed by the reference's `.mean()` would have given."""
     d = text_feat.shape[-1]
     tn = F.normalize(text_feat.reshape(-1, d), dim=-1)
     vn = F.normalize(video_feat.reshape(-1, d), dim=-1)
-    gtn = F.normalize(gt.squeeze(1), dim=-1)
+    gtn = F.normalize(gt.squeeze(1), dim=-1)                        # :409  (squeeze is a no-op when G > 1)
     gvn = F.normalize(gv.squeeze(1), dim=-1)
-    ct = (gtn @ tn.t()).mean(-1)
+    ct = (gtn @ tn.t()).mean(-1)                                    # [B] or [B,G]
     cv = (gvn @ vn.t()).mean(-1)
-    return torch.exp(ct * centrality_scale), torch.exp(cv * centrality_scale)
+    wt, wv = torch.exp(ct * centrality_scale), torch.exp(cv * centrality_scale)
+    if multi_token == "mean":
+        if wt.dim() == 2:
+            wt = wt.mean(-1)
+        if wv.dim() == 2:
+            wv = wv.mean(-1)
+    elif multi_token != "raise":
+        raise ValueError(f"multi_token={multi_token!r}")
+    return wt, wv
 
 
 # ---------------------------------------------------------------------------
@@ -103,7 +118,7 @@ def centrality_weights(text_feat, video_feat, gt, gv, centrality_scale):
 # ---------------------------------------------------------------------------
 def centrality_weighting_loss(S_scaled, w):
     lp = F.log_softmax(S_scaled, dim=-1)
-    return -(torch.diag(lp) * w).mean()
+    return -(torch.diag(lp) * w).mean()          # [B] * [B,G] raises RuntimeError, as until_module.py:321 does
 
 
 def centrality_loss(S, w_text, w_video, logit_scale):
@@ -212,8 +227,17 @@ def kl_loss(G, S):
 # ---------------------------------------------------------------------------
 # a-10  merge_global_features (DPC-KNN token merging) (cluster.py, modeling.py:446-481)
 # ---------------------------------------------------------------------------
-def dpc_knn(x, cluster_num, k, mask, noise):
-    """cluster.py:453-509.  `noise` replaces the reference's torch.rand draw (:483)."""
+def dpc_knn(x, cluster_num, k, mask, noise, centre_ties="lowest_index"):
+    """cluster.py:453-509.  `noise` replaces the reference's torch.rand draw (:483).
+
+    `centre_ties` states how EXACT ties in the centre score are broken (:498, torch.topk there).  The only
+    exact ties that occur are the zero scores of padding tokens (density * valid == 0, :488): a sample with fewer
+    valid tokens than `cluster_num` takes its extra centres among them.
+      "lowest_index"  the tied token with the lower index wins (a stable descending sort) -- the documented rule
+                      of this build; what the HIP kernels implement.
+      "torch_topk"    whatever torch.topk does on this host (implementation-defined: an nth_element artefact on
+                      CPU, a radix select on GPU) -- what the reference executes; used by capture_golden.py and
+                      by the CPU test that records on which fixture rows the two rules pick different centres."""
     B, N, C = x.shape
     dist = torch.cdist(x, x) / (C ** 0.5)
     if mask is not None:
@@ -227,7 +251,12 @@ def dpc_knn(x, cluster_num, k, mask, noise):
     dmax = dist.flatten(1).max(-1)[0][:, None, None]
     parent_dist = (dist * higher + dmax * (1 - higher)).min(-1)[0]                  # :494
     score = parent_dist * density                                                   # :497
-    centres = torch.topk(score, k=cluster_num, dim=-1)[1]                           # :498
+    if centre_ties == "torch_topk":
+        centres = torch.topk(score, k=cluster_num, dim=-1)[1]                       # :498
+    elif centre_ties == "lowest_index":
+        centres = torch.sort(score, dim=-1, descending=True, stable=True)[1][:, :cluster_num]
+    else:
+        raise ValueError(f"centre_ties={centre_ties!r}")
     to_centre = torch.gather(dist, 1, centres[:, :, None].expand(B, cluster_num, N))
     assign = to_centre.argmin(dim=1)                                                # :501-502
     assign.scatter_(1, centres, torch.arange(cluster_num)[None, :].expand(B, cluster_num))  # :505-507
@@ -243,7 +272,7 @@ def merge_tokens(x, assign, cluster_num, tok_w):
     return torch.einsum("bnc,bnd->bcd", onehot, x * nw[..., None])  # :543-547
 
 
-def ctm_stage(x, mask, P, ctm, blk, ratio, k, noise):
+def ctm_stage(x, mask, P, ctm, blk, ratio, k, noise, centre_ties="lowest_index"):
     """CTM (cluster.py:689-717) followed by TCBlock (cluster.py:938-965)."""
     B, N, C = x.shape
     x = x + F.conv1d(x.transpose(1, 2), P[ctm + ".conv.conv.weight"], padding=1).transpose(1, 2)  # :664
@@ -255,7 +284,7 @@ def ctm_stage(x, mask, P, ctm, blk, ratio, k, noise):
         score = score.masked_fill((1 - mask).to(torch.bool), float("-inf"))
     tok_w = score.exp()
     cnum = max(math.ceil(N * ratio), 1)
-    assign = dpc_knn(x.detach(), cnum, k, mask, noise)
+    assign = dpc_knn(x.detach(), cnum, k, mask, noise, centre_ties)
     merged = merge_tokens(x, assign, cnum, tok_w)
     # TCBlock: q = merged tokens, kv = un-merged tokens, both through norm1
     qn = F.layer_norm(merged, (C,), P[blk + ".norm1.weight"], P[blk + ".norm1.bias"])
@@ -281,12 +310,12 @@ def merged_token_counts(Nt, Nv):
     return (t0, t1), (v0, v1)
 
 
-def merge_global_features(text_feat, video_feat, text_mask, video_mask, P, noise):
+def merge_global_features(text_feat, video_feat, text_mask, video_mask, P, noise, centre_ties="lowest_index"):
     """modeling.py:446-481.  noise = dict(t0,t1,v0,v1) of [B,N_stage] uniform draws."""
-    t = ctm_stage(text_feat, text_mask, P, "text_ctm0", "text_block0", 1 / 6, 3, noise["t0"])
-    v = ctm_stage(video_feat, video_mask, P, "video_ctm0", "video_block0", 1 / 4, 3, noise["v0"])
-    t = ctm_stage(t, None, P, "text_ctm1", "text_block1", 1 / 4, 3, noise["t1"])
-    v = ctm_stage(v, None, P, "video_ctm1", "video_block1", 1 / 3, 3, noise["v1"])
+    t = ctm_stage(text_feat, text_mask, P, "text_ctm0", "text_block0", 1 / 6, 3, noise["t0"], centre_ties)
+    v = ctm_stage(video_feat, video_mask, P, "video_ctm0", "video_block0", 1 / 4, 3, noise["v0"], centre_ties)
+    t = ctm_stage(t, None, P, "text_ctm1", "text_block1", 1 / 4, 3, noise["t1"], centre_ties)
+    v = ctm_stage(v, None, P, "video_ctm1", "video_block1", 1 / 3, 3, noise["v1"], centre_ties)
     return t, v
 
 
@@ -295,18 +324,20 @@ def merge_global_features(text_feat, video_feat, text_mask, video_mask, P, noise
 # ---------------------------------------------------------------------------
 def compute_losses(text_feat, video_feat, text_mask, video_mask,
                    mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v, P, hp, logit_scale, noise,
-                   return_parts=False):
+                   return_parts=False, centrality_multi_token="raise", centre_ties="lowest_index"):
     """hp: dict(centrality_scale, beta, num_neighbors, temperature,
-    uniform_weight, neighbor_weight, kl_weight)."""
+    uniform_weight, neighbor_weight, kl_weight).
+    centrality_multi_token: see centrality_weights (only matters with > 1 global token per sample).
+    centre_ties: see dpc_knn."""
     S, _ = local_level(text_feat, video_feat, text_mask, video_mask, P)
-    gt, gv = merge_global_features(text_feat, video_feat, text_mask, video_mask, P, noise)
+    gt, gv = merge_global_features(text_feat, video_feat, text_mask, video_mask, P, noise, centre_ties)
     G, _ = global_level(gt, gv, P)
     L_u = uniform_loss(G, hp["temperature"], hp["beta"])
     L_kl = kl_loss(G, S)
-    if gt.shape[1] != 1 or gv.shape[1] != 1:
+    if (gt.shape[1] != 1 or gv.shape[1] != 1) and centrality_multi_token == "raise":
         raise RuntimeError("reference crashes here when >1 global token survives "
                            "(until_module.py:321); parity unpinned for this term")
-    w_text, w_video = centrality_weights(text_feat, video_feat, gt, gv, hp["centrality_scale"])
+    w_text, w_video = centrality_weights(text_feat, video_feat, gt, gv, hp["centrality_scale"], centrality_multi_token)
     L_c = centrality_loss(S, w_text, w_video, logit_scale)
     bank_t2v = local_level(text_feat, mb_feat_v, text_mask, mb_mask_v, P)[0]       # :389
     bank_v2t = local_level(mb_feat_t, video_feat, mb_mask_t, video_mask, P)[1]     # :390

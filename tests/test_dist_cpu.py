@@ -32,7 +32,7 @@ def _worker(rank, world, port, q):
         tm = (torch.rand(b, Nt, generator=g) > 0.3).long()
         vm = (torch.rand(b, Nv, generator=g) > 0.3).long()
         G_tf, G_vf, G_idx, G_tm, G_vm = packed_allgather(tf, vf, idx, tm, vm, args)
-        assert G_tf.shape == (world * b, Nt, d) and G_vm.dtype == vm.dtype and G_idx.dtype == torch.int64
+        assert G_tf.shape == (world * b, Nt, d) and G_vm.dtype == torch.float32 and G_idx.dtype == torch.int64
         # every rank must see rank r's shard at rows [r*b, (r+1)*b)
         for r in range(world):
             gr = torch.Generator().manual_seed(100 + r)
@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
             e_vf = torch.randn(b, Nv, d, generator=gr)
             assert torch.equal(G_tf[r * b:(r + 1) * b], e_tf) and torch.equal(G_vf[r * b:(r + 1) * b], e_vf)
             assert G_idx[r * b:(r + 1) * b].tolist() == (torch.arange(b) + 10 * r).tolist()
-        assert torch.equal(G_tm[rank * b:(rank + 1) * b], tm) and torch.equal(G_vm[rank * b:(rank + 1) * b], vm)
+        assert torch.equal(G_tm[rank * b:(rank + 1) * b], tm.float()) and torch.equal(G_vm[rank * b:(rank + 1) * b], vm.float())
         # backward = this rank's slice of the upstream gradient, no reduction (until_module.py:383-388)
         w = torch.arange(G_tf.numel(), dtype=torch.float32).view_as(G_tf)
         ((G_tf * w).sum() + 2.0 * G_vf.sum()).backward()

@@ -21,3 +21,83 @@ def test_main_retrieval_synthetic_trains_and_evaluates(tmp_path, hip_graph):
     losses = [float(l.split(" loss ")[1].split()[0]) for l in r.stdout.splitlines() if " loss " in l]
     assert all(x == x and x < 1e4 for x in losses), losses           # finite
     assert os.path.exists(os.path.join(str(tmp_path), "pytorch_model.bin.0"))
+
+
+def _trainable_model(K=4):
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from neighborretr_amd import modeling
+    from util import params
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K))
+    m.load_state_dict(params(), strict=False)
+    m = m.to("cuda").train()
+    with torch.no_grad():
+        m.clip.logit_scale.fill_(float(np.log(100.0)))
+    return m
+
+
+def test_graphed_training_step_keeps_the_reference_fifo():
+    """the bank after N graph-replayed training steps equals the bank after N eager steps (the capture
+    warm-up must not push), also across a bank replaced from outside (MemoryBankManager does that every epoch:
+    the graph is re-captured through the bank's storage generation, never replayed on stale tensors)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from main_retrieval import GraphedStep
+    from util import problem
+    B, Nt, Nv, M = 8, 24, 12, 40
+    dev = "cuda"
+    x = problem(1003, B, Nt, Nv, M, device=dev)
+
+    def batch(r):
+        return (x["text_feat"] + 0.01 * r, x["text_mask"], x["video_feat"] + r, x["video_mask"], x["idx"] + 100 * r)
+
+    def load_bank(m, shift):
+        m.mb_feat_t, m.mb_feat_v = x["mb_feat_t"].clone() + shift, x["mb_feat_v"].clone() + shift
+        m.mb_mask_t, m.mb_mask_v = x["mb_mask_t"].clone(), x["mb_mask_v"].clone()
+        m.mb_ind = torch.arange(5000 + shift, 5000 + shift + M, device=dev)
+
+    eager, graphed = _trainable_model(), _trainable_model()
+    params_g = [p for p in graphed.parameters() if p.requires_grad]
+    step = None
+    for epoch in range(2):
+        load_bank(eager, epoch)
+        load_bank(graphed, epoch)
+        for r in range(3):
+            bt = batch(3 * epoch + r)
+            eager.zero_grad(set_to_none=True)
+            le = eager(*bt, 0)
+            le[0].backward()
+            if step is None:
+                step = GraphedStep(graphed, bt, params_g)
+            lg = step.run(bt)
+            torch.cuda.synchronize()
+            assert abs(float(lg[0]) - float(le[0])) < 1e-3 * abs(float(le[0])), (epoch, r, float(lg[0]), float(le[0]))
+        torch.cuda.synchronize()
+        gen = graphed._mb_gen
+        assert torch.equal(graphed.mb_ind, eager.mb_ind), (epoch, graphed.mb_ind[:3 * B], eager.mb_ind[:3 * B])
+        assert torch.equal(graphed.mb_feat_v, eager.mb_feat_v) and torch.equal(graphed.mb_feat_t, eager.mb_feat_t)
+        assert torch.equal(graphed.mb_mask_v, eager.mb_mask_v)
+        assert graphed._mb_gen > gen                  # reading the bank from outside re-ordered it: next run() re-captures
+        # newest first: the three batches of this epoch, then the head of the epoch's initial bank
+        want = torch.cat([batch(3 * epoch + r)[4] for r in (2, 1, 0)] + [torch.arange(5000 + epoch, 5000 + epoch + M, device=dev)])[:M]
+        assert torch.equal(graphed.mb_ind, want)
+
+
+@pytest.mark.parametrize("shard", [0])
+def test_main_retrieval_two_ranks_on_one_gpu(tmp_path, shard):
+    """The W>1 branch of the entry point (process-group init, DDP wrap, packed exchange step in forward and in the bank
+    load, reduce_losses) with two gloo ranks sharing the card.  RCCL needs one GPU per rank; the code around the
+    collective calls is what executes here."""
+    port = 29631
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "main_retrieval.py"), "--do_train", "1", "--synthetic",
+           "--batch_size", "32", "--num_neighbors", "8", "--mb_batch", "2", "--epochs", "1", "--synthetic_train", "128",
+           "--synthetic_test", "100", "--n_display", "2", "--output_dir", str(tmp_path), "--dist_backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "memory bank: 64 samples" in r.stdout                       # 2 batches x 16 per rank x 2 ranks, gathered
+    losses = [float(l.split(" loss ")[1].split()[0]) for l in r.stdout.splitlines() if " loss " in l]
+    assert losses and all(x == x and x < 1e4 for x in losses), r.stdout[-2000:]
+    assert "text->video R@1" in r.stdout

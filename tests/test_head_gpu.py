@@ -1,9 +1,9 @@
 """GPU: the drop-in model API end to end -- forward losses and gradients against (a) the vectors
 captured from the reference (tests/golden) and (b) the CPU oracle's autograd on the same inputs.
 
-Tolerances: split-bf16 ("bf16x3") path <= 2e-4 on every loss and 1e-3 relative on gradients;
-single-pass bf16 path <= 1e-3 on losses / logits (BASELINE.json north_star) and retrieval ranks
-identical on the bf16x3 path.
+Tolerances (flat, absolute): split-bf16 ("bf16x3") path <= 2e-4 on every loss and 2e-3 relative on gradients;
+training plan ("bf16") <= 1e-3 on losses / logits (BASELINE.json north_star); retrieval ranks identical on the
+bf16x3 path.  The measured deviations are printed (pytest -s).
 """
 import numpy as np
 import pytest
@@ -45,8 +45,11 @@ def test_forward_losses_match_reference(name, precision, tol):
     with torch.no_grad():
         losses = torch.stack(_losses(m, x, nz, K)).cpu().numpy()
         S, St = m.get_similarity_logits(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"])
-    assert np.max(np.abs(losses - g["losses"])) < tol * max(1.0, float(np.abs(g["losses"]).max()) / 10), (losses, g["losses"])
-    assert maxdiff(S, g["S"]) < (2e-6 if precision == "bf16x3" else 1e-3)
+    dL = np.abs(losses - g["losses"])
+    dS = maxdiff(S, g["S"])
+    print(f"\n[{name} {precision}] |dL| (total, centrality, uniform, neighbour, kl) = {dL.tolist()}  max|dS| = {dS:.2e}")
+    assert dL.max() < tol, (losses, g["losses"])
+    assert dS < (2e-6 if precision == "bf16x3" else 1e-3)
     assert torch.equal(St, S.T)
     if precision == "bf16x3":
         # identical retrieval ranks (north_star): same `cols` as the reference's metrics on its own S
@@ -102,14 +105,14 @@ def test_fused_clustering_matches_oracle_and_torch_path(B, Nt, Nv):
     with torch.no_grad():
         gt_t, gv_t = m.merge_global_features(xg["text_feat"], xg["video_feat"], xg["text_mask"], xg["video_mask"], nzg)
     scale = float(gt_o.abs().max())
-    # A sample with fewer valid tokens than cluster centres (video of 1-2 frames, 3 centres) takes
-    # its extra centres among zero-score padding tokens: a tie that torch.topk breaks differently on
-    # CPU and GPU in the reference itself.  Those samples are compared between our two GPU paths only.
-    ok_t = (x["text_mask"].sum(1) >= max(1, -(-Nt // 6))).to(DEV)
-    ok_v = (x["video_mask"].sum(1) >= max(1, -(-Nv // 4))).to(DEV)
-    for got, ref, ok in ((gt_f, gt_o, ok_t), (gv_f, gv_o, ok_v), (gt_t, gt_o, ok_t), (gv_t, gv_o, ok_v)):
+    # EVERY sample is compared, including those with fewer valid tokens than cluster centres (a video of 1-2 frames
+    # and 3 centres takes its extra centres among zero-score padding tokens) and those with an exact density tie
+    # between valid tokens (sample 5 of the B=16 case): the oracle states the tie rule the kernels implement --
+    # dpc_knn(centre_ties="lowest_index"); where the reference's torch.topk differs is recorded by
+    # tests/test_oracle_golden.py::test_centre_tie_rule_and_where_torch_topk_differs.
+    for got, ref in ((gt_f, gt_o), (gv_f, gv_o), (gt_t, gt_o), (gv_t, gv_o)):
         assert got.shape == ref.shape
-        assert maxdiff(got[ok], ref[ok.cpu()]) < 2e-5 * scale
+        assert maxdiff(got, ref) < 2e-5 * scale
     assert maxdiff(gt_f, gt_t) < 2e-5 * scale and maxdiff(gv_f, gv_t) < 2e-5 * scale
 
 

@@ -114,3 +114,20 @@ def test_multi_sentence_metrics_against_counting():
     v2t = RetrievalMetrics.tensor_video_to_text_sim(sim.clone())
     ref = torch.where(torch.isnan(sim), torch.full_like(sim, float("-inf")), sim).max(1)[0].t()
     assert v2t.shape == (nv, nv) and torch.equal(v2t, ref)
+
+
+def test_fresh_tcblock_initialises_like_the_reference():
+    """cluster.py:918-932: a new TCBlock applies trunc_normal(0.02) to q / kv / proj, zero biases, LayerNorm 1 / 0 --
+    also when built after the model-wide init (modeling.py:63-72), so a run without --init_model starts from the
+    reference's distribution."""
+    torch.manual_seed(0)
+    m = modeling.NeighborRetr(modeling.default_config())
+    for name in ("text_block0", "text_block1", "video_block0", "video_block1"):
+        blk = getattr(m, name)
+        for lin in (blk.attn.q, blk.attn.kv, blk.attn.proj):
+            w = lin.weight.detach()
+            assert abs(float(w.std()) - 0.02) < 1.5e-3 and abs(float(w.mean())) < 1e-3, (name, float(w.std()))
+            assert float(w.abs().max()) <= 2.0 and float(lin.bias.abs().max()) == 0.0
+        assert float((blk.norm1.weight - 1).abs().max()) == 0.0 and float(blk.norm1.bias.abs().max()) == 0.0
+    # the CTM modules keep torch's defaults, as in the reference (no init hook there: cluster.py:670-688)
+    assert float(m.text_ctm0.score.bias.abs().max()) >= 0.0

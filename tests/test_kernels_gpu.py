@@ -236,12 +236,10 @@ def test_dpc_knn_assign_matches_oracle(B, N, cnum, masked):
     noise = torch.rand(B, N, generator=g)
     ref = O.dpc_knn(x, cnum, 3, mask, noise)
     got = ops.dpc_knn_assign(x.to(DEV), cnum, 3, None if mask is None else mask.to(DEV), noise.to(DEV)).cpu()
-    # cluster ids of the VALID tokens must agree; ids of all-padding clusters are tie-break dependent
-    if mask is None:
-        assert torch.equal(got, ref)
-    else:
-        enough = mask.sum(1) >= cnum                # fewer valid tokens than centres: zero-score ties
-        assert torch.equal(got[enough], ref[enough])
+    # every sample and every token (padding included): the oracle's documented tie rule -- exact ties in the centre
+    # score go to the lower index (dpc_knn(centre_ties="lowest_index")) -- is the kernel's rule, so samples with
+    # fewer valid tokens than centres (zero-score ties among padding tokens) agree too
+    assert torch.equal(got, ref)
 
 
 @pytest.mark.parametrize("M,N,K,bias,res", [(3072, 512, 1536, False, True), (1536, 1024, 512, True, False),

@@ -69,6 +69,11 @@ def test_c4_components_and_reference_crash():
     g, x, P, nz, (B, Nt, Nv, M, K) = _case("c4_b8")
     gt, gv = O.merge_global_features(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"], P, nz)
     assert gt.shape[1] == 3 and gv.shape[1] == 6
+    # the documented reduction for several global tokens: w_i = mean over the sample's tokens of the reference's [B,G] weights
+    w_raw = O.centrality_weights(x["text_feat"], x["video_feat"], gt, gv, 0.3)
+    w_mean = O.centrality_weights(x["text_feat"], x["video_feat"], gt, gv, 0.3, multi_token="mean")
+    assert w_raw[0].shape == (B, 3) and w_raw[1].shape == (B, 6) and w_mean[0].shape == (B,)
+    assert maxdiff(w_mean[0], w_raw[0].mean(-1)) == 0.0 and maxdiff(w_mean[1], w_raw[1].mean(-1)) == 0.0
     assert maxdiff(gt, g["gt"]) < TOL and maxdiff(gv, g["gv"]) < TOL
     G, _ = O.global_level(gt, gv, P)
     assert maxdiff(G, g["G"]) < 1e-4
@@ -79,6 +84,84 @@ def test_c4_components_and_reference_crash():
         O.compute_losses(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"], x["mb_feat_t"],
                          x["mb_feat_v"], x["mb_mask_t"], x["mb_mask_v"], P, dict(synth.DEFAULT_HP, num_neighbors=K),
                          torch.tensor(100.0), nz)
+    hp = dict(synth.DEFAULT_HP, num_neighbors=K)
+    losses, parts = O.compute_losses(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"], x["mb_feat_t"],
+                                     x["mb_feat_v"], x["mb_mask_t"], x["mb_mask_v"], P, hp, torch.tensor(100.0), nz,
+                                     return_parts=True, centrality_multi_token="mean")
+    # under the flag the terms the reference can still compute are the reference's
+    assert abs(float(losses[2]) - float(g["L_uniform_direct"])) < 1e-4
+    assert abs(float(losses[3]) - float(g["L_neighbor_direct"])) < 1e-4
+    assert abs(float(losses[4]) - float(g["L_kl_direct"])) < 1e-4
+    # ... and the centrality term is -mean_i w_i log_softmax(100 S)[i,i] with the averaged weights
+    lp = torch.log_softmax(parts["S"] * 100.0, -1).diag()
+    lpt = torch.log_softmax(parts["S"].t() * 100.0, -1).diag()
+    want = (-(lp * parts["w_text"]).mean() - (lpt * parts["w_video"]).mean()) / 2
+    assert abs(float(losses[1]) - float(want)) < 1e-6 and torch.isfinite(losses[0])
+
+
+def _stage0_scores(x, P, which, noise):
+    """Centre scores of the stage-0 DPC-KNN call of one modality, as oracle.dpc_knn computes them."""
+    import torch.nn.functional as F
+    feat, mask = x[which + "_feat"], x[which + "_mask"]
+    ctm = which + "_ctm0"
+    C = feat.shape[-1]
+    y = feat + F.conv1d(feat.transpose(1, 2), P[ctm + ".conv.conv.weight"], padding=1).transpose(1, 2)
+    y = F.layer_norm(y, (C,), P[ctm + ".norm.weight"], P[ctm + ".norm.bias"])
+    dist = torch.cdist(y, y) / (C ** 0.5)
+    valid = mask > 0
+    dist = dist * valid[:, None, :] + (dist.max() + 1) * (~valid[:, None, :])
+    near = torch.topk(dist, k=3, dim=-1, largest=False)[0]
+    density = ((-(near ** 2).mean(-1)).exp() + noise * 1e-6) * valid
+    higher = (density[:, None, :] > density[:, :, None]).to(y.dtype)
+    dmax = dist.flatten(1).max(-1)[0][:, None, None]
+    return (dist * higher + dmax * (1 - higher)).min(-1)[0] * density
+
+
+@pytest.mark.parametrize("name", ["c1_b16", "c2_b128", "c4_b8"])
+def test_centre_tie_rule_on_the_fixtures(name):
+    """The build's tie rule for the cluster centres (exact score ties -> lower index; oracle.dpc_knn) against the
+    vectors the reference produced with torch.topk (cluster.py:498): on every fixture the two rules pick different
+    PADDING centres in the samples that have fewer valid tokens than centres -- and give the same global tokens,
+    because an all-padding cluster merges to the zero vector whichever padding token leads it."""
+    g, x, P, nz, (B, Nt, Nv, M, K) = _case(name)
+    args = (x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"], P, nz)
+    gt_l, gv_l = O.merge_global_features(*args, centre_ties="lowest_index")
+    gt_k, gv_k = O.merge_global_features(*args, centre_ties="torch_topk")
+    for mine in ((gt_l, gv_l), (gt_k, gv_k)):
+        assert maxdiff(mine[0], g["gt"]) < TOL and maxdiff(mine[1], g["gv"]) < TOL
+    # the rows on which torch.topk (this host) and the documented rule choose different centres: exactly the short ones
+    (t0, _), (v0, _) = O.merged_token_counts(Nt, Nv)
+    for which, nzk, cnum in (("text", "t0", t0), ("video", "v0", v0)):
+        score = _stage0_scores(x, P, which, nz[nzk])
+        c_topk = torch.topk(score, k=cnum, dim=-1)[1]
+        c_low = torch.sort(score, dim=-1, descending=True, stable=True)[1][:, :cnum]
+        differ = (c_topk != c_low).any(1)
+        short = x[which + "_mask"].sum(1) < cnum
+        assert not (differ & ~short).any(), "the rules may only differ where exact (zero-score) ties exist"
+        # ... and in the valid part of those rows they agree: the padding centres come after every valid centre
+        for r in differ.nonzero().flatten().tolist():
+            nv = int(x[which + "_mask"][r].sum())
+            assert c_topk[r, :nv].tolist() == c_low[r, :nv].tolist()
+
+
+def test_centre_tie_rule_and_where_torch_topk_differs():
+    """A case where the two rules give DIFFERENT global tokens: seed 77, B=16, video sample 5 has two valid frames
+    whose densities tie exactly (equal k-NN sets; the 1e-6 noise is below one ulp of the density), so their centre
+    scores tie and the ORDER of the two clusters depends on the rule -- the next stage's token convolution sees them
+    in a different order.  The reference's torch.topk puts token 1 first on this host; the documented rule (and the
+    HIP kernels, tests/test_head_gpu.py) token 0.  Every other sample is identical under both rules."""
+    x = problem(77, 16, 24, 12, 4)
+    P, nz = params(), noise(77, 16, 24, 12)
+    args = (x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"], P, nz)
+    gt_l, gv_l = O.merge_global_features(*args, centre_ties="lowest_index")
+    gt_k, gv_k = O.merge_global_features(*args, centre_ties="torch_topk")
+    assert maxdiff(gt_l, gt_k) == 0.0
+    rows = ((gv_l - gv_k).abs().flatten(1).max(1)[0] > 0).nonzero().flatten().tolist()
+    score = _stage0_scores(x, P, "video", nz["v0"])
+    assert rows in ([5], [])                      # [] if this host's torch.topk happens to agree
+    assert int(x["video_mask"][5].sum()) == 2 and float(score[5, 0]) == float(score[5, 1])      # the exact tie
+    c_low = torch.sort(score, dim=-1, descending=True, stable=True)[1][:, :3]
+    assert c_low[5].tolist() == [0, 1, 2]
 
 
 def test_blank_video_poisons_reference_losses():
