@@ -148,7 +148,7 @@ def test_r32_blank_fully_masked_video_matches_reference_pattern(precision):
         pv = ops.prepare_tokens(x["video_feat"], x["video_mask"])
         w_v, _ = head.token_weights(pv, x["video_mask"].float(), m.scorer_weights("video_weight_fc"), B, Nv, 1)
         dev["w_v"] = maxdiff(w_v, g["w_v"])
-        assert dev["w_v"] < 2e-6 and maxdiff(w_v[blank], torch.full((Nv,), 1.0 / Nv)) < 1e-7
+        assert dev["w_v"] < 1e-5 and maxdiff(w_v[blank], torch.full((Nv,), 1.0 / Nv)) < 1e-7
         # global tokens: NaN exactly where the reference's are (the blank video), equal elsewhere
         gt, gv = m.merge_global_features(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"], nz)
         gv_nan = torch.isnan(gv).flatten(1).any(1).cpu().numpy()
