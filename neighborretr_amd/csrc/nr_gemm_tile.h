@@ -122,7 +122,7 @@ struct NrGemmTile {
     __device__ __forceinline__ void run(const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
                                         int a_row0, int a_rows,
                                         const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
-                                        int b_row0, int b_rows, int K, char* smem) {
+                                        int b_row0, int b_rows, int K, char* smem, int rot = 0, bool dma_front = false) {
         const int tid = threadIdx.x;
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,6 +150,7 @@ struct NrGemmTile {
             gb_h[i] = reinterpret_cast<const char*>(b_hi + (size_t)gr * K + kc * 8);
             if constexpr (X3) gb_l[i] = reinterpret_cast<const char*>(b_lo + (size_t)gr * K + kc * 8);
         }
+        const int KT_ = K / BK;
         // DMA instruction `idx` (0 .. DMA_PER_STAGE-1) of slice kt: A pieces first (hi, then lo), then B pieces
         auto issue_one = [&](int kt, auto idx_c) {
             constexpr int idx = decltype(idx_c)::value;
@@ -159,7 +160,11 @@ struct NrGemmTile {
             constexpr int piece = j / per;
             constexpr bool lo = (j % per) == 1;
             char* st = smem + (kt % STAGES) * STAGE_BYTES;
-            const int kb = kt * BK * 2;                 // byte offset along K
+            // byte offset along K.  `rot` rotates the order in which this workgroup walks the K slices (slice kt of
+            // the loop is slice (kt + rot) mod KT of the operands): workgroups that share operand rows through one L2
+            // then first-touch DIFFERENT slices and find the others' already there (see nr_sim_reg.hip)
+            const int kr = kt + rot;
+            const int kb = (kr >= KT_ ? kr - KT_ : kr) * BK * 2;
             char* dst = st + (is_a ? 0 : A_BYTES) + (wave + NW * piece) * 1024 + (lo ? A_BYTES + B_BYTES : 0);
             const char* src;
             if constexpr (is_a) src = lo ? ga_l[X3 ? piece : 0] : ga_h[piece];
@@ -167,6 +172,7 @@ struct NrGemmTile {
             __builtin_amdgcn_global_load_lds((nr_glb_ptr_t)(src + kb), (nr_lds_ptr_t)dst, 16, 0, 0);
         };
         auto issue = [&](int kt) { nr_static_for<0, DMA_PER_STAGE>([&](auto i) { issue_one(kt, i); }); };
+
 
         // fragment addresses (lane-constant): row within the wave's strip, k-chunk lane>>4
         const int frow = lane & 15, fq = lane >> 4;
@@ -254,7 +260,10 @@ struct NrGemmTile {
                             constexpr int i = decltype(i_c)::value;
                             // instruction i belongs to group floor(i * G / DMA_PER_STAGE)
                             constexpr int home = (i * G) / DMA_PER_STAGE;
-                            if (prefetch && ks * MI * NI + g == home) issue_one(kt_pf, i_c);
+                            // dma_front (A/B hook): the slice's pieces go out in two bursts right behind the fragment
+                            // reads of each k-step instead of between the MFMAs
+                            const bool here = dma_front ? (g == 0 && (2 * i) / DMA_PER_STAGE == ks) : (ks * MI * NI + g == home);
+                            if (prefetch && here) issue_one(kt_pf, i_c);
                         });
                     }
                 });
@@ -267,6 +276,214 @@ struct NrGemmTile {
         // every wave is done with the ring before the caller reuses the LDS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- ping-pong K loop (8-wave workgroups: WC == 4, two-stage ring) ------------------------------------------------
+    // The plain loop above lets both waves of a SIMD walk the same instruction mix in lockstep: they fetch their
+    // fragments at the same time, queue their LDS-DMA instructions on the CU's one texture-address unit at the same
+    // time (a piece is held ~100-185 cycles behind the other seven waves' pieces) and compete for the matrix pipe at
+    // the same time; in-kernel stamps of the 192 x 384 block show the older wave of a SIMD finishing a slice in 2092
+    // cycles and then waiting 1170 at the barrier for the younger one, 3302 cycles for 2304 cycles of MFMA work.
+    // Here the two wave rows are two GROUPS (waves w and w+4 share a SIMD) that alternate roles phase by phase:
+    //   phase:       A(kt)          B(kt)          C(kt)          D(kt)
+    //   group 0:  MFMA k-step 0 |  mem          | MFMA k-step 1 |  mem
+    //   group 1:  mem           |  MFMA k-step 0|  mem          |  MFMA k-step 1
+    // "mem" = the group's fragment reads for its NEXT MFMA phase plus its share of the LDS-DMA of a later slice; the
+    // matrix pipe always belongs to one group, whose MFMAs go out back to back from registers, while the other
+    // group's memory instructions use the LDS and the address unit alone.  One s_barrier per phase.
+    // Ring discipline (2 stages): slice kt+1 is issued in D(kt-1) and B(kt) by group 0 and in A(kt) by group 1, into
+    // the stage slice kt-1 left (its last reader, group 1's k-step 1, ended with C(kt-1)); every wave waits for its
+    // own pieces (vmcnt 0) before the barrier that opens D(kt), where group 0 starts reading slice kt+1.
+    // LDS-DMA pieces (1 KiB = 8 rows x 128 B) per stage: NA_P of operand A, NB_P of operand B (BS per column strip).
+    // The memory side of the loop -- ~72 KB of LDS-DMA (about 21 cycles of the CU's address unit per piece) plus
+    // 192 KB of fragment reads per slice of the 192 x 384 block -- is as long as its MFMA side, so the pieces are dealt
+    // EVENLY over the four phases of a slice:
+    //   C(kt-1)  group 1, PC1 pieces per wave: B pieces of the wave's OWN column strip of slice kt+1 -- the stage is
+    //            still being read in that phase, but that strip only by this wave (its group-0 twin read it in B), so
+    //            the wave may overwrite it as soon as its own reads have returned;
+    //   D(kt-1)  group 0, PD0 per wave;   A(kt)  group 1, PA1 per wave (own strip again);   B(kt)  group 0, PB0 per wave.
+    // Group 0's waves own the A pieces and what is left of their column strip.
+    static constexpr int NA_P = BM / 8, NB_P = BN / 8, BS = NB_P / 4;
+    static constexpr int PQ = (NA_P + NB_P + 8) / 16;                  // ~ a quarter of the pieces, per wave
+    static constexpr int PC1 = PQ < BS ? PQ : BS;
+    static constexpr int PA1 = (BS - PC1) < PQ + 1 ? (BS - PC1) : PQ + 1;
+    static constexpr int PB_0 = BS - PC1 - PA1;                         // B pieces left for the strip's group-0 wave
+    static constexpr int P0 = NA_P / 4 + PB_0;                          // pieces per group-0 wave
+    static constexpr int PB0 = (P0 + 1) / 2, PD0 = P0 - PB0;
+    static_assert(NA_P % 4 == 0 && NB_P % 4 == 0, "piece counts must split over four waves");
+    static_assert(P0 <= 21 && PC1 + PA1 <= 21, "chunk indices are packed 3 bits per slot into 64 bits");
+
+    __device__ __forceinline__ void run_pp(const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
+                                           int a_row0, int a_rows,
+                                           const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
+                                           int b_row0, int b_rows, int K, char* smem) {
+        static_assert(WC == 4 && STAGES == 2, "ping-pong loop: 2 x 4 waves, two-stage ring");
+        const int tid = threadIdx.x;
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int grp = wave / WC, wc = wave % WC;        // group = wave row
+        const int KT = K / BK;
+
+        // The pieces go out as buffer loads to LDS: per lane ONE row offset ((lane / 8) rows) and the piece's swizzled
+        // 16-byte chunk (3 bits per slot, packed); operand, first row of the piece, K offset of the slice and LDS
+        // destination are wave-uniform (SGPRs).  Rows past the operand's end read as zeros (buffer bounds): no clamping.
+        const __amdgpu_buffer_rsrc_t rs_ah = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a_hi), 0, a_rows * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_bh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(b_hi), 0, b_rows * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_al = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X3 ? a_lo : a_hi), 0, a_rows * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_bl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X3 ? b_lo : b_hi), 0, b_rows * K * 2, 0x00020000);
+        const int row_off = (lane >> 3) * K * 2;
+        // slot s of a group-1 wave: B piece BS wc + s (s < PC1 + PA1); of a group-0 wave: s < NA_P/4: A piece
+        // (NA_P/4) wc + s, else B piece BS wc + PC1 + PA1 + (s - NA_P/4)
+        constexpr int SA0 = NA_P / 4;
+        unsigned long long kc_pack = 0;                    // this wave's slots, 3 bits each
+        {
+            constexpr int SMAX = P0 > PC1 + PA1 ? P0 : PC1 + PA1;
+#pragma unroll
+            for (int s_ = 0; s_ < SMAX; ++s_) {
+                const bool is_a = grp == 0 && s_ < SA0;
+                const int piece = grp == 1 ? BS * wc + s_ : (is_a ? SA0 * wc + s_ : BS * wc + PC1 + PA1 + (s_ - SA0));
+                const int r = piece * 8 + (lane >> 3);
+                const int kc = (lane & 7) ^ (is_a ? row_key<TPS_A, MI>(r % BM) : row_key<TPS_B, NI>(r % BN));
+                kc_pack |= (unsigned long long)kc << (3 * s_);
+            }
+        }
+        // slots [S0, S1) of group G (compile time) for slice kt
+        auto issue = [&](auto g_c, auto s0_c, auto s1_c, int kt) {
+            constexpr int G = decltype(g_c)::value, S0 = decltype(s0_c)::value, S1 = decltype(s1_c)::value;
+            char* st = smem + (kt & 1) * STAGE_BYTES;
+            const int kb = kt * BK * 2;
+            nr_static_for<S0, S1>([&](auto s_c) {
+                constexpr int s_ = decltype(s_c)::value;
+                constexpr bool is_a = G == 0 && s_ < SA0;
+                const int piece = G == 1 ? BS * wc + s_ : (is_a ? SA0 * wc + s_ : BS * wc + PC1 + PA1 + (s_ - SA0));
+                const int voff = row_off + (int)(((kc_pack >> (3 * s_)) & 7ull) << 4);
+                const int so = ((is_a ? a_row0 : b_row0) + piece * 8) * K * 2 + kb;
+                char* d = st + (is_a ? 0 : A_BYTES) + piece * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? rs_ah : rs_bh, (nr_lds_ptr_t)d, 16, voff, so, 0, 0);
+                if constexpr (X3)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? rs_al : rs_bl, (nr_lds_ptr_t)(d + A_BYTES + B_BYTES), 16, voff, so, 0, 0);
+            });
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using IPB0 = std::integral_constant<int, PB0>;
+        using IP0 = std::integral_constant<int, P0>;
+        using IPC1 = std::integral_constant<int, PC1>;
+        using IP1 = std::integral_constant<int, PC1 + PA1>;
+
+        const int frow = lane & 15, fq = lane >> 4;
+        bf16x8_t fa_h[MI], fb_h[NI], fa_l[X3 ? MI : 1], fb_l[X3 ? NI : 1];
+        auto load_frags = [&](int step) {
+            const char* sAh = smem + ((step >> 1) & 1) * STAGE_BYTES;
+            const char* sBh = sAh + A_BYTES;
+            const char* sAl = sAh + A_BYTES + B_BYTES;
+            const char* sBl = sAl + A_BYTES;
+            const int ks = step & 1;
+#pragma unroll
+            for (int m = 0; m < MI; ++m) {
+                int r = grp * 16 * MI + strip_row<TPS_A, MI>(m, frow);
+                int off = lds_off(r, ks * 4 + fq, frow & 7);
+                fa_h[m] = *reinterpret_cast<const bf16x8_t*>(sAh + off);
+                if constexpr (X3) fa_l[m] = *reinterpret_cast<const bf16x8_t*>(sAl + off);
+            }
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                int r = wc * 16 * NI + strip_row<TPS_B, NI>(n, frow);
+                int off = lds_off(r, ks * 4 + fq, frow & 7);
+                fb_h[n] = *reinterpret_cast<const bf16x8_t*>(sBh + off);
+                if constexpr (X3) fb_l[n] = *reinterpret_cast<const bf16x8_t*>(sBl + off);
+            }
+        };
+        auto frags_in = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+#ifdef NR_STAMP
+        unsigned long long pp_t = __builtin_readcyclecounter(), pp_work = 0, pp_bar = 0, pp_mma = 0;
+#endif
+        auto mma = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int m = 0; m < MI; ++m)
+#pragma unroll
+                for (int n = 0; n < NI; ++n) {
+                    if constexpr (X3) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_l[m], fb_h[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[m], fb_l[n], acc[m][n], 0, 0, 0);
+                    }
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[m], fb_h[n], acc[m][n], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+#ifdef NR_STAMP
+            __builtin_amdgcn_sched_barrier(0);
+            pp_mma += __builtin_readcyclecounter() - pp_t;
+#endif
+        };
+        auto phase = [&]() {                 // phase boundary
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef NR_STAMP
+            { unsigned long long n = __builtin_readcyclecounter(); pp_work += n - pp_t; pp_t = n; }
+#endif
+            __builtin_amdgcn_s_barrier();
+#ifdef NR_STAMP
+            { unsigned long long n = __builtin_readcyclecounter(); pp_bar += n - pp_t; pp_t = n; }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        // group 1 in phase C: everything but the PC1 pieces (x2 with split-bf16) it has just issued for slice kt+2
+        auto landed_but = [&](bool newest_issued) {
+            if (newest_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PC1 * (X3 ? 2 : 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+
+        // prologue: slice 0 by everyone; then the phases "C(-1)" / "D(-1)": first pieces of slice 1, group 0's fragments
+        if (grp == 0) issue(I0{}, I0{}, IP0{}, 0);
+        else issue(I1{}, I0{}, IP1{}, 0);
+        landed();
+        phase();
+        if (grp == 0) {
+            load_frags(0);
+            if (KT > 1) issue(I0{}, IPB0{}, IP0{}, 1);                     // D(-1): its PD0 pieces of slice 1
+            frags_in();
+            for (int kt = 0; kt < KT; ++kt) {
+                phase();                                                   // A: MFMA k-step 0
+                mma();
+                phase();                                                   // B: fragments of k-step 1, PB0 pieces of slice kt+1
+                load_frags(2 * kt + 1);
+                if (kt + 1 < KT) issue(I0{}, I0{}, IPB0{}, kt + 1);
+                frags_in();
+                phase();                                                   // C: MFMA k-step 1
+                mma();
+                landed();                                                  // this wave's pieces of slice kt+1
+                phase();                                                   // D: fragments of slice kt+1, PD0 pieces of slice kt+2
+                if (kt + 1 < KT) load_frags(2 * kt + 2);
+                if (kt + 2 < KT) issue(I0{}, IPB0{}, IP0{}, kt + 2);
+                frags_in();
+            }
+        } else {
+            if (KT > 1) issue(I1{}, I0{}, IPC1{}, 1);                      // C(-1): own-strip pieces of slice 1
+            for (int kt = 0; kt < KT; ++kt) {
+                phase();                                                   // A: fragments of k-step 0, PA1 pieces of slice kt+1
+                load_frags(2 * kt);
+                if (kt + 1 < KT) issue(I1{}, IPC1{}, IP1{}, kt + 1);
+                frags_in();
+                phase();                                                   // B: MFMA k-step 0
+                mma();
+                phase();                                                   // C: fragments of k-step 1; then, the reads of this
+                load_frags(2 * kt + 1);                                    // stage done, its own strip's pieces of slice kt+2
+                frags_in();
+                if (kt + 2 < KT) issue(I1{}, I0{}, IPC1{}, kt + 2);
+                landed_but(kt + 2 < KT);                                   // pieces of slice kt+1 (the newest PC1 may fly)
+                phase();                                                   // D: MFMA k-step 1
+                mma();
+            }
+        }
+        phase();                             // every wave is done with the ring before the caller reuses the LDS
+#ifdef NR_STAMP
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && wc == 0) {
+            nr_stamp_buf[8 + 2 * grp] = pp_work;       // cycles between barriers (MFMA + memory phases of this wave)
+            nr_stamp_buf[9 + 2 * grp] = pp_bar;        // cycles waiting at the phase barriers
+            nr_stamp_buf[12 + grp] = pp_mma;           // of `work`: the MFMA phases
+        }
+#endif
     }
 
     // C element (m, n, j) of this lane sits at tile row/col:

@@ -42,6 +42,8 @@ struct NrSimRegArgs {
     float *pmax, *qmax;
     int A, Bv, K, out_mode;
     int ntx, nty, PR, PC;      // tile grid and its partition over the 8 XCDs (PR*PC == 8, or PR == 0: none)
+    int rot_x, rot_y;          // K-slice rotation of workgroup (slot_x, slot_y) of an XCD part: rot_x*slot_x + rot_y*slot_y
+    int dma_front;             // A/B hook: LDS-DMA issued in bursts behind the fragment reads
 };
 
 template <int W>   // max over W adjacent lanes (W = 2, 4, 8, 16) with the index of the first maximum
@@ -68,7 +70,7 @@ __device__ __forceinline__ float nr_lanes_sum(float v) {
     return v;
 }
 
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC>
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false>
 __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES, WC>;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     // XCD-aware tile order: workgroups b and b+8 land on the same XCD (round-robin dispatch), so XCD x is
     // given one contiguous PR x PC part of the tile grid and its private L2 pulls only that part's
     // operand rows.  Pure speed: any placement computes the same tiles.
-    int bx, by;
+    int bx, by, rot = 0;
     {
         const int bid = blockIdx.x;
         if (p.PR > 0) {
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
             bx = (xcd % p.PC) * sub_w + slot % sub_w;
             by = (xcd / p.PC) * sub_h + slot / sub_w;
             (void)sub_h;
+            rot = (p.rot_x * (slot % sub_w) + p.rot_y * (slot / sub_w)) % (p.K / 64);
         } else {
             bx = bid % p.ntx;
             by = bid / p.ntx;
@@ -124,11 +127,42 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
 
     Tile tile;
     tile.zero();
-    tile.run(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
+    if constexpr (PP) tile.run_pp(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
+    else tile.run(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem, rot, p.dma_front != 0);
     if constexpr (LATE_W) load_weights();
 
+    float t2v = 0.f, v2t = 0.f;
+    if constexpr (!ARGS) {
+        // Loss-only / evaluation form: only the pooled VALUES are needed, so the pools are plain max chains
+        // (v_max3_f32) -- a fifth of the instructions of the arg-tracking form below, which spent ~1000 VALU
+        // instructions per wave (compare + select per element) and with them a third of the kernel's time.
+        // Same values: max is exact, the weighted sums run in the same order.
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float m = tile.acc[i][0][j];
+#pragma unroll
+                for (int n = 1; n < NI; ++n) m = fmaxf(m, tile.acc[i][n][j]);
+                m = nr_lanes_max<FPS>(m);
+                t2v += m * wt[i][j];
+            }
+        if constexpr (GX >= 2) t2v += __shfl_xor(t2v, 16);
+        if constexpr (GX >= 4) t2v += __shfl_xor(t2v, 32);
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            float m = tile.acc[0][n][0];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m = fmaxf(m, tile.acc[i][n][j]);
+            if constexpr (GX >= 2) m = fmaxf(m, __shfl_xor(m, 16));
+            if constexpr (GX >= 4) m = fmaxf(m, __shfl_xor(m, 32));
+            v2t += m * wv[n];
+        }
+        v2t = nr_lanes_sum<FPS>(v2t);
+    } else {
     // ---- t2v: P[t] = max over the video's frames; sum_t w_t[t] * P[t] -------------------------------
-    float t2v = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -157,7 +191,6 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     if constexpr (GX >= 4) t2v += __shfl_xor(t2v, 32);
 
     // ---- v2t: Q[v] = max over the text's tokens; sum_v w_v[v] * Q[v] --------------------------------
-    float v2t = 0.f;
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
         const int v = FPS * n + phi;
@@ -192,6 +225,8 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     }
     v2t = nr_lanes_sum<FPS>(v2t);
 
+    }
+
     const float S = 0.5f * (t2v + v2t);
 #ifdef NR_STAMP
     if (blockIdx.x == 0 && threadIdx.x == 0) nr_stamp_buf[4] = __builtin_readcyclecounter() - t_start;
@@ -222,10 +257,10 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     }
 }
 
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC>
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false>
 static int nr_sim_reg_launch_s(NrSimRegArgs& a, hipStream_t st) {
     using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES, WC>;
-    auto kern = nr_sim_reg_kernel<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC>;
+    auto kern = nr_sim_reg_kernel<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC, PP>;
     size_t lds = Tile::RING_BYTES;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -258,6 +293,13 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
         if (sscanf(e, "%dx%d", &pr, &pc) == 2 && pr * pc == 8 && a.nty % pr == 0 && a.ntx % pc == 0) { a.PR = pr; a.PC = pc; }
         else a.PR = a.PC = 0;
     }
+    a.rot_x = a.rot_y = 0;
+    a.dma_front = 0;
+    if (const char* e = nr_tune_env("NR_SIM_DMA_FRONT")) a.dma_front = atoi(e);
+    if (const char* e = nr_tune_env("NR_SIM_ROT")) {          // tuning hook: "XxY" K-slice rotation per slot column / row
+        int rx = 0, ry = 0;
+        if (sscanf(e, "%dx%d", &rx, &ry) == 2) { a.rot_x = rx; a.rot_y = ry; }
+    }
     // 192 x 192 blocks (8 waves, one workgroup per CU): nobody else hides their DMA latency, so they run the
     // 2-deep ring -- except split-bf16, whose two stages (196 KB) exceed the LDS
     constexpr bool big = WC == 4;
@@ -269,6 +311,11 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
         if constexpr (big && NI == 3) {          // 192 x 192: three stages fit (144 KB)
             const char* e = nr_tune_env("NR_SIM_STAGES");
             if (e && atoi(e) == 3) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 3, WC>(a, st);
+        }
+        if constexpr (big) {
+            // 8-wave blocks on the two-stage ring: ping-pong K loop (NrGemmTile::run_pp); NR_SIM_PP=0 = the plain loop (A/B)
+            const char* e = nr_tune_env("NR_SIM_PP");
+            if (!(e && atoi(e) == 0) && a.K >= 128) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 2, WC, true>(a, st);
         }
         return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 2, WC>(a, st);
     }
