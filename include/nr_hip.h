@@ -223,6 +223,24 @@ int nr_row_losses_fwd(const float* S, const float* G, const float* tgt_rows, con
                       const float* logit_scale, int B, int K, float temperature, float* rowloss, void* stream);
 int nr_loss_finalize(const float* rowloss, int B, float uniform_weight, float neighbor_weight, float kl_weight,
                      float* losses, void* stream);
+/* The split tail of the loss-only step as two CONCURRENT launches that finalize themselves (B <= 128, B % 4 == 0):
+ *   nr_sinkhorn_uniform_rows_final      Sinkhorn solve + uniform-CE row terms into rowloss[:,1,:]  (2 workgroups)
+ *   nr_row_losses_fwd_no_uniform_final  centrality / neighbour / KL row terms into rowloss[:,(0,2,3),:], reading the
+ *                                       bank centralities as the PARTIAL sums the fused local_level kernel writes
+ *                                       (c0_parts [n_c0,B], c1_parts [n_c1,B], c_j = c_scale * sum_p part[p][j]:
+ *                                       until_module.py:181 without a reduction launch)
+ * Every workgroup of both launches adds to `counter` (one zero-initialised device word the caller keeps); the one that
+ * arrives last -- nr_split_tail_workgroups(B) in all -- reduces rowloss [2,4,B] to losses[5] exactly as
+ * nr_loss_finalize does and resets the counter.  Neither launch may be issued without the other.                    */
+int nr_split_tail_workgroups(int B);
+int nr_sinkhorn_uniform_rows_final(const float* G, int B, float beta, int iters, float temperature, float* rowloss,
+                                   uint32_t* counter, float uniform_weight, float neighbor_weight, float kl_weight,
+                                   float* losses, void* workspace, void* stream);
+int nr_row_losses_fwd_no_uniform_final(const float* S, const float* G, const float* c0_parts, int n_c0,
+                                       const float* c1_parts, int n_c1, float c_scale, const float* wc_text,
+                                       const float* wc_video, const float* logit_scale, int B, int K, float temperature,
+                                       float* rowloss, uint32_t* counter, float uniform_weight, float neighbor_weight,
+                                       float kl_weight, float* losses, void* stream);
 /* nr_row_losses_fwd without the uniform term: rowloss[dir][0,2,3][i] only, no dependence on the Sinkhorn targets. */
 int nr_row_losses_fwd_no_uniform(const float* S, const float* G, const float* bank_c0, const float* bank_c1,
                                  const float* wc_text, const float* wc_video, const float* logit_scale, int B, int K,

@@ -22,6 +22,10 @@ static inline const char* nr_tune_env(const char* name) { return getenv(name); }
 static inline const char* nr_tune_env(const char*) { return nullptr; }
 #endif
 
+// Kernels on the step's critical chain (clustering, global logits, Sinkhorn, finalize) raise their waves' issue priority:
+// they share CUs with the MFMA kernels of the local branch, which only have throughput to lose.
+#define NR_CRITICAL_PATH() __builtin_amdgcn_s_setprio(3)
+
 // status codes returned by every extern "C" entry point
 #define NR_OK 0
 #define NR_EINVAL (-1)

@@ -26,12 +26,14 @@ struct NrGroupOf {
 };
 
 __global__ __launch_bounds__(256) void nr_group_shift_kernel(NrGroupOf<NrShiftArgs> g) {
+    NR_CRITICAL_PATH();
     const int gi = g.find(blockIdx.x);
     nr_shift_split_body(g.p[gi], blockIdx.x - g.start[gi]);
 }
 
 template <int CPL>
 __global__ __launch_bounds__(CF_THREADS) void nr_group_front_kernel(NrGroupOf<NrCtmFrontArgs> g) {
+    NR_CRITICAL_PATH();
     extern __shared__ __attribute__((aligned(16))) float sx[];
     const int gi = g.find(blockIdx.x);
     nr_ctm_front_body<CPL>(g.p[gi], blockIdx.x - g.start[gi], sx);
@@ -41,6 +43,7 @@ __global__ __launch_bounds__(CF_THREADS) void nr_group_front_kernel(NrGroupOf<Nr
 // other workgroups then, and the normalised rows it merges are the ones the front half left in LDS
 template <int CPL>
 __global__ __launch_bounds__(CF_THREADS) void nr_group_front_back_kernel(NrGroupOf<NrCtmFrontArgs> gf, NrGroupOf<NrCtmBackArgs> gb) {
+    NR_CRITICAL_PATH();
     extern __shared__ __attribute__((aligned(16))) float sx[];
     const int gi = gf.find(blockIdx.x);
     const int b = blockIdx.x - gf.start[gi];
@@ -51,12 +54,14 @@ __global__ __launch_bounds__(CF_THREADS) void nr_group_front_back_kernel(NrGroup
 }
 
 __global__ __launch_bounds__(BK_THREADS) void nr_group_back_kernel(NrGroupOf<NrCtmBackArgs> g, int use_lds) {
+    NR_CRITICAL_PATH();
     extern __shared__ __attribute__((aligned(16))) float sxn[];
     const int gi = g.find(blockIdx.x);
     nr_ctm_back_body(g.p[gi], blockIdx.x - g.start[gi], use_lds ? sxn : nullptr);
 }
 
 __global__ __launch_bounds__(1024) void nr_group_attention_kernel(NrGroupOf<NrAttnArgs> g, int use_lds) {
+    NR_CRITICAL_PATH();
     extern __shared__ __attribute__((aligned(16))) float skv[];
     const int gi = g.find(blockIdx.x);
     nr_tc_attention_body(g.p[gi], blockIdx.x - g.start[gi], use_lds ? skv : nullptr);

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void nr_linear_kernel(NrLinearArgs p) {
 // grouped: workgroup -> (problem, tile) through the prefix table; tiles of a problem are column-fastest
 template <int MI, int NI, int STAGES, int WC>
 __global__ __launch_bounds__(128 * WC) void nr_linear_group_kernel(NrLinearGroup g) {
+    NR_CRITICAL_PATH();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int gi = 0;
     // tiles are numbered problem by problem, column-fastest: the column tiles of one row tile (same X rows) are

@@ -12,6 +12,7 @@
 //               -sum_{E} p_j log_softmax_E(S)_j / sum p,   E = N u {i}.
 // rowloss[dir][term][i] is reduced by nr_loss_finalize (fixed order => deterministic).
 #include "nr_common.h"
+#include "nr_finalize.h"
 #include "../../include/nr_hip.h"
 
 struct NrRowArgs {
@@ -24,6 +25,11 @@ struct NrRowArgs {
     // Zero / nullptr in the full form.
     const float* S_cols;
     int row0, n_rows;
+    // Bank centralities as PARTIAL SUMS (what the fused local_level kernel's row / column-sum modes write): bank_c0 is
+    // [n_c0, B], bank_c1 [n_c1, B], c_j = c_scale * sum_p part[p][j] (until_module.py:181) -- the nr_reduce_parts
+    // launches of the bank chains disappear.  0: bank_c0 / bank_c1 are the finished [B] vectors.
+    int n_c0, n_c1;
+    float c_scale;
 };
 
 // Everything the forward and the backward need about one row, recomputed identically in both.
@@ -48,6 +54,7 @@ struct NrRowState {
         ls = a.logit_scale[0];
         wci = dir == 0 ? a.wc_text[row] : a.wc_video[row];
         const float* cvec = dir == 0 ? a.bank_c0 : a.bank_c1;
+        const int n_cp = dir == 0 ? a.n_c0 : a.n_c1;
         const float* tgt = dir == 0 ? a.tgt_rows : a.tgt_cols;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
@@ -58,7 +65,21 @@ struct NrRowState {
             if (a.S_cols) s[e] = dir == 0 ? a.S[(size_t)(row - a.row0) * B + jj] : a.S_cols[(size_t)jj * a.n_rows + (row - a.row0)];
             else s[e] = a.S[idx];
             g[e] = a.G[idx];
-            c[e] = cvec[jj];
+            if (n_cp > 0) {
+                // four independent loads in flight (L2 latency, not bandwidth, is what this costs); fixed order
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                int q = 0;
+                for (; q + 3 < n_cp; q += 4) {
+                    a0 += cvec[(size_t)q * B + jj];
+                    a1 += cvec[(size_t)(q + 1) * B + jj];
+                    a2 += cvec[(size_t)(q + 2) * B + jj];
+                    a3 += cvec[(size_t)(q + 3) * B + jj];
+                }
+                for (; q < n_cp; ++q) a0 += cvec[(size_t)q * B + jj];
+                c[e] = ((a0 + a1) + (a2 + a3)) * a.c_scale;
+            } else {
+                c[e] = cvec[jj];
+            }
             tg[e] = tgt ? tgt[(size_t)row * B + jj] : 0.f;      // no targets: the uniform term comes from the Sinkhorn kernel
         }
     }
@@ -152,10 +173,6 @@ struct NrRowState {
     }
 };
 
-template <bool COHERENT>
-__device__ __forceinline__ void nr_loss_finalize_body(const float* __restrict__ rowloss, int B, float wu, float wn, float wkl,
-                                                      float* __restrict__ losses);
-
 // Optional tail of the forward launch: the workgroup that finishes LAST reduces the row terms to the five
 // losses (same arithmetic and summation order as nr_loss_finalize, so the result is bit-identical) --
 // one launch less on the step's critical path.  `counter` is a zero-initialised device word that the
@@ -164,6 +181,7 @@ struct NrRowFinal {
     unsigned int* counter;
     float wu, wn, wkl;
     float* losses;
+    unsigned int total;        // workgroups that add to `counter` before the last one finalizes; 0 = this launch's grid
 };
 
 template <int NE>
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(256) void nr_row_losses_fwd_kernel(NrRowArgs a, flo
     __threadfence();                               // this workgroup's row terms are visible device-wide
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int total = gridDim.x * gridDim.y;
+        const unsigned int total = f.total ? f.total : gridDim.x * gridDim.y;
         s_last = atomicAdd(f.counter, 1u) == total - 1;
     }
     __syncthreads();
@@ -217,40 +235,6 @@ __global__ __launch_bounds__(256) void nr_row_losses_fwd_kernel(NrRowArgs a, flo
     __threadfence();
     nr_loss_finalize_body<true>(rowloss, a.B, f.wu, f.wn, f.wkl, f.losses);
     if (threadIdx.x == 0) *f.counter = 0;
-}
-
-// losses = (total, centrality, uniform, neighbour, kl)   (modeling.py:329-358); 256 threads
-template <bool COHERENT>
-__device__ __forceinline__ void nr_loss_finalize_body(const float* __restrict__ rowloss, int B, float wu, float wn, float wkl,
-                                                      float* __restrict__ losses) {
-    __shared__ float red[8][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // wave w handles term w; both directions
-    float acc0 = 0.f, acc1 = 0.f;
-    for (int j = lane; j < B; j += 64) {
-        const float* p0 = rowloss + (size_t)(0 * 4 + wave) * B + j;
-        const float* p1 = rowloss + (size_t)(1 * 4 + wave) * B + j;
-        if constexpr (COHERENT) {      // written by other workgroups of the same launch: read past the L1
-            acc0 += __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            acc1 += __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            acc0 += *p0;
-            acc1 += *p1;
-        }
-    }
-    acc0 = nr_wave_sum(acc0);
-    acc1 = nr_wave_sum(acc1);
-    if (lane == 0) { red[wave][0] = acc0; red[wave][1] = acc1; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float invB = 1.0f / (float)B;
-        float c = (red[0][0] * invB + red[0][1] * invB) * 0.5f;
-        float u = (red[1][0] * invB + red[1][1] * invB) * 0.5f;
-        float n = (red[2][0] * invB + red[2][1] * invB) * 0.5f;
-        float k = (red[3][0] * invB * invB + red[3][1] * invB * invB) * 0.5f;   // kl_div 'mean' divides by B*B
-        losses[0] = c + u * wu + n * wn + k * wkl;
-        losses[1] = c; losses[2] = u; losses[3] = n; losses[4] = k;
-    }
 }
 
 __global__ __launch_bounds__(256) void nr_loss_finalize_kernel(const float* __restrict__ rowloss, int B, float wu, float wn,
@@ -288,8 +272,8 @@ extern "C" int nr_row_losses_fwd(const float* S, const float* G, const float* tg
     if (!S || !G || !tgt_rows || !tgt_cols || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale || !rowloss)
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;    // the reference raises IndexError for K > B
-    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0};
-    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr}, (hipStream_t)stream);
+    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f};
+    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr, 0u}, (hipStream_t)stream);
 }
 
 // centrality, neighbour and KL terms only (rowloss[dir][0,2,3][i]); the uniform term rowloss[dir][1][i] is left to
@@ -299,8 +283,27 @@ extern "C" int nr_row_losses_fwd_no_uniform(const float* S, const float* G, cons
                                             float temperature, float* rowloss, void* stream) {
     if (!S || !G || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale || !rowloss) return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;
-    NrRowArgs a{S, G, nullptr, nullptr, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0};
-    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr}, (hipStream_t)stream);
+    NrRowArgs a{S, G, nullptr, nullptr, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f};
+    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr, 0u}, (hipStream_t)stream);
+}
+
+// The split tail's row-loss launch: centrality / neighbour / KL terms from the bank products' PARTIAL sums, and the
+// five losses from whichever workgroup -- of this launch or of the concurrent nr_sinkhorn_uniform_rows_final --
+// finishes last (`counter`: one zero-initialised device word shared by both launches, reset by that workgroup).
+extern "C" int nr_split_tail_workgroups(int B) { return B > 0 ? 2 + 2 * ((B + 3) / 4) : 0; }
+
+extern "C" int nr_row_losses_fwd_no_uniform_final(const float* S, const float* G, const float* c0_parts, int n_c0,
+                                                  const float* c1_parts, int n_c1, float c_scale, const float* wc_text,
+                                                  const float* wc_video, const float* logit_scale, int B, int K,
+                                                  float temperature, float* rowloss, uint32_t* counter, float uniform_weight,
+                                                  float neighbor_weight, float kl_weight, float* losses, void* stream) {
+    if (!S || !G || !c0_parts || !c1_parts || !wc_text || !wc_video || !logit_scale || !rowloss || !counter || !losses)
+        return NR_EINVAL;
+    if (B <= 0 || K < 0 || K > B || n_c0 <= 0 || n_c1 <= 0) return NR_EINVAL;
+    NrRowArgs a{S, G, nullptr, nullptr, c0_parts, c1_parts, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0,
+                n_c0, n_c1, c_scale};
+    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{counter, uniform_weight, neighbor_weight, kl_weight, losses,
+                                                           (unsigned)nr_split_tail_workgroups(B)}, (hipStream_t)stream);
 }
 
 extern "C" int nr_row_losses_fwd_slab(const float* S_rows, const float* S_cols, int row0, int n_rows, const float* G,
@@ -310,8 +313,8 @@ extern "C" int nr_row_losses_fwd_slab(const float* S_rows, const float* S_cols, 
     if (!S_rows || !S_cols || !G || !tgt_rows || !tgt_cols || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale || !rowloss)
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B || row0 < 0 || n_rows <= 0 || row0 + n_rows > B) return NR_EINVAL;
-    NrRowArgs a{S_rows, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, S_cols, row0, n_rows};
-    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr}, (hipStream_t)stream);
+    NrRowArgs a{S_rows, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, S_cols, row0, n_rows, 0, 0, 0.f};
+    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr, 0u}, (hipStream_t)stream);
 }
 
 extern "C" int nr_row_losses_fwd_final(const float* S, const float* G, const float* tgt_rows, const float* tgt_cols,
@@ -323,8 +326,8 @@ extern "C" int nr_row_losses_fwd_final(const float* S, const float* G, const flo
         !counter || !losses)
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;
-    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0};
-    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{counter, uniform_weight, neighbor_weight, kl_weight, losses},
+    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f};
+    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{counter, uniform_weight, neighbor_weight, kl_weight, losses, 0u},
                                     (hipStream_t)stream);
 }
 
@@ -463,7 +466,7 @@ extern "C" int nr_row_losses_bwd(const float* S, const float* G, const float* tg
         !dS_dir || !dG_dir || !d_c_rows || !d_wc || !d_ls_rows)
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;
-    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0};
+    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f};
     dim3 grid((B + 3) / 4, 2);
     hipStream_t st = (hipStream_t)stream;
 #define NR_BWD_CASE(N_) \

@@ -20,6 +20,7 @@
 // the column pass running on a transposed copy held in the workspace (log domain throughout).
 #include <cstdlib>
 #include "nr_common.h"
+#include "nr_finalize.h"
 #include "../../include/nr_hip.h"
 
 // sum / max over the 128/EPT adjacent lanes that share a line (8, 4 or 2 lanes)
@@ -38,13 +39,25 @@ __device__ __forceinline__ float sk_group_max(float v) {
     return v;
 }
 
+// Optional tail (split tail of the loss-only step): the row terms are complete once this launch AND the concurrent
+// row-loss launch have finished; every workgroup of both adds to `counter`, the one that arrives last reduces
+// rowloss [2,4,B] (= uniform_rows - B) to the five losses and resets the counter.
+struct NrSkFinal {
+    unsigned int* counter;
+    unsigned int total;
+    float wu, wn, wkl;
+    float* losses;
+};
+
 // SK_EPT entries of a line per thread, LPL = 128 / SK_EPT lanes per line, 128 * LPL threads.  Measured (MI355X,
 // B = 128, 50 iterations): see the launcher.
 template <int SK_EPT>
 __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel(const float* __restrict__ G, int B, float beta, int iters,
                                                                               float* __restrict__ tgt_rows, float* __restrict__ tgt_cols,
-                                                                              float temperature, float* __restrict__ uniform_rows, int uniform_stride) {
+                                                                              float temperature, float* __restrict__ uniform_rows, int uniform_stride,
+                                                                              NrSkFinal fin) {
     constexpr int LPL = 128 / SK_EPT;
+    NR_CRITICAL_PATH();
     __shared__ __attribute__((aligned(16))) float s_a[128];
     __shared__ __attribute__((aligned(16))) float s_b[128];
     const int dir = blockIdx.x;                 // 0: problem on G, 1: problem on G^T
@@ -204,6 +217,16 @@ __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel
             }
         }
     }
+    if (fin.counter == nullptr) return;
+    __shared__ int s_last;
+    __threadfence();                               // this workgroup's row terms are visible device-wide
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(fin.counter, 1u) == fin.total - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    nr_loss_finalize_body<true>(uniform_rows - B, B, fin.wu, fin.wn, fin.wkl, fin.losses);
+    if (threadIdx.x == 0) *fin.counter = 0;
 }
 
 // ---- large-B path ---------------------------------------------------------------------------------
@@ -263,7 +286,8 @@ extern "C" size_t nr_sinkhorn_workspace_bytes(int B) {
 }
 
 static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols, float temperature,
-                           float* uniform_rows, int uniform_stride, void* workspace, void* stream);
+                           float* uniform_rows, int uniform_stride, void* workspace, void* stream,
+                           NrSkFinal fin = NrSkFinal{nullptr, 0u, 0.f, 0.f, 0.f, nullptr});
 
 extern "C" int nr_sinkhorn_targets(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols,
                                    void* workspace, void* stream) {
@@ -278,12 +302,25 @@ extern "C" int nr_sinkhorn_uniform_rows(const float* G, int B, float beta, int i
     return nr_sinkhorn_run(G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_dir_stride, workspace, stream);
 }
 
+// nr_sinkhorn_uniform_rows writing into rowloss [2,4,B] (rows 1) and taking part in the shared finalize: see NrSkFinal
+extern "C" int nr_sinkhorn_uniform_rows_final(const float* G, int B, float beta, int iters, float temperature, float* rowloss,
+                                              uint32_t* counter, float uniform_weight, float neighbor_weight, float kl_weight,
+                                              float* losses, void* workspace, void* stream) {
+    if (!rowloss || !counter || !losses || B > 128 || (B % 4) != 0) return (rowloss && counter && losses) ? NR_EUNSUPPORTED : NR_EINVAL;
+    NrSkFinal fin{counter, (unsigned)(2 + 2 * ((B + 3) / 4)), uniform_weight, neighbor_weight, kl_weight, losses};
+    return nr_sinkhorn_run(G, B, beta, iters, nullptr, nullptr, temperature, rowloss + B, 4 * B, workspace, stream, fin);
+}
+
 static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols, float temperature,
-                           float* uniform_rows, int uniform_stride, void* workspace, void* stream) {
+                           float* uniform_rows, int uniform_stride, void* workspace, void* stream, NrSkFinal fin) {
     if (!G || B <= 0 || iters < 0) return NR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (B <= 128 && (B % 4) == 0) {
-        const size_t lds = (size_t)B * 129 * sizeof(float);
+        // Nearly the whole LDS of the CU is requested (156 of 160 KiB; the static arrays take the rest), although B x 129 floats would do: the solve
+        // is a latency chain on ONE workgroup per direction, and no LDS-using workgroup of another kernel (scorer, bank
+        // products run beside it in the step) can then be placed on its CU to compete for issue slots and the LDS.
+        const size_t lds = 156 * 1024;                   // + the kernel's static arrays (< 4 KiB)
+        if ((size_t)B * 129 * sizeof(float) > lds) return NR_EUNSUPPORTED;
         // entries per thread: 16 (1024 threads) / 32 (512) / 64 (256); NR_SINKHORN_EPT overrides (tuning hook)
         int ept = 32;
         if (const char* e = nr_tune_env("NR_SINKHORN_EPT")) ept = atoi(e);
@@ -293,9 +330,9 @@ static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* 
             hipError_t er = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (er != hipSuccess) return (int)er;
         }
-        if (ept == 16) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<16>, dim3(2), dim3(1024), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride);
-        else if (ept == 64) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<64>, dim3(2), dim3(256), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride);
-        else hipLaunchKernelGGL(nr_sinkhorn_small_kernel<32>, dim3(2), dim3(512), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride);
+        if (ept == 16) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<16>, dim3(2), dim3(1024), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride, fin);
+        else if (ept == 64) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<64>, dim3(2), dim3(256), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride, fin);
+        else hipLaunchKernelGGL(nr_sinkhorn_small_kernel<32>, dim3(2), dim3(512), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride, fin);
         NR_LAUNCH_CHECK();
         return NR_OK;
     }

@@ -45,6 +45,7 @@ extern "C" int nr_reduce_parts(const float* part, int n_parts, int n, float scal
 // k = k0 + 4*(lane>>4) + s on both operands -- a permutation of the k order, identical for A and B.
 __global__ __launch_bounds__(256) void nr_gemm_nt_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              int M, int N, int K, float* __restrict__ c) {
+    NR_CRITICAL_PATH();
     __shared__ f32x4_t s_part[3][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = blockIdx.y * 16, col0 = blockIdx.x * 16;

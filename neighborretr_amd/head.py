@@ -105,7 +105,7 @@ def precision_plan(prec):
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                  gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None,
                  bank_streams=None, local_stream=None, bank_early=0,
-                 capture_order=((7, 9), (7, 1 << 30)), bank_prepared=None, prepared_out=None):
+                 capture_order=((7, 9), (7, 1 << 30)), bank_prepared=None, prepared_out=None, bank_push=None):
     """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None).
 
     `join`: optional callable run right before the first use of gt / gv.  Either the caller produces the
@@ -116,7 +116,10 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     `bank_streams`: optional pair of side streams for the two memory-bank chains (see below).
     `bank_prepared`: optional (text, video) ops.Prepared of the bank (its persistent normalised bf16 shadow): the
     two bank prepare launches are skipped.  `prepared_out`: optional dict that receives the batch's prepared
-    tokens ("pt", "pv") -- what the bank shadow is extended with at the push."""
+    tokens ("pt", "pv") -- what the bank shadow is extended with at the push.
+    `bank_push`: optional callable that pushes the batch into the memory bank (modeling.py:309-310).  The split tail
+    calls it on its side stream as soon as both bank products have read the bank -- beside the Sinkhorn solve instead
+    of behind it on the critical path; the other paths leave it to the caller."""
     B, Nt, d = text_feat.shape
     Nv = video_feat.shape[1]
     M = mb_feat_v.shape[0]
@@ -135,6 +138,9 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     lo_b = keep or hip.PREC_BF16X3 in (p_bb, p_mlp, p_bank)
     lo_k = keep or p_bank == hip.PREC_BF16X3
     cur = torch.cuda.current_stream()
+    # Loss-only step at B <= 128 ("split tail", below): the bank centralities stay PARTIAL sums (the row-loss kernel adds
+    # them up itself: two reduction launches less per step)
+    split_tail = (not keep) and bank_streams is not None and local_stream is not None and B <= 128 and B % 4 == 0
 
     # The local branch, one kernel launch per step (a generator, so that it can be interleaved launch by launch
     # with the clustering -- see below); its results land in `L`.
@@ -181,6 +187,8 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         yield
         p1, aux1 = ops.local_level(L["pt"], pbv, L["w_t"], w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM, keep)
         yield
+        if split_tail:
+            return pbv, w_bv, lg_bv, aux1, p1
         c1 = ops.reduce_parts(p1, 1.0 / M)
         yield
         return pbv, w_bv, lg_bv, aux1, c1
@@ -198,6 +206,8 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         yield
         p0, aux2 = ops.local_level(pbt, L["pv"], w_bt, L["w_v"], M, Nt, B, Nv, p_bank, hip.OUT_COLSUM, keep)
         yield
+        if split_tail:
+            return pbt, w_bt, lg_bt, aux2, p0
         c0 = ops.reduce_parts(p0, 1.0 / M)
         yield
         return pbt, w_bt, lg_bt, aux2, c0
@@ -273,30 +283,50 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     ls = logit_scale.detach().float().reshape(1).contiguous()
     # Loss-only step at B <= 128 ("split tail"): the global logits and the Sinkhorn solve depend on the clustering
     # alone, so they follow it on THIS stream without waiting for the local branch; the Sinkhorn kernel emits the
-    # uniform-CE row terms itself, and everything that needs the local branch (leftover bank chains, centrality
-    # weights, the row-loss kernel with its top-K) gathers on a side stream that joins only for the 5-number
-    # finalize.  Critical path: prologue -> clustering -> logits -> Sinkhorn -> finalize -> push.
-    split_tail = (not keep) and bank_streams is not None and local_stream is not None and B <= 128 and B % 4 == 0
+    # uniform-CE row terms itself, and everything that needs the local branch (leftover bank chains, bank push,
+    # centrality weights, the row-loss kernel with its top-K) gathers on a side stream.  The two tail kernels finalize
+    # themselves (whichever workgroup finishes last reduces the row terms to the five losses), so the critical path
+    # is prologue -> clustering -> logits -> Sinkhorn, with neither a finalize launch nor the push behind it.
     if split_tail:
         G = global_logits(gt, gv, sw_t1, sw_v1)
         g_ready = torch.cuda.Event()
         g_ready.record(cur)
         rowloss = torch.empty((2, 4, B), dtype=torch.float32, device=G.device)
-        ops.sinkhorn_uniform_rows(G, hp["beta"], hp["temperature"], rowloss, 50)
+        losses = torch.empty((5,), dtype=torch.float32, device=G.device)
+        counter = ops.split_tail_counter(G.device)
+        wts = (hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
+        ops.sinkhorn_uniform_rows_final(G, hp["beta"], hp["temperature"], rowloss, counter, *wts, losses, 50)
         tgt_r = tgt_c = None
-        side, side2 = bank_streams
+        side, side2 = bank_streams[0], bank_streams[1]
+        push_stream = bank_streams[2] if len(bank_streams) > 2 else None
         side.wait_stream(local_stream)
         side2.wait_stream(local_stream)
         with torch.cuda.stream(side2):
             pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
         with torch.cuda.stream(side):
             pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
+            side.wait_stream(side2)
+            if bank_push is not None:
+                # both bank products have read the bank (and its prepared shadow): the batch may take the oldest rows'
+                # place -- on a stream of its own, beside the centrality weights and the row losses.  (A stream that
+                # has already been joined must not be forked again inside one capture: putting the push back on
+                # `side2` after `side.wait_stream(side2)` made the ROCm 7.2 runtime segfault at capture time.)
+                pst = push_stream if push_stream is not None else side
+                if push_stream is not None:
+                    push_stream.wait_stream(side)
+                with torch.cuda.stream(pst):
+                    for t_ in (pt.hi, pt.norm, pv.hi, pv.norm) + ((pt.lo, pv.lo) if pt.lo is not None else ()):
+                        t_.record_stream(pst)
+                    with torch.no_grad():
+                        bank_push()
             side.wait_event(g_ready)
             wc_t, wc_v, cw_aux = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
-            side.wait_stream(side2)
-            ops.row_losses_no_uniform(S, G, c0, c1, wc_t, wc_v, ls, K, hp["temperature"], rowloss)
+            ops.row_losses_no_uniform_final(S, G, c0, c1, 1.0 / M, wc_t, wc_v, ls, K, hp["temperature"], rowloss, counter,
+                                            *wts, losses)
         cur.wait_stream(side)
-        for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi, c0, c1, wc_t, wc_v):
+        if push_stream is not None:
+            cur.wait_stream(push_stream)
+        for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi, c0, c1, wc_t, wc_v, G, rowloss, losses):
             t_.record_stream(cur)
             t_.record_stream(side)
         if pt.lo is not None:
@@ -304,7 +334,6 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
             pv.lo.record_stream(cur)
         pt.norm.record_stream(cur)
         pv.norm.record_stream(cur)
-        losses = ops.loss_finalize(rowloss, hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
     else:
         if local_stream is not None:
             cur.wait_stream(local_stream)

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnr_hip.so")
+# NR_HIP_LIB: developer hook to A/B two builds of the library in one GPU session (tools/); never a fallback
+LIB_PATH = os.environ.get("NR_HIP_LIB") or os.path.join(_HERE, "libnr_hip.so")
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
@@ -64,6 +65,9 @@ _SIGNATURES = {
     "nr_sinkhorn_workspace_bytes": ([_I], _Z),
     "nr_sinkhorn_uniform_rows": ([_P, _I, _F, _I, _F, _P, _I, _P, _P, _P, _P], _I),
     "nr_row_losses_fwd_no_uniform": ([_P] * 7 + [_I, _I, _F, _P, _P], _I),
+    "nr_split_tail_workgroups": ([_I], _I),
+    "nr_sinkhorn_uniform_rows_final": ([_P, _I, _F, _I, _F, _P, _P, _F, _F, _F, _P, _P, _P], _I),
+    "nr_row_losses_fwd_no_uniform_final": ([_P, _P, _P, _I, _P, _I, _F, _P, _P, _P, _I, _I, _F, _P, _P, _F, _F, _F, _P, _P], _I),
     "nr_sinkhorn_targets": ([_P, _I, _F, _I, _P, _P, _P, _P], _I),
     "nr_row_losses_fwd": ([_P] * 9 + [_I, _I, _F, _P, _P], _I),
     "nr_row_losses_fwd_slab": ([_P, _P, _I, _I] + [_P] * 8 + [_I, _I, _F, _P, _P], _I),

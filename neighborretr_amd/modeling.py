@@ -82,6 +82,8 @@ class NeighborRetr(nn.Module):
         self._bstreams = None
         self._lstream = None
         self._rng_state = None
+        self._push_fn = None
+        self._pushed = False
         # capture order of the loss-only step: (clustering launches, local-branch launches) per turn, last repeats
         self.capture_order = ((7, 9), (7, 1 << 30))
         self.bank_early = 2                 # bank chains started beside the clustering instead of the Sinkhorn (0..2)
@@ -297,13 +299,22 @@ class NeighborRetr(nn.Module):
             text_mask, video_mask = text_mask.float(), video_mask.float()
             logit_scale = raw_scale.exp()
         cfg = self.config
+        # the push (modeling.py:309-310): the loss-only head may run it itself as soon as the bank has been read
+        # (head.head_forward `bank_push`); otherwise it follows the losses here
+        self._pushed = False
+
+        def push():
+            self.update_memory_bank(idx, text_feat, video_feat, text_mask, video_mask)
+            self._pushed = True
+        self._push_fn = None if self.bank_frozen else push
         losses = self._compute_losses(text_feat, video_feat, text_mask, video_mask,
                                       self._mb["mb_feat_t"], self._mb["mb_feat_v"], self._mb["mb_mask_t"], self._mb["mb_mask_v"],
                                       cfg.centrality_scale, cfg.beta, cfg.num_neighbors, cfg.temperature,
                                       logit_scale, noise=noise)
-        if not self.bank_frozen:
+        self._push_fn = None
+        if not self.bank_frozen and not self._pushed:
             with torch.no_grad():
-                self.update_memory_bank(idx, text_feat, video_feat, text_mask, video_mask)
+                push()
         return losses
 
     # ------------------------------------------------------------------ losses (modeling.py:314-360)
@@ -469,7 +480,8 @@ class NeighborRetr(nn.Module):
         if not (self.use_side_streams and self.bank_side_streams and device.type == "cuda"):
             return None
         if self._bstreams is None or self._bstreams[0].device != device:
-            self._bstreams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+            # two bank chains + the bank push
+            self._bstreams = tuple(torch.cuda.Stream(device=device) for _ in range(3))
         return self._bstreams
 
     def _take_join(self):

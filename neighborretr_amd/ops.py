@@ -12,6 +12,9 @@ from . import hip
 Prepared = namedtuple("Prepared", "hi lo norm colsum n_tok d")
 
 
+_COUNTERS = {}
+
+
 def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
@@ -181,6 +184,39 @@ def sinkhorn_uniform_rows(G, beta, T, rowloss, iters=50):
     return True
 
 
+def split_tail_counter(dev):
+    """The zero-initialised device word shared by the two self-finalizing launches of the split tail (one per
+    device: the launch that finishes last resets it, and steps on one device are ordered)."""
+    key = ("split_tail", dev)
+    c = _COUNTERS.get(key)
+    if c is None:
+        c = _COUNTERS[key] = torch.zeros((1,), dtype=torch.int32, device=dev)
+    return c
+
+
+def sinkhorn_uniform_rows_final(G, beta, T, rowloss, counter, wu, wn, wkl, losses, iters=50):
+    """nr_sinkhorn_uniform_rows_final: Sinkhorn + uniform-CE row terms into rowloss[:, 1, :], taking part in the shared
+    finalize (see row_losses_no_uniform_final)."""
+    G = _f32(G).contiguous()
+    B = G.shape[0]
+    ws = torch.empty((hip.sinkhorn_workspace_bytes(B),), dtype=torch.uint8, device=G.device)
+    hip.call("nr_sinkhorn_uniform_rows_final", hip.ptr(G), B, float(beta), int(iters), float(T), hip.ptr(rowloss, torch.float32),
+             hip.ptr(counter, torch.int32), float(wu), float(wn), float(wkl), hip.ptr(losses, torch.float32), hip.ptr(ws),
+             hip.stream_ptr())
+
+
+def row_losses_no_uniform_final(S, G, c0_parts, c1_parts, c_scale, wc_text, wc_video, logit_scale, K, T, rowloss, counter,
+                                wu, wn, wkl, losses):
+    """nr_row_losses_fwd_no_uniform_final: the other row terms from the bank products' partial sums; the workgroup (of
+    either launch) that finishes last writes the five losses."""
+    B = S.shape[0]
+    hip.call("nr_row_losses_fwd_no_uniform_final", hip.ptr(S, torch.float32), hip.ptr(G, torch.float32),
+             hip.ptr(c0_parts, torch.float32), c0_parts.shape[0], hip.ptr(c1_parts, torch.float32), c1_parts.shape[0],
+             float(c_scale), hip.ptr(wc_text, torch.float32), hip.ptr(wc_video, torch.float32),
+             hip.ptr(logit_scale, torch.float32), B, int(K), float(T), hip.ptr(rowloss, torch.float32),
+             hip.ptr(counter, torch.int32), float(wu), float(wn), float(wkl), hip.ptr(losses, torch.float32), hip.stream_ptr())
+
+
 def row_losses_no_uniform(S, G, bank_c0, bank_c1, wc_text, wc_video, logit_scale, K, T, rowloss):
     """Centrality / neighbour / KL row terms into rowloss[:, (0, 2, 3), :] (nr_row_losses_fwd_no_uniform)."""
     B = S.shape[0]
@@ -208,9 +244,6 @@ def row_losses_slab(S_rows, S_cols, row0, G, tgt_rows, tgt_cols, bank_c0, bank_c
              hip.ptr(bank_c1, torch.float32), hip.ptr(wc_text, torch.float32), hip.ptr(wc_video, torch.float32),
              hip.ptr(logit_scale, torch.float32), B, int(K), float(T), hip.ptr(rowloss), hip.stream_ptr())
     return rowloss
-
-
-_COUNTERS = {}
 
 
 def row_losses_final(S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, K, T, wu, wn, wkl):
