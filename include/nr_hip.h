@@ -366,6 +366,13 @@ int nr_bank_ring_push(int n_tensors, void* const* banks, const void* const* batc
  *   greater[i] = #{j : S[i,j] > S[i,i]},  equal[i] = #{j : S[i,j] == S[i,i]} (includes j=i). */
 int nr_diag_ranks(const float* S, int N, int32_t* greater, int32_t* equal, void* stream);
 
+/* Sharded evaluation (evaluator.py:21-63 with the N x N matrix split into row slabs over the ranks; metrics.py:58-66):
+ * rank counts from S_slab = S[row0 : row0 + n_rows, :] and the full diagonal diag [N] (gathered by the caller).
+ *   greater_rows / equal_rows [n_rows]: text->video counts of the slab's rows (complete);
+ *   greater_cols / equal_cols [N]: this slab's PARTIAL video->text counts per column (sum them over the ranks).      */
+int nr_slab_ranks(const float* S_slab, int n_rows, int N, int row0, const float* diag, int32_t* greater_rows,
+                  int32_t* equal_rows, int32_t* greater_cols, int32_t* equal_cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -252,23 +252,19 @@ def train_epoch(args, model, ddp, data, optimizer, epoch, global_step):
 
 
 def eval_epoch(args, model, test):
-    """evaluator.py:66-291 for the single-sentence case: full N x N similarity (every rank, like the
-    reference), ranks counted on the GPU."""
-    from neighborretr_amd.metrics import RetrievalMetrics
+    """evaluator.py:66-291 for the single-sentence case with the work SHARDED over the ranks (neighborretr_amd.evaluator):
+    every rank "extracts" the features of its samples (rank, rank + W, ...: a DistributedSampler's split; feature mode:
+    they are the inputs), one packed all-gather + index scatter restores dataset order (evaluator.py:173-189), rank r
+    computes rows [r N/W, (r+1) N/W) of the N x N similarity and the rank counts of its slab on the GPU, three small
+    collectives complete them."""
+    from neighborretr_amd.evaluator import gather_eval_features, sharded_metrics
     model.eval()
     dev = args.device
-    t, tm, v, vm = (x.to(dev) for x in (test.t, test.tm, test.v, test.vm))
-    old = model.precision
-    model.precision = "bf16x3"                      # rank-exact path for retrieval
-    rows = []
-    with torch.no_grad():
-        for lo in range(0, t.shape[0], 256):
-            S, _ = model.get_similarity_logits(t[lo:lo + 256], v, tm[lo:lo + 256], vm)
-            rows.append(S)
-    model.precision = old
-    S = torch.cat(rows, 0)
-    t2v = RetrievalMetrics.compute_metrics(S)
-    v2t = RetrievalMetrics.compute_metrics(S.t().contiguous())
+    mine = torch.arange(args.rank, test.n, args.world_size)
+    t, tm, v, vm = (x[mine].to(dev) for x in (test.t, test.tm, test.v, test.vm))
+    if args.world_size > 1:
+        t, v, tm, vm = gather_eval_features(t, v, mine.to(dev), tm, vm, args)
+    t2v, v2t = sharded_metrics(model, t, v, tm.float(), vm.float(), args)
     log(args, f"text->video R@1 {t2v['R1']:.1f} R@5 {t2v['R5']:.1f} R@10 {t2v['R10']:.1f} MedR {t2v['MR']:.1f} | "
               f"video->text R@1 {v2t['R1']:.1f} R@5 {v2t['R5']:.1f} R@10 {v2t['R10']:.1f} MedR {v2t['MR']:.1f}")
     return t2v, v2t

@@ -317,6 +317,60 @@ extern "C" int nr_diag_ranks(const float* S, int N, int32_t* greater, int32_t* e
     return NR_OK;
 }
 
+// ---- ranks from a ROW SLAB of the similarity matrix (sharded evaluation: evaluator.py:21-63 + metrics.py:58-66) -----
+// Rank r of W holds S[row0 : row0 + n, :] (its texts against all N videos) and the full diagonal (gathered: N floats).
+// Text->video ranks are row-local: greater/equal counts of row i against diag[row0 + i].  Video->text ranks need a
+// whole column: the slab contributes PARTIAL counts per column j against diag[j], summed over the ranks afterwards
+// (one all-reduce of 2N integers).  blockIdx.y = 0: rows (one wave per row); 1: columns (one thread per column,
+// coalesced over adjacent columns, rows walked in order).
+__global__ __launch_bounds__(256) void nr_slab_ranks_kernel(const float* __restrict__ S, int n, int N, int row0,
+                                                            const float* __restrict__ diag, int32_t* __restrict__ g_rows,
+                                                            int32_t* __restrict__ e_rows, int32_t* __restrict__ g_cols,
+                                                            int32_t* __restrict__ e_cols) {
+    if (blockIdx.y == 0) {
+        const int lane = threadIdx.x & 63;
+        const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (i >= n) return;
+        const float* row = S + (size_t)i * N;
+        const float dval = diag[row0 + i];
+        int g = 0, e = 0;
+        for (int j = lane; j < N; j += 64) {
+            const float x = row[j];
+            g += (x > dval);
+            e += (x == dval);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            g += __shfl_xor(g, o);
+            e += __shfl_xor(e, o);
+        }
+        if (lane == 0) { g_rows[i] = g; e_rows[i] = e; }
+    } else {
+        const int j = blockIdx.x * 256 + threadIdx.x;
+        if (j >= N) return;
+        const float dval = diag[j];
+        int g = 0, e = 0;
+        for (int i = 0; i < n; ++i) {
+            const float x = S[(size_t)i * N + j];
+            g += (x > dval);
+            e += (x == dval);
+        }
+        g_cols[j] = g;
+        e_cols[j] = e;
+    }
+}
+
+extern "C" int nr_slab_ranks(const float* S_slab, int n_rows, int N, int row0, const float* diag, int32_t* greater_rows,
+                             int32_t* equal_rows, int32_t* greater_cols, int32_t* equal_cols, void* stream) {
+    if (!S_slab || !diag || !greater_rows || !equal_rows || !greater_cols || !equal_cols) return NR_EINVAL;
+    if (n_rows <= 0 || N <= 0 || row0 < 0 || row0 + n_rows > N) return NR_EINVAL;
+    const int gx = max((n_rows + 3) / 4, (N + 255) / 256);
+    hipLaunchKernelGGL(nr_slab_ranks_kernel, dim3(gx, 2), dim3(256), 0, (hipStream_t)stream, S_slab, n_rows, N, row0, diag,
+                       greater_rows, equal_rows, greater_cols, equal_cols);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
 // ---- step prologue -------------------------------------------------------------------------------------------
 // What the step needs before anything else can start, in ONE launch instead of six ATen kernels on the serial
 // front of the critical path: the int64 masks of the loader as fp32 multipliers (modeling.py:283-287 keeps them

@@ -31,12 +31,21 @@ class RetrievalMetrics:
         if not S.is_cuda:
             S = S.cuda()
         greater, equal = ops.diag_ranks(S)
-        greater, equal = greater.cpu().numpy(), equal.cpu().numpy()
+        return RetrievalMetrics.ranks_from_counts(greater.cpu().numpy(), equal.cpu().numpy())
+
+    @staticmethod
+    def ranks_from_counts(greater, equal):
+        """`ind` from the per-row counts #{j: S[i,j] > S[i,i]} and #{j: S[i,j] == S[i,i]} (the latter includes the diagonal):
+        row i contributes the consecutive ranks greater[i] .. greater[i] + equal[i] - 1, rows in order."""
+        greater, equal = np.asarray(greater, dtype=np.int64), np.asarray(equal, dtype=np.int64)
         return np.repeat(greater, equal) + (np.arange(int(equal.sum())) - np.repeat(np.cumsum(equal) - equal, equal))
 
     @staticmethod
     def compute_metrics(similarity_matrix):
-        ind = RetrievalMetrics.diagonal_ranks(similarity_matrix)
+        return RetrievalMetrics.metrics_from_ranks(RetrievalMetrics.diagonal_ranks(similarity_matrix))
+
+    @staticmethod
+    def metrics_from_ranks(ind):
         n = len(ind)
         m = {
             "R1": float(np.sum(ind == 0)) * 100 / n,

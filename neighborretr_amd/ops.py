@@ -475,3 +475,17 @@ def diag_ranks(S):
     e = torch.empty((N,), dtype=torch.int32, device=S.device)
     hip.call("nr_diag_ranks", hip.ptr(S), N, hip.ptr(g), hip.ptr(e), hip.stream_ptr())
     return g, e
+
+
+def slab_ranks(S_slab, row0, diag):
+    """(greater_rows, equal_rows [n], greater_cols, equal_cols [N]) of a row slab against the full diagonal (nr_slab_ranks)."""
+    S_slab = _f32(S_slab).contiguous()
+    n, N = S_slab.shape
+    dev = S_slab.device
+    gr = torch.empty((n,), dtype=torch.int32, device=dev)
+    er = torch.empty((n,), dtype=torch.int32, device=dev)
+    gc = torch.empty((N,), dtype=torch.int32, device=dev)
+    ec = torch.empty((N,), dtype=torch.int32, device=dev)
+    hip.call("nr_slab_ranks", hip.ptr(S_slab), n, N, int(row0), hip.ptr(diag, torch.float32), hip.ptr(gr), hip.ptr(er),
+             hip.ptr(gc), hip.ptr(ec), hip.stream_ptr())
+    return gr, er, gc, ec
