@@ -85,6 +85,10 @@ def get_args():
     p.add_argument("--centrality_multi_token", default="raise", choices=["raise", "mean"],
                    help="several global tokens per sample (ActivityNet token counts): 'raise' like the reference "
                         "(until_module.py:321), 'mean' = centrality weight averaged over the sample's global tokens")
+    p.add_argument("--encoders", type=int, default=0,
+                   help="1: BASELINE configs[4] -- ViT-B/32 image tower, text tower and temporal transformer (stock "
+                        "PyTorch-ROCm modules, random init unless --init_model) in front of the HIP head; --synthetic then "
+                        "feeds random pixels [b, frames, 3, 224, 224] and token ids instead of token features")
     p.add_argument("--hip_graph", type=int, default=0,
                    help="1: forward + backward of the training step replayed from ONE captured HIP graph "
                         "(single rank; the eager step is bound by the host issuing ~560 launches)")
@@ -143,12 +147,53 @@ class SyntheticFeatures:
         return tuple(x.to(device, non_blocking=True) for x in (self.t[sl], self.tm[sl], self.v[sl], self.vm[sl], idx))
 
 
+class SyntheticClips:
+    """Per-rank shard of seeded raw inputs for --encoders 1: token ids [b, Nt] (EOT at the end of the mask) and pixels
+    [b, Nv, 3, 224, 224], generated on the device batch by batch (a whole epoch of frames would not fit the host)."""
+
+    def __init__(self, args, n, stream, seed, resolution=224):
+        from neighborretr_amd import synth
+        from neighborretr_amd.encoders import synthetic_text_ids
+        _, _, tm, vm = synth.make_samples(seed, stream, n, args.max_words, args.max_frames, d=8)
+        self.tm, self.vm = torch.from_numpy(tm), torch.from_numpy(vm)
+        self.ids = synthetic_text_ids(self.tm, seed=seed)
+        self.n, self.res, self.seed = n, resolution, seed
+        self.b = args.batch_size // args.world_size
+        self.W, self.rank, self.B = args.world_size, args.rank, args.batch_size
+
+    def __len__(self):
+        return self.n // self.B
+
+    def rows(self, index, device):
+        g = torch.Generator(device=device).manual_seed(self.seed * 1000003 + int(index[0]))
+        video = torch.randn((len(index), self.vm.shape[1], 3, self.res, self.res), generator=g, device=device)
+        return (self.ids[index].to(device), self.tm[index].to(device), video, self.vm[index].to(device), index.to(device))
+
+    def batch(self, i, device):
+        lo = i * self.B + self.rank * self.b
+        return self.rows(torch.arange(lo, lo + self.b), device)
+
+
+def encode(model, batch):
+    """(text_feat, text_mask, video_feat, video_mask, idx) of a raw batch: the encoders' outputs, or the inputs themselves
+    in feature mode."""
+    text, tm, video, vm, idx = batch
+    if model.feature_mode:
+        return batch
+    with torch.no_grad():
+        tf, vf = model.get_text_video_feat(text, tm, video, vm)
+    return tf, tm, vf, vm, idx
+
+
 def load_memory_bank(args, model, data):
     """memory_bank.py:80-229: run mb_batch batches through the (feature-mode) encoders under no_grad,
     gather them over the ranks, hand them to the model as plain attributes."""
     from neighborretr_amd.dist import packed_allgather
     n = min(args.mb_batch, len(data))
-    feats = [data.batch(i, args.device) for i in range(n)]
+    was_training = model.training
+    model.eval()                                            # memory_bank.py:102
+    feats = [encode(model, data.batch(i, args.device)) for i in range(n)]
+    model.train(was_training)
     with torch.no_grad():
         tf, tm, vf, vm, idx = (torch.cat([f[k] for f in feats], 0) for k in range(5))
         tf, vf, idx, tm, vm = packed_allgather(tf, vf, idx, tm, vm, args)
@@ -261,7 +306,11 @@ def eval_epoch(args, model, test):
     model.eval()
     dev = args.device
     mine = torch.arange(args.rank, test.n, args.world_size)
-    t, tm, v, vm = (x[mine].to(dev) for x in (test.t, test.tm, test.v, test.vm))
+    if model.feature_mode:
+        t, tm, v, vm = (x[mine].to(dev) for x in (test.t, test.tm, test.v, test.vm))
+    else:                                                   # evaluator.py:162-171: features cached batch by batch
+        parts = [encode(model, test.rows(mine[lo:lo + 32], dev)) for lo in range(0, len(mine), 32)]
+        t, tm, v, vm = (torch.cat([p[k] for p in parts], 0) for k in range(4))
     if args.world_size > 1:
         t, v, tm, vm = gather_eval_features(t, v, mine.to(dev), tm, vm, args)
     t2v, v2t = sharded_metrics(model, t, v, tm.float(), vm.float(), args)
@@ -279,7 +328,7 @@ def main():
         raise SystemExit("datasets / CLIP towers are outside this build (SURVEY.md 2.1): run with --synthetic, "
                          "or import neighborretr_amd.modeling.NeighborRetr into the reference's main.py")
     from neighborretr_amd.modeling import NeighborRetr
-    model = NeighborRetr(args, precision=args.precision)
+    model = NeighborRetr(args, precision=args.precision, with_encoders=bool(args.encoders))
     if args.init_model:
         sd = torch.load(args.init_model, map_location="cpu")
         missing, unexpected = model.load_state_dict(sd, strict=False)          # main.py:60-67
@@ -289,8 +338,9 @@ def main():
     if args.world_size > 1:
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[args.device_index],
                                                         find_unused_parameters=True)   # optimizer.py:79-84
-    train = SyntheticFeatures(args, args.synthetic_train, "train", args.seed)
-    test = SyntheticFeatures(args, args.synthetic_test, "test", args.seed + 1)
+    Data = SyntheticClips if args.encoders else SyntheticFeatures
+    train = Data(args, args.synthetic_train, "train", args.seed)
+    test = Data(args, args.synthetic_test, "test", args.seed + 1)
     optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
     os.makedirs(args.output_dir, exist_ok=True)
     global_step = 0

@@ -41,15 +41,27 @@ class FeatureModeCLIP(nn.Module):
 
 
 class NeighborRetr(nn.Module):
-    def __init__(self, config, clip=None, width=512, precision="bf16"):
+    def __init__(self, config, clip=None, width=512, precision="bf16", with_encoders=False, encoder_dims=None):
+        """clip: any module with encode_text / encode_image / logit_scale (e.g. the reference's own CLIP).
+        with_encoders=True: build the ViT-B/32 towers + the temporal transformer of the reference model here
+        (neighborretr_amd.encoders: stock PyTorch-ROCm modules, reference parameter names, random init unless a
+        checkpoint is loaded) -- BASELINE configs[4], pixel / token-id inputs.  Neither: feature mode."""
         super().__init__()
         self.config = config
         for k, v in DEFAULTS.items():
             if not hasattr(config, k):
                 setattr(config, k, v)
         self.transformer_width = width
+        if clip is None and with_encoders:
+            from .encoders import ClipEncoders, TemporalTransformer
+            clip = ClipEncoders(**(encoder_dims or {}))
+            width = self.transformer_width = clip.transformer.width
+            # modeling.py:154-166: frame position embeddings + `num_hidden_layers` temporal blocks
+            self.frame_position_embeddings = nn.Embedding(clip.context_length, width)
+            self.transformerClip = TemporalTransformer(width, int(getattr(config, "num_hidden_layers", 4)), width // 64)
         self.clip = clip if clip is not None else FeatureModeCLIP()
         self.feature_mode = clip is None
+        self.encoder_dtype = torch.bfloat16
         # "bf16"    training plan: bank products / bank scorer one bf16 pass, B x B product split-bf16
         # "bf16x3"  everything split-bf16 (rank-exact eval, golden parity)
         # "bf16_all" everything one bf16 pass (fastest; ~2e-3 on the centrality loss at small B)
@@ -64,7 +76,19 @@ class NeighborRetr(nn.Module):
         self.uniform_regularization_loss = UniformRegularizationLoss()
         self.kl_loss = KLDivergenceLoss()
         self._init_memory_bank()
+        clip_sd = None
+        if hasattr(self, "transformerClip"):
+            clip_sd = {k: v.clone() for k, v in self.clip.state_dict().items()}
         self.apply(self._init_weights)
+        if clip_sd is not None:
+            # modeling.py:62-69: the model-wide init runs over the CLIP towers too, then CLIP's own weights are put back
+            # and the temporal transformer starts from the text tower's first blocks / positional embedding (:199-219)
+            self.clip.load_state_dict(clip_sd)
+            own = {"frame_position_embeddings.weight": clip_sd["positional_embedding"].clone()}
+            for k, v in clip_sd.items():
+                if k.startswith("transformer.resblocks.") and int(k.split(".")[2]) < len(self.transformerClip.resblocks):
+                    own[k.replace("transformer.", "transformerClip.", 1)] = v.clone()
+            self.load_state_dict(own, strict=False)
         # token clustering (modeling.py:186-197)
         self.text_ctm0 = CTM(sample_ratio=1 / 6, embed_dim=width, dim_out=width, k=3)
         self.text_block0 = TCBlock(dim=width, num_heads=8)
@@ -268,6 +292,10 @@ class NeighborRetr(nn.Module):
     def forward(self, text_ids, text_mask, video, video_mask=None, idx=None, global_step=0, logger=None):
         text_mask = text_mask.view(-1, text_mask.shape[-1])
         video_mask = video_mask.view(-1, video_mask.shape[-1])
+        if not self.feature_mode:                      # modeling.py:253-265: token ids [b, Nt], frames [b*Nv, 3, H, W]
+            text_ids = text_ids.view(-1, text_ids.shape[-1])
+            video = torch.as_tensor(video)
+            video = video.reshape((-1,) + tuple(video.shape[-3:]))
         text_feat, video_feat = self.get_text_video_feat(text_ids, text_mask, video, video_mask, shaped=True)
         if not self.training:
             return None
@@ -516,16 +544,42 @@ class NeighborRetr(nn.Module):
             text_ids = text_ids.view(-1, text_ids.shape[-1])
             text_mask = text_mask.view(-1, text_mask.shape[-1])
         bs = text_ids.size(0)
-        _, feat = self.clip.encode_text(text_ids, return_hidden=True, mask=text_mask)
+        with self._encoder_autocast(text_ids.device):
+            _, feat = self.clip.encode_text(text_ids, return_hidden=True, mask=text_mask)
         return feat.float().view(bs, -1, feat.size(-1))
 
+    def _encoder_autocast(self, device):
+        on = device.type == "cuda" and self.encoder_dtype is not None
+        return torch.autocast("cuda", dtype=self.encoder_dtype, enabled=on)
+
     def get_video_feat(self, video, video_mask, shaped=False):
+        """modeling.py:553-567: frames through the image tower (class token of every frame), then the temporal
+        transformer over the frames of a video (aggregate_video_features, :601-623)."""
         if self.feature_mode:
             return torch.as_tensor(video).float().view(-1, video.shape[-2], video.shape[-1])
-        raise NotImplementedError("pixel input needs a CLIP tower and temporal transformer (out of scope, "
-                                  "SURVEY.md 2.1); construct NeighborRetr(config, clip=...) and override")
+        if not hasattr(self, "transformerClip"):
+            raise NotImplementedError("pixel input needs the temporal transformer: construct NeighborRetr(config, "
+                                      "with_encoders=True) (or subclass with your own get_video_feat)")
+        if shaped is False:
+            video_mask = video_mask.view(-1, video_mask.shape[-1])
+            video = torch.as_tensor(video)
+            video = video.reshape((-1,) + tuple(video.shape[-3:]))          # [b, n_v, 3, H, W] or the 7-D loader layout
+        bs, n_v = video_mask.shape
+        from .encoders import aggregate_video_features
+        with self._encoder_autocast(video.device):
+            frame = self.clip.encode_image(video.to(self.clip.visual.conv1.weight.dtype), return_hidden=True)[0]
+            frame = frame.float().view(bs, -1, frame.size(-1))
+            feat = aggregate_video_features(frame, video_mask, self.frame_position_embeddings, self.transformerClip)
+        return feat.float()
 
     def get_text_video_feat(self, text_ids, text_mask, video, video_mask, shaped=False):
+        if not self.feature_mode and shaped is False:
+            text_ids = text_ids.view(-1, text_ids.shape[-1])
+            text_mask = text_mask.view(-1, text_mask.shape[-1])
+            video_mask = video_mask.view(-1, video_mask.shape[-1])
+            video = torch.as_tensor(video)
+            video = video.reshape((-1,) + tuple(video.shape[-3:]))
+            shaped = True
         return self.get_text_feat(text_ids, text_mask, shaped), self.get_video_feat(video, video_mask, shaped)
 
 

@@ -108,3 +108,18 @@ def test_main_retrieval_two_ranks_on_one_gpu(tmp_path, shard):
     losses = [float(l.split(" loss ")[1].split()[0]) for l in r.stdout.splitlines() if " loss " in l]
     assert losses and all(x == x and x < 1e4 for x in losses), r.stdout[-2000:]
     assert "text->video R@1" in r.stdout
+
+
+def test_main_retrieval_with_encoders_end_to_end(tmp_path):
+    """BASELINE configs[4] glue: ViT-B/32 towers + temporal transformer (stock PyTorch-ROCm, random init, bf16
+    autocast) feeding the HIP head from synthetic pixels / token ids: bank load through the encoders, training steps with
+    gradients into the towers, sharded evaluation."""
+    cmd = [sys.executable, os.path.join(ROOT, "main_retrieval.py"), "--do_train", "1", "--synthetic", "--encoders", "1",
+           "--batch_size", "8", "--max_words", "18", "--max_frames", "12", "--num_neighbors", "4", "--mb_batch", "1", "--epochs", "1",
+           "--synthetic_train", "16", "--synthetic_test", "16", "--n_display", "1", "--output_dir", str(tmp_path), "--lr", "1e-6"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "memory bank: 8 samples" in r.stdout
+    losses = [float(l.split(" loss ")[1].split()[0]) for l in r.stdout.splitlines() if " loss " in l]
+    assert len(losses) == 2 and all(x == x and x < 1e4 for x in losses), r.stdout[-2000:]
+    assert "text->video R@1" in r.stdout
