@@ -96,6 +96,25 @@ def host_cores():
     return len(allowed), (len(phys) or len(allowed))
 
 
+def cpu_quota():
+    """CPUs this container may use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown: a GPU
+    box gives each GPU a share of the host's cores, and threads beyond it only fight over the same quota."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // p)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(samples=7):
     """The CPU port of the reference algorithm (oracle/nr_oracle.py, pinned against the reference's own outputs) on the
     same workload, timed on this host: forward at 1 thread and at one thread per physical core (median of `samples`
@@ -104,6 +123,8 @@ def cpu_baseline(samples=7):
     import nr_oracle as O
     from neighborretr_amd import synth
     logical, physical = host_cores()
+    quota = cpu_quota()
+    threads = min(physical, quota) if quota else physical
     c = CFG
     prob = {k: torch.from_numpy(v) for k, v in synth.make_problem(1002, c["B"], c["Nt"], c["Nv"], c["M"]).items()}
     P = {k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}
@@ -131,17 +152,17 @@ def cpu_baseline(samples=7):
             one(grad)
             ts.append(time.perf_counter() - t0)
         return float(np.median(ts))
-    t_all = timed(physical, samples)
+    t_all = timed(threads, samples)
     t_one = timed(1, samples)
-    t_fb = timed(physical, 3, grad=True, warm=1)
-    return {"value": round(1.0 / t_all, 3), "unit": "steps/s", "cores": physical, "kind": "port",
-            "physical_cores": physical, "logical_cpus": logical,
-            "sample": f"configs[1] (B=128,Nt=24,Nv=12,M=512,K=20), torch CPU ops: forward x{samples} at {physical} threads "
-                      f"(one per physical core) and x{samples} at 1 thread, forward+backward x3 at {physical} threads; "
-                      "medians after warm-ups",
+    t_fb = timed(threads, 3, grad=True, warm=1)
+    return {"value": round(1.0 / t_all, 3), "unit": "steps/s", "cores": threads, "kind": "port",
+            "physical_cores": physical, "logical_cpus": logical, "cpu_quota": quota,
+            "sample": f"configs[1] (B=128,Nt=24,Nv=12,M=512,K=20), torch CPU ops: forward x{samples} at {threads} threads "
+                      f"(host: {physical} physical cores, this container's CPU quota: {quota or 'none'}) and x{samples} at 1 "
+                      f"thread, forward+backward x3 at {threads} threads; medians after warm-ups",
             "ms_per_step": round(t_all * 1e3, 2),
             "one_thread": {"value": round(1.0 / t_one, 3), "ms_per_step": round(t_one * 1e3, 2), "cores": 1},
-            "fwd_bwd": {"value": round(1.0 / t_fb, 3), "ms_per_step": round(t_fb * 1e3, 2), "cores": physical}}
+            "fwd_bwd": {"value": round(1.0 / t_fb, 3), "ms_per_step": round(t_fb * 1e3, 2), "cores": threads}}
 
 
 def parity_gates(model, dev):
@@ -399,15 +420,20 @@ def main():
             torch.cuda.synchronize()
         per_launch_s = e0.elapsed_time(e1) * 1e-3 / (3 * reps * inner)
         achieved = (f_sim / 3) / per_launch_s / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_sim.json")
-        if os.path.exists(pmc):     # PMC counters need rocprofv3; the committed pass is quoted, not re-measured
-            traffic = json.load(open(pmc)).get("bytes_per_launch_avg_over_step")
+        traffic = mfma_busy = None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_sim.json")
+        if os.path.exists(pmc):     # PMC counters need rocprofv3 (separate passes): the committed passes are quoted here
+            pj = json.load(open(pmc))
+            traffic, mfma_busy = pj.get("bytes_per_launch_avg_over_step"), pj.get("mfma_busy_frac_flops_weighted")
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r01_pmc_sim.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch)",
-                    "kernel": "nr_sim_reg_kernel (fused local_level: 2 bank products on 192x384 blocks + the split-bf16 "
-                              "batch product on 96x192 blocks = 3 launches/step)",
+                    "traffic_source": "profiles/r02_pmc_sim.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 "
+                                      "correction on FETCH_SIZE; bytes per launch, mean of the three launches; not re-measured in this run)",
+                    "mfma_busy_frac": mfma_busy,
+                    "mfma_busy_source": "profiles/r02_pmc_sim.json: SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / (SQ_BUSY_CYCLES / shader engines), "
+                                        "weighted by the MFMA flops each launch issues",
+                    "kernel": "nr_sim_reg_kernel (fused local_level: 2 bank products on 192x384 blocks, ping-pong K loop + the "
+                              "split-bf16 batch product on 96x192 blocks = 3 launches/step)",
                     "avg_launch_us": round(per_launch_s * 1e6, 2),
                     "algorithmic_flops_per_launch": f_sim / 3}
 

@@ -21,25 +21,34 @@ def _coef_rowloss(g, hp, B):
     return c.float()[None, :, None].expand(2, 4, B).contiguous()
 
 
+OWN_MLP_GEMMS = True       # False: library GEMMs (torch.matmul -> hipBLASLt) for A/B timing (tools/train_times.py)
+
+
+def _mm(a, b_t):
+    """a [M,K] x b_t[N,K]^T on the build's split-bf16 engine, or through the library for A/B."""
+    if OWN_MLP_GEMMS:
+        return ops.linear_x3(a, b_t)
+    return a @ b_t.t()
+
+
 def _mlp_backward(feats, dlogits, w1, b1, w2, n_dx, exact):
-    """Backward of Linear(d,H)-ReLU-Linear(H,1) over the concatenation of `feats` (list of
-    [n_i,d] tensors) with upstream `dlogits` (list of [n_i]).  Plain GEMMs -> library matmul
-    (bf16 inputs / fp32 accumulate, or fp32 when `exact`).  Returns dW1, db1, dW2, db2 and dX of
-    the first `n_dx` rows (or None)."""
+    """Backward of Linear(d,H)-ReLU-Linear(H,1) over the concatenation of `feats` (list of [n_i,d] tensors) with upstream
+    `dlogits` (list of [n_i]).  The three GEMMs -- the recomputed hidden layer X W1^T, dW1 = dh^T X and dX = dh W1 -- run
+    on the build's split-bf16 MFMA engine (nr_linear_x3, fp32-grade products; no library GEMM on the training path); the
+    two H-vectors dW2 / db1 are plain column sums.  `exact` is kept for the callers' signature: both precision
+    plans now get the same fp32-grade gradients.  Returns dW1, db1, dW2, db2 and dX of the first `n_dx` rows (or None)."""
     X = torch.cat([f.reshape(-1, f.shape[-1]) for f in feats], 0).float()
     dl = torch.cat([d.reshape(-1) for d in dlogits], 0).float()
-    cd = torch.float32 if exact else torch.bfloat16
-    Xc, W1c = X.to(cd), w1.to(cd)
-    h = (Xc @ W1c.t()).float() + b1.float()
+    w1f = w1.detach().float()
+    h = ops.linear_x3(X, w1f, b1.detach().float()) if OWN_MLP_GEMMS else torch.addmm(b1.detach().float(), X, w1f.t())   # [n, H]
     act = h > 0
-    a = torch.where(act, h, torch.zeros_like(h))
-    dW2 = (dl[None, :] @ a)                                   # [1,H]
+    a_dl = torch.where(act, h * dl[:, None], torch.zeros_like(h))
+    dW2 = a_dl.sum(0).reshape(1, -1)                                     # sum_t dl_t relu(h_t)
     db2 = dl.sum().reshape(1)
-    dh = torch.where(act, dl[:, None] * w2.float().reshape(1, -1), torch.zeros_like(h))
-    dhc = dh.to(cd)
-    dW1 = (dhc.t() @ Xc).float()
+    dh = torch.where(act, dl[:, None] * w2.detach().float().reshape(1, -1), torch.zeros_like(h))
     db1 = dh.sum(0)
-    dX = (dhc[:n_dx] @ W1c).float() if n_dx else None
+    dW1 = _mm(dh.t().contiguous(), X.t().contiguous())                   # [H, d] = dh^T X   (K = tokens)
+    dX = _mm(dh[:n_dx].contiguous(), w1f.t().contiguous()) if n_dx else None      # [n_dx, d] = dh W1
     return dW1, db1, dW2, db2, dX
 
 

@@ -96,7 +96,9 @@ class CTM(nn.Module):
         self.score = nn.Linear(dim_out, 1)
         self.k = k
 
-    def forward(self, tokens, noise=None):
+    def forward(self, tokens, noise=None, assign=None):
+        """assign: optional precomputed cluster ids [B,N] (the fused HIP forward saves them: cluster_fused.ClusterStagesFn
+        recomputes this stage in its backward without re-running DPC-KNN, whose indices carry no gradient)."""
         x = self.norm(self.conv(tokens["x"]))
         score = self.score(x).squeeze(-1)
         mask = tokens.get("mask")
@@ -105,7 +107,8 @@ class CTM(nn.Module):
             # is also what the following attention adds to its logits for masked tokens
             score = score.masked_fill((1 - mask).to(torch.bool), float("-inf"))
         n_out = max(math.ceil(x.shape[1] * self.sample_ratio), 1)
-        assign = dpc_knn_assign(x, n_out, self.k, mask, noise)
+        if assign is None:
+            assign = dpc_knn_assign(x, n_out, self.k, mask, noise)
         merged = merge_by_cluster(x, assign, n_out, score.exp())
         down = {"x": merged, "mask": None}
         full = {"x": x, "mask": mask, "token_score": score}

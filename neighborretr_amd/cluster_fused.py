@@ -117,16 +117,17 @@ def _addr(t):
     return None if t is None else t.data_ptr()
 
 
-def ctm_stage_group(problems, cache, stepwise=False):
+def ctm_stage_group(problems, cache, stepwise=False, want_assign=False):
     """One CTM + TCBlock stage of several independent problems (text and video) in the SAME seven launches
     (nr_ctm_stage_fwd).  problems: list of (key, x [B,N,C], mask or None, ctm, blk, noise or None).
     Returns the list of outputs [B,cnum,C]; with stepwise=True returns (outputs, generator) where every
-    next() of the generator issues ONE of the seven launches on the then-current stream."""
+    next() of the generator issues ONE of the seven launches on the then-current stream.  want_assign=True: returns
+    (outputs, cluster ids [B,N] int64 per problem) -- what a backward pass needs to recompute the stage."""
     import ctypes
     if not 0 < len(problems) <= hip.CTM_MAX_GROUP:
         raise hip.NrHipError(f"1..{hip.CTM_MAX_GROUP} problems per grouped stage")
     descs = (hip.CtmStageDesc * len(problems))()
-    keep, outs = [], []
+    keep, outs, assigns = [], [], []
     for d, (key, x, mask, ctm, blk, noise) in zip(descs, problems):
         x = x.detach().float().contiguous()
         B, N, C = x.shape
@@ -144,12 +145,14 @@ def ctm_stage_group(problems, cache, stepwise=False):
         nbytes = int(hip.lib().nr_ctm_stage_workspace_bytes(B, N, C, cnum))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         out = torch.empty((B, cnum, C), dtype=torch.float32, device=dev)
+        assign = torch.empty((B, N), dtype=torch.int64, device=dev) if want_assign else None
+        assigns.append(assign)
         conv_bias = getattr(ctm.conv.conv, "bias", None)
         tensors = dict(x=x, mask=m, noise=noise, wconv_hi=sw.wconv_hi, wconv_lo=sw.wconv_lo, conv_bias=conv_bias,
                        ln_w=ctm.norm.weight, ln_b=ctm.norm.bias, sc_w=ctm.score.weight, sc_b=ctm.score.bias,
                        n1_w=blk.norm1.weight, n1_b=blk.norm1.bias, wq_hi=sw.wq_hi, wq_lo=sw.wq_lo, q_bias=attn.q.bias,
                        wkv_hi=sw.wkv_hi, wkv_lo=sw.wkv_lo, kv_bias=attn.kv.bias, wp_hi=sw.wp_hi, wp_lo=sw.wp_lo,
-                       proj_bias=attn.proj.bias, workspace=ws, out=out, assign=None)
+                       proj_bias=attn.proj.bias, workspace=ws, out=out, assign=assign)
         d.n_samples, d.N, d.C, d.k, d.cnum, d.heads = B, N, C, int(ctm.k), cnum, int(attn.num_heads)
         d.eps_ctm, d.eps_n1 = float(ctm.norm.eps), float(blk.norm1.eps)
         for name, t in tensors.items():
@@ -167,4 +170,50 @@ def ctm_stage_group(problems, cache, stepwise=False):
         return outs, launches()
     hip.call("nr_ctm_stage_fwd", descs, len(problems), hip.stream_ptr())
     del keep
-    return outs
+    return (outs, assigns) if want_assign else outs
+
+
+class ClusterStagesFn(torch.autograd.Function):
+    """One CTM + TCBlock stage of the text AND the video tokens for the TRAINING step: the forward runs the grouped HIP
+    kernels (7 launches for both modalities, like the loss-only step) and keeps only the inputs and the cluster ids;
+    the backward recomputes the stage with the autograd-traced torch ops of cluster.py on those ids (DPC-KNN itself has
+    no gradient: cluster.py:467 runs it under no_grad) and differentiates that.  The reference traces ~45 ATen launches
+    per stage and modality in the forward and keeps every intermediate alive until the backward."""
+
+    @staticmethod
+    def forward(ctx, modules, cache, keys, x_t, mask_t, noise_t, x_v, mask_v, noise_v, *params):
+        (ctm_t, blk_t), (ctm_v, blk_v) = modules
+        (out_t, out_v), (as_t, as_v) = ctm_stage_group([(keys[0], x_t, mask_t, ctm_t, blk_t, noise_t),
+                                                        (keys[1], x_v, mask_v, ctm_v, blk_v, noise_v)], cache, want_assign=True)
+        ctx.modules = modules
+        ctx.masks = (mask_t, mask_v)
+        ctx.n_params = len(params)
+        ctx.save_for_backward(x_t, x_v, as_t, as_v)
+        return out_t, out_v
+
+    @staticmethod
+    def backward(ctx, g_t, g_v):
+        x_t, x_v, as_t, as_v = ctx.saved_tensors
+        grads_x, grads_p = [], {}
+        with torch.enable_grad():
+            for (ctm, blk), x, mask, assign, g in zip(ctx.modules, (x_t, x_v), ctx.masks, (as_t, as_v), (g_t, g_v)):
+                xg = x.detach().requires_grad_(True)
+                out = blk(ctm({"x": xg, "mask": mask}, assign=assign))["x"]
+                ps = [p for p in list(ctm.parameters()) + list(blk.parameters()) if p.requires_grad]
+                gr = torch.autograd.grad(out, [xg] + ps, g.contiguous(), allow_unused=True)
+                grads_x.append(gr[0])
+                for p, gp in zip(ps, gr[1:]):
+                    grads_p[id(p)] = gp
+        ordered = []
+        for ctm, blk in ctx.modules:
+            for p in list(ctm.parameters()) + list(blk.parameters()):
+                ordered.append(grads_p.get(id(p)))
+        assert len(ordered) == ctx.n_params
+        return (None, None, None, grads_x[0], None, None, grads_x[1], None, None) + tuple(ordered)
+
+
+def cluster_stages_train(modules, cache, keys, x_t, mask_t, noise_t, x_v, mask_v, noise_v):
+    """Differentiable grouped stage (ClusterStagesFn); the stage's parameters ride along as explicit inputs so that
+    autograd routes their gradients."""
+    params = [p for ctm, blk in modules for p in list(ctm.parameters()) + list(blk.parameters())]
+    return ClusterStagesFn.apply(modules, cache, keys, x_t, mask_t, noise_t, x_v, mask_v, noise_v, *params)

@@ -5,8 +5,9 @@
     global_level_sim(...) global_level (modeling.py:516-539)
     row_loss_terms(...)   the raw [2,4,B] per-row loss terms (used by the until_module classes)
 
-Forward and backward both run on the HIP kernels; the only library calls are the bf16 GEMMs of
-the token-scorer MLP backward (plain GEMMs -> hipBLASLt through torch.matmul).
+Forward and backward both run on the HIP kernels (the token-scorer MLP backward on nr_linear_x3); the only library
+GEMMs left on the training path are the tiny dG products of the global logits and the torch-op recompute of the
+clustering stage's backward (cluster_fused.ClusterStagesFn).
 """
 import torch
 

@@ -113,6 +113,11 @@ class NeighborRetr(nn.Module):
         self.bank_early = 2                 # bank chains started beside the clustering instead of the Sinkhorn (0..2)
         self.group_clustering = True        # text + video clustering in the same launches (no-grad forward)
         self.fuse_clustering = True
+        # training: fused clustering forward + recompute backward (cluster_fused.ClusterStagesFn).  Correct (gradient
+        # parity tests run it) but OFF by default: the recompute runs text and video one after the other on one stream,
+        # 7.0 ms per graph-captured training step against 4.1 ms with the autograd-traced forward on two side streams
+        # (tools/train_times.py, MI355X)
+        self.fused_training_clustering = False
         self._ctm_cache = {}
 
     # ------------------------------------------------------------------ construction helpers
@@ -380,6 +385,16 @@ class NeighborRetr(nn.Module):
             gt = gv = None
 
             self._join_global = self._merge_grouped_steps(text_feat, video_feat, text_mask, video_mask, nz)
+        elif (text_feat.is_cuda and self.fuse_clustering and self.fused_training_clustering and torch.is_grad_enabled()
+              and text_feat.shape[1] <= 64 and video_feat.shape[1] <= 64 and text_feat.shape[2] % 128 == 0):
+            # training step: the clustering forward on the grouped HIP kernels (ClusterStagesFn: inputs + cluster ids
+            # saved, the stage recomputed on torch ops in the backward)
+            from .cluster_fused import cluster_stages_train
+            t, v = cluster_stages_train(((self.text_ctm0, self.text_block0), (self.video_ctm0, self.video_block0)),
+                                        self._ctm_cache, ("text0", "video0"), text_feat, text_mask, nz.get("t0"),
+                                        video_feat, video_mask, nz.get("v0"))
+            gt, gv = cluster_stages_train(((self.text_ctm1, self.text_block1), (self.video_ctm1, self.video_block1)),
+                                          self._ctm_cache, ("text1", "video1"), t, None, nz.get("t1"), v, None, nz.get("v1"))
         elif text_feat.is_cuda and self.use_side_streams:
             # three independent branches: text clustering | video clustering | local products.
             # The two clustering branches run on side streams (in a captured HIP graph: parallel

@@ -489,3 +489,27 @@ def slab_ranks(S_slab, row0, diag):
     hip.call("nr_slab_ranks", hip.ptr(S_slab), n, N, int(row0), hip.ptr(diag, torch.float32), hip.ptr(gr), hip.ptr(er),
              hip.ptr(gc), hip.ptr(ec), hip.stream_ptr())
     return gr, er, gc, ec
+
+
+def linear_x3(x, w, bias=None, residual=None):
+    """Y = X W^T (+ bias) (+ residual) on the split-bf16 MFMA tile engine (nr_linear_x3): x [M,K], w [N,K] fp32, K padded to
+    a multiple of 64 with zeros.  ~fp32-grade products (3 bf16 passes); used for the clustering GEMMs and for the
+    backward of the token-scorer MLP."""
+    x, w = _f32(x).contiguous(), _f32(w).contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError("inner dimensions differ")
+    if K % 64:
+        pad = 64 - K % 64
+        x = torch.nn.functional.pad(x, (0, pad))
+        w = torch.nn.functional.pad(w, (0, pad))
+        K += pad
+    xh, xl = split_bf16(x)
+    wh, wl = split_bf16(w)
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    b = _f32(bias).contiguous() if bias is not None else None
+    r = _f32(residual).contiguous() if residual is not None else None
+    hip.call("nr_linear_x3", hip.ptr(xh), hip.ptr(xl), hip.ptr(wh), hip.ptr(wl), hip.ptr(b, allow_none=True), hip.ptr(r, allow_none=True),
+             M, N, K, hip.ptr(out), hip.stream_ptr())
+    return out
