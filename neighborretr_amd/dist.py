@@ -30,6 +30,7 @@ class PackedAllGather(torch.autograd.Function):
         W = _world(args)
         b = text_feat.shape[0]
         ctx.rank, ctx.b, ctx.W = int(getattr(args, "local_rank", 0)), b, W
+        ctx.sharded = bool(getattr(args, "shard_loss", False))
         if dist.is_initialized():
             ctx.rank = dist.get_rank()
         if W == 1:
@@ -85,7 +86,22 @@ class PackedAllGather(torch.autograd.Function):
         if ctx.W == 1:
             return g_tf, g_vf, None, None, None, None
         sl = slice(ctx.b * ctx.rank, ctx.b * (ctx.rank + 1))
-        return g_tf[sl], g_vf[sl], None, None, None, None
+        if not ctx.sharded:
+            return g_tf[sl], g_vf[sl], None, None, None, None
+        # sharded loss (neighborretr_amd.sharded): every rank holds W x its share of dL/dX for ALL samples; the mean over
+        # ranks of this rank's rows is dL/dX of its own samples (the AllGather2 pattern, until_module.py:408-412)
+        outs = []
+        for g in (g_tf, g_vf):
+            g = g.contiguous()
+            if dist.get_backend() == "gloo":
+                g = g.clone()
+                dist.all_reduce(g)
+                outs.append(g[sl] / ctx.W)
+            else:
+                o = torch.empty((ctx.b,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+                dist.reduce_scatter_tensor(o, g)
+                outs.append(o / ctx.W)
+        return outs[0], outs[1], None, None, None, None
 
 
 def packed_allgather(text_feat, video_feat, idx, text_mask, video_mask, args):

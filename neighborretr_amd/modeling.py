@@ -159,9 +159,11 @@ class NeighborRetr(nn.Module):
         self._mb_shadow = None
         self._last_prepared = {}
         self.use_bank_shadow = True
-        # loss-only step with the similarity / bank work sharded over the ranks (head.head_forward_sharded) instead
-        # of the reference's replicated loss; off by default (the collectives are not graph-captured)
-        self.shard_loss = False
+        # similarity / bank work sharded over the ranks instead of the reference's replicated loss (loss-only step:
+        # head.head_forward_sharded; training step: neighborretr_amd.sharded).  None = automatic: on from a gathered
+        # batch of 512 (BASELINE configs[2]), off below -- at B = 128 the step is a latency chain that sharding cannot
+        # shorten; True / False force it.  Its collectives run eagerly (not graph-captured).
+        self.shard_loss = None
 
     # The bank attributes keep the reference's names and FIFO meaning (newest sample first; written
     # wholesale by MemoryBankManager, memory_bank.py:206-211).  Internally the bank is a RING: a push
@@ -304,8 +306,12 @@ class NeighborRetr(nn.Module):
         text_feat, video_feat = self.get_text_video_feat(text_ids, text_mask, video, video_mask, shaped=True)
         if not self.training:
             return None
-        if getattr(self.config, "world_size", 1) > 1:
-            # the reference's 5 all_gathers + barrier (modeling.py:274-280) as one packed collective
+        world = int(getattr(self.config, "world_size", 1))
+        if world > 1:
+            # the reference's 5 all_gathers + barrier (modeling.py:274-280) as one packed collective.  Its backward depends
+            # on how the loss is evaluated (replicated: slice; sharded: reduce-scatter), decided before the gather
+            shard = self.shard_loss if self.shard_loss is not None else text_feat.shape[0] * world >= 512
+            self.config.shard_loss = bool(shard and text_feat.is_cuda)
             from .dist import packed_allgather
             text_feat, video_feat, idx, text_mask, video_mask = packed_allgather(
                 text_feat, video_feat, idx, text_mask, video_mask, self.config)
@@ -367,9 +373,20 @@ class NeighborRetr(nn.Module):
         mods = tuple(getattr(self, f"{w}_{k}") for w in ("text", "video") for k in ("ctm0", "block0", "ctm1", "block1"))
         nz = noise or {}
         world = int(getattr(self.config, "world_size", 1))
-        if (self.shard_loss and world > 1 and text_feat.is_cuda and not torch.is_grad_enabled()
+        if self._shard_now(world, text_feat) and torch.is_grad_enabled():
+            # training step with the loss sharded over the ranks (neighborretr_amd.sharded)
+            import torch.distributed as dist
+            from .sharded import sharded_training_losses
+            losses = sharded_training_losses(self, text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v,
+                                             mb_mask_t, mb_mask_v, hp, logit_scale, dist.get_rank(), world, noise)
+            return losses[0], losses[1], losses[2], losses[3], losses[4]
+        if (self._shard_now(world, text_feat) and not torch.is_grad_enabled()
                 and self._can_fuse_clustering(text_feat, mods) and self._can_fuse_clustering(video_feat, mods)):
             import torch.distributed as dist
+            # The clustering stays replicated: its masked stage fills distances with the maximum over the WHOLE gathered
+            # batch (cluster.py:473-475, `dist_matrix.max()`), so clustering a rank's own samples alone would change the
+            # densities of samples with fewer than k valid tokens; sharding it by samples needs that maximum exchanged
+            # between the stage's front and back kernels.
             gt, gv = self._merge_grouped(text_feat, video_feat, text_mask, video_mask, nz)
             losses = head.head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v,
                                                mb_mask_t, mb_mask_v, gt, gv, self.scorer_weights("text_weight_fc"),
@@ -420,6 +437,15 @@ class NeighborRetr(nn.Module):
                              mb_mask_t, mb_mask_v, gt, gv, hp, logit_scale)
         self._take_join()      # joined by now; never leave a stale closure behind
         return losses[0], losses[1], losses[2], losses[3], losses[4]
+
+    def _shard_now(self, world, text_feat):
+        """Sharded loss: when asked for (`shard_loss` = True, also config.shard_loss for the exchange step's backward), or
+        by default once the gathered batch reaches 512 samples (BASELINE configs[2]: the replicated loss would repeat
+        677 GF on every rank) -- `shard_loss` = False keeps the reference's replicated form at any size."""
+        if world < 2 or not text_feat.is_cuda:
+            return False
+        want = self.shard_loss if self.shard_loss is not None else text_feat.shape[0] >= 512
+        return bool(want and text_feat.shape[0] % world == 0)
 
     # ------------------------------------------------------------------ token clustering (modeling.py:446-481)
     def merge_global_features(self, text_feat, video_feat, text_mask, video_mask, noise=None):

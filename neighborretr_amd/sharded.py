@@ -1,0 +1,171 @@
+"""The loss of the TRAINING step sharded over the ranks (reference sketch: AllGather2, until_module.py:391-412).
+
+The reference replicates: after the all-gather every rank evaluates the full B x B problem plus both B x M bank
+products, and gradients need no reduction because every rank differentiates the whole loss.  At global B = 1024
+(BASELINE configs[2]) that is 677 GF per step repeated W times.  Here rank r owns the samples [r b, (r+1) b):
+
+  heavy, on the HIP kernels (differentiable: functional.local_level_sim -> LocalLevelFn):
+      S[r-slab, :]  = local_level(text_r, video_all)        [b, B]     rows of the text->video direction
+      S[:, r-slab]  = local_level(text_all, video_r)        [B, b]     rows of the video->text direction
+      text_r x bank-video [b, M],  bank-text x video_r [M, b]          1/W of both bank products -> centrality slices
+  replicated: the token clustering (its masked stage uses the maximum distance over the WHOLE gathered batch,
+      cluster.py:473-475, so a rank cannot cluster its own samples alone without an extra exchange -- DESIGN.md 7)
+  light, replicated or row-local, in torch ops on [b, B] slabs: global logits G = gt gv^T, Sinkhorn targets (no
+      gradient), centrality weights, and the four row-wise loss terms of the rank's 2 b rows
+      (until_module.py:56-359 restated row-wise).
+
+Each rank's L_r is ITS rows' share of every term, so sum_r L_r = L (the reference's loss).  Cross-rank values enter
+through differentiable collectives whose backward is the matching reduction (all-gather <-> reduce-scatter(sum),
+all-reduce <-> all-reduce), so every rank's autograd graph yields dL_r/dtheta and dL_r/dX for ALL gathered samples.
+DDP averages parameter gradients over ranks, so L_r is differentiated as W L_r (`_ScaleGrad`): mean_r(W dL_r) = dL,
+the reference's effective gradient; the exchange step's backward then AVERAGES the feature gradients over the ranks
+(dist.PackedAllGather with args.shard_loss: reduce-scatter / W), which gives every rank dL/dX of its own samples.
+Returned values are the FULL losses on every rank (one all-reduce of five numbers), with the partial gradient attached.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .functional import local_level_sim
+
+NEG_BIG = -9e15
+
+
+class _GatherCat(torch.autograd.Function):
+    """all-gather + cat on dim 0; backward: every rank's gradient of the gathered tensor summed, this rank's slice."""
+
+    @staticmethod
+    def forward(ctx, x, rank, world):
+        ctx.rank, ctx.world, ctx.n = rank, world, x.shape[0]
+        x = x.contiguous()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        if dist.get_backend() == "gloo":                      # no reduce_scatter in gloo
+            g = g.clone()
+            dist.all_reduce(g)
+            return g[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n], None, None
+        out = torch.empty((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        dist.reduce_scatter_tensor(out, g)
+        return out, None, None
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """y = sum over ranks of x (every rank gets y); backward: sum over ranks of the upstream gradients."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = x.clone()
+        dist.all_reduce(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        dist.all_reduce(g)
+        return g
+
+
+class _ScaleGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.s, None
+
+
+def _neighbor_rows(S, c, K, T, diag_col):
+    """until_module.py:161-211 for the rows of a slab: S [n,B] (row k's own sample sits in column diag_col[k]), c [B]
+    bank centralities.  Returns the per-row loss [n]."""
+    n, B = S.shape
+    cols = torch.arange(B, device=S.device)[None, :]
+    is_diag = cols == diag_col[:, None]
+    s_off = torch.where(is_diag, torch.full_like(S, NEG_BIG), S.detach())
+    idx = torch.sort(s_off, dim=-1, descending=True, stable=True)[1][:, :K]          # :100-129
+    nb = torch.zeros_like(S, dtype=torch.bool).scatter_(1, idx, True)
+    ext = nb | is_diag
+    rest = ~ext
+
+    def minmax(X):                                                                   # :65-86
+        lo = torch.where(rest, X, torch.full_like(X, 9e15)).min(-1, keepdim=True)[0]
+        hi = torch.where(rest, X, torch.full_like(X, -9e15)).max(-1, keepdim=True)[0]
+        return (X - lo) / (hi - lo)
+    ns = minmax(S)
+    nc = minmax(c[None, :].expand(n, -1))
+    adj = torch.where(nb, ns - nc, torch.full_like(S, NEG_BIG))                       # :189-193
+    p = torch.softmax(adj * T, dim=-1)                                                # :147
+    p = torch.where(nb, p, torch.zeros_like(p))
+    p = torch.where(is_diag, torch.ones_like(p), p)                                   # fill_diagonal_(1) :157
+    masked = torch.where(ext, S, torch.full_like(S, NEG_BIG))                         # :199-203
+    lp = torch.log_softmax(masked, dim=-1) * p
+    return -lp.sum(-1) / p.sum(-1)                                                    # :206-207
+
+
+def _direction_terms(S, G, tgt, c, w, ls, K, T, diag_col):
+    """The four row terms (summed over the slab's rows) of one direction: S, G, tgt [n,B]; w [n] centrality weights."""
+    rows = torch.arange(S.shape[0], device=S.device)
+    lp_c = torch.log_softmax(S * ls, dim=-1)[rows, diag_col]                           # until_module.py:315-327
+    cent = -(lp_c * w).sum()
+    unif = -(torch.log_softmax(G * T, dim=-1) * tgt).sum()                             # :285-289
+    p = torch.softmax(S, dim=-1)
+    kl = (p * (torch.log_softmax(S, dim=-1) - torch.log_softmax(G, dim=-1))).sum()     # :351-357
+    neigh = _neighbor_rows(S, c, K, T, diag_col).sum()
+    return cent, unif, neigh, kl
+
+
+def sharded_training_losses(model, text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
+                            hp, logit_scale, rank, world, noise=None):
+    """-> [5] tensor (total, centrality, uniform, neighbour, kl): full values, this rank's share of the gradient (x W)."""
+    B, Nt, d = text_feat.shape
+    M = mb_feat_v.shape[0]
+    K, T = int(hp["num_neighbors"]), float(hp["temperature"])
+    if B % world:
+        raise ValueError("the gathered batch must divide over the ranks")
+    if K > B:
+        raise ValueError(f"num_neighbors={K} > batch={B}")
+    b, r0 = B // world, rank * (B // world)
+    sl = slice(r0, r0 + b)
+    text_mask, video_mask, mb_mask_t, mb_mask_v = (m if m.dtype == torch.float32 else m.float()
+                                                   for m in (text_mask, video_mask, mb_mask_t, mb_mask_v))
+    # ---- token clustering: replicated (see the module docstring); every rank differentiates it for ITS rows' terms
+    gt, gv = model.merge_global_features(text_feat, video_feat, text_mask, video_mask, noise)
+    if gt.shape[1] != 1 or gv.shape[1] != 1:
+        raise RuntimeError("the sharded training loss covers one global token per sample (until_module.py:321)")
+    gt, gv = gt.reshape(B, d).float(), gv.reshape(B, d).float()
+    # ---- the rank's slabs of S and its slices of the bank centralities (HIP kernels, differentiable)
+    S_rows = local_level_sim(model, text_feat[sl], video_feat, text_mask[sl], video_mask)           # [b, B]
+    S_cols = local_level_sim(model, text_feat, video_feat[sl], text_mask, video_mask[sl])           # [B, b]
+    bank_t2v = local_level_sim(model, text_feat[sl], mb_feat_v, text_mask[sl], mb_mask_v)           # [b, M]
+    bank_v2t = local_level_sim(model, mb_feat_t, video_feat[sl], mb_mask_t, video_mask[sl])         # [M, b]
+    c1 = _GatherCat.apply(bank_t2v.sum(-1) / M, rank, world)        # [B] text centralities (used by the v2t neighbour loss)
+    c0 = _GatherCat.apply(bank_v2t.sum(0) / M, rank, world)         # [B] video centralities (used by the t2v neighbour loss)
+    # ---- global logits (un-normalised, modeling.py:526-537 with one global token) and Sinkhorn targets (no gradient)
+    G = gt @ gv.t()
+    tgt_r, tgt_c = ops.sinkhorn_targets(G.detach().contiguous(), hp["beta"], 50)
+    # ---- centrality weights: exp(c <g_hat_i, mean of ALL normalised tokens>), padding included (modeling.py:403-430)
+    tn = torch.nn.functional.normalize(text_feat[sl].reshape(-1, d), dim=-1).sum(0)
+    vn = torch.nn.functional.normalize(video_feat[sl].reshape(-1, d), dim=-1).sum(0)
+    mean_t = _AllReduceSum.apply(tn) / (B * Nt)
+    mean_v = _AllReduceSum.apply(vn) / (B * video_feat.shape[1])
+    w_text = torch.exp(hp["centrality_scale"] * (torch.nn.functional.normalize(gt[sl], dim=-1) @ mean_t))      # [b]
+    w_video = torch.exp(hp["centrality_scale"] * (torch.nn.functional.normalize(gv[sl], dim=-1) @ mean_v))
+    # ---- the four terms on this rank's rows of either direction
+    ls = logit_scale.reshape(()).float()
+    diag = torch.arange(r0, r0 + b, device=text_feat.device)
+    c_t, u_t, n_t, k_t = _direction_terms(S_rows, G[sl], tgt_r[sl], c0, w_text, ls, K, T, diag)
+    c_v, u_v, n_v, k_v = _direction_terms(S_cols.t(), G.t()[sl], tgt_c[sl], c1, w_video, ls, K, T, diag)
+    cent, unif, neigh = ((x + y) / (2 * B) for x, y in ((c_t, c_v), (u_t, u_v), (n_t, n_v)))
+    kl = (k_t + k_v) / (2 * B * B)                                                     # kl_div 'mean' divides by B*B
+    total = cent + unif * hp["uniform_weight"] + neigh * hp["neighbor_weight"] + kl * hp["kl_weight"]
+    part = torch.stack((total, cent, unif, neigh, kl))
+    full = part.detach().clone()
+    dist.all_reduce(full)                                                              # the reference's (full) values
+    # value: full;  gradient: W x this rank's share (DDP's mean over ranks then yields the full-loss gradient)
+    return full + (_ScaleGrad.apply(part, float(world)) - part.detach())

@@ -50,3 +50,75 @@ def test_sharded_loss_equals_replicated_loss(tmp_path):
         assert torch.isfinite(r["ref"]).all()
         assert torch.allclose(r["got"], r["ref"], rtol=2e-6, atol=2e-6), (r["got"], r["ref"])
     assert torch.equal(res[0]["got"], res[1]["got"])              # every rank holds the same losses
+
+
+def _train_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import torch.distributed as dist
+    from neighborretr_amd import modeling, synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B, Nt, Nv, M, K = 32, 24, 12, 64, 8
+    b = B // world
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K, world_size=world, local_rank=rank), precision="bf16x3")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}, strict=False)
+    m = m.to(dev).train()
+    with torch.no_grad():
+        m.clip.logit_scale.fill_(float(np.log(100.0)))
+    full = synth.make_problem(2024, B, Nt, Nv, M)
+    sl = slice(rank * b, (rank + 1) * b)
+    bank = {k: torch.from_numpy(full[k]).to(dev) for k in ("mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v")}
+    res = {}
+    for mode in ("replicated", "sharded"):
+        m.shard_loss = mode == "sharded"
+        m.mb_feat_t, m.mb_feat_v = bank["mb_feat_t"].clone(), bank["mb_feat_v"].clone()
+        m.mb_mask_t, m.mb_mask_v = bank["mb_mask_t"].clone(), bank["mb_mask_v"].clone()
+        m.mb_ind = torch.arange(M, device=dev)
+        m._rng_state = None
+        torch.manual_seed(1234)                       # the same DPC-KNN noise stream in both runs
+        tf = torch.from_numpy(full["text_feat"][sl]).to(dev).requires_grad_(True)
+        vf = torch.from_numpy(full["video_feat"][sl]).to(dev).requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        losses = m(tf, torch.from_numpy(full["text_mask"][sl]).to(dev), vf, torch.from_numpy(full["video_mask"][sl]).to(dev),
+                   torch.from_numpy(full["idx"][sl]).to(dev), 0)
+        losses[0].backward()
+        grads = {}
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                g = p.grad.detach().clone()
+                if mode == "sharded":                 # what DDP would do: the mean over the ranks
+                    dist.all_reduce(g)
+                    g /= world
+                grads[n] = g.cpu()
+        res[mode] = dict(losses=torch.stack([l.detach() for l in losses]).cpu(), g_text=tf.grad.cpu(), g_video=vf.grad.cpu(), params=grads)
+    torch.save(res, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_training_loss_gradients_equal_replicated(tmp_path):
+    """Training step, two ranks: losses, the gradient of this rank's features and the DDP-averaged parameter gradients of
+    the sharded loss (neighborretr_amd.sharded: row slabs + differentiable collectives, reduce-scatter in the exchange
+    step's backward) equal those of the reference's replicated loss."""
+    import torch.multiprocessing as mp
+    world, port = 2, 29653
+    out = str(tmp_path / "res")
+    mp.spawn(_train_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(f"{out}.{r}", weights_only=False)
+        rep, sh = res["replicated"], res["sharded"]
+        assert torch.isfinite(rep["losses"]).all()
+        assert torch.allclose(sh["losses"], rep["losses"], rtol=1e-4, atol=1e-4), (sh["losses"], rep["losses"])
+        for k in ("g_text", "g_video"):
+            scale = float(rep[k].abs().max())
+            assert float((sh[k] - rep[k]).abs().max()) < 3e-3 * scale, (k, float((sh[k] - rep[k]).abs().max()), scale)
+        assert set(sh["params"]) >= {n for n, g in rep["params"].items() if float(g.abs().max()) > 0}
+        for n, g in rep["params"].items():
+            scale = float(g.abs().max())
+            if scale == 0:
+                continue
+            assert float((sh["params"][n] - g).abs().max()) < 5e-3 * scale + 2e-6, (n, float((sh["params"][n] - g).abs().max()), scale)
