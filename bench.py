@@ -54,6 +54,10 @@ def parse():
                     help="N>1 only: similarity / bank work sharded over the ranks (head.head_forward_sharded) instead of "
                          "the reference's replicated loss; runs eagerly (its collectives are not graph-captured)")
     ap.add_argument("--backward", action="store_true", help="also time forward+backward (reported as extra fields)")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time BASELINE configs[4] on this GPU: ViT-B/32 towers + temporal transformer (stock PyTorch-ROCm, "
+                         "random init, bf16 autocast) feeding the HIP head from synthetic pixels, forward and forward+backward "
+                         "(extra field `e2e`; never the headline value)")
     return ap.parse_args()
 
 
@@ -204,6 +208,52 @@ def parity_gates(model, dev):
             "losses": [round(float(x), 5) for x in losses], "ref_losses": [round(float(x), 5) for x in g["losses"]],
             "cols_identical": bool(np.array_equal(np.asarray(mine["cols"]), ref_cols)),
             "R1": mine["R1"], "tol_losses": 1e-3, "pass": bool(dL.max() < 1e-3 and np.array_equal(np.asarray(mine["cols"]), ref_cols))}
+
+
+def e2e_bench(dev, B=128, steps=5):
+    """configs[4] at one GPU: pixels [B, 12, 3, 224, 224] + token ids [B, 24] -> encoders -> head -> losses (-> backward)."""
+    from neighborretr_amd import modeling, synth
+    from neighborretr_amd.encoders import synthetic_text_ids
+    c = CFG
+    torch.manual_seed(0)
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=c["K"], num_hidden_layers=4), with_encoders=True).to(dev).train()
+    _, _, tm, vm = synth.make_samples(5005, "e2e", B, c["Nt"], c["Nv"], d=8)
+    tm, vm = torch.from_numpy(tm).to(dev), torch.from_numpy(vm).to(dev)
+    ids = synthetic_text_ids(tm.cpu(), seed=5).to(dev)
+    video = torch.randn((B, c["Nv"], 3, 224, 224), device=dev)
+    idx = torch.arange(B, device=dev)
+    with torch.no_grad():                                   # the bank: M encoded samples (memory_bank.py:80-229)
+        tf, vf = m.get_text_video_feat(ids, tm, video, vm)
+        reps = c["M"] // B
+        m.mb_feat_t, m.mb_feat_v = tf.repeat(reps, 1, 1).contiguous(), vf.repeat(reps, 1, 1).contiguous()
+        m.mb_mask_t, m.mb_mask_v = tm.repeat(reps, 1).float(), vm.repeat(reps, 1).float()
+        m.mb_ind = torch.arange(c["M"], device=dev)
+
+    def fwd():
+        with torch.no_grad():
+            return m(ids, tm, video, vm, idx, 0)
+
+    def fwd_bwd():
+        m.zero_grad(set_to_none=True)
+        m(ids, tm, video, vm, idx, 0)[0].backward()
+
+    out = {}
+    for name, fn in (("forward", fwd), ("forward_backward", fwd_bwd)):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        out[name + "_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 2)
+    out["workload"] = (f"BASELINE configs[4] on ONE GPU: B={B}, 12 frames x 224x224, 24 tokens, bank {c['M']}; ViT-B/32 + text tower + "
+                       "4-layer temporal transformer (stock PyTorch-ROCm modules, random init, bf16 autocast, SDPA) -> HIP head")
+    out["samples_per_s_forward_backward"] = round(B / (out["forward_backward_ms"] * 1e-3), 1)
+    out["params_millions"] = round(sum(p.numel() for p in m.parameters()) / 1e6, 1)
+    del m
+    torch.cuda.empty_cache()
+    return out
 
 
 def launch_ranks(n):
@@ -373,6 +423,9 @@ def main():
             except Exception as e:
                 print(f"[bench] fwd+bwd graph capture unavailable ({type(e).__name__}: {e})", file=sys.stderr)
                 torch.cuda.synchronize()
+
+    if args.e2e and world == 1:
+        extra["e2e"] = e2e_bench(dev)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------------
     roofline = None

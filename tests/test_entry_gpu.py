@@ -123,3 +123,19 @@ def test_main_retrieval_with_encoders_end_to_end(tmp_path):
     losses = [float(l.split(" loss ")[1].split()[0]) for l in r.stdout.splitlines() if " loss " in l]
     assert len(losses) == 2 and all(x == x and x < 1e4 for x in losses), r.stdout[-2000:]
     assert "text->video R@1" in r.stdout
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` typed without a launcher: the parent starts two rank processes before any
+    GPU call and relays rank 0's JSON line.  gloo backend: the two ranks share this box's one GPU (RCCL needs a GPU each)."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "2",
+           "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["config"]["per_rank_batch"] == 64
+    assert d["parity"]["pass"] and d["roofline"]["frac"] > 0.1
