@@ -57,27 +57,32 @@ class HeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, hp, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
-                text_feat, video_feat, gt, gv, logit_scale, w1t, b1t, w2t, b2t, w1v, b1v, w2v, b2v):
+                text_feat, video_feat, gt, gv, logit_scale, w1t, b1t, w2t, b2t, w1v, b1v, w2v, b2v,
+                g1_w1t, g1_b1t, g1_w2t, g1_b2t, g1_w1v, g1_b1v, g1_w2v, g1_b2v):
+        """The last eight inputs are the *_weight_fc1 scorers of global_level (modeling.py:518-523): they matter (and get a
+        gradient) only with several global tokens per sample; with one token their softmax weight is the constant 1."""
         prec = model._prec()
         losses, sv = head.head_forward(text_feat.detach(), video_feat.detach(), text_mask, video_mask,
                                        mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v, gt.detach(), gv.detach(),
                                        model.scorer_weights("text_weight_fc"), model.scorer_weights("video_weight_fc"),
                                        hp, logit_scale.detach(), prec, keep=True, join=model._take_join(),
-                                       bank_streams=model._bank_streams(text_feat.device))
+                                       bank_streams=model._bank_streams(text_feat.device),
+                                       **model._global_scorers(text_feat, video_feat))
         ctx.sv, ctx.hp, ctx.exact = sv, dict(hp), prec == hip.PREC_BF16X3
         ctx.masks = (text_mask, video_mask)
         ctx.shapes = (text_feat.shape, video_feat.shape, mb_feat_t.shape, mb_feat_v.shape, gt.shape, gv.shape)
-        if gt.shape[1] != 1 or gv.shape[1] != 1:
-            raise NotImplementedError("gradient of the head with several global tokens per sample is not implemented")
         sv["gt2"], sv["gv2"] = sv["gt2"].reshape(-1, sv["gt2"].shape[-1]), sv["gv2"].reshape(-1, sv["gv2"].shape[-1])
-        ctx.save_for_backward(text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v)
+        ctx.save_for_backward(text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v,
+                              g1_w1t, g1_b1t, g1_w2t, g1_w1v, g1_b1v, g1_w2v)
         return losses
 
     @staticmethod
     def backward(ctx, g):
         sv, hp = ctx.sv, ctx.hp
-        text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v = ctx.saved_tensors
+        (text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v,
+         g1_w1t, g1_b1t, g1_w2t, g1_w1v, g1_b1v, g1_w2v) = ctx.saved_tensors
         (B, Nt, d), (_, Nv, _), (M, _, _), _, gt_shape, gv_shape = ctx.shapes
+        Gt, Gv = gt_shape[1], gv_shape[1]
         text_mask, video_mask = ctx.masks
         K, T = int(hp["num_neighbors"]), hp["temperature"]
         g = g.float().contiguous()
@@ -89,14 +94,30 @@ class HeadLossFn(torch.autograd.Function):
         d_c0 = ops.colsum(dC_rows[0])
         d_c1 = ops.colsum(dC_rows[1])
         d_ls = dls_rows.sum()
-        # global logits G = gt gv^T   (tiny plain GEMMs)
-        d_gt = dG @ sv["gv2"]
-        d_gv = dG.t() @ sv["gt2"]
-        # centrality weights
+        g1 = [None] * 8
+        if sv["g_saved"] is None:
+            # global logits G = gt gv^T   (tiny plain GEMMs)
+            d_gt = dG @ sv["gv2"]
+            d_gv = dG.t() @ sv["gt2"]
+        else:
+            # several global tokens per sample: G is the fused product on the un-normalised global tokens with the
+            # *_weight_fc1 softmax weights (modeling.py:516-539): arg-max-routed gradient + softmax + scorer-MLP backward
+            gs = sv["g_saved"]
+            d_gt, d_wgt = ops.local_level_bwd(0, dG, 0, 1.0, gs["pv"], gs["w_t"], gs["w_v"], gs["aux"], B, Gt, B, Gv, use_lo=True)
+            d_gv, d_wgv = ops.local_level_bwd(1, dG, 0, 1.0, gs["pt"], gs["w_v"], gs["w_t"], gs["aux"], B, Gt, B, Gv, use_lo=True)
+            dl_gt = ops.token_softmax_bwd(gs["w_t"], d_wgt.view(B, Gt))
+            dl_gv = ops.token_softmax_bwd(gs["w_v"], d_wgv.view(B, Gv))
+            gW1t, gb1t, gW2t, gb2t, gXt = _mlp_backward([sv["gt2"]], [dl_gt], g1_w1t, g1_b1t, g1_w2t, B * Gt, True)
+            gW1v, gb1v, gW2v, gb2v, gXv = _mlp_backward([sv["gv2"]], [dl_gv], g1_w1v, g1_b1v, g1_w2v, B * Gv, True)
+            d_gt, d_gv = d_gt + gXt, d_gv + gXv
+            g1 = [gW1t, gb1t, gW2t, gb2t, gW1v, gb1v, gW2v, gb2v]
+        # centrality weights: w_i = mean over the sample's global tokens of exp(c <g_hat, mean>)  (one token: the reference's)
         cs = hp["centrality_scale"]
-        gn_t, gn_v = sv["cw_aux"][0], sv["cw_aux"][1]
-        dg_t, dmean_t = ops.centrality_weights_bwd(sv["gt2"], gn_t, sv["mean_t"], sv["wc_t"], dwc[0], cs)
-        dg_v, dmean_v = ops.centrality_weights_bwd(sv["gv2"], gn_v, sv["mean_v"], sv["wc_v"], dwc[1], cs)
+        gn_t, gn_v, wtok_t, wtok_v = sv["cw_aux"]
+        dw_t = (dwc[0] / Gt)[:, None].expand(B, Gt).reshape(-1).contiguous()
+        dw_v = (dwc[1] / Gv)[:, None].expand(B, Gv).reshape(-1).contiguous()
+        dg_t, dmean_t = ops.centrality_weights_bwd(sv["gt2"], gn_t, sv["mean_t"], wtok_t, dw_t, cs)
+        dg_v, dmean_v = ops.centrality_weights_bwd(sv["gv2"], gn_v, sv["mean_v"], wtok_v, dw_v, cs)
         d_gt = (d_gt + dg_t).reshape(gt_shape)
         d_gv = (d_gv + dg_v).reshape(gv_shape)
         # similarity kernels: batch x batch, text x bank-video (row mean), bank-text x video (col mean)
@@ -126,7 +147,7 @@ class HeadLossFn(torch.autograd.Function):
         ctx.sv = None
         return (None, None, None, None, None, None, None, None,
                 d_text, d_video, d_gt, d_gv, d_ls,
-                dW1t, db1t, dW2t, db2t, dW1v, db1v, dW2v, db2v)
+                dW1t, db1t, dW2t, db2t, dW1v, db1v, dW2v, db2v, *g1)
 
 
 class LocalLevelFn(torch.autograd.Function):

@@ -52,21 +52,23 @@ def similarity_matrix(text_feat, video_feat, text_mask, video_mask, sw_t, sw_v, 
     return S
 
 
-def global_logits(gt, gv, sw_t1=None, sw_v1=None):
+def global_logits(gt, gv, sw_t1=None, sw_v1=None, keep=False):
     """global_level (modeling.py:516-539).  One global token per sample: an exact-fp32 GEMM.
-    Several tokens (ActivityNet token counts): the fused kernel on un-normalised tokens, split-bf16."""
+    Several tokens (ActivityNet token counts): the fused kernel on un-normalised tokens, split-bf16.
+    keep=True: returns (G, saved) with what the backward of the multi-token form needs (None for one token)."""
     B, Ngt, d = gt.shape
     Ngv = gv.shape[1]
     if Ngt == 1 and Ngv == 1:
-        return ops.gemm_nt_f32(gt.reshape(B, d), gv.reshape(gv.shape[0], d))
+        G = ops.gemm_nt_f32(gt.reshape(B, d), gv.reshape(gv.shape[0], d))
+        return (G, None) if keep else G
     pt = ops.prepare_tokens(gt, None, normalize=False)
     pv = ops.prepare_tokens(gv, None, normalize=False)
     ones_t = torch.ones_like(pt.norm)
     ones_v = torch.ones_like(pv.norm)
     w_t, _ = token_weights(pt, None, sw_t1, B, Ngt, hip.PREC_BF16X3, scale_override=ones_t)
     w_v, _ = token_weights(pv, None, sw_v1, gv.shape[0], Ngv, hip.PREC_BF16X3, scale_override=ones_v)
-    G, _ = ops.local_level(pt, pv, w_t, w_v, B, Ngt, gv.shape[0], Ngv, hip.PREC_BF16X3)
-    return G
+    G, aux = ops.local_level(pt, pv, w_t, w_v, B, Ngt, gv.shape[0], Ngv, hip.PREC_BF16X3, hip.OUT_FULL, keep)
+    return (G, dict(pt=pt, pv=pv, w_t=w_t, w_v=w_v, aux=aux)) if keep else G
 
 
 def _check_global_tokens(gt, gv, hp):
@@ -346,7 +348,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         if bank_streams is not None:
             fork = torch.cuda.Event()
             fork.record(cur)
-        G = global_logits(gt, gv, sw_t1, sw_v1)
+        G, g_saved = global_logits(gt, gv, sw_t1, sw_v1, keep=True) if keep else (global_logits(gt, gv, sw_t1, sw_v1), None)
         tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
         if bank_streams is not None:
             for st_ in bank_streams:
@@ -372,7 +374,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
                      lg_t=lg_t, lg_v=lg_v, lg_bt=lg_bt, lg_bv=lg_bv,
                      aux=(aux0, aux1, aux2), S=S, G=G, tgt_r=tgt_r, tgt_c=tgt_c,
                      c0=c0, c1=c1, wc_t=wc_t, wc_v=wc_v, cw_aux=cw_aux, mean_t=mean_t, mean_v=mean_v,
-                     ls=ls, gt2=gt2, gv2=gv2)
+                     ls=ls, gt2=gt2, gv2=gv2, g_saved=g_saved)
     return losses, saved
 
 

@@ -222,3 +222,56 @@ def test_configs3_full_size_step_runs_under_mean_flag():
         out = m(prob["text_feat"], prob["text_mask"], prob["video_feat"], prob["video_mask"], prob["idx"], 0)
     assert len(out) == 5 and all(torch.isfinite(o) for o in out)
     assert torch.equal(m.mb_ind[:B], prob["idx"]) and m.mb_feat_v.shape[0] == M
+    # ... and the TRAINING step at full size: finite gradients for the features, both scorer pairs and the clustering
+    tf = prob["text_feat"].clone().requires_grad_(True)
+    vf = prob["video_feat"].clone().requires_grad_(True)
+    out = m(tf, prob["text_mask"], vf, prob["video_mask"], prob["idx"] + 1000, 0)
+    out[0].backward()
+    named = dict(m.named_parameters())
+    for t_ in (tf.grad, vf.grad, named["text_weight_fc.0.weight"].grad, named["video_weight_fc1.0.weight"].grad,
+               named["text_ctm1.conv.conv.weight"].grad, m.clip.logit_scale.grad):
+        assert t_ is not None and torch.isfinite(t_).all() and float(t_.abs().max()) > 0
+    assert abs(float(out[0]) - float(L[0])) < 0.5          # same batch, the bank moved on by one push
+
+
+def test_c4_b8_backward_matches_oracle_autograd_under_mean_flag():
+    """ActivityNet token counts in TRAINING (3 / 6 global tokens per sample): gradients of the HIP head -- through the
+    multi-token global level (arg-max routing, *_weight_fc1 scorers) and the token-averaged centrality weights -- against
+    the oracle's autograd under the same `centrality_multi_token="mean"` flag (the reference itself raises here)."""
+    g, x, nz, (B, Nt, Nv, M, K) = _case("c4_b8")
+    m = _model("bf16x3", K, centrality_multi_token="mean")
+    tf = x["text_feat"].clone().requires_grad_(True)
+    vf = x["video_feat"].clone().requires_grad_(True)
+    c = m.config
+    losses = m._compute_losses(tf, vf, x["text_mask"], x["video_mask"], x["mb_feat_t"], x["mb_feat_v"], x["mb_mask_t"],
+                               x["mb_mask_v"], c.centrality_scale, c.beta, K, c.temperature, m.clip.logit_scale.exp(), noise=nz)
+    losses[0].backward()
+    P = {k: v.clone().requires_grad_(True) for k, v in params().items()}
+    tfc = x["text_feat"].cpu().clone().requires_grad_(True)
+    vfc = x["video_feat"].cpu().clone().requires_grad_(True)
+    xc = {k: v.cpu() for k, v in x.items()}
+    nzc = {k: v.cpu() for k, v in nz.items()}
+    ls = torch.tensor(100.0, requires_grad=True)
+    ref = O.compute_losses(tfc, vfc, xc["text_mask"], xc["video_mask"], xc["mb_feat_t"], xc["mb_feat_v"], xc["mb_mask_t"],
+                           xc["mb_mask_v"], P, dict(synth.DEFAULT_HP, num_neighbors=K), ls, nzc, centrality_multi_token="mean")
+    ref[0].backward()
+    assert abs(float(losses[0]) - float(ref[0])) < 2e-4
+    for mine, want, name in ((tf.grad, tfc.grad, "text"), (vf.grad, vfc.grad, "video")):
+        scale = float(want.abs().max())
+        err = maxdiff(mine, want)
+        print(f"\n[c4_b8 backward] d{name}: max|err| {err:.2e} of {scale:.2e}")
+        assert err < 3e-3 * scale, (name, err, scale)
+    assert abs(float(m.clip.logit_scale.grad) / 100.0 - float(ls.grad)) < 2e-3 * abs(float(ls.grad)) + 1e-7
+    named = dict(m.named_parameters())
+    checked = 0
+    for n, p in P.items():
+        if p.grad is None or float(p.grad.abs().max()) == 0.0:
+            continue
+        mine = named[n].grad
+        assert mine is not None, n
+        scale = float(p.grad.abs().max())
+        assert maxdiff(mine, p.grad) < 5e-3 * scale + 2e-6, (n, maxdiff(mine, p.grad), scale)
+        checked += 1
+    # the *_weight_fc1 scorers of the global level DO get a gradient at this shape (zero with one global token)
+    assert float(named["text_weight_fc1.0.weight"].grad.abs().max()) > 0 and float(named["video_weight_fc1.2.weight"].grad.abs().max()) > 0
+    assert checked > 60
