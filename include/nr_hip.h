@@ -335,6 +335,15 @@ int nr_centrality_weights_bwd(const float* g, const float* gnorm, const float* m
 int nr_pack_shard(int n, const void* const* srcs, const size_t* bytes, const size_t* offsets, void* packed, void* stream);
 int nr_unpack_gathered(int n, const void* gathered, int world, size_t record_bytes, const size_t* bytes,
                        const size_t* offsets, void* const* dsts, const int* u8_to_f32, void* stream);
+/* The whole exchange step in one call (SURVEY.md 8b minimum set): nr_pack_shard into `packed` [record_bytes], ONE RCCL
+ * all-gather of record_bytes uint8 per rank over xGMI on the caller's communicator (`nccl_comm` = its ncclComm_t),
+ * nr_unpack_gathered from `gathered` [world * record_bytes] into the rank-major outputs -- all on `stream`.  RCCL is
+ * resolved at run time (the librccl.so.1 already loaded in the process, else the system one): NR_EUNSUPPORTED if there is
+ * none, 1000 + ncclResult_t if the collective fails.  The Python host reaches the same collective through
+ * torch.distributed (neighborretr_amd/dist.py), whose communicator is not exposed as a raw handle.                      */
+int nr_allgather_packed(void* nccl_comm, int world, int n, const void* const* srcs, const size_t* bytes,
+                        const size_t* offsets, size_t record_bytes, void* packed, void* gathered, void* const* dsts,
+                        const int* u8_to_f32, void* stream);
 
 /* Front of the step in one launch (any part may be switched off with n = 0 / NULL):
  *   out0[i] = (float)mask0[i], out1[i] = (float)mask1[i]   the loader's int64 masks as fp32 multipliers;

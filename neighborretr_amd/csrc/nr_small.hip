@@ -1,5 +1,6 @@
 // Small supporting kernels of the loss head: partial-sum reduction, the exact-fp32 global-logit
 // GEMM, centrality weights, memory-bank FIFO push, diagonal ranks for R@K.
+#include <dlfcn.h>
 #include "nr_common.h"
 #include "../../include/nr_hip.h"
 
@@ -519,4 +520,37 @@ extern "C" int nr_unpack_gathered(int n, const void* gathered, int world, size_t
     hipLaunchKernelGGL(nr_unpack_kernel, dim3(gx, n, world), dim3(256), 0, (hipStream_t)stream, a, static_cast<const char*>(gathered));
     NR_LAUNCH_CHECK();
     return NR_OK;
+}
+
+// ---- the whole exchange step behind the C ABI: pack -> ONE RCCL all-gather over xGMI -> unpack --------------------------
+// (reference: 5 x all_gather + barrier per step, modeling.py:274-280 via until_module.py:367-388).  RCCL is resolved at
+// run time -- the copy the caller's framework has already loaded (PyTorch-ROCm ships its own librccl.so.1), else the
+// system one -- so that this library carries no link-time dependency on it and a process never ends up with two.
+typedef int (*nr_nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+static nr_nccl_allgather_t nr_resolve_allgather() {
+    static nr_nccl_allgather_t fn = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) fn = reinterpret_cast<nr_nccl_allgather_t>(dlsym(h, "ncclAllGather"));
+    }
+    return fn;
+}
+
+extern "C" int nr_allgather_packed(void* nccl_comm, int world, int n, const void* const* srcs, const size_t* bytes,
+                                   const size_t* offsets, size_t record_bytes, void* packed, void* gathered,
+                                   void* const* dsts, const int* u8_to_f32, void* stream) {
+    if (!nccl_comm || world <= 0 || !packed || !gathered || record_bytes == 0) return NR_EINVAL;
+    nr_nccl_allgather_t allgather = nr_resolve_allgather();
+    if (!allgather) return NR_EUNSUPPORTED;            // no RCCL in this process and none loadable
+    int rc = nr_pack_shard(n, srcs, bytes, offsets, packed, stream);
+    if (rc != NR_OK) return rc;
+    const int nccl_uint8 = 1;                          // ncclUint8 (rccl.h)
+    const int nrc = allgather(packed, gathered, record_bytes, nccl_uint8, nccl_comm, (hipStream_t)stream);
+    if (nrc != 0) return 1000 + nrc;                   // ncclResult_t of the collective, offset past hipError_t
+    return nr_unpack_gathered(n, gathered, world, record_bytes, bytes, offsets, dsts, u8_to_f32, stream);
 }

@@ -78,3 +78,43 @@ def test_packed_allgather_device_branch_two_ranks(tmp_path):
         sl = slice(rank * b, (rank + 1) * b)
         assert torch.equal(res["grad_t"], res["w"][sl])              # backward = this rank's slice, no reduction
         assert torch.equal(res["grad_v"], torch.full((b, Nv, d), 3.0))
+
+
+def test_nr_allgather_packed_with_a_real_rccl_communicator():
+    """The C-ABI exchange step (nr_allgather_packed) on RCCL itself: a ONE-rank communicator is all a one-GPU box
+    can build (ncclCommInitRank through ctypes on the librccl the process already holds), which still runs the real
+    pack kernel -> ncclAllGather -> unpack kernel on the stream."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    from neighborretr_amd import hip
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        dev = "cuda"
+        b, Nt, Nv, d = 5, 24, 12, 512
+        tf, vf, idx, tm, vm = _shard(0, b, Nt, Nv, d)
+        pieces = [tf.to(dev), vf.to(dev), idx.to(dev), tm.to(torch.uint8).to(dev), vm.to(torch.uint8).to(dev)]
+        sizes = [p.numel() * p.element_size() for p in pieces]
+        offs = [sum(sizes[:k]) for k in range(5)]
+        total = (sum(sizes) + 15) // 16 * 16
+        packed = torch.empty(total, dtype=torch.uint8, device=dev)
+        gathered = torch.empty(total, dtype=torch.uint8, device=dev)
+        outs = [torch.empty_like(pieces[0]), torch.empty_like(pieces[1]), torch.empty_like(pieces[2]),
+                torch.empty(tm.shape, dtype=torch.float32, device=dev), torch.empty(vm.shape, dtype=torch.float32, device=dev)]
+        P5, Z5, I5 = ctypes.c_void_p * 5, ctypes.c_size_t * 5, ctypes.c_int * 5
+        hip.call("nr_allgather_packed", comm, 1, 5, P5(*[p.data_ptr() for p in pieces]), Z5(*sizes), Z5(*offs), total,
+                 hip.ptr(packed), hip.ptr(gathered), P5(*[o.data_ptr() for o in outs]), I5(0, 0, 0, 1, 1), hip.stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0].cpu(), tf) and torch.equal(outs[1].cpu(), vf) and torch.equal(outs[2].cpu(), idx)
+        assert torch.equal(outs[3].cpu(), tm.float()) and torch.equal(outs[4].cpu(), vm.float())
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
