@@ -13,6 +13,43 @@ CHILD = r'''
 import sys, torch
 variant = sys.argv[1]
 x = torch.zeros(1 << 16, device="cuda")
+if variant.startswith("many") or variant.startswith("nest"):
+    # many: N side streams forked from the capture stream and joined back; nest: a forked stream forks N/2 of its own
+    n = int(variant.lstrip("manyestw"))
+    ss = [torch.cuda.Stream() for _ in range(n)]
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    outs = []
+    with torch.cuda.graph(g):
+        cur = torch.cuda.current_stream()
+        if variant.startswith("many"):
+            for s_ in ss:
+                s_.wait_stream(cur)
+                with torch.cuda.stream(s_):
+                    outs.append(x + 1)
+            for s_ in ss:
+                cur.wait_stream(s_)
+        else:
+            half = n // 2
+            roots = ss[:2]
+            for ri, r in enumerate(roots):
+                r.wait_stream(cur)
+                with torch.cuda.stream(r):
+                    if variant.startswith("nestw"):
+                        outs.append(x * 3)           # the forked stream has a node of its own before it forks
+                    kids = ss[2 + ri * (half - 1): 2 + (ri + 1) * (half - 1)]
+                    for k_ in kids:
+                        k_.wait_stream(r)
+                        with torch.cuda.stream(k_):
+                            outs.append(x + 1)
+                    outs.append(x + 2)
+                    for k_ in kids:
+                        r.wait_stream(k_)
+            for r in roots:
+                cur.wait_stream(r)
+    g.replay(); torch.cuda.synchronize()
+    print("ok", len(outs))
+    sys.exit(0)
 s1, s2, s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
 torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
@@ -38,7 +75,7 @@ print("ok", float(c[0]), float(d[0]))
 
 
 def main():
-    for variant in ("fresh", "refork"):
+    for variant in (sys.argv[1:] or ("fresh", "refork")):
         try:
             r = subprocess.run([sys.executable, "-c", CHILD, variant], capture_output=True, text=True, timeout=120)
         except subprocess.TimeoutExpired:
