@@ -382,6 +382,18 @@ int nr_diag_ranks(const float* S, int N, int32_t* greater, int32_t* equal, void*
 int nr_slab_ranks(const float* S_slab, int n_rows, int N, int row0, const float* diag, int32_t* greater_rows,
                   int32_t* equal_rows, int32_t* greater_cols, int32_t* equal_cols, void* stream);
 
+/* Multi-sentence retrieval (several captions per video: evaluator.py:114-149,225-262; metrics.py:82-148) from a row slab
+ * S_slab = S[row0 : row0 + n_rows, :] of the sentence x video matrix.  group_end [G] (device, int32, increasing): the
+ * sentences of video g are the global rows [group_end[g-1], group_end[g]); the last entry is the sentence count and
+ * row0 + n_rows must not exceed it (checked by the caller: the array lives on the device).
+ *   greater_rows / equal_before_rows [n_rows]: #{j : S[i,j] > S[i,g(i)]} and #{j < g(i) : S[i,j] == S[i,g(i)]}; their sum
+ *     is the text->video rank of sentence i (metrics.py:103-106 with a stable sort; NaN scores rank first, as torch.argsort
+ *     puts them); greater = -1 marks a sentence whose own score is NaN / infinite: not ranked (metrics.py:108-111);
+ *   group_max [G, V]: max over this slab's sentences of video g of S[., j], -inf where the slab has none (NaN scores
+ *     ignored): MAX-reduce over the ranks, transpose, and nr_diag_ranks gives the video->text ranks (metrics.py:141-146). */
+int nr_group_slab_ranks(const float* S_slab, int n_rows, int V, int row0, const int32_t* group_end, int G,
+                        int32_t* greater_rows, int32_t* equal_before_rows, float* group_max, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -198,7 +198,7 @@ def load_memory_bank(args, model, data):
         tf, tm, vf, vm, idx = (torch.cat([f[k] for f in feats], 0) for k in range(5))
         tf, vf, idx, tm, vm = packed_allgather(tf, vf, idx, tm, vm, args)
     model.mb_ind, model.mb_feat_t, model.mb_feat_v = idx, tf.contiguous(), vf.contiguous()
-    model.mb_mask_t, model.mb_mask_v, model.mb_batch = tm.contiguous(), vm.contiguous(), n
+    model.mb_mask_t, model.mb_mask_v, model.mb_batch = tm.contiguous(), vm.contiguous(), tf.shape[0]   # memory_bank.py:211
     log(args, f"memory bank: {tf.shape[0]} samples ({n} batches x {args.batch_size})")
     return tf.shape[0]
 

@@ -372,6 +372,74 @@ extern "C" int nr_slab_ranks(const float* S_slab, int n_rows, int N, int row0, c
     return NR_OK;
 }
 
+// ---- multi-sentence retrieval (evaluator.py:114-149,225-262; metrics.py:82-148) from a row slab --------------------------
+// Rows are SENTENCES (all captions of video 0, then of video 1, ...: group g owns the global rows [group_end[g-1],
+// group_end[g])), columns are videos.  blockIdx.y = 0: one wave per sentence row -> the position of its OWN video in the
+// row's descending order, as greater[i] = #{j : S[i,j] > S[i,g] or NaN} and equal_before[i] = #{j < g : S[i,j] == S[i,g]} (the
+// order a stable descending argsort gives; the reference's double argsort, metrics.py:103-106, is that up to the sort's
+// choice among exact ties).  blockIdx.y = 1: one workgroup per (group, 256 columns) -> group_max[g, j] = the best score
+// any of this slab's sentences of group g gives video j (-inf when the slab holds none of them): the video->text matrix
+// of metrics.py:141-146 after a MAX all-reduce over the ranks.
+__global__ __launch_bounds__(256) void nr_group_slab_ranks_kernel(const float* __restrict__ S, int n, int V, int row0,
+                                                                  const int32_t* __restrict__ group_end, int G,
+                                                                  int32_t* __restrict__ greater,
+                                                                  int32_t* __restrict__ equal_before,
+                                                                  float* __restrict__ group_max) {
+    if (blockIdx.y == 0) {
+        const int lane = threadIdx.x & 63;
+        const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (i >= n) return;
+        const int s = row0 + i;
+        int lo = 0, hi = G - 1;                 // first group whose end lies beyond s
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (group_end[mid] > s) hi = mid; else lo = mid + 1;
+        }
+        const int g = lo;
+        const float* row = S + (size_t)i * V;
+        const float own = row[g];
+        int gt = 0, eb = 0;
+        for (int j = lane; j < V; j += 64) {
+            const float x = row[j];
+            gt += (x > own) || (x != x);        // torch.argsort(descending=True) ranks NaN scores first
+            eb += (x == own && j < g);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            gt += __shfl_xor(gt, o);
+            eb += __shfl_xor(eb, o);
+        }
+        // a sentence whose own score is NaN or infinite is not ranked at all (metrics.py:108-111): greater = -1
+        if (lane == 0) { greater[i] = (own != own || fabsf(own) == INFINITY) ? -1 : gt; equal_before[i] = eb; }
+    } else {
+        const int cols_blocks = (V + 255) / 256;
+        const int g = blockIdx.x / cols_blocks;
+        const int j = (blockIdx.x % cols_blocks) * 256 + threadIdx.x;
+        if (g >= G || j >= V) return;
+        const int begin = max((g ? group_end[g - 1] : 0) - row0, 0);
+        const int end = min(group_end[g] - row0, n);
+        float m = -INFINITY;
+        for (int i = begin; i < end; ++i) {
+            const float x = S[(size_t)i * V + j];
+            m = (x != x) ? m : fmaxf(m, x);     // NaN entries count as -inf (metrics.py:141)
+        }
+        group_max[(size_t)g * V + j] = m;
+    }
+}
+
+extern "C" int nr_group_slab_ranks(const float* S_slab, int n_rows, int V, int row0, const int32_t* group_end, int G,
+                                   int32_t* greater_rows, int32_t* equal_before_rows, float* group_max, void* stream) {
+    if (!S_slab || !group_end || !greater_rows || !equal_before_rows || !group_max) return NR_EINVAL;
+    if (n_rows <= 0 || V <= 0 || G <= 0 || G > V || row0 < 0) return NR_EINVAL;
+    const long long col_part = (long long)G * ((V + 255) / 256);
+    if (col_part > 0x7fffffffLL) return NR_EINVAL;
+    const int gx = max((n_rows + 3) / 4, (int)col_part);
+    hipLaunchKernelGGL(nr_group_slab_ranks_kernel, dim3(gx, 2), dim3(256), 0, (hipStream_t)stream, S_slab, n_rows, V, row0,
+                       group_end, G, greater_rows, equal_before_rows, group_max);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
 // ---- step prologue -------------------------------------------------------------------------------------------
 // What the step needs before anything else can start, in ONE launch instead of six ATen kernels on the serial
 // front of the critical path: the int64 masks of the loader as fp32 multipliers (modeling.py:283-287 keeps them

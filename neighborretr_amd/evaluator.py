@@ -29,11 +29,19 @@ def gather_eval_features(text_feat, video_feat, idx, text_mask, video_mask, args
     from .dist import packed_allgather
     with torch.no_grad():
         tf, vf, ix, tm, vm = packed_allgather(text_feat, video_feat, idx, text_mask, video_mask, args)
-        n = int(ix.max().item()) + 1
+    return dataset_order(tf, vf, ix, tm, vm)
+
+
+def dataset_order(text_feat, video_feat, idx, text_mask, video_mask):
+    """evaluator.py:180-189: row idx[k] of every output <- row k of the input (later duplicates win), trimmed to
+    idx.max() + 1; positions no sample maps to stay zero."""
+    with torch.no_grad():
+        idx = idx.reshape(-1).long()
+        n = int(idx.max().item()) + 1
         out = []
-        for t in (tf, vf, tm, vm):
+        for t in (text_feat, video_feat, text_mask, video_mask):
             dst = torch.zeros((max(n, t.shape[0]),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            dst.index_copy_(0, ix, t)
+            dst.index_copy_(0, idx, t)
             out.append(dst[:n].contiguous())
     return tuple(out)
 
@@ -43,6 +51,24 @@ def slab_bounds(n, world, rank):
     base, extra = divmod(n, world)
     r0 = rank * base + min(rank, extra)
     return r0, r0 + base + (1 if rank < extra else 0)
+
+
+def _slab_similarity(model, text_feat, video_feat, text_mask, video_mask, r0, r1, chunk=256):
+    """Rows [r0, r1) of the text x video similarity, on the rank-exact (split-bf16) path of the fused kernel."""
+    old = model.precision
+    model.precision = "bf16x3"
+    try:
+        with torch.no_grad():
+            rows = []
+            for lo in range(r0, r1, chunk):                 # [chunk, N] pieces keep the kernel's outputs small
+                hi = min(lo + chunk, r1)
+                S, _ = model.get_similarity_logits(text_feat[lo:hi], video_feat, text_mask[lo:hi], video_mask, shaped=True)
+                rows.append(S)
+            if rows:
+                return torch.cat(rows, 0)
+            return torch.empty((0, video_feat.shape[0]), dtype=torch.float32, device=text_feat.device)
+    finally:
+        model.precision = old
 
 
 def sharded_retrieval_ranks(model, text_feat, video_feat, text_mask, video_mask, args, chunk=256):
@@ -56,18 +82,7 @@ def sharded_retrieval_ranks(model, text_feat, video_feat, text_mask, video_mask,
         raise ValueError("single-sentence retrieval: one text per video expected")
     r0, r1 = slab_bounds(N, W, rank)
     dev = text_feat.device
-    old = model.precision
-    model.precision = "bf16x3"                          # rank-exact path
-    try:
-        with torch.no_grad():
-            rows = []
-            for lo in range(r0, r1, chunk):                 # [chunk, N] pieces keep the kernel's outputs small
-                hi = min(lo + chunk, r1)
-                S, _ = model.get_similarity_logits(text_feat[lo:hi], video_feat, text_mask[lo:hi], video_mask, shaped=True)
-                rows.append(S)
-            S_slab = torch.cat(rows, 0) if rows else torch.empty((0, N), dtype=torch.float32, device=dev)
-    finally:
-        model.precision = old
+    S_slab = _slab_similarity(model, text_feat, video_feat, text_mask, video_mask, r0, r1, chunk)
     n = r1 - r0
     # the diagonal of the whole matrix: this slab's part, gathered (slabs differ by at most one row: padded to the largest)
     width = -(-N // W)
@@ -107,4 +122,43 @@ def sharded_metrics(model, text_feat, video_feat, text_mask, video_mask, args):
     gt, et, gv, ev = sharded_retrieval_ranks(model, text_feat, video_feat, text_mask, video_mask, args)
     t2v = RetrievalMetrics.metrics_from_ranks(RetrievalMetrics.ranks_from_counts(gt, et))
     v2t = RetrievalMetrics.metrics_from_ranks(RetrievalMetrics.ranks_from_counts(gv, ev))
+    return t2v, v2t
+
+
+def sharded_multi_sentence_metrics(model, text_feat, video_feat, text_mask, video_mask, cut_off_points, args, chunk=256):
+    """Several captions per video (evaluator.py:114-149 features, :225-262 metrics): text_feat [Ns,...] holds every
+    sentence in dataset order, video_feat [V,...] one entry per video, cut_off_points[g] = index of the LAST sentence of
+    video g (the dataset's cut_off_points minus one, evaluator.py:98).  -> (text->video, video->text) metric dictionaries.
+
+    The reference pads the Ns x V matrix to [V, max_sentences, V] with -inf on the host and ranks it with two argsorts
+    (metrics.py:82-126) and a max over the padded axis (:128-148).  Here rank r scores its slab of sentence rows, one
+    launch (nr_group_slab_ranks) gives every row's rank and the slab's per-video best scores, and a MAX all-reduce of
+    the V x V best-score matrix + an all-gather of the Ns ranks complete them; no padded tensor exists."""
+    W = _world(args)
+    rank = dist.get_rank() if (W > 1 and dist.is_initialized()) else 0
+    Ns, V = text_feat.shape[0], video_feat.shape[0]
+    ends = np.asarray(cut_off_points, dtype=np.int64) + 1
+    if len(ends) != V or (np.diff(ends) <= 0).any() or ends[0] <= 0 or ends[-1] != Ns:
+        raise ValueError(f"cut_off_points must give {V} non-empty, increasing sentence groups ending at {Ns - 1}")
+    dev = text_feat.device
+    group_end = torch.from_numpy(ends.astype(np.int32)).to(dev)
+    r0, r1 = slab_bounds(Ns, W, rank)
+    n = r1 - r0
+    S_slab = _slab_similarity(model, text_feat, video_feat, text_mask, video_mask, r0, r1, chunk)
+    width = -(-Ns // W)
+    mine = torch.zeros((width,), dtype=torch.int32, device=dev)
+    if n:
+        greater, equal_before, gmax = ops.group_slab_ranks(S_slab, r0, group_end)
+        mine[:n] = torch.where(greater < 0, greater, greater + equal_before)
+    else:
+        gmax = torch.full((V, V), float("-inf"), dtype=torch.float32, device=dev)
+    if W > 1:
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+        allr = torch.empty((W, width), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(allr.view(-1), mine)
+        ranks = torch.cat([allr[r, :slab_bounds(Ns, W, r)[1] - slab_bounds(Ns, W, r)[0]] for r in range(W)])
+    else:
+        ranks = mine[:n]
+    t2v = RetrievalMetrics.multi_sentence_metrics_from_ranks(ranks[ranks >= 0])      # < 0: own score NaN / inf, not ranked
+    v2t = RetrievalMetrics.compute_metrics(gmax.T.contiguous())          # [video, caption group], metrics.py:146-148
     return t2v, v2t

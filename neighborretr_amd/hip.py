@@ -92,6 +92,7 @@ _SIGNATURES = {
     "nr_bank_ring_push": ([_I, _P, _P, _P, _I, _I, _P, _I, _P], _I),
     "nr_diag_ranks": ([_P, _I, _P, _P, _P], _I),
     "nr_slab_ranks": ([_P, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),
+    "nr_group_slab_ranks": ([_P, _I, _I, _I, _P, _I, _P, _P, _P, _P], _I),
 }
 
 

@@ -73,6 +73,12 @@ class RetrievalMetrics:
         ranks = torch.flatten(torch.diagonal(second, dim1=1, dim2=2))
         diag = torch.flatten(torch.diagonal(sim_tensor, dim1=0, dim2=2))
         valid = ranks[~torch.logical_or(torch.isinf(diag), torch.isnan(diag))].cpu()
+        return RetrievalMetrics.multi_sentence_metrics_from_ranks(valid, top_k)
+
+    @staticmethod
+    def multi_sentence_metrics_from_ranks(ranks, top_k=(1, 5, 10, 50)):
+        """The result dictionary of metrics.py:113-126 from the 0-based rank of every valid sentence's own video."""
+        valid = torch.as_tensor(ranks).to(torch.int64).cpu()
         res = {f"R{k}": float(torch.sum(valid < k) * 100 / len(valid)) for k in top_k}
         res["MedianR"] = float(torch.median(valid + 1))
         res["MeanR"] = float(np.mean(valid.numpy() + 1))
@@ -93,18 +99,43 @@ class RetrievalMetrics:
 
     def print_metrics(self, metrics, prefix=""):
         msg = (f"{prefix}R@1: {metrics['R1']:.1f} - R@5: {metrics['R5']:.1f} - R@10: {metrics['R10']:.1f} - "
-               f"R@50: {metrics['R50']:.1f} - Median R: {metrics['MR']:.1f} - Mean R: {metrics['MeanR']:.1f}")
-        (self.logger.info if self.logger else print)(msg)
+               f"R@50: {metrics.get('R50', 0.0):.1f} - Median R: {metrics['MR']:.1f} - Mean R: {metrics['MeanR']:.1f}")
+        if self.logger is not None:                         # metrics.py:154: silent without a logger
+            self.logger.info(msg)
 
-    def update_best_metrics(self, t2v_metrics, v2t_metrics):
-        """Keep the best t2v / v2t / mean R@1 seen so far; returns True when the mean improved."""
-        improved = False
-        mean_r1 = (t2v_metrics["R1"] + v2t_metrics["R1"]) / 2
-        if t2v_metrics["R1"] > self.best_t2v_r1:
-            self.best_t2v_r1, self.best_t2v_metrics = t2v_metrics["R1"], dict(t2v_metrics)
-        if v2t_metrics["R1"] > self.best_v2t_r1:
-            self.best_v2t_r1, self.best_v2t_metrics = v2t_metrics["R1"], dict(v2t_metrics)
-        if mean_r1 > self.best_mean_r1:
-            self.best_mean_r1 = mean_r1
-            improved = True
-        return improved
+    def update_best_metrics(self, t2v_metrics, v2t_metrics, t2v_r1=None, v2t_r1=None):
+        """metrics.py:168-203: keep the best t2v / v2t R@1 seen so far (ties update too) -> (is_updated, mean R@1 now)."""
+        t2v_r1 = t2v_metrics["R1"] if t2v_r1 is None else t2v_r1
+        v2t_r1 = v2t_metrics["R1"] if v2t_r1 is None else v2t_r1
+        is_updated = False
+        if self.best_t2v_r1 <= t2v_r1:
+            self.best_t2v_r1, self.best_t2v_metrics = t2v_r1, dict(t2v_metrics)
+            self.best_mean_r1 = (self.best_t2v_r1 + self.best_v2t_r1) / 2
+            is_updated = True
+        if self.best_v2t_r1 <= v2t_r1:
+            self.best_v2t_r1, self.best_v2t_metrics = v2t_r1, dict(v2t_metrics)
+            self.best_mean_r1 = (self.best_t2v_r1 + self.best_v2t_r1) / 2
+            is_updated = True
+        return is_updated, (t2v_r1 + v2t_r1) / 2
+
+    def log_current_metrics(self, t2v_metrics, v2t_metrics, mean_r1):
+        if self.logger is None:
+            return
+        self.logger.info(f"Mean R@1: {mean_r1:.4f}")
+        self.logger.info("Text-to-Video Retrieval:")
+        self.print_metrics(t2v_metrics, prefix="  ")
+        self.logger.info("Video-to-Text Retrieval:")
+        self.print_metrics(v2t_metrics, prefix="  ")
+
+    def log_best_metrics(self):
+        if self.logger is None or self.best_t2v_metrics is None or self.best_v2t_metrics is None:
+            return
+        self.logger.info(f"Best Mean R@1: {self.best_mean_r1:.4f}")
+        self.logger.info("Best Text-to-Video Retrieval:")
+        self.print_metrics(self.best_t2v_metrics, prefix="  ")
+        self.logger.info("Best Video-to-Text Retrieval:")
+        self.print_metrics(self.best_v2t_metrics, prefix="  ")
+
+    def get_best_metrics(self):
+        return {"score": self.best_mean_r1, "text_to_video": self.best_t2v_metrics, "video_to_text": self.best_v2t_metrics,
+                "t2v_r1": self.best_t2v_r1, "v2t_r1": self.best_v2t_r1}

@@ -491,6 +491,21 @@ def slab_ranks(S_slab, row0, diag):
     return gr, er, gc, ec
 
 
+def group_slab_ranks(S_slab, row0, group_end):
+    """(greater_rows, equal_before_rows [n] int32, group_max [G,V] fp32) of a sentence-row slab (nr_group_slab_ranks);
+    group_end [G] int32 on the device, its last entry >= row0 + n (the caller built it: not re-read here)."""
+    S_slab = _f32(S_slab).contiguous()
+    n, V = S_slab.shape
+    G = group_end.shape[0]
+    dev = S_slab.device
+    gr = torch.empty((n,), dtype=torch.int32, device=dev)
+    eb = torch.empty((n,), dtype=torch.int32, device=dev)
+    gmax = torch.empty((G, V), dtype=torch.float32, device=dev)
+    hip.call("nr_group_slab_ranks", hip.ptr(S_slab), n, V, int(row0), hip.ptr(group_end, torch.int32), G, hip.ptr(gr),
+             hip.ptr(eb), hip.ptr(gmax), hip.stream_ptr())
+    return gr, eb, gmax
+
+
 def linear_x3(x, w, bias=None, residual=None):
     """Y = X W^T (+ bias) (+ residual) on the split-bf16 MFMA tile engine (nr_linear_x3): x [M,K], w [N,K] fp32, K padded to
     a multiple of 64 with zeros.  ~fp32-grade products (3 bf16 passes); used for the clustering GEMMs and for the

@@ -383,3 +383,49 @@ def compute_metrics(sim):
         "MeanR": float(np.mean(ind)) + 1,
         "cols": [int(i) for i in ind],
     }
+
+
+# ---------------------------------------------------------------------------
+# a-12b  multi-sentence retrieval  (training/evaluator.py:225-262, utils/metrics.py:82-148)
+# ---------------------------------------------------------------------------
+def pad_sentence_groups(S, cut_off_points):
+    """evaluator.py:236-250: the [n_sentences, n_videos] matrix cut at the groups' last sentences
+    (`cut_off_points`, already minus one as in :98) and padded with -inf to [n_videos, max_len, n_videos]."""
+    S = np.asarray(S)
+    ends = [c + 1 for c in cut_off_points]
+    starts = [0] + ends[:-1]
+    max_len = max(e - s for s, e in zip(starts, ends))
+    return np.stack([np.concatenate((S[s:e], np.full((max_len - e + s, S.shape[1]), -np.inf)), axis=0)
+                     for s, e in zip(starts, ends)], axis=0)
+
+
+def tensor_text_to_video_metrics(sim_tensor, top_k=(1, 5, 10, 50), stable=True):
+    """metrics.py:82-126: rank of video i in the row of every valid sentence (i, s), by a double argsort
+    (stable=True pins what the sort does among exact ties: lower video index first)."""
+    T = np.asarray(sim_tensor)
+    stacked = T.transpose(1, 0, 2)                              # [sentence slot, group, video]
+    stacked = np.where(np.isnan(stacked), np.inf, stacked)      # torch.argsort(descending=True) puts NaN first
+    first = np.argsort(-stacked, axis=-1, kind="stable" if stable else "quicksort")
+    second = np.argsort(first, axis=-1, kind="stable")
+    ranks = np.diagonal(second, axis1=1, axis2=2).reshape(-1)
+    own = np.diagonal(T, axis1=0, axis2=2).reshape(-1)          # [sentence slot, group] flattened the same way
+    valid = ranks[~(np.isinf(own) | np.isnan(own))]
+    res = {f"R{k}": float(np.sum(valid < k) * 100 / len(valid)) for k in top_k}
+    res["MedianR"] = float(np.sort(valid + 1)[(len(valid) - 1) // 2])   # torch.median: the LOWER middle element
+    res["MeanR"] = float(np.mean(valid + 1))
+    res["Std_Rank"] = float(np.std(valid + 1))
+    res["MR"] = res["MedianR"]
+    return res
+
+
+def tensor_video_to_text_sim(sim_tensor):
+    """metrics.py:128-148: NaN -> -inf, best sentence of every group, transposed to [video, group]."""
+    T = np.array(sim_tensor, copy=True)
+    T[T != T] = -np.inf
+    return T.max(axis=1).T
+
+
+def multi_sentence_metrics(S, cut_off_points):
+    """evaluator.py:225-262 -> (text->video, video->text) from the sentence x video matrix."""
+    padded = pad_sentence_groups(S, cut_off_points)
+    return tensor_text_to_video_metrics(padded), compute_metrics(tensor_video_to_text_sim(padded))

@@ -196,3 +196,14 @@ def test_memory_bank_fifo():
     assert bank[0].tolist() == [100, 101, 102, 103, 0, 1]          # newest first, capacity stays 6
     bank = O.update_memory_bank(bank, mk(8, 200))
     assert bank[0].tolist() == list(range(200, 206))                 # B > capacity: first rows of the batch
+
+
+def test_multi_sentence_metrics_against_reference_vector():
+    """oracle/capture_multi_sentence.py: the reference's own multi-sentence metrics (metrics.py:82-148 on the padded
+    tensor of evaluator.py:236-250), NaN scores on and off the own column included."""
+    g = golden("multi_sentence")
+    t2v, v2t = O.multi_sentence_metrics(g["S"], g["cut_off_points"].tolist())
+    keys_t = ("R1", "R5", "R10", "R50", "MedianR", "MeanR", "Std_Rank", "MR")
+    assert np.allclose([t2v[k] for k in keys_t], g["t2v"], rtol=1e-6)
+    assert np.array_equal(np.array(v2t["cols"]), g["v2t_cols"])
+    assert np.allclose([v2t[k] for k in ("R1", "R5", "R10", "R50", "MR", "MeanR")], g["v2t"])
