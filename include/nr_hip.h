@@ -80,6 +80,22 @@ int nr_local_level_fwd(const uint16_t* t_hi, const uint16_t* t_lo, const uint16_
                        int prec, int out_mode, float* out, uint8_t* arg_v, uint8_t* arg_t,
                        float* pmax, float* qmax, void* stream);
 
+/* Several fused local_level products of ONE step in a single grid (modeling.py:499-512 is called three times per step:
+ * batch x batch, :283-287, and the two memory-bank products of until_module.py:170-185): every product as
+ * nr_local_level_fwd would compute it, without arg-max outputs, outputs in the same layout.  A CU picks up the next
+ * product's block when its previous block retires instead of paying one dispatch + drain per product.
+ * nr_local_level_group_kind: >= 0 if a product can join a group (24 x 12 tokens at sizes where the single launch runs the
+ * 192 x 384 bf16 or the 96 x 192 split-bf16 blocks), -1 otherwise; nr_local_level_group returns NR_EUNSUPPORTED then
+ * (nothing launched: call nr_local_level_fwd per product).  At most 4 products.                                        */
+typedef struct NrLocalLevelProblem {
+    const uint16_t *t_hi, *t_lo, *v_hi, *v_lo;   /* prepared tokens, as for nr_local_level_fwd (lo: split-bf16 only) */
+    const float *w_t, *w_v;                      /* token weights [A*Nt], [Bv*Nv]                                   */
+    float* out;                                  /* per out_mode                                                     */
+    int A, Nt, Bv, Nv, d, prec, out_mode;
+} NrLocalLevelProblem;
+int nr_local_level_group_kind(int A, int Nt, int Bv, int Nv, int d, int prec);
+int nr_local_level_group(int n, const NrLocalLevelProblem* problems, void* stream);
+
 /* out[i] = scale * sum_p part[p, i]   (memory-bank centrality, until_module.py:181) */
 int nr_reduce_parts(const float* part, int n_parts, int n, float scale, float* out, void* stream);
 

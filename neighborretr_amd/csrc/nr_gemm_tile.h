@@ -74,7 +74,6 @@ struct NrGemmTile {
     static constexpr int RING_BYTES = STAGES * STAGE_BYTES;
     static constexpr int PA = (BM / 8) / NW;           // 8-row DMA pieces per wave, A and B
     static constexpr int PB = (BN / 8) / NW;
-    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
     static constexpr int DMA_PER_STAGE = (PA + PB) * (X3 ? 2 : 1);   // per wave
 
     f32x4_t acc[MI][NI];
@@ -123,6 +122,7 @@ struct NrGemmTile {
                                         int a_row0, int a_rows,
                                         const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
                                         int b_row0, int b_rows, int K, char* smem, int rot = 0, bool dma_front = false) {
+        static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
         const int tid = threadIdx.x;
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

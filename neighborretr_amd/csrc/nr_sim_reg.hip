@@ -70,9 +70,10 @@ __device__ __forceinline__ float nr_lanes_sum(float v) {
     return v;
 }
 
+// One block of one product: the whole kernel body, callable from the single-product kernel and from the grouped one
+// (nr_sim_group_kernel, below).  `bid`: the block's index inside ITS product's tile grid.
 template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false>
-__global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int bid, char* smem) {
     using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES, WC>;
     constexpr int Nt = MI * TPS, Nv = NI * FPS;
     constexpr int TAW = 16 / TPS, TBW = 16 / FPS;     // texts / videos per wave
@@ -88,7 +89,6 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     // operand rows.  Pure speed: any placement computes the same tiles.
     int bx, by, rot = 0;
     {
-        const int bid = blockIdx.x;
         if (p.PR > 0) {
             const int xcd = bid & 7, slot = bid >> 3;
             const int sub_w = p.ntx / p.PC, sub_h = p.nty / p.PR;
@@ -111,24 +111,61 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     const bool ok = ag < p.A && bg < p.Bv;
     const int agc = min(ag, p.A - 1), bgc = min(bg, p.Bv - 1);
     // this lane's token weights: fetched before the main loop so their latency hides under it -- except in the
-    // largest blocks, whose accumulators leave no registers to park them in
+    // largest blocks, whose accumulators leave no registers to park them in: there the workgroup's TA*Nt + TB*Nv
+    // weights are parked in the LDS behind the ring (LDS-DMA, 64 floats per instruction, issued ahead of the loop's
+    // first slice and landed with it) and picked up after the loop -- a global load there would expose its whole
+    // latency (~1.5 us of a 16 us launch) in front of the epilogue.
     constexpr bool LATE_W = MI * NI >= 36;
     float wt[MI][4], wv[NI];
+    float* w_lds = reinterpret_cast<float*>(smem + Tile::RING_BYTES);
+    constexpr int WT_N = TA * Nt, WV_N = TB * Nv;
+    static_assert(!LATE_W || (WT_N % 64 == 0 && WV_N % 64 == 0), "weights go to the LDS 64 floats per instruction");
     auto load_weights = [&]() {
+        if constexpr (LATE_W) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            f32x4_t q = *reinterpret_cast<const f32x4_t*>(p.w_t + (size_t)agc * Nt + TPS * i + tau0);
-            wt[i][0] = q[0]; wt[i][1] = q[1]; wt[i][2] = q[2]; wt[i][3] = q[3];
+            for (int i = 0; i < MI; ++i) {
+                f32x4_t q = *reinterpret_cast<const f32x4_t*>(w_lds + (wr * TAW + al) * Nt + TPS * i + tau0);
+                wt[i][0] = q[0]; wt[i][1] = q[1]; wt[i][2] = q[2]; wt[i][3] = q[3];
+            }
+#pragma unroll
+            for (int n = 0; n < NI; ++n) wv[n] = w_lds[WT_N + (wc * TBW + bl) * Nv + FPS * n + phi];
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                f32x4_t q = *reinterpret_cast<const f32x4_t*>(p.w_t + (size_t)agc * Nt + TPS * i + tau0);
+                wt[i][0] = q[0]; wt[i][1] = q[1]; wt[i][2] = q[2]; wt[i][3] = q[3];
+            }
+#pragma unroll
+            for (int n = 0; n < NI; ++n) wv[n] = p.w_v[(size_t)bgc * Nv + FPS * n + phi];
         }
-#pragma unroll
-        for (int n = 0; n < NI; ++n) wv[n] = p.w_v[(size_t)bgc * Nv + FPS * n + phi];
     };
     if constexpr (!LATE_W) load_weights();
+    else {
+        // pieces of 64 floats: [0, WT_N/64) text weights, then the video weights; piece q goes out from wave q mod waves
+        constexpr int NPIECE = (WT_N + WV_N) / 64;
+#pragma unroll
+        for (int q0 = 0; q0 < NPIECE; q0 += 2 * WC) {
+            const int q = q0 + wave;
+            if (q < NPIECE) {
+                const bool is_t = q < WT_N / 64;
+                const int e = (is_t ? q : q - WT_N / 64) * 64 + lane;           // element inside the block's weights
+                const long src = is_t ? min((long)by * WT_N + e, (long)p.A * Nt - 1) : min((long)bx * WV_N + e, (long)p.Bv * Nv - 1);
+                const float* gp = (is_t ? p.w_t : p.w_v) + src;
+                __builtin_amdgcn_global_load_lds((nr_glb_ptr_t)gp, (nr_lds_ptr_t)(w_lds + q * 64), 4, 0, 0);
+            }
+        }
+    }
 
     Tile tile;
     tile.zero();
+#ifdef NR_STAMP
+    if (blockIdx.x == 0 && threadIdx.x == 0) nr_stamp_buf[5] = __builtin_readcyclecounter() - t_start;
+#endif
     if constexpr (PP) tile.run_pp(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
     else tile.run(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem, rot, p.dma_front != 0);
+#ifdef NR_STAMP
+    if (blockIdx.x == 0 && threadIdx.x == 0) nr_stamp_buf[6] = __builtin_readcyclecounter() - t_start;
+#endif
     if constexpr (LATE_W) load_weights();
 
     float t2v = 0.f, v2t = 0.f;
@@ -258,10 +295,46 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
 }
 
 template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false>
+__global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    nr_sim_reg_body<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC, PP>(p, blockIdx.x, smem);
+}
+
+// ---- grouped launch: several products of ONE step in one grid --------------------------------------------------------
+// The step's three products (two bank products on 192 x 384 bf16 blocks, the batch x batch product on 96 x 192
+// split-bf16 blocks) all run 8-wave workgroups on a 144 KB ring, one per CU, 256 blocks each.  Launched one by one every
+// product pays its own dispatch, first-slice latency and drain (t0 of `tools/sim_ksweep.py`: ~5 us of a 16 us launch);
+// in one grid a CU picks up its next block the moment the previous one retires.  Block b of the grid works on product
+// g.first[k] <= b < g.first[k+1], block b - g.first[k] of its tile grid (each product keeps its own XCD-aware order
+// as long as the block counts ahead of it are multiples of 8 -- block index mod 8 is the XCD; after a ragged product the
+// following ones land on shifted XCDs: slower L2 reuse, same results).
+#define NR_SIM_GROUP_MAX 4
+struct NrSimGroup {
+    NrSimRegArgs p[NR_SIM_GROUP_MAX];
+    int first[NR_SIM_GROUP_MAX + 1];
+    int kind[NR_SIM_GROUP_MAX];       // 0: bf16, 192 x 384 blocks; 1: split-bf16, 96 x 192 blocks
+    int n;
+};
+
+__global__ __launch_bounds__(512) void nr_sim_group_kernel(NrSimGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < NR_SIM_GROUP_MAX; ++i)
+        if (i < g.n && b >= g.first[i]) k = i;
+    k = __builtin_amdgcn_readfirstlane(k);
+    if (g.kind[k] == 0) nr_sim_reg_body<6, 6, 4, 2, false, false, 2, 4, true>(g.p[k], b - g.first[k], smem);
+    else nr_sim_reg_body<3, 3, 8, 4, true, false, 2, 4, true>(g.p[k], b - g.first[k], smem);
+}
+
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false>
 static int nr_sim_reg_launch_s(NrSimRegArgs& a, hipStream_t st) {
     using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES, WC>;
     auto kern = nr_sim_reg_kernel<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC, PP>;
     size_t lds = Tile::RING_BYTES;
+    if constexpr (MI * NI >= 36)          // the block's token weights, parked behind the ring (LATE_W in the kernel)
+        lds += sizeof(float) * (2 * (16 / TPS) * MI * TPS + WC * (16 / FPS) * NI * FPS);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -271,8 +344,9 @@ static int nr_sim_reg_launch_s(NrSimRegArgs& a, hipStream_t st) {
     return NR_OK;
 }
 
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int WC = 2>
-static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
+// tile grid of a product and its partition over the 8 XCDs
+template <int MI, int NI, int TPS, int FPS, int WC>
+static void nr_sim_reg_plan(NrSimRegArgs& a) {
     constexpr int TA = 2 * (16 / TPS), TB = WC * (16 / FPS);
     a.ntx = (a.Bv + TB - 1) / TB;
     a.nty = (a.A + TA - 1) / TA;
@@ -295,6 +369,11 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
     }
     a.rot_x = a.rot_y = 0;
     a.dma_front = 0;
+}
+
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int WC = 2>
+static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
+    nr_sim_reg_plan<MI, NI, TPS, FPS, WC>(a);
     if (const char* e = nr_tune_env("NR_SIM_DMA_FRONT")) a.dma_front = atoi(e);
     if (const char* e = nr_tune_env("NR_SIM_ROT")) {          // tuning hook: "XxY" K-slice rotation per slot column / row
         int rx = 0, ry = 0;
@@ -304,6 +383,9 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
     // 2-deep ring -- except split-bf16, whose two stages (196 KB) exceed the LDS
     constexpr bool big = WC == 4;
     constexpr bool mid = WC == 2 && MI * NI >= 18;          // 96 x 192 split-bf16: 144 KB for two stages, one workgroup per CU
+    // 96 x 192 split-bf16 on 2 x 4 waves (48 x 48 per wave): the two-stage ring fits (144 KB) -> ping-pong K loop
+    if constexpr (big && X3 && MI * NI == 9) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 2, WC, true>(a, st);
+    else {
     const bool one_stage = big ? X3 : (mid ? false : nr_pick_stages((long)a.ntx * a.nty) == 1);
     if (one_stage) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 1, WC>(a, st);
     if constexpr (big && X3) return NR_EUNSUPPORTED;
@@ -318,6 +400,7 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
             if (!(e && atoi(e) == 0) && a.K >= 128) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 2, WC, true>(a, st);
         }
         return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 2, WC>(a, st);
+    }
     }
 }
 
@@ -379,6 +462,9 @@ int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16
         return args ? nr_sim_reg_launch<4, 4, 16, 16, false, true, 4>(a, st) : nr_sim_reg_launch<4, 4, 16, 16, false, false, 4>(a, st);
     }
     if (nr_sim_reg_big(A, Nt, Bv, Nv, prec) == 3) {     // split-bf16, 96 x 192 blocks (4 texts x 16 videos), 2-deep ring
+        // 2 x 4 waves of 48 x 48 on the ping-pong K loop (13.7 -> 13.2 us at B = 128); NR_SIM_X3PP=0: the 2 x 2-wave form (A/B)
+        if (const char* e = nr_tune_env("NR_SIM_X3PP"); !(e && atoi(e) == 0) && d >= 128)
+            return args ? nr_sim_reg_launch<3, 3, 8, 4, true, true, 4>(a, st) : nr_sim_reg_launch<3, 3, 8, 4, true, false, 4>(a, st);
         return args ? nr_sim_reg_launch<3, 6, 8, 2, true, true, 2>(a, st) : nr_sim_reg_launch<3, 6, 8, 2, true, false, 2>(a, st);
     }
     if (nr_sim_reg_big(A, Nt, Bv, Nv, prec) == 2) {     // 24 x 12 tokens, 192 x 384 blocks on 2 x 4 waves
@@ -394,4 +480,50 @@ int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16
     NR_REG_CASE(4, 16, 3, 4)     // 64 x 12
 #undef NR_REG_CASE
     return NR_EUNSUPPORTED;
+}
+
+// ---- grouped launch (see nr_sim_group_kernel) -------------------------------------------------------------------------
+// kind of block a product runs inside a group: 0 = bf16 on 192 x 384 blocks, 1 = split-bf16 on 96 x 192 blocks; -1: the
+// product is not one a group takes (other token counts, or a size at which the single launch picks another block shape --
+// the partial-sum outputs then have another layout).
+extern "C" int nr_local_level_group_kind(int A, int Nt, int Bv, int Nv, int d, int prec) {
+    if (A <= 0 || Bv <= 0 || d < 128 || (d % 64) != 0) return -1;
+    const int big = nr_sim_reg_big(A, Nt, Bv, Nv, prec);
+    if (big == 2 && prec == NR_PREC_BF16) return 0;
+    if (big == 3 && prec == NR_PREC_BF16X3) return 1;
+    return -1;
+}
+
+extern "C" int nr_local_level_group(int n, const NrLocalLevelProblem* probs, void* stream) {
+    if (!probs || n <= 0) return NR_EINVAL;
+    if (n > NR_SIM_GROUP_MAX) return NR_EUNSUPPORTED;
+    NrSimGroup g;
+    g.n = n;
+    g.first[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const NrLocalLevelProblem& q = probs[i];
+        if (!q.t_hi || !q.v_hi || !q.w_t || !q.w_v || !q.out) return NR_EINVAL;
+        if (q.out_mode < 0 || q.out_mode > 2) return NR_EINVAL;
+        if (q.prec == NR_PREC_BF16X3 && (!q.t_lo || !q.v_lo)) return NR_EINVAL;
+        const int kind = nr_local_level_group_kind(q.A, q.Nt, q.Bv, q.Nv, q.d, q.prec);
+        if (kind < 0) return NR_EUNSUPPORTED;
+        NrSimRegArgs a{q.t_hi, q.t_lo, q.v_hi, q.v_lo, q.w_t, q.w_v, q.out, nullptr, nullptr, nullptr, nullptr,
+                       q.A, q.Bv, q.d, q.out_mode};
+        if (kind == 0) nr_sim_reg_plan<6, 6, 4, 2, 4>(a);
+        else nr_sim_reg_plan<3, 3, 8, 4, 4>(a);
+        g.p[i] = a;
+        g.kind[i] = kind;
+        g.first[i + 1] = g.first[i] + a.ntx * a.nty;
+    }
+    for (int i = n; i < NR_SIM_GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.kind[i] = g.kind[0]; g.first[i + 1] = g.first[n]; }
+    using TileA = NrGemmTile<6, 6, false, 4, 2, 2, 4>;
+    using TileB = NrGemmTile<3, 3, true, 8, 4, 2, 4>;
+    constexpr size_t lds_a = TileA::RING_BYTES + sizeof(float) * (8 * 24 + 32 * 12);
+    constexpr size_t lds_b = TileB::RING_BYTES;
+    constexpr size_t lds = lds_a > lds_b ? lds_a : lds_b;
+    hipError_t e = hipFuncSetAttribute((const void*)nr_sim_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(nr_sim_group_kernel, dim3(g.first[n]), dim3(512), lds, (hipStream_t)stream, g);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
 }

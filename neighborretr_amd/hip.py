@@ -33,6 +33,13 @@ class CtmStageDesc(ctypes.Structure):
                                      "proj_bias", "workspace", "out", "assign")])
 
 
+class LocalLevelProblem(ctypes.Structure):
+    """NrLocalLevelProblem of include/nr_hip.h."""
+    _fields_ = ([(n, _P) for n in ("t_hi", "t_lo", "v_hi", "v_lo", "w_t", "w_v", "out")]
+                + [(n, ctypes.c_int) for n in ("A", "Nt", "Bv", "Nv", "d", "prec", "out_mode")])
+
+
+LOCAL_LEVEL_GROUP_MAX = 4
 CTM_MAX_GROUP = 4
 CTM_STAGE_LAUNCHES = 7
 
@@ -45,6 +52,8 @@ _SIGNATURES = {
     "nr_token_softmax": ([_P, _I, _P, _P, _I, _I, _P, _P, _P], _I),
     "nr_local_level_tiles": ([_I, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)], _I),
     "nr_local_level_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),
+    "nr_local_level_group_kind": ([_I, _I, _I, _I, _I, _I], _I),
+    "nr_local_level_group": ([_I, ctypes.POINTER(LocalLevelProblem), _P], _I),
     "nr_reduce_parts": ([_P, _I, _I, _F, _P, _P], _I),
     "nr_gemm_nt_f32": ([_P, _P, _I, _I, _I, _P, _P], _I),
     "nr_centrality_weights": ([_P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P], _I),
@@ -167,6 +176,11 @@ def local_level_tiles(A, Nt, Bv, Nv, prec=PREC_BF16):
     r, c = _I(0), _I(0)
     _check("nr_local_level_tiles", lib().nr_local_level_tiles(A, Nt, Bv, Nv, int(prec), ctypes.byref(r), ctypes.byref(c)))
     return r.value, c.value
+
+
+def local_level_group_kind(A, Nt, Bv, Nv, d, prec):
+    """>= 0 if nr_local_level_group takes this product, -1 if it has to be launched on its own."""
+    return int(lib().nr_local_level_group_kind(int(A), int(Nt), int(Bv), int(Nv), int(d), int(prec)))
 
 
 def sinkhorn_workspace_bytes(B):

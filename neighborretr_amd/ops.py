@@ -95,6 +95,37 @@ def local_level(prep_t, prep_v, w_t, w_v, A, Nt, Bv, Nv, prec=hip.PREC_BF16, out
     return out, ((arg_v, arg_t, pmax, qmax) if want_arg else None)
 
 
+def local_level_group(problems):
+    """Several loss-only products of one step: [(prep_t, prep_v, w_t, w_v, A, Nt, Bv, Nv, prec, out_mode), ...] -> list of
+    outputs as local_level(...)[0] would return them.  One grid for all of them (nr_local_level_group) when every product
+    can join a group; one launch each otherwise."""
+    if not problems:
+        return []
+    groupable = 1 < len(problems) <= hip.LOCAL_LEVEL_GROUP_MAX and all(
+        hip.local_level_group_kind(A, Nt, Bv, Nv, pt.d, prec) >= 0 for (pt, pv, wt, wv, A, Nt, Bv, Nv, prec, mode) in problems)
+    if not groupable:
+        return [local_level(*q)[0] for q in problems]
+    arr = (hip.LocalLevelProblem * len(problems))()
+    outs = []
+    for i, (pt, pv, wt, wv, A, Nt, Bv, Nv, prec, mode) in enumerate(problems):
+        dev = pt.hi.device
+        if pt.n_tok != A * Nt or pv.n_tok != Bv * Nv:
+            raise ValueError("prepared token counts do not match A*Nt / Bv*Nv")
+        if mode == hip.OUT_FULL:
+            out = torch.empty((A, Bv), dtype=torch.float32, device=dev)
+        else:
+            nr, nc = hip.local_level_tiles(A, Nt, Bv, Nv, prec)
+            out = torch.empty((nc, A) if mode == hip.OUT_ROWSUM else (nr, Bv), dtype=torch.float32, device=dev)
+        outs.append(out)
+        q = arr[i]
+        q.t_hi, q.v_hi = hip.ptr(pt.hi), hip.ptr(pv.hi)
+        q.t_lo, q.v_lo = hip.ptr(pt.lo, allow_none=True), hip.ptr(pv.lo, allow_none=True)
+        q.w_t, q.w_v, q.out = hip.ptr(wt, torch.float32), hip.ptr(wv, torch.float32), hip.ptr(out)
+        q.A, q.Nt, q.Bv, q.Nv, q.d, q.prec, q.out_mode = A, Nt, Bv, Nv, pt.d, int(prec), int(mode)
+    hip.call("nr_local_level_group", len(problems), arr, hip.stream_ptr())
+    return outs
+
+
 def reduce_parts(parts, scale):
     out = torch.empty((parts.shape[1],), dtype=torch.float32, device=parts.device)
     hip.call("nr_reduce_parts", hip.ptr(parts, torch.float32), parts.shape[0], parts.shape[1], float(scale), hip.ptr(out),

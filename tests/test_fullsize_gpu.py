@@ -146,3 +146,33 @@ def test_diag_ranks_at_1000():
     assert mine["cols"] == ref["cols"]
     for k in ("R1", "R5", "R10", "R50", "MR", "MeanR"):
         assert mine[k] == ref[k]
+
+
+@pytest.mark.parametrize("B,M,all_groupable", [(128, 512, True), (130, 520, True), (256, 1024, False)])
+def test_grouped_products_equal_the_single_launches(B, M, all_groupable):
+    """nr_local_level_group: the step's three products (two bank products in bf16, batch x batch in split-bf16) in one grid
+    give, bit for bit, what one nr_local_level_fwd per product gives -- ragged block edges included; a product a group
+    cannot take (other token counts) sends the whole list down the single-launch path."""
+    t, tm, wt = _tokens(21, B, 24)
+    v, vm, wv = _tokens(22, B, 12)
+    bt, btm, wbt = _tokens(23, M, 24)
+    bv, bvm, wbv = _tokens(24, M, 12)
+    pt, pv = ops.prepare_tokens(t, tm, want_lo=True), ops.prepare_tokens(v, vm, want_lo=True)
+    pbt, pbv = ops.prepare_tokens(bt, btm), ops.prepare_tokens(bv, bvm)
+    probs = [(pt, pbv, wt, wbv, B, 24, M, 12, hip.PREC_BF16, hip.OUT_ROWSUM),
+             (pbt, pv, wbt, wv, M, 24, B, 12, hip.PREC_BF16, hip.OUT_COLSUM),
+             (pt, pv, wt, wv, B, 24, B, 12, hip.PREC_BF16X3, hip.OUT_FULL)]
+    # B = 256: the batch x batch product runs 192 x 192 blocks on its own and cannot join (the call then launches one by one)
+    assert all(hip.local_level_group_kind(q[4], q[5], q[6], q[7], 512, q[8]) >= 0 for q in probs) == all_groupable
+    ref = [ops.local_level(*q)[0] for q in probs]
+    for sel in ((0, 1, 2), (0, 1), (1, 2), (2, 1, 0)):
+        got = ops.local_level_group([probs[i] for i in sel])
+        for i, g in zip(sel, got):
+            assert torch.equal(g, ref[i]), (sel, i)
+    # 64-token products cannot join a group: the call falls back to one launch each, same results
+    t64, tm64, wt64 = _tokens(25, 8, 64)
+    v64, vm64, wv64 = _tokens(26, 8, 64)
+    odd = (ops.prepare_tokens(t64, tm64), ops.prepare_tokens(v64, vm64), wt64, wv64, 8, 64, 8, 64, hip.PREC_BF16, hip.OUT_FULL)
+    assert hip.local_level_group_kind(8, 64, 8, 64, 512, hip.PREC_BF16) < 0
+    got = ops.local_level_group([probs[0], odd])
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ops.local_level(*odd)[0])

@@ -33,6 +33,7 @@ def main():
     print(f"tiles {hip.local_level_tiles(A, Nt, Bv, Nv, prec)}  slices {n}")
     print(f"per slice: wait for own DMA {wait / n:7.0f}   barrier {bar / n:7.0f}   compute {comp / n:7.0f}   sum {(wait + bar + comp) / n:7.0f} cycles")
     print(f"whole kernel (this wave): {total} cycles; K loop {wait + bar + comp} ({100.0 * (wait + bar + comp) / max(total, 1):.0f} %)")
+    print(f"wave 0: setup before the K loop {buf[5]} cycles, K loop {buf[6] - buf[5]}, epilogue {buf[4] - buf[6]}")
     if buf[8] or buf[10]:
         print(f"ping-pong loop: group 0 wave: work {buf[8]} + barrier wait {buf[9]} = {buf[8] + buf[9]} cycles;  "
               f"group 1 wave: work {buf[10]} + barrier wait {buf[11]} = {buf[10] + buf[11]}")

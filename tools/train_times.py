@@ -31,9 +31,11 @@ def main():
         tf.grad = vf.grad = None
         m(tf, p["text_mask"], vf, p["video_mask"], p["idx"], 0)[0].backward()
 
-    for fused in (True, False):
-        for own in (True, False):
+    for fused, own, side_streams in ((True, True, True), (True, False, True), (False, True, True), (False, False, True),
+                                     (False, True, False)):
+        if True:
             m.fused_training_clustering = fused
+            m.use_side_streams = side_streams
             backward.OWN_MLP_GEMMS = own
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -60,7 +62,8 @@ def main():
             for _ in range(30):
                 g.replay()
             torch.cuda.synchronize()
-            print(f"clustering forward {'fused HIP ' if fused else 'torch ops '} | MLP backward GEMMs {'own split-bf16' if own else 'library      '}: "
+            print(f"clustering forward {'fused HIP ' if fused else 'torch ops '} | {'side streams' if side_streams else 'ONE stream  '} | "
+                  f"MLP backward GEMMs {'own split-bf16' if own else 'library      '}: "
                   f"eager {eager:6.2f} ms   graph {(time.perf_counter() - t0) / 30 * 1e3:6.2f} ms", flush=True)
 
 
