@@ -486,7 +486,7 @@ def main():
                     "mfma_busy_source": "profiles/r02_pmc_sim.json: SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / (SQ_BUSY_CYCLES / shader engines), "
                                         "weighted by the MFMA flops each launch issues",
                     "kernel": "nr_sim_reg_kernel (fused local_level: 2 bank products on 192x384 blocks, ping-pong K loop + the "
-                              "split-bf16 batch product on 96x192 blocks = 3 launches/step)",
+                              "split-bf16 batch product on 96x192 blocks, both on 2x4 waves = 3 launches/step)",
                     "avg_launch_us": round(per_launch_s * 1e6, 2),
                     "algorithmic_flops_per_launch": f_sim / 3}
 

@@ -131,3 +131,46 @@ def test_fresh_tcblock_initialises_like_the_reference():
         assert float((blk.norm1.weight - 1).abs().max()) == 0.0 and float(blk.norm1.bias.abs().max()) == 0.0
     # the CTM modules keep torch's defaults, as in the reference (no init hook there: cluster.py:670-688)
     assert float(m.text_ctm0.score.bias.abs().max()) >= 0.0
+
+
+def test_reference_import_paths_resolve_to_this_package():
+    """with this repository ahead of the reference on PYTHONPATH, the reference's own import lines
+    (main.py:44, training/trainer.py, training/evaluator.py:14-16, utils/memory_bank.py:17) bind the HIP-backed modules."""
+    import importlib
+    import neighborretr_amd.cluster as C
+    import neighborretr_amd.metrics as Mx
+    import neighborretr_amd.modeling as Mo
+    import neighborretr_amd.training as T
+    import neighborretr_amd.until_module as U
+    expect = {
+        "NeighborRetr.models.modeling": {"NeighborRetr": Mo.NeighborRetr, "AllGather": U.AllGather},
+        "NeighborRetr.models.until_module": {"CentralityWeightingLoss": U.CentralityWeightingLoss, "AllGather": U.AllGather},
+        "NeighborRetr.models.cluster": {"CTM": C.CTM, "TCBlock": C.TCBlock},
+        "NeighborRetr.utils.metrics": {"RetrievalMetrics": Mx.RetrievalMetrics},
+        "NeighborRetr.utils.memory_bank": {"MemoryBankManager": T.MemoryBankManager},
+        "NeighborRetr.utils.comm": {"is_main_process": T.is_main_process},
+        "NeighborRetr.training.trainer": {"train_epoch": T.train_epoch},
+        "NeighborRetr.training.evaluator": {"eval_epoch": T.eval_epoch},
+    }
+    for mod, names in expect.items():
+        m = importlib.import_module(mod)
+        for name, obj in names.items():
+            assert getattr(m, name) is obj, (mod, name)
+
+
+def test_metrics_tracker_follows_the_reference_update_rule():
+    """utils/metrics.py:168-203: a tie with the best R@1 updates too; the mean of the BEST t2v / v2t is tracked."""
+    from neighborretr_amd.metrics import RetrievalMetrics
+    tr = RetrievalMetrics()
+    a = {"R1": 10.0, "R5": 30.0, "R10": 40.0, "MR": 12.0, "MeanR": 20.0}
+    b = {"R1": 20.0, "R5": 35.0, "R10": 45.0, "MR": 10.0, "MeanR": 18.0}
+    updated, mean = tr.update_best_metrics(a, b, a["R1"], b["R1"])
+    assert updated and mean == 15.0 and tr.get_best_metrics()["score"] == 15.0
+    updated, mean = tr.update_best_metrics({**a, "R1": 12.0}, {**b, "R1": 5.0}, 12.0, 5.0)
+    assert updated and mean == 8.5
+    best = tr.get_best_metrics()
+    assert best["t2v_r1"] == 12.0 and best["v2t_r1"] == 20.0 and best["score"] == 16.0
+    updated, _ = tr.update_best_metrics({**a, "R1": 1.0}, {**b, "R1": 1.0}, 1.0, 1.0)
+    assert not updated
+    updated, _ = tr.update_best_metrics({**a, "R1": 12.0}, {**b, "R1": 1.0})          # R@1 taken from the dictionaries
+    assert updated

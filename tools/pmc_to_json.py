@@ -42,4 +42,15 @@ for name, cs in sorted(acc.items()):
     if dur.get(name):
         k["profiled_avg_duration_us"] = round(sum(dur[name]) / len(dur[name]) / 1e3, 2)
     out["per_kernel"][name] = k
+# the step launches the bank kernel (192 x 384 blocks, "<6, 6, ...") twice and the split-bf16 batch kernel ("<3, ...") once
+bank = [k for n, k in out["per_kernel"].items() if "<6, 6" in n]
+x3 = [k for n, k in out["per_kernel"].items() if "<3, " in n]
+if bank and x3:
+    b, x = bank[0], x3[0]
+    if "fabric_read_bytes_per_launch" in b and "fabric_read_bytes_per_launch" in x:
+        tot = lambda k: k["fabric_read_bytes_per_launch"] + k.get("fabric_write_bytes_per_launch", 0)      # noqa: E731
+        out["bytes_per_launch_avg_over_step"] = round((2 * tot(b) + tot(x)) / 3)
+    if "mfma_busy_frac" in b and "mfma_busy_frac" in x:
+        fb, fx = 2 * 19.33, 3 * 4.83            # issued MFMA GF: two bank products, the 3-pass batch product
+        out["mfma_busy_frac_flops_weighted"] = round((fb * b["mfma_busy_frac"] + fx * x["mfma_busy_frac"]) / (fb + fx), 4)
 json.dump(out, sys.stdout, indent=1)
