@@ -399,19 +399,20 @@ def main():
         # step is bound by the host issuing the autograd-traced clustering ops, the replay is not
         if not args.no_graph:
             try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for _ in range(3):
-                        fb()
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                gfb = torch.cuda.CUDAGraph()
-                model.zero_grad(set_to_none=True)
-                tf.grad = vf.grad = None
-                with torch.cuda.graph(gfb):
-                    ls = model(tf, shard["text_mask"], vf, shard["video_mask"], shard["idx"], 0)
-                    ls[0].backward()
+                with model.graph_capture_mode():
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        for _ in range(3):
+                            fb()
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                    gfb = torch.cuda.CUDAGraph()
+                    model.zero_grad(set_to_none=True)
+                    tf.grad = vf.grad = None
+                    with torch.cuda.graph(gfb):
+                        ls = model(tf, shard["text_mask"], vf, shard["video_mask"], shard["idx"], 0)
+                        ls[0].backward()
                 for _ in range(5):
                     gfb.replay()
                 torch.cuda.synchronize()

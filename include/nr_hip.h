@@ -196,6 +196,11 @@ typedef struct NrCtmStageDesc {
     int64_t* assign;
 } NrCtmStageDesc;
 size_t nr_ctm_stage_workspace_bytes(int n_samples, int N, int C, int cluster_num);
+/* What the stage leaves in its workspace for a backward pass (neighborretr_amd/cluster_backward.py): byte offsets of
+ *   [0] y [n,N,C] conv output + residual (LayerNorm input)   [1] xn [n,N,C] LayerNorm output   [2] score [n,N] (-inf on
+ *   masked tokens)   [3] tokw [n,N] = exp(score)   [4] merged_pb [n,cnum,C] cluster means + proj bias   [5] q [n*cnum,C]
+ *   [6] kv [n*N,2C];  all fp32.  offsets: 7 entries.                                                                    */
+int nr_ctm_stage_workspace_layout(int n_samples, int N, int C, int cluster_num, size_t* offsets);
 int nr_ctm_stage_fwd(const NrCtmStageDesc* problems, int n_problems, void* stream);
 /* Launches [first, last) of the stage's NR_CTM_STAGE_LAUNCHES only (0 shift|split, 1 conv GEMM, 2 front, 3 back,
  * 4 q+kv GEMMs, 5 attention, 6 proj GEMM): a host that captures the step into a HIP graph interleaves them with

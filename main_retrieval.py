@@ -218,6 +218,10 @@ class GraphedStep:
         self.capture()
 
     def capture(self):
+        with self.model.graph_capture_mode():
+            self._capture()
+
+    def _capture(self):
         model, params = self.model, self.params
         B = self.static[0].shape[0]
         # Warm-up on a side stream, as graph capture requires -- with the bank FROZEN: a warm-up step that pushed its

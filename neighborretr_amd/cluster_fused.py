@@ -117,17 +117,34 @@ def _addr(t):
     return None if t is None else t.data_ptr()
 
 
-def ctm_stage_group(problems, cache, stepwise=False, want_assign=False):
+def _workspace_views(ws, B, N, C, cnum):
+    """fp32 views of the intermediates a backward pass needs, inside a stage's workspace (nr_ctm_stage_workspace_layout)."""
+    import ctypes
+    off = (ctypes.c_size_t * 7)()
+    hip.call("nr_ctm_stage_workspace_layout", B, N, C, cnum, off)
+    shapes = {"y": (B, N, C), "xn": (B, N, C), "score": (B, N), "w": (B, N), "merged_pb": (B, cnum, C), "q": (B * cnum, C),
+              "kv": (B * N, 2 * C)}
+    out = {}
+    for o, (name, shape) in zip(off, shapes.items()):
+        n = 1
+        for k in shape:
+            n *= k
+        out[name] = ws[int(o): int(o) + 4 * n].view(torch.float32).view(shape)
+    return out
+
+
+def ctm_stage_group(problems, cache, stepwise=False, want_assign=False, want_saved=False):
     """One CTM + TCBlock stage of several independent problems (text and video) in the SAME seven launches
     (nr_ctm_stage_fwd).  problems: list of (key, x [B,N,C], mask or None, ctm, blk, noise or None).
     Returns the list of outputs [B,cnum,C]; with stepwise=True returns (outputs, generator) where every
     next() of the generator issues ONE of the seven launches on the then-current stream.  want_assign=True: returns
-    (outputs, cluster ids [B,N] int64 per problem) -- what a backward pass needs to recompute the stage."""
+    (outputs, cluster ids [B,N] int64 per problem) -- what a backward pass needs to recompute the stage; want_saved=True:
+    (outputs, per problem a dict of the stage's intermediates: views into its workspace + "x0", "assign", "mask")."""
     import ctypes
     if not 0 < len(problems) <= hip.CTM_MAX_GROUP:
         raise hip.NrHipError(f"1..{hip.CTM_MAX_GROUP} problems per grouped stage")
     descs = (hip.CtmStageDesc * len(problems))()
-    keep, outs, assigns = [], [], []
+    keep, outs, assigns, saved = [], [], [], []
     for d, (key, x, mask, ctm, blk, noise) in zip(descs, problems):
         x = x.detach().float().contiguous()
         B, N, C = x.shape
@@ -145,8 +162,10 @@ def ctm_stage_group(problems, cache, stepwise=False, want_assign=False):
         nbytes = int(hip.lib().nr_ctm_stage_workspace_bytes(B, N, C, cnum))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         out = torch.empty((B, cnum, C), dtype=torch.float32, device=dev)
-        assign = torch.empty((B, N), dtype=torch.int64, device=dev) if want_assign else None
+        assign = torch.empty((B, N), dtype=torch.int64, device=dev) if (want_assign or want_saved) else None
         assigns.append(assign)
+        if want_saved:
+            saved.append(dict(_workspace_views(ws, B, N, C, cnum), x0=x, assign=assign, mask=m))
         conv_bias = getattr(ctm.conv.conv, "bias", None)
         tensors = dict(x=x, mask=m, noise=noise, wconv_hi=sw.wconv_hi, wconv_lo=sw.wconv_lo, conv_bias=conv_bias,
                        ln_w=ctm.norm.weight, ln_b=ctm.norm.bias, sc_w=ctm.score.weight, sc_b=ctm.score.bias,
@@ -170,44 +189,51 @@ def ctm_stage_group(problems, cache, stepwise=False, want_assign=False):
         return outs, launches()
     hip.call("nr_ctm_stage_fwd", descs, len(problems), hip.stream_ptr())
     del keep
+    if want_saved:
+        return outs, saved
     return (outs, assigns) if want_assign else outs
+
+
+_SAVED = ("x0", "y", "xn", "score", "w", "assign", "merged_pb", "q", "kv")
 
 
 class ClusterStagesFn(torch.autograd.Function):
     """One CTM + TCBlock stage of the text AND the video tokens for the TRAINING step: the forward runs the grouped HIP
-    kernels (7 launches for both modalities, like the loss-only step) and keeps only the inputs and the cluster ids;
-    the backward recomputes the stage with the autograd-traced torch ops of cluster.py on those ids (DPC-KNN itself has
-    no gradient: cluster.py:467 runs it under no_grad) and differentiates that.  The reference traces ~45 ATen launches
-    per stage and modality in the forward and keeps every intermediate alive until the backward."""
+    kernels (7 launches for both modalities, like the loss-only step) and keeps what they leave in their workspaces; the
+    backward is the hand-derived one of cluster_backward.stage_backward on those tensors (~45 torch launches per modality;
+    DPC-KNN itself has no gradient: cluster.py:467 runs it under no_grad).  The reference -- and this package's traced
+    path -- spend ~37 forward and ~75 backward launches per stage and modality and keep every intermediate alive."""
 
     @staticmethod
     def forward(ctx, modules, cache, keys, x_t, mask_t, noise_t, x_v, mask_v, noise_v, *params):
         (ctm_t, blk_t), (ctm_v, blk_v) = modules
-        (out_t, out_v), (as_t, as_v) = ctm_stage_group([(keys[0], x_t, mask_t, ctm_t, blk_t, noise_t),
-                                                        (keys[1], x_v, mask_v, ctm_v, blk_v, noise_v)], cache, want_assign=True)
+        (out_t, out_v), saved = ctm_stage_group([(keys[0], x_t, mask_t, ctm_t, blk_t, noise_t),
+                                                 (keys[1], x_v, mask_v, ctm_v, blk_v, noise_v)], cache, want_saved=True)
         ctx.modules = modules
-        ctx.masks = (mask_t, mask_v)
+        ctx.masks = tuple(sv["mask"] for sv in saved)
         ctx.n_params = len(params)
-        ctx.save_for_backward(x_t, x_v, as_t, as_v)
+        ctx.save_for_backward(*[sv[k] for sv in saved for k in _SAVED])
         return out_t, out_v
 
     @staticmethod
     def backward(ctx, g_t, g_v):
-        x_t, x_v, as_t, as_v = ctx.saved_tensors
+        from .cluster_backward import stage_backward
+        tensors = ctx.saved_tensors
         grads_x, grads_p = [], {}
-        with torch.enable_grad():
-            for (ctm, blk), x, mask, assign, g in zip(ctx.modules, (x_t, x_v), ctx.masks, (as_t, as_v), (g_t, g_v)):
-                xg = x.detach().requires_grad_(True)
-                out = blk(ctm({"x": xg, "mask": mask}, assign=assign))["x"]
-                ps = [p for p in list(ctm.parameters()) + list(blk.parameters()) if p.requires_grad]
-                gr = torch.autograd.grad(out, [xg] + ps, g.contiguous(), allow_unused=True)
-                grads_x.append(gr[0])
-                for p, gp in zip(ps, gr[1:]):
-                    grads_p[id(p)] = gp
+        with torch.no_grad():
+            for i, ((ctm, blk), mask, g) in enumerate(zip(ctx.modules, ctx.masks, (g_t, g_v))):
+                sv = dict(zip(_SAVED, tensors[i * len(_SAVED): (i + 1) * len(_SAVED)]))
+                sv["mask"] = mask
+                pb = blk.attn.proj.bias
+                sv["merged"] = sv["merged_pb"] - pb if pb is not None else sv["merged_pb"]
+                d_x0, gp = stage_backward(ctm, blk, sv, g)
+                grads_x.append(d_x0)
+                for p_, gr in gp.items():
+                    grads_p[id(p_)] = gr
         ordered = []
         for ctm, blk in ctx.modules:
-            for p in list(ctm.parameters()) + list(blk.parameters()):
-                ordered.append(grads_p.get(id(p)))
+            for p_ in list(ctm.parameters()) + list(blk.parameters()):
+                ordered.append(grads_p.get(id(p_)) if p_.requires_grad else None)
         assert len(ordered) == ctx.n_params
         return (None, None, None, grads_x[0], None, None, grads_x[1], None, None) + tuple(ordered)
 

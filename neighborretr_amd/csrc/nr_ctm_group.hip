@@ -124,6 +124,17 @@ extern "C" size_t nr_ctm_stage_workspace_bytes(int n_samples, int N, int C, int 
     return carve(nullptr, n_samples, N, C, cluster_num).bytes;
 }
 
+// byte offsets inside the stage workspace of what a backward pass needs: y (conv output + residual, pre-LayerNorm),
+// xn (LayerNorm output), score (masked tokens: -inf), tokw (exp(score)), merged_pb (cluster means + proj bias), q, kv
+extern "C" int nr_ctm_stage_workspace_layout(int n_samples, int N, int C, int cluster_num, size_t* offsets) {
+    if (n_samples <= 0 || N <= 0 || C <= 0 || cluster_num <= 0 || !offsets) return NR_EINVAL;
+    char* const base = reinterpret_cast<char*>(4096);
+    const StageBuffers s = carve(base, n_samples, N, C, cluster_num);
+    const void* p[7] = {s.y, s.xn, s.score, s.tokw, s.merged_pb, s.q, s.kv};
+    for (int i = 0; i < 7; ++i) offsets[i] = (size_t)(static_cast<const char*>(p[i]) - base);
+    return NR_OK;
+}
+
 extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
     return nr_ctm_stage_fwd_range(d, n, 0, NR_CTM_STAGE_LAUNCHES, stream);
 }

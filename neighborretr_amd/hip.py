@@ -69,6 +69,7 @@ _SIGNATURES = {
     "nr_shift_concat_split": ([_P, _I, _I, _I, _P, _P, _P], _I),
     "nr_ctm_back": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
     "nr_ctm_stage_workspace_bytes": ([_I, _I, _I, _I], _Z),
+    "nr_ctm_stage_workspace_layout": ([_I, _I, _I, _I, ctypes.POINTER(_Z)], _I),
     "nr_ctm_stage_fwd": ([ctypes.POINTER(CtmStageDesc), _I, _P], _I),
     "nr_ctm_stage_fwd_range": ([ctypes.POINTER(CtmStageDesc), _I, _I, _I, _P], _I),
     "nr_sinkhorn_workspace_bytes": ([_I], _Z),

@@ -11,6 +11,7 @@ feature PRODUCERS; pass any module with `encode_text` / `encode_image` + `logit_
 `text_ids` / `video` given to forward() are taken to be the token features [b,Nt,d] / [b,Nv,d]
 already -- which is what bench.py, the tests and `main_retrieval.py --synthetic` use.
 """
+import contextlib
 import math
 from types import SimpleNamespace
 
@@ -117,7 +118,11 @@ class NeighborRetr(nn.Module):
         # parity tests run it) but OFF by default: the recompute runs text and video one after the other on one stream,
         # 7.0 ms per graph-captured training step against 4.1 ms with the autograd-traced forward on two side streams
         # (tools/train_times.py, MI355X)
-        self.fused_training_clustering = False
+        # Training step: clustering forward on the grouped HIP kernels + hand-derived backward (cluster_backward.py) or the
+        # autograd-traced torch ops on two side streams.  None = by how the step is launched: launched eagerly (DDP steps,
+        # whose collectives keep them out of a graph) the fused form is host-bound on ~50 launches less (8.3 vs 11.0 ms);
+        # replayed from a captured graph the traced form's two side streams overlap and win (4.2 vs 6.6 ms).
+        self.fused_training_clustering = None
         self._ctm_cache = {}
 
     # ------------------------------------------------------------------ construction helpers
@@ -402,10 +407,12 @@ class NeighborRetr(nn.Module):
             gt = gv = None
 
             self._join_global = self._merge_grouped_steps(text_feat, video_feat, text_mask, video_mask, nz)
-        elif (text_feat.is_cuda and self.fuse_clustering and self.fused_training_clustering and torch.is_grad_enabled()
+        elif (text_feat.is_cuda and self.fuse_clustering and torch.is_grad_enabled()
+              and (self.fused_training_clustering if self.fused_training_clustering is not None
+                   else not torch.cuda.is_current_stream_capturing())
               and text_feat.shape[1] <= 64 and video_feat.shape[1] <= 64 and text_feat.shape[2] % 128 == 0):
-            # training step: the clustering forward on the grouped HIP kernels (ClusterStagesFn: inputs + cluster ids
-            # saved, the stage recomputed on torch ops in the backward)
+            # training step: the clustering forward on the grouped HIP kernels, the backward hand-derived from what they
+            # leave in their workspaces (cluster_fused.ClusterStagesFn, cluster_backward.stage_backward)
             from .cluster_fused import cluster_stages_train
             t, v = cluster_stages_train(((self.text_ctm0, self.text_block0), (self.video_ctm0, self.video_block0)),
                                         self._ctm_cache, ("text0", "video0"), text_feat, text_mask, nz.get("t0"),
@@ -437,6 +444,20 @@ class NeighborRetr(nn.Module):
                              mb_mask_t, mb_mask_v, gt, gv, hp, logit_scale)
         self._take_join()      # joined by now; never leave a stale closure behind
         return losses[0], losses[1], losses[2], losses[3], losses[4]
+
+    @contextlib.contextmanager
+    def graph_capture_mode(self):
+        """For the warm-up AND the capture of a training step as a HIP graph: pins the choices that otherwise follow the launch
+        mode (`fused_training_clustering` = None) to the captured form, so that the warm-up runs exactly the kernels -- and
+        initialises exactly the library handles -- the capture will record (hipBLASLt refuses to set itself up inside a
+        capture)."""
+        old = self.fused_training_clustering
+        if old is None:
+            self.fused_training_clustering = False
+        try:
+            yield self
+        finally:
+            self.fused_training_clustering = old
 
     def _shard_now(self, world, text_feat):
         """Sharded loss: when asked for (`shard_loss` = True, also config.shard_loss for the exchange step's backward), or

@@ -174,3 +174,36 @@ def test_metrics_tracker_follows_the_reference_update_rule():
     assert not updated
     updated, _ = tr.update_best_metrics({**a, "R1": 12.0}, {**b, "R1": 1.0})          # R@1 taken from the dictionaries
     assert updated
+
+
+@pytest.mark.parametrize("B,N,C,ratio,masked", [(5, 24, 64, 1 / 6, True), (4, 12, 64, 0.25, True), (6, 4, 64, 0.25, False),
+                                                (3, 3, 64, 1 / 3, False)])
+def test_hand_derived_stage_backward_equals_autograd(B, N, C, ratio, masked):
+    """cluster_backward.stage_backward (what the training step's fused clustering uses) against autograd through the traced
+    stage of cluster.py, fp64, cluster ids fixed: inputs and all 13 parameter gradients."""
+    import math
+    from neighborretr_amd import cluster, cluster_backward as CB
+    torch.manual_seed(B * 100 + N)
+    ctm, blk = cluster.CTM(ratio, C, C, k=3).double(), cluster.TCBlock(C, 8).double()
+    for p in list(ctm.parameters()) + list(blk.parameters()):
+        p.data.add_(0.05 * torch.randn_like(p))
+    x0 = torch.randn(B, N, C, dtype=torch.float64)
+    mask = None
+    if masked:
+        ln = torch.randint(1, N + 1, (B,))
+        ln[0], ln[1] = N, 1                                       # a full sample and one with a single valid token
+        mask = (torch.arange(N)[None] < ln[:, None]).double()
+    c = max(math.ceil(N * ratio), 1)
+    with torch.no_grad():
+        assign = cluster.dpc_knn_assign(ctm.norm(ctm.conv(x0)), c, ctm.k, mask, torch.rand(B, N, dtype=torch.float64))
+    xg = x0.clone().requires_grad_(True)
+    out = blk(ctm({"x": xg, "mask": mask}, assign=assign))["x"]
+    g = torch.randn_like(out)
+    ps = list(ctm.parameters()) + list(blk.parameters())
+    ref = torch.autograd.grad(out, [xg] + ps, g)
+    dx, grads = CB.stage_backward(ctm, blk, CB.saved_from_modules(ctm, blk, x0, mask, assign), g)
+    assert len(grads) == len(ps) == 13
+    assert float((dx - ref[0]).abs().max()) < 1e-8 * float(ref[0].abs().max())
+    for p, r in zip(ps, ref[1:]):
+        assert grads[p].shape == r.shape
+        assert float((grads[p] - r).abs().max()) < 1e-8 * max(float(r.abs().max()), 1e-12)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""The captured training step (forward + backward, configs[1]) replayed 12 times for rocprofv3 --kernel-trace."""
+"""The captured training step (forward + backward, configs[1]) replayed 12 times for rocprofv3 --kernel-trace
+(--fused: clustering forward on the grouped HIP kernels + hand-derived backward)."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -8,6 +9,7 @@ B, Nt, Nv, M, K = 128, 24, 12, 512, 20
 m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K))
 m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}, strict=False)
 m = m.cuda().train()
+m.fused_training_clustering = "--fused" in sys.argv[1:]
 p = {k: torch.from_numpy(v).cuda() for k, v in synth.make_problem(1002, B, Nt, Nv, M).items()}
 m.mb_feat_t, m.mb_feat_v, m.mb_mask_t, m.mb_mask_v = p["mb_feat_t"], p["mb_feat_v"], p["mb_mask_t"], p["mb_mask_v"]
 m.mb_ind = torch.arange(M).cuda()
