@@ -199,7 +199,10 @@ size_t nr_ctm_stage_workspace_bytes(int n_samples, int N, int C, int cluster_num
 /* What the stage leaves in its workspace for a backward pass (neighborretr_amd/cluster_backward.py): byte offsets of
  *   [0] y [n,N,C] conv output + residual (LayerNorm input)   [1] xn [n,N,C] LayerNorm output   [2] score [n,N] (-inf on
  *   masked tokens)   [3] tokw [n,N] = exp(score)   [4] merged_pb [n,cnum,C] cluster means + proj bias   [5] q [n*cnum,C]
- *   [6] kv [n*N,2C];  all fp32.  offsets: 7 entries.                                                                    */
+ *   [6] kv [n*N,2C]   [7] smax [n]: per-sample maximum pairwise distance, written by the front launch (launch 2 of
+ *   nr_ctm_stage_fwd_range) and max-reduced over the samples by the back launch (3): a caller that clusters only a shard of
+ *   the batch stores the maximum over ALL shards in smax[0] between the two (cluster.py:473-475 uses the batch-wide
+ *   maximum).  All fp32.  offsets: 8 entries.                                                                          */
 int nr_ctm_stage_workspace_layout(int n_samples, int N, int C, int cluster_num, size_t* offsets);
 int nr_ctm_stage_fwd(const NrCtmStageDesc* problems, int n_problems, void* stream);
 /* Launches [first, last) of the stage's NR_CTM_STAGE_LAUNCHES only (0 shift|split, 1 conv GEMM, 2 front, 3 back,

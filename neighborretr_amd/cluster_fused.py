@@ -120,10 +120,10 @@ def _addr(t):
 def _workspace_views(ws, B, N, C, cnum):
     """fp32 views of the intermediates a backward pass needs, inside a stage's workspace (nr_ctm_stage_workspace_layout)."""
     import ctypes
-    off = (ctypes.c_size_t * 7)()
+    off = (ctypes.c_size_t * 8)()
     hip.call("nr_ctm_stage_workspace_layout", B, N, C, cnum, off)
     shapes = {"y": (B, N, C), "xn": (B, N, C), "score": (B, N), "w": (B, N), "merged_pb": (B, cnum, C), "q": (B * cnum, C),
-              "kv": (B * N, 2 * C)}
+              "kv": (B * N, 2 * C), "smax": (B,)}
     out = {}
     for o, (name, shape) in zip(off, shapes.items()):
         n = 1
@@ -133,18 +133,21 @@ def _workspace_views(ws, B, N, C, cnum):
     return out
 
 
-def ctm_stage_group(problems, cache, stepwise=False, want_assign=False, want_saved=False):
+def ctm_stage_group(problems, cache, stepwise=False, want_assign=False, want_saved=False, exchange=None):
     """One CTM + TCBlock stage of several independent problems (text and video) in the SAME seven launches
     (nr_ctm_stage_fwd).  problems: list of (key, x [B,N,C], mask or None, ctm, blk, noise or None).
     Returns the list of outputs [B,cnum,C]; with stepwise=True returns (outputs, generator) where every
     next() of the generator issues ONE of the seven launches on the then-current stream.  want_assign=True: returns
     (outputs, cluster ids [B,N] int64 per problem) -- what a backward pass needs to recompute the stage; want_saved=True:
-    (outputs, per problem a dict of the stage's intermediates: views into its workspace + "x0", "assign", "mask")."""
+    (outputs, per problem a dict of the stage's intermediates: views into its workspace + "x0", "assign", "mask").
+    exchange: optional callable(list of per-problem smax tensors [B]) run between the front and the back launch of a stage
+    that carries masks -- a rank clustering only ITS samples of a sharded batch puts the maximum over all ranks into
+    smax[0] there (the masked stage uses the batch-wide maximum distance, cluster.py:473-475)."""
     import ctypes
     if not 0 < len(problems) <= hip.CTM_MAX_GROUP:
         raise hip.NrHipError(f"1..{hip.CTM_MAX_GROUP} problems per grouped stage")
     descs = (hip.CtmStageDesc * len(problems))()
-    keep, outs, assigns, saved = [], [], [], []
+    keep, outs, assigns, saved, smax = [], [], [], [], []
     for d, (key, x, mask, ctm, blk, noise) in zip(descs, problems):
         x = x.detach().float().contiguous()
         B, N, C = x.shape
@@ -164,8 +167,11 @@ def ctm_stage_group(problems, cache, stepwise=False, want_assign=False, want_sav
         out = torch.empty((B, cnum, C), dtype=torch.float32, device=dev)
         assign = torch.empty((B, N), dtype=torch.int64, device=dev) if (want_assign or want_saved) else None
         assigns.append(assign)
-        if want_saved:
-            saved.append(dict(_workspace_views(ws, B, N, C, cnum), x0=x, assign=assign, mask=m))
+        if want_saved or exchange is not None:
+            views = _workspace_views(ws, B, N, C, cnum)
+            smax.append(views.pop("smax"))
+            if want_saved:
+                saved.append(dict(views, x0=x, assign=assign, mask=m))
         conv_bias = getattr(ctm.conv.conv, "bias", None)
         tensors = dict(x=x, mask=m, noise=noise, wconv_hi=sw.wconv_hi, wconv_lo=sw.wconv_lo, conv_bias=conv_bias,
                        ln_w=ctm.norm.weight, ln_b=ctm.norm.bias, sc_w=ctm.score.weight, sc_b=ctm.score.bias,
@@ -181,13 +187,21 @@ def ctm_stage_group(problems, cache, stepwise=False, want_assign=False, want_sav
         keep.append(tensors)
         outs.append(out)
     if stepwise:
+        if exchange is not None:
+            raise hip.NrHipError("the exchange between front and back is not available in the stepwise form")
+
         def launches(alive=keep):
             for i in range(hip.CTM_STAGE_LAUNCHES):
                 hip.call("nr_ctm_stage_fwd_range", descs, len(problems), i, i + 1, hip.stream_ptr())
                 yield
             del alive                            # the tensors behind the descriptors stay alive until here
         return outs, launches()
-    hip.call("nr_ctm_stage_fwd", descs, len(problems), hip.stream_ptr())
+    if exchange is not None and any(t["mask"] is not None for t in keep):
+        hip.call("nr_ctm_stage_fwd_range", descs, len(problems), 0, 3, hip.stream_ptr())
+        exchange(smax)
+        hip.call("nr_ctm_stage_fwd_range", descs, len(problems), 3, hip.CTM_STAGE_LAUNCHES, hip.stream_ptr())
+    else:
+        hip.call("nr_ctm_stage_fwd", descs, len(problems), hip.stream_ptr())
     del keep
     if want_saved:
         return outs, saved
@@ -205,10 +219,11 @@ class ClusterStagesFn(torch.autograd.Function):
     path -- spend ~37 forward and ~75 backward launches per stage and modality and keep every intermediate alive."""
 
     @staticmethod
-    def forward(ctx, modules, cache, keys, x_t, mask_t, noise_t, x_v, mask_v, noise_v, *params):
+    def forward(ctx, modules, cache, keys, exchange, x_t, mask_t, noise_t, x_v, mask_v, noise_v, *params):
         (ctm_t, blk_t), (ctm_v, blk_v) = modules
         (out_t, out_v), saved = ctm_stage_group([(keys[0], x_t, mask_t, ctm_t, blk_t, noise_t),
-                                                 (keys[1], x_v, mask_v, ctm_v, blk_v, noise_v)], cache, want_saved=True)
+                                                 (keys[1], x_v, mask_v, ctm_v, blk_v, noise_v)], cache, want_saved=True,
+                                                exchange=exchange)
         ctx.modules = modules
         ctx.masks = tuple(sv["mask"] for sv in saved)
         ctx.n_params = len(params)
@@ -235,11 +250,11 @@ class ClusterStagesFn(torch.autograd.Function):
             for p_ in list(ctm.parameters()) + list(blk.parameters()):
                 ordered.append(grads_p.get(id(p_)) if p_.requires_grad else None)
         assert len(ordered) == ctx.n_params
-        return (None, None, None, grads_x[0], None, None, grads_x[1], None, None) + tuple(ordered)
+        return (None, None, None, None, grads_x[0], None, None, grads_x[1], None, None) + tuple(ordered)
 
 
-def cluster_stages_train(modules, cache, keys, x_t, mask_t, noise_t, x_v, mask_v, noise_v):
+def cluster_stages_train(modules, cache, keys, x_t, mask_t, noise_t, x_v, mask_v, noise_v, exchange=None):
     """Differentiable grouped stage (ClusterStagesFn); the stage's parameters ride along as explicit inputs so that
-    autograd routes their gradients."""
+    autograd routes their gradients.  exchange: see ctm_stage_group (sample-sharded clustering)."""
     params = [p for ctm, blk in modules for p in list(ctm.parameters()) + list(blk.parameters())]
-    return ClusterStagesFn.apply(modules, cache, keys, x_t, mask_t, noise_t, x_v, mask_v, noise_v, *params)
+    return ClusterStagesFn.apply(modules, cache, keys, exchange, x_t, mask_t, noise_t, x_v, mask_v, noise_v, *params)

@@ -125,13 +125,16 @@ extern "C" size_t nr_ctm_stage_workspace_bytes(int n_samples, int N, int C, int 
 }
 
 // byte offsets inside the stage workspace of what a backward pass needs: y (conv output + residual, pre-LayerNorm),
-// xn (LayerNorm output), score (masked tokens: -inf), tokw (exp(score)), merged_pb (cluster means + proj bias), q, kv
+// xn (LayerNorm output), score (masked tokens: -inf), tokw (exp(score)), merged_pb (cluster means + proj bias), q, kv;
+// and smax [n]: every sample's largest pairwise distance, written by the front launch and max-reduced over the samples by
+// the back launch (cluster.py:473-475 fills masked columns with the maximum over the WHOLE batch + 1) -- a rank that
+// clusters only its own samples puts the all-reduced maximum into smax[0] between the two launches
 extern "C" int nr_ctm_stage_workspace_layout(int n_samples, int N, int C, int cluster_num, size_t* offsets) {
     if (n_samples <= 0 || N <= 0 || C <= 0 || cluster_num <= 0 || !offsets) return NR_EINVAL;
     char* const base = reinterpret_cast<char*>(4096);
     const StageBuffers s = carve(base, n_samples, N, C, cluster_num);
-    const void* p[7] = {s.y, s.xn, s.score, s.tokw, s.merged_pb, s.q, s.kv};
-    for (int i = 0; i < 7; ++i) offsets[i] = (size_t)(static_cast<const char*>(p[i]) - base);
+    const void* p[8] = {s.y, s.xn, s.score, s.tokw, s.merged_pb, s.q, s.kv, s.smax};
+    for (int i = 0; i < 8; ++i) offsets[i] = (size_t)(static_cast<const char*>(p[i]) - base);
     return NR_OK;
 }
 

@@ -123,6 +123,7 @@ class NeighborRetr(nn.Module):
         # whose collectives keep them out of a graph) the fused form is host-bound on ~50 launches less (8.3 vs 11.0 ms);
         # replayed from a captured graph the traced form's two side streams overlap and win (4.2 vs 6.6 ms).
         self.fused_training_clustering = None
+        self.shard_clustering = True               # with the sharded loss: every rank clusters its own samples only
         self._ctm_cache = {}
 
     # ------------------------------------------------------------------ construction helpers
@@ -388,11 +389,16 @@ class NeighborRetr(nn.Module):
         if (self._shard_now(world, text_feat) and not torch.is_grad_enabled()
                 and self._can_fuse_clustering(text_feat, mods) and self._can_fuse_clustering(video_feat, mods)):
             import torch.distributed as dist
-            # The clustering stays replicated: its masked stage fills distances with the maximum over the WHOLE gathered
-            # batch (cluster.py:473-475, `dist_matrix.max()`), so clustering a rank's own samples alone would change the
-            # densities of samples with fewer than k valid tokens; sharding it by samples needs that maximum exchanged
-            # between the stage's front and back kernels.
-            gt, gv = self._merge_grouped(text_feat, video_feat, text_mask, video_mask, nz)
+            # The clustering is sharded by samples too: every rank clusters ITS b samples and the [b, c, d] global tokens are
+            # all-gathered.  Its masked stage fills distances with the maximum over the WHOLE gathered batch
+            # (cluster.py:473-475, `dist_matrix.max()`), so the ranks exchange that maximum (one all-reduce of two floats)
+            # between the stage's front and back kernels -- without it the densities of samples with fewer than k valid
+            # tokens would differ from the replicated result.
+            if self.shard_clustering:
+                gt, gv = self._gather_global(*self._merge_sharded(text_feat, video_feat, text_mask, video_mask, nz,
+                                                                  dist.get_rank(), world), world)
+            else:
+                gt, gv = self._merge_grouped(text_feat, video_feat, text_mask, video_mask, nz)
             losses = head.head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v,
                                                mb_mask_t, mb_mask_v, gt, gv, self.scorer_weights("text_weight_fc"),
                                                self.scorer_weights("video_weight_fc"), hp, logit_scale, self._prec(),
@@ -499,6 +505,52 @@ class NeighborRetr(nn.Module):
                                 ("video1", v, None, self.video_ctm1, self.video_block1, nz.get("v1"))],
                                self._ctm_cache)
         return t, v
+
+    def _merge_sharded(self, text_feat, video_feat, text_mask, video_mask, nz, rank, world):
+        """Both clustering stages on THIS rank's samples of the gathered batch (rows [rank b, (rank+1) b)) -> the rank's
+        global tokens (gt [b,c,d], gv [b,c,d]); differentiable when gradients are enabled (ClusterStagesFn).  The noise rows
+        are the rank's rows of the batch-wide draw, so the result equals the rank's rows of the replicated clustering."""
+        import torch.distributed as dist
+        from .cluster_fused import cluster_stages_train, ctm_stage_group
+        b = text_feat.shape[0] // world
+        rows = slice(rank * b, (rank + 1) * b)
+        tf, vf = text_feat[rows].contiguous(), video_feat[rows].contiguous()
+        tm, vm = text_mask[rows].float().contiguous(), video_mask[rows].float().contiguous()
+        n = {k: (v[rows].contiguous() if v is not None else None) for k, v in nz.items()}
+
+        def exchange(smax):
+            g = torch.stack([s_.max() for s_ in smax])
+            dist.all_reduce(g, op=dist.ReduceOp.MAX)
+            for s_, v in zip(smax, g):
+                s_[:1] = v
+        mods0 = ((self.text_ctm0, self.text_block0), (self.video_ctm0, self.video_block0))
+        mods1 = ((self.text_ctm1, self.text_block1), (self.video_ctm1, self.video_block1))
+        if torch.is_grad_enabled():
+            t, v = cluster_stages_train(mods0, self._ctm_cache, ("text0", "video0"), tf, tm, n.get("t0"), vf, vm, n.get("v0"),
+                                        exchange=exchange)
+            return cluster_stages_train(mods1, self._ctm_cache, ("text1", "video1"), t, None, n.get("t1"), v, None, n.get("v1"))
+        t, v = ctm_stage_group([("text0", tf, tm, self.text_ctm0, self.text_block0, n.get("t0")),
+                                ("video0", vf, vm, self.video_ctm0, self.video_block0, n.get("v0"))], self._ctm_cache,
+                               exchange=exchange)
+        t, v = ctm_stage_group([("text1", t, None, self.text_ctm1, self.text_block1, n.get("t1")),
+                                ("video1", v, None, self.video_ctm1, self.video_block1, n.get("v1"))], self._ctm_cache)
+        return t, v
+
+    @staticmethod
+    def _gather_global(gt, gv, world):
+        """The ranks' global tokens (equal shapes for text and video: [b,c,d]) in ONE all-gather -> ([B,c,d], [B,c,d])."""
+        import torch.distributed as dist
+        if gt.shape != gv.shape:
+            out = []
+            for g in (gt, gv):
+                full = torch.empty((world,) + tuple(g.shape), dtype=g.dtype, device=g.device)
+                dist.all_gather_into_tensor(full.view(-1), g.contiguous().view(-1))
+                out.append(full.flatten(0, 1))
+            return tuple(out)
+        pair = torch.stack((gt, gv)).contiguous()                                  # [2,b,c,d]
+        full = torch.empty((world,) + tuple(pair.shape), dtype=pair.dtype, device=pair.device)
+        dist.all_gather_into_tensor(full.view(-1), pair.view(-1))
+        return full[:, 0].flatten(0, 1), full[:, 1].flatten(0, 1)
 
     def _merge_one(self, which, feat, mask, noise0=None, noise1=None):
         """Two CTM + TCBlock stages of one modality: [B,N,d] -> [B,1,d] at the MSR-VTT token counts."""

@@ -8,8 +8,9 @@ products, and gradients need no reduction because every rank differentiates the 
       S[r-slab, :]  = local_level(text_r, video_all)        [b, B]     rows of the text->video direction
       S[:, r-slab]  = local_level(text_all, video_r)        [B, b]     rows of the video->text direction
       text_r x bank-video [b, M],  bank-text x video_r [M, b]          1/W of both bank products -> centrality slices
-  replicated: the token clustering (its masked stage uses the maximum distance over the WHOLE gathered batch,
-      cluster.py:473-475, so a rank cannot cluster its own samples alone without an extra exchange -- DESIGN.md 7)
+  sharded by samples as well: the token clustering of the rank's b samples (fused HIP forward, hand-derived backward).  Its
+      masked stage uses the maximum distance over the WHOLE gathered batch (cluster.py:473-475): the ranks all-reduce that
+      one number per modality between the stage's front and back kernels; the [b, d] global tokens are all-gathered
   light, replicated or row-local, in torch ops on [b, B] slabs: global logits G = gt gv^T, Sinkhorn targets (no
       gradient), centrality weights, and the four row-wise loss terms of the rank's 2 b rows
       (until_module.py:56-359 restated row-wise).
@@ -134,11 +135,22 @@ def sharded_training_losses(model, text_feat, video_feat, text_mask, video_mask,
     sl = slice(r0, r0 + b)
     text_mask, video_mask, mb_mask_t, mb_mask_v = (m if m.dtype == torch.float32 else m.float()
                                                    for m in (text_mask, video_mask, mb_mask_t, mb_mask_v))
-    # ---- token clustering: replicated (see the module docstring); every rank differentiates it for ITS rows' terms
-    gt, gv = model.merge_global_features(text_feat, video_feat, text_mask, video_mask, noise)
-    if gt.shape[1] != 1 or gv.shape[1] != 1:
-        raise RuntimeError("the sharded training loss covers one global token per sample (until_module.py:321)")
-    gt, gv = gt.reshape(B, d).float(), gv.reshape(B, d).float()
+    # ---- token clustering: every rank clusters ITS samples (fused forward + hand-derived backward; the batch-wide maximum
+    # distance of the masked stage is exchanged inside, modeling._merge_sharded) and the global tokens are gathered with a
+    # differentiable all-gather: d gt of a rank's samples = the sum of every rank's W dL_r / d gt, so the clustering
+    # parameters receive W x (the contribution of this rank's samples) and DDP's mean over the ranks is the full gradient.
+    # `model.shard_clustering = False`: the replicated form (every rank differentiates the whole clustering).
+    if model.shard_clustering and text_feat.is_cuda and text_feat.shape[1] <= 64 and video_feat.shape[1] <= 64 and d % 128 == 0:
+        gt_l, gv_l = model._merge_sharded(text_feat, video_feat, text_mask, video_mask, noise or {}, rank, world)
+        if gt_l.shape[1] != 1 or gv_l.shape[1] != 1:
+            raise RuntimeError("the sharded training loss covers one global token per sample (until_module.py:321)")
+        gt = _GatherCat.apply(gt_l.reshape(b, d).float(), rank, world)
+        gv = _GatherCat.apply(gv_l.reshape(b, d).float(), rank, world)
+    else:
+        gt, gv = model.merge_global_features(text_feat, video_feat, text_mask, video_mask, noise)
+        if gt.shape[1] != 1 or gv.shape[1] != 1:
+            raise RuntimeError("the sharded training loss covers one global token per sample (until_module.py:321)")
+        gt, gv = gt.reshape(B, d).float(), gv.reshape(B, d).float()
     # ---- the rank's slabs of S and its slices of the bank centralities (HIP kernels, differentiable)
     S_rows = local_level_sim(model, text_feat[sl], video_feat, text_mask[sl], video_mask)           # [b, B]
     S_cols = local_level_sim(model, text_feat, video_feat[sl], text_mask, video_mask[sl])           # [B, b]

@@ -35,7 +35,37 @@ def _worker(rank, world, port, out_path):
         ref = torch.stack(m._compute_losses(*args, noise=nz)).cpu()
         m.shard_loss = True
         got = torch.stack(m._compute_losses(*args, noise=nz)).cpu()
-    torch.save({"ref": ref, "got": got}, f"{out_path}.{rank}")
+        # sample-sharded clustering alone, on data where the batch-wide maximum distance matters: a sample with two valid
+        # tokens (fewer than k = 3: its kNN density sees the fill value) on rank 0, the batch's farthest token pair on rank 1
+        tf, vf, tm, vm = p["text_feat"].clone(), p["video_feat"].clone(), p["text_mask"].float().clone(), p["video_mask"].float().clone()
+        tm[1, 2:] = 0
+        vm[2, 2:] = 0
+        tf[B - 1, 1] = -tf[B - 1, 0]                  # distances are taken between LayerNorm outputs: opposite tokens are
+        vf[B - 2, 1] = -vf[B - 2, 0]                  # as far apart as tokens get
+        ref_t, ref_v = m._merge_grouped(tf, vf, tm, vm, nz)
+        rows = slice(rank * (B // world), (rank + 1) * (B // world))
+        got_t, got_v = m._merge_sharded(tf, vf, tm, vm, nz, rank, world)
+        shard_ok = bool(torch.equal(got_t, ref_t[rows]) and torch.equal(got_v, ref_v[rows]))
+        all_t, all_v = m._gather_global(got_t, got_v, world)
+        gather_ok = bool(torch.equal(all_t, ref_t) and torch.equal(all_v, ref_v))
+        # the exchange itself: rank 0's own maximum is smaller than the batch's (the farthest pair sits on rank 1); what the
+        # back kernel reads after the exchange is the batch-wide one
+        import neighborretr_amd.cluster_fused as CF
+        seen = {}
+
+        def exchange(smax):
+            seen["local"] = [float(x.max()) for x in smax]
+            g = torch.stack([x.max() for x in smax])
+            dist.all_reduce(g, op=dist.ReduceOp.MAX)
+            for x, v in zip(smax, g):
+                x[:1] = v
+            seen["after"] = [float(x.max()) for x in smax]
+        CF.ctm_stage_group([("text0", tf[rows].contiguous(), tm[rows].contiguous(), m.text_ctm0, m.text_block0, nz["t0"][rows].contiguous()),
+                            ("video0", vf[rows].contiguous(), vm[rows].contiguous(), m.video_ctm0, m.video_block0,
+                             nz["v0"][rows].contiguous())], m._ctm_cache, exchange=exchange)
+        torch.cuda.synchronize()
+    torch.save({"ref": ref, "got": got, "shard_ok": shard_ok, "gather_ok": gather_ok, "seen": seen},
+               f"{out_path}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,6 +80,12 @@ def test_sharded_loss_equals_replicated_loss(tmp_path):
         assert torch.isfinite(r["ref"]).all()
         assert torch.allclose(r["got"], r["ref"], rtol=2e-6, atol=2e-6), (r["got"], r["ref"])
     assert torch.equal(res[0]["got"], res[1]["got"])              # every rank holds the same losses
+    # sample-sharded clustering == the rank's rows of the replicated clustering, bit for bit; rank 0 (short samples, but not
+    # the batch's farthest pair) reads the batch-wide maximum distance after the exchange
+    assert all(r["shard_ok"] and r["gather_ok"] for r in res)
+    for k in (0, 1):                                               # text, video
+        assert res[0]["seen"]["local"][k] < res[1]["seen"]["local"][k]
+        assert res[0]["seen"]["after"][k] == res[1]["seen"]["after"][k] == res[1]["seen"]["local"][k]
 
 
 def _train_worker(rank, world, port, out_path):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Clustering alone (configs[1] shape), as HIP graphs: per-modality fused path vs the grouped stage."""
+"""Clustering alone (configs[1] shape, or B samples: cluster_times.py B), as HIP graphs: per-modality fused path vs the
+grouped stage."""
 import os
 import sys
 
@@ -12,7 +13,7 @@ from neighborretr_amd.cluster_fused import ctm_stage_group  # noqa: E402
 from tools.branch_times import graph_time  # noqa: E402
 
 DEV = "cuda"
-B, Nt, Nv, M, K = 128, 24, 12, 512, 20
+B, Nt, Nv, M, K = (int(sys.argv[1]) if len(sys.argv) > 1 else 128), 24, 12, 512, 20
 
 
 def main():
