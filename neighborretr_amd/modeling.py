@@ -13,6 +13,7 @@ already -- which is what bench.py, the tests and `main_retrieval.py --synthetic`
 """
 import contextlib
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -102,7 +103,9 @@ class NeighborRetr(nn.Module):
         self._scorer_cache = {}
         self._streams = None
         self._join_global = None
-        self.use_side_streams = True
+        # side streams inside the step (and inside its capture).  With ONE hardware queue (GPU_MAX_HW_QUEUES=1) any capture
+        # that forks a stream segfaults in the ROCm 7.2 runtime (tools/capture_one_queue.py: plain torch ops): one stream then
+        self.use_side_streams = os.environ.get("GPU_MAX_HW_QUEUES", "") != "1"
         self.bank_side_streams = True       # bank chains beside the Sinkhorn solve (head.head_forward)
         self._bstreams = None
         self._lstream = None
