@@ -313,24 +313,48 @@ struct NrGemmTile {
     static_assert(NA_P % 4 == 0 && NB_P % 4 == 0, "piece counts must split over four waves");
     static_assert(P0 <= 21 && PC1 + PA1 <= 21, "chunk indices are packed 3 bits per slot into 64 bits");
 
+    // One operand pair of the ping-pong loop.  Two segments CHAIN two tiles through one loop: the K slices of the second
+    // tile follow the first tile's in the ring (its first two slices are requested while the first tile's last slice is
+    // multiplied), `between(0)` -- the first tile's epilogue; the caller zeroes nothing: the loop does -- runs at the seam.
+    struct Seg {
+        const uint16_t *a_hi, *a_lo;
+        int a_row0, a_rows;
+        const uint16_t *b_hi, *b_lo;
+        int b_row0, b_rows;
+    };
+
     __device__ __forceinline__ void run_pp(const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
                                            int a_row0, int a_rows,
                                            const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
                                            int b_row0, int b_rows, int K, char* smem) {
+        const Seg sg[1] = {{a_hi, a_lo, a_row0, a_rows, b_hi, b_lo, b_row0, b_rows}};
+        run_pp_segs<1>(sg, K, smem, [](int) {});
+    }
+
+    template <int NSEG, typename Between>
+    __device__ __forceinline__ void run_pp_segs(const Seg (&sg)[NSEG], int K, char* smem, Between&& between) {
         static_assert(WC == 4 && STAGES == 2, "ping-pong loop: 2 x 4 waves, two-stage ring");
+        static_assert(NSEG == 1 || NSEG == 2, "one tile, or two chained tiles");
         const int tid = threadIdx.x;
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int grp = wave / WC, wc = wave % WC;        // group = wave row
-        const int KT = K / BK;
+        const int KS = K / BK;                            // slices per tile
+        const int KT = NSEG * KS;                         // slices of the whole loop
 
         // The pieces go out as buffer loads to LDS: per lane ONE row offset ((lane / 8) rows) and the piece's swizzled
         // 16-byte chunk (3 bits per slot, packed); operand, first row of the piece, K offset of the slice and LDS
         // destination are wave-uniform (SGPRs).  Rows past the operand's end read as zeros (buffer bounds): no clamping.
-        const __amdgpu_buffer_rsrc_t rs_ah = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a_hi), 0, a_rows * K * 2, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_bh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(b_hi), 0, b_rows * K * 2, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_al = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X3 ? a_lo : a_hi), 0, a_rows * K * 2, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_bl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X3 ? b_lo : b_hi), 0, b_rows * K * 2, 0x00020000);
+        constexpr int SEC = NSEG - 1;                     // index of the second segment (the first again when there is one)
+        const __amdgpu_buffer_rsrc_t rs_ah = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(sg[0].a_hi), 0, sg[0].a_rows * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_bh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(sg[0].b_hi), 0, sg[0].b_rows * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_al = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X3 ? sg[0].a_lo : sg[0].a_hi), 0, sg[0].a_rows * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_bl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X3 ? sg[0].b_lo : sg[0].b_hi), 0, sg[0].b_rows * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rt_ah = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(sg[SEC].a_hi), 0, sg[SEC].a_rows * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rt_bh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(sg[SEC].b_hi), 0, sg[SEC].b_rows * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rt_al = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X3 ? sg[SEC].a_lo : sg[SEC].a_hi), 0, sg[SEC].a_rows * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rt_bl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X3 ? sg[SEC].b_lo : sg[SEC].b_hi), 0, sg[SEC].b_rows * K * 2, 0x00020000);
+        const int a_row0 = sg[0].a_row0, b_row0 = sg[0].b_row0, a_row1 = sg[SEC].a_row0, b_row1 = sg[SEC].b_row0;
         const int row_off = (lane >> 3) * K * 2;
         // slot s of a group-1 wave: B piece BS wc + s (s < PC1 + PA1); of a group-0 wave: s < NA_P/4: A piece
         // (NA_P/4) wc + s, else B piece BS wc + PC1 + PA1 + (s - NA_P/4)
@@ -351,17 +375,21 @@ struct NrGemmTile {
         auto issue = [&](auto g_c, auto s0_c, auto s1_c, int kt) {
             constexpr int G = decltype(g_c)::value, S0 = decltype(s0_c)::value, S1 = decltype(s1_c)::value;
             char* st = smem + (kt & 1) * STAGE_BYTES;
-            const int kb = kt * BK * 2;
+            const bool second = NSEG > 1 && kt >= KS;         // slice of the second tile (wave-uniform)
+            const int kb = (second ? kt - KS : kt) * BK * 2;
+            const int ar0 = second ? a_row1 : a_row0, br0 = second ? b_row1 : b_row0;
+            const __amdgpu_buffer_rsrc_t r_ah = second ? rt_ah : rs_ah, r_bh = second ? rt_bh : rs_bh;
+            const __amdgpu_buffer_rsrc_t r_al = second ? rt_al : rs_al, r_bl = second ? rt_bl : rs_bl;
             nr_static_for<S0, S1>([&](auto s_c) {
                 constexpr int s_ = decltype(s_c)::value;
                 constexpr bool is_a = G == 0 && s_ < SA0;
                 const int piece = G == 1 ? BS * wc + s_ : (is_a ? SA0 * wc + s_ : BS * wc + PC1 + PA1 + (s_ - SA0));
                 const int voff = row_off + (int)(((kc_pack >> (3 * s_)) & 7ull) << 4);
-                const int so = ((is_a ? a_row0 : b_row0) + piece * 8) * K * 2 + kb;
+                const int so = ((is_a ? ar0 : br0) + piece * 8) * K * 2 + kb;
                 char* d = st + (is_a ? 0 : A_BYTES) + piece * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? rs_ah : rs_bh, (nr_lds_ptr_t)d, 16, voff, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? r_ah : r_bh, (nr_lds_ptr_t)d, 16, voff, so, 0, 0);
                 if constexpr (X3)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? rs_al : rs_bl, (nr_lds_ptr_t)(d + A_BYTES + B_BYTES), 16, voff, so, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? r_al : r_bl, (nr_lds_ptr_t)(d + A_BYTES + B_BYTES), 16, voff, so, 0, 0);
             });
         };
         using I0 = std::integral_constant<int, 0>;
@@ -439,11 +467,16 @@ struct NrGemmTile {
         else issue(I1{}, I0{}, IP1{}, 0);
         landed();
         phase();
+        // The seam of two chained tiles (NSEG == 2) lies behind slice KS-1: each wave runs `between(0)` -- the first tile's
+        // epilogue -- right after its own last MFMA of that slice and zeroes its accumulators; group 0 takes the fragments
+        // of the second tile's first k-step only afterwards (they would not fit beside the epilogue's registers).  The
+        // pieces of the second tile's first two slices went out in the regular places, phases earlier.
         if (grp == 0) {
             load_frags(0);
             if (KT > 1) issue(I0{}, IPB0{}, IP0{}, 1);                     // D(-1): its PD0 pieces of slice 1
             frags_in();
             for (int kt = 0; kt < KT; ++kt) {
+                const bool seam = NSEG > 1 && kt == KS - 1;
                 phase();                                                   // A: MFMA k-step 0
                 mma();
                 phase();                                                   // B: fragments of k-step 1, PB0 pieces of slice kt+1
@@ -454,8 +487,15 @@ struct NrGemmTile {
                 mma();
                 landed();                                                  // this wave's pieces of slice kt+1
                 phase();                                                   // D: fragments of slice kt+1, PD0 pieces of slice kt+2
-                if (kt + 1 < KT) load_frags(2 * kt + 2);
-                if (kt + 2 < KT) issue(I0{}, IPB0{}, IP0{}, kt + 2);
+                if (seam) {
+                    if (kt + 2 < KT) issue(I0{}, IPB0{}, IP0{}, kt + 2);
+                    between(0);
+                    zero();
+                    load_frags(2 * kt + 2);
+                } else {
+                    if (kt + 1 < KT) load_frags(2 * kt + 2);
+                    if (kt + 2 < KT) issue(I0{}, IPB0{}, IP0{}, kt + 2);
+                }
                 frags_in();
             }
         } else {
@@ -474,6 +514,10 @@ struct NrGemmTile {
                 landed_but(kt + 2 < KT);                                   // pieces of slice kt+1 (the newest PC1 may fly)
                 phase();                                                   // D: MFMA k-step 1
                 mma();
+                if (NSEG > 1 && kt == KS - 1) {                            // the seam: see above
+                    between(0);
+                    zero();
+                }
             }
         }
         phase();                             // every wave is done with the ring before the caller reuses the LDS

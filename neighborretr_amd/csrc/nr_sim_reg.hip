@@ -300,6 +300,142 @@ __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     nr_sim_reg_body<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC, PP>(p, blockIdx.x, smem);
 }
 
+// ---- two chained tiles per workgroup (the step's two bank products) ---------------------------------------------------
+// A launch of the 192 x 384 block spends ~29 % of its time outside the K loop, INSIDE every block (tools/sim_ksweep.py,
+// tools/stamps.py: set-up, first-slice latency, epilogue) -- a grouped grid does not touch that.  Here block b computes tile
+// b of product 0 and then tile b of product 1 through ONE ping-pong loop (NrGemmTile::run_pp_segs<2>): the second tile's
+// first two K slices are requested while the first tile's last slice is multiplied, the first tile's epilogue runs at the
+// seam -- group 0's part of it beside group 1's last MFMA phase --, and set-up / dispatch are paid once.  Both products
+// must have the same tile count and K.  LDS: ring + both tiles' token weights + the block-sum staging row (the ring is
+// never free at the seam).
+template <int MI, int NI, int TPS, int FPS>
+__device__ __forceinline__ void nr_sim_pair_body(const NrSimRegArgs& p0, const NrSimRegArgs& p1, const int bid, char* smem) {
+    constexpr int WC = 4;
+    using Tile = NrGemmTile<MI, NI, false, TPS, FPS, 2, WC>;
+    constexpr int Nt = MI * TPS, Nv = NI * FPS;
+    constexpr int TAW = 16 / TPS, TBW = 16 / FPS;
+    constexpr int TA = 2 * TAW, TB = WC * TBW;
+    constexpr int GX = TPS / 4;
+    constexpr int WT_N = TA * Nt, WV_N = TB * Nv;
+    static_assert(WT_N % 64 == 0 && WV_N % 64 == 0, "weights go to the LDS 64 floats per instruction");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int g = lane >> 4, kap = lane & 15;
+    const int al = g / GX, tau0 = 4 * (g % GX);
+    const int bl = kap / FPS, phi = kap % FPS;
+    float* w_lds = reinterpret_cast<float*>(smem + Tile::RING_BYTES);
+    float* sSP = w_lds + 2 * (WT_N + WV_N);
+
+    auto coords = [&](const NrSimRegArgs& p, int& bx, int& by) {
+        if (p.PR > 0) {
+            const int xcd = bid & 7, slot = bid >> 3;
+            const int sub_w = p.ntx / p.PC, sub_h = p.nty / p.PR;
+            bx = (xcd % p.PC) * sub_w + slot % sub_w;
+            by = (xcd / p.PC) * sub_h + slot / sub_w;
+        } else {
+            bx = bid % p.ntx;
+            by = bid / p.ntx;
+        }
+    };
+    int bx0, by0, bx1, by1;
+    coords(p0, bx0, by0);
+    coords(p1, bx1, by1);
+
+    // both tiles' token weights -> LDS (pieces of 64 floats, dealt over the waves)
+    auto park_weights = [&](const NrSimRegArgs& p, int bx, int by, float* dst) {
+        constexpr int NPIECE = (WT_N + WV_N) / 64;
+#pragma unroll
+        for (int q0 = 0; q0 < NPIECE; q0 += 2 * WC) {
+            const int q = q0 + wave;
+            if (q < NPIECE) {
+                const bool is_t = q < WT_N / 64;
+                const int e = (is_t ? q : q - WT_N / 64) * 64 + lane;
+                const long src = is_t ? min((long)by * WT_N + e, (long)p.A * Nt - 1) : min((long)bx * WV_N + e, (long)p.Bv * Nv - 1);
+                const float* gp = (is_t ? p.w_t : p.w_v) + src;
+                __builtin_amdgcn_global_load_lds((nr_glb_ptr_t)gp, (nr_lds_ptr_t)(dst + q * 64), 4, 0, 0);
+            }
+        }
+    };
+    park_weights(p0, bx0, by0, w_lds);
+    park_weights(p1, bx1, by1, w_lds + WT_N + WV_N);
+
+    Tile tile;
+    tile.zero();
+    // the loss-only epilogue of nr_sim_reg_body (pooled values by max chains), on the weights parked at `wl`
+    auto epilogue = [&](const NrSimRegArgs& p, int bx, int by, const float* wl) {
+        const int ag = by * TA + wr * TAW + al;
+        const int bg = bx * TB + wc * TBW + bl;
+        const bool ok = ag < p.A && bg < p.Bv;
+        float wt[MI][4], wv[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            f32x4_t q = *reinterpret_cast<const f32x4_t*>(wl + (wr * TAW + al) * Nt + TPS * i + tau0);
+            wt[i][0] = q[0]; wt[i][1] = q[1]; wt[i][2] = q[2]; wt[i][3] = q[3];
+        }
+#pragma unroll
+        for (int n = 0; n < NI; ++n) wv[n] = wl[WT_N + (wc * TBW + bl) * Nv + FPS * n + phi];
+        float t2v = 0.f, v2t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float m = tile.acc[i][0][j];
+#pragma unroll
+                for (int n = 1; n < NI; ++n) m = fmaxf(m, tile.acc[i][n][j]);
+                m = nr_lanes_max<FPS>(m);
+                t2v += m * wt[i][j];
+            }
+        if constexpr (GX >= 2) t2v += __shfl_xor(t2v, 16);
+        if constexpr (GX >= 4) t2v += __shfl_xor(t2v, 32);
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            float m = tile.acc[0][n][0];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m = fmaxf(m, tile.acc[i][n][j]);
+            if constexpr (GX >= 2) m = fmaxf(m, __shfl_xor(m, 16));
+            if constexpr (GX >= 4) m = fmaxf(m, __shfl_xor(m, 32));
+            v2t += m * wv[n];
+        }
+        v2t = nr_lanes_sum<FPS>(v2t);
+        const float S = 0.5f * (t2v + v2t);
+        const bool writer = (phi == 0) && ((g % GX) == 0);
+        if (p.out_mode == NR_OUT_FULL) {
+            if (writer && ok) p.out[(size_t)ag * p.Bv + bg] = S;
+            return;
+        }
+        if (writer) sSP[(wr * TAW + al) * TB + wc * TBW + bl] = ok ? S : 0.f;
+        __syncthreads();
+        if (p.out_mode == NR_OUT_ROWSUM) {
+            if (tid < TA) {
+                float s_ = 0.f;
+                for (int b = 0; b < TB; ++b) s_ += sSP[tid * TB + b];
+                int a = by * TA + tid;
+                if (a < p.A) p.out[(size_t)bx * p.A + a] = s_;
+            }
+        } else {
+            if (tid < TB) {
+                float s_ = 0.f;
+                for (int a = 0; a < TA; ++a) s_ += sSP[a * TB + tid];
+                int b = bx * TB + tid;
+                if (b < p.Bv) p.out[(size_t)by * p.Bv + b] = s_;
+            }
+        }
+        __syncthreads();                       // the staging row is free again (the next epilogue is thousands of cycles away anyway)
+    };
+    const typename Tile::Seg sg[2] = {
+        {p0.t_hi, p0.t_lo, by0 * TA * Nt, p0.A * Nt, p0.v_hi, p0.v_lo, bx0 * TB * Nv, p0.Bv * Nv},
+        {p1.t_hi, p1.t_lo, by1 * TA * Nt, p1.A * Nt, p1.v_hi, p1.v_lo, bx1 * TB * Nv, p1.Bv * Nv}};
+    tile.template run_pp_segs<2>(sg, p0.K, smem, [&](int) { epilogue(p0, bx0, by0, w_lds); });
+    epilogue(p1, bx1, by1, w_lds + WT_N + WV_N);
+}
+
+__global__ __launch_bounds__(512) void nr_sim_pair_kernel(NrSimRegArgs p0, NrSimRegArgs p1) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    nr_sim_pair_body<6, 6, 4, 2>(p0, p1, blockIdx.x, smem);
+}
+
 // ---- grouped launch: several products of ONE step in one grid --------------------------------------------------------
 // The step's three products (two bank products on 192 x 384 bf16 blocks, the batch x batch product on 96 x 192
 // split-bf16 blocks) all run 8-wave workgroups on a 144 KB ring, one per CU, 256 blocks each.  Launched one by one every
@@ -515,9 +651,21 @@ extern "C" int nr_local_level_group(int n, const NrLocalLevelProblem* probs, voi
         g.kind[i] = kind;
         g.first[i + 1] = g.first[i] + a.ntx * a.nty;
     }
-    for (int i = n; i < NR_SIM_GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.kind[i] = g.kind[0]; g.first[i + 1] = g.first[n]; }
     using TileA = NrGemmTile<6, 6, false, 4, 2, 2, 4>;
     using TileB = NrGemmTile<3, 3, true, 8, 4, 2, 4>;
+    // two bf16 products of equal tile count and K at the front (the step's two bank products): chained tile pairs, one
+    // launch; what is left of the list goes out grouped behind it
+    if (n >= 2 && g.kind[0] == 0 && g.kind[1] == 0 && g.p[0].K == g.p[1].K &&
+        g.p[0].ntx * g.p[0].nty == g.p[1].ntx * g.p[1].nty && !nr_tune_env("NR_SIM_NOPAIR")) {
+        constexpr size_t lds_pair = TileA::RING_BYTES + sizeof(float) * (2 * (8 * 24 + 32 * 12) + 8 * 32);
+        hipError_t e = hipFuncSetAttribute((const void*)nr_sim_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(nr_sim_pair_kernel, dim3(g.p[0].ntx * g.p[0].nty), dim3(512), lds_pair, (hipStream_t)stream, g.p[0], g.p[1]);
+        NR_LAUNCH_CHECK();
+        if (n == 2) return NR_OK;
+        return nr_local_level_group(n - 2, probs + 2, stream);
+    }
+    for (int i = n; i < NR_SIM_GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.kind[i] = g.kind[0]; g.first[i + 1] = g.first[n]; }
     constexpr size_t lds_a = TileA::RING_BYTES + sizeof(float) * (8 * 24 + 32 * 12);
     constexpr size_t lds_b = TileB::RING_BYTES;
     constexpr size_t lds = lds_a > lds_b ? lds_a : lds_b;

@@ -16,6 +16,8 @@ It is differentiable: `HeadLossFn` is a torch.autograd.Function whose backward r
 backward kernels (row losses, arg-max-routed similarity gradient, normalisation) and library
 GEMMs for the scorer MLP.  Nothing here falls back to eager PyTorch for the forward math.
 """
+import os
+
 import torch
 
 from . import hip, ops
@@ -104,6 +106,12 @@ def precision_plan(prec):
     return prec, prec, prec
 
 
+# The split tail's two bank products as chained tile pairs (one launch).  Off: measured alone the pair is 1.9 us shorter
+# than two launches (33.8 -> 31.9 us), inside the step it is not (0.3233 vs 0.3207 ms over three A/B pairs): the pair has to
+# wait for BOTH bank scorer chains and sits on the queue that is not the critical one.  NR_PAIR_BANK=1 turns it on (tools/).
+PAIR_BANK_PRODUCTS = os.environ.get("NR_PAIR_BANK", "0") == "1"
+
+
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                  gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None,
                  bank_streams=None, local_stream=None, bank_early=0,
@@ -143,6 +151,13 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     # Loss-only step at B <= 128 ("split tail", below): the bank centralities stay PARTIAL sums (the row-loss kernel adds
     # them up itself: two reduction launches less per step)
     split_tail = (not keep) and bank_streams is not None and local_stream is not None and B <= 128 and B % 4 == 0
+
+    # split tail: the two bank products as ONE launch of chained tile pairs (nr_local_level_group -> nr_sim_pair_kernel:
+    # every workgroup computes a tile of the first and then a tile of the second product through one K loop) when both
+    # run the 192 x 384 bf16 blocks on equally many tiles
+    pair_bank = (split_tail and bank_early == 0 and PAIR_BANK_PRODUCTS
+                 and hip.local_level_group_kind(B, Nt, M, Nv, d, p_bank) == 0
+                 and hip.local_level_group_kind(M, Nt, B, Nv, d, p_bank) == 0)
 
     # The local branch, one kernel launch per step (a generator, so that it can be interleaved launch by launch
     # with the clustering -- see below); its results land in `L`.
@@ -187,6 +202,8 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         yield
         w_bv, lg_bv = ops.token_softmax(parts, sw_v.b2, mb_mask_v, M, Nv, keep)
         yield
+        if pair_bank:
+            return pbv, w_bv, lg_bv, None, None          # the product itself: one launch with the other chain's (below)
         p1, aux1 = ops.local_level(L["pt"], pbv, L["w_t"], w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM, keep)
         yield
         if split_tail:
@@ -206,6 +223,8 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         yield
         w_bt, lg_bt = ops.token_softmax(parts, sw_t.b2, mb_mask_t, M, Nt, keep)
         yield
+        if pair_bank:
+            return pbt, w_bt, lg_bt, None, None
         p0, aux2 = ops.local_level(pbt, L["pv"], w_bt, L["w_v"], M, Nt, B, Nv, p_bank, hip.OUT_COLSUM, keep)
         yield
         if split_tail:
@@ -308,6 +327,11 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         with torch.cuda.stream(side):
             pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
             side.wait_stream(side2)
+            if pair_bank:
+                for t_ in (pbt.hi, w_bt):
+                    t_.record_stream(side)
+                c1, c0 = ops.local_level_group([(L["pt"], pbv, L["w_t"], w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM),
+                                                (pbt, L["pv"], w_bt, L["w_v"], M, Nt, B, Nv, p_bank, hip.OUT_COLSUM)])
             if bank_push is not None:
                 # both bank products have read the bank (and its prepared shadow): the batch may take the oldest rows'
                 # place -- on a stream of its own, beside the centrality weights and the row losses.  (A stream that
