@@ -106,9 +106,11 @@ def precision_plan(prec):
     return prec, prec, prec
 
 
-# The split tail's two bank products as chained tile pairs (one launch).  Off: measured alone the pair is 1.9 us shorter
-# than two launches (33.8 -> 31.9 us), inside the step it is not (0.3233 vs 0.3207 ms over three A/B pairs): the pair has to
-# wait for BOTH bank scorer chains and sits on the queue that is not the critical one.  NR_PAIR_BANK=1 turns it on (tools/).
+# The step's two bank products as chained tile pairs (one launch, nr_sim_pair_kernel).  OFF: measured alone the pair is
+# 1.9 us shorter than two launches (33.8 -> 31.9 us), but the step with it is 2.5 % SLOWER (0.3308 vs 0.3227 ms, six A/B
+# pairs of 1000 steps in one session): the first bank product can no longer start before the second chain's scorer has
+# finished, and one 32 us launch that owns every CU's LDS holds the clustering kernels up longer than two 16 us ones.
+# NR_PAIR_BANK=1 turns it on (developer A/B switch, tools/).
 PAIR_BANK_PRODUCTS = os.environ.get("NR_PAIR_BANK", "0") == "1"
 
 
@@ -155,7 +157,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     # split tail: the two bank products as ONE launch of chained tile pairs (nr_local_level_group -> nr_sim_pair_kernel:
     # every workgroup computes a tile of the first and then a tile of the second product through one K loop) when both
     # run the 192 x 384 bf16 blocks on equally many tiles
-    pair_bank = (split_tail and bank_early == 0 and PAIR_BANK_PRODUCTS
+    pair_bank = (split_tail and bank_early in (0, 2) and PAIR_BANK_PRODUCTS
                  and hip.local_level_group_kind(B, Nt, M, Nv, d, p_bank) == 0
                  and hip.local_level_group_kind(M, Nt, B, Nv, d, p_bank) == 0)
 
@@ -190,6 +192,12 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
             early[0] = yield from bank_video_steps()
             if bank_early > 1:
                 early[1] = yield from bank_text_steps()
+                if pair_bank:                         # both chains stopped in front of their product: one launch for the two
+                    (pbv_, w_bv_, lg_bv_, _, _), (pbt_, w_bt_, lg_bt_, _, _) = early
+                    c1_, c0_ = ops.local_level_group([(L["pt"], pbv_, L["w_t"], w_bv_, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM),
+                                                      (pbt_, L["pv"], w_bt_, L["w_v"], M, Nt, B, Nv, p_bank, hip.OUT_COLSUM)])
+                    yield
+                    early[0], early[1] = (pbv_, w_bv_, lg_bv_, None, c1_), (pbt_, w_bt_, lg_bt_, None, c0_)
 
     def bank_video_steps():
         # text x bank-video, row mean  -> centrality of text j  (used by the v2t neighbour loss)
@@ -327,7 +335,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         with torch.cuda.stream(side):
             pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
             side.wait_stream(side2)
-            if pair_bank:
+            if pair_bank and early[0] is None:
                 for t_ in (pbt.hi, w_bt):
                     t_.record_stream(side)
                 c1, c0 = ops.local_level_group([(L["pt"], pbv, L["w_t"], w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM),

@@ -251,3 +251,27 @@ def test_forward_updates_memory_bank_fifo_and_eval_returns_none():
     m.config.num_neighbors = 20
     with pytest.raises((ValueError, IndexError)):
         m(x["text_feat"], x["text_mask"], x["video_feat"], x["video_mask"], x["idx"], 0)
+
+
+@pytest.mark.parametrize("bank_early", [0, 2])
+def test_step_with_the_bank_products_as_chained_tile_pairs(bank_early):
+    """head.PAIR_BANK_PRODUCTS (off by default: it loses inside the step): the loss-only step at the
+    bench workload with both bank products in one launch of chained tile pairs gives bit-identical losses, whether the bank
+    chains run early on the local stream or beside the Sinkhorn solve."""
+    from neighborretr_amd import head
+    B, Nt, Nv, M, K = 128, 24, 12, 512, 20
+    x = problem(1002, B, Nt, Nv, M, device=DEV)
+    nz = {k: v.to(DEV) for k, v in noise(1002, B, Nt, Nv).items()}
+    out = []
+    for pair in (False, True):
+        m = _model("bf16", K=K)
+        m.bank_early = bank_early
+        m.bank_frozen = True
+        old = head.PAIR_BANK_PRODUCTS
+        head.PAIR_BANK_PRODUCTS = pair
+        try:
+            with torch.no_grad():
+                out.append(torch.stack(_losses(m, x, nz, K)).cpu())
+        finally:
+            head.PAIR_BANK_PRODUCTS = old
+    assert torch.isfinite(out[0]).all() and torch.equal(out[0], out[1])

@@ -12,11 +12,11 @@ acc = defaultdict(lambda: defaultdict(list))
 dur = defaultdict(list)
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "sim_reg" in r.get("Kernel_Name", ""):
+        if "nr_sim_" in r.get("Kernel_Name", ""):
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob(root + "/a/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "sim_reg" in r.get("Kernel_Name", ""):
+        if "nr_sim_" in r.get("Kernel_Name", ""):
             dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 out = {"source": "rocprofv3 --kernel-trace --pmc <counters> -- python3 tools/sim_pmc.py (separate passes per counter group; "
                  "MI355X, the step's three products of configs[1], 20 eager launches each)",
@@ -42,15 +42,22 @@ for name, cs in sorted(acc.items()):
     if dur.get(name):
         k["profiled_avg_duration_us"] = round(sum(dur[name]) / len(dur[name]) / 1e3, 2)
     out["per_kernel"][name] = k
-# the step launches the bank kernel (192 x 384 blocks, "<6, 6, ...") twice and the split-bf16 batch kernel ("<3, ...") once
+# the step launches the two bank products as ONE launch of chained tile pairs ("nr_sim_pair_kernel": 2 x 19.33 GF) -- or, when
+# that kernel is absent from the passes, the bank kernel (192 x 384 blocks, "<6, 6, ...") twice -- and the split-bf16 batch
+# kernel ("<3, ...": 3 x 4.83 GF issued) once
+# (the step as shipped launches the three products one by one: the pair kernel's counters are reported, not folded into
+# the step's figures, unless asked for with a second argument "pair")
+pair = [k for n, k in out["per_kernel"].items() if "pair" in n] if sys.argv[2:3] == ["pair"] else []
 bank = [k for n, k in out["per_kernel"].items() if "<6, 6" in n]
 x3 = [k for n, k in out["per_kernel"].items() if "<3, " in n]
-if bank and x3:
-    b, x = bank[0], x3[0]
+if (pair or bank) and x3:
+    b, x = (pair or bank)[0], x3[0]
+    nb = 1 if pair else 2                       # launches that carry the bank flops
     if "fabric_read_bytes_per_launch" in b and "fabric_read_bytes_per_launch" in x:
         tot = lambda k: k["fabric_read_bytes_per_launch"] + k.get("fabric_write_bytes_per_launch", 0)      # noqa: E731
-        out["bytes_per_launch_avg_over_step"] = round((2 * tot(b) + tot(x)) / 3)
+        out["bytes_per_launch_avg_over_step"] = round((nb * tot(b) + tot(x)) / (nb + 1))
     if "mfma_busy_frac" in b and "mfma_busy_frac" in x:
         fb, fx = 2 * 19.33, 3 * 4.83            # issued MFMA GF: two bank products, the 3-pass batch product
         out["mfma_busy_frac_flops_weighted"] = round((fb * b["mfma_busy_frac"] + fx * x["mfma_busy_frac"]) / (fb + fx), 4)
+    out["step_uses"] = "nr_sim_pair_kernel + the split-bf16 nr_sim_reg_kernel" if pair else "nr_sim_reg_kernel x 3"
 json.dump(out, sys.stdout, indent=1)

@@ -18,6 +18,7 @@ CASES = [(128, 24, 512, 12, hip.PREC_BF16, hip.OUT_ROWSUM), (512, 24, 128, 12, h
 
 def main():
     g = torch.Generator().manual_seed(0)
+    pair = []
     for (A, Nt, Bv, Nv, prec, mode) in CASES:
         t = torch.randn(A, Nt, 512, generator=g).to(DEV)
         v = torch.randn(Bv, Nv, 512, generator=g).to(DEV)
@@ -28,6 +29,11 @@ def main():
         for _ in range(N):
             ops.local_level(pt, pv, wt, wv, A, Nt, Bv, Nv, prec, mode)
         torch.cuda.synchronize()
+        if prec == hip.PREC_BF16:
+            pair.append((pt, pv, wt, wv, A, Nt, Bv, Nv, prec, mode))
+    for _ in range(N):                       # the two bank products as one launch of chained tile pairs (nr_sim_pair_kernel)
+        ops.local_level_group(pair)
+    torch.cuda.synchronize()
 
 
 if __name__ == "__main__":
