@@ -226,14 +226,30 @@ __global__ __launch_bounds__(256) void nr_centrality_bwd_dg_kernel(const float* 
     for (int c = lane; c < d; c += 64) dg[(size_t)i * d + c] = a * (mean[c] - gi[c] * inv * dot) * inv;
 }
 
+// 64 columns per workgroup; wave w sums the rows w, w+4, ... with four independent loads in flight, the four partial sums
+// meet in LDS in a fixed order (the shape of nr_reduce_parts).  One thread per column walking all B rows one after the
+// other took 30 us of dependent loads for 128 rows.
 __global__ __launch_bounds__(256) void nr_centrality_bwd_dmean_kernel(const float* __restrict__ g, const float* __restrict__ gnorm,
                                                                       const float* __restrict__ w, const float* __restrict__ dw,
                                                                       int B, int d, float scale, float* __restrict__ dmean) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= d) return;
-    float s = 0.f;
-    for (int i = 0; i < B; ++i) s += dw[i] * w[i] * scale * g[(size_t)i * d + c] / gnorm[i];
-    dmean[c] = s;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < d) {
+        auto term = [&](int i) { return dw[i] * w[i] * scale * g[(size_t)i * d + c] / gnorm[i]; };
+        int i = wave;
+        for (; i + 12 < B; i += 16) {
+            s0 += term(i);
+            s1 += term(i + 4);
+            s2 += term(i + 8);
+            s3 += term(i + 12);
+        }
+        for (; i < B; i += 4) s0 += term(i);
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && c < d) dmean[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 extern "C" int nr_centrality_weights_bwd(const float* g, const float* gnorm, const float* mean, const float* w, const float* dw,
@@ -241,7 +257,7 @@ extern "C" int nr_centrality_weights_bwd(const float* g, const float* gnorm, con
     if (!g || !gnorm || !mean || !w || !dw || !dg || !dmean || B <= 0 || d <= 0) return NR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(nr_centrality_bwd_dg_kernel, dim3((B + 3) / 4), dim3(256), 0, st, g, gnorm, mean, w, dw, B, d, scale, dg);
-    hipLaunchKernelGGL(nr_centrality_bwd_dmean_kernel, dim3((d + 255) / 256), dim3(256), 0, st, g, gnorm, w, dw, B, d, scale, dmean);
+    hipLaunchKernelGGL(nr_centrality_bwd_dmean_kernel, dim3((d + 63) / 64), dim3(256), 0, st, g, gnorm, w, dw, B, d, scale, dmean);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }
@@ -272,16 +288,28 @@ extern "C" int nr_add_transposed(const float* a, const float* b, int B, float* o
 }
 
 __global__ __launch_bounds__(256) void nr_colsum_kernel(const float* __restrict__ a, int rows, int cols, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += a[(size_t)r * cols + c];
-    out[c] = s;
+    __shared__ float red[4][64];                 // same shape as nr_centrality_bwd_dmean_kernel above
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cols) {
+        int r = wave;
+        for (; r + 12 < rows; r += 16) {
+            s0 += a[(size_t)r * cols + c];
+            s1 += a[(size_t)(r + 4) * cols + c];
+            s2 += a[(size_t)(r + 8) * cols + c];
+            s3 += a[(size_t)(r + 12) * cols + c];
+        }
+        for (; r < rows; r += 4) s0 += a[(size_t)r * cols + c];
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && c < cols) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 extern "C" int nr_colsum(const float* a, int rows, int cols, float* out, void* stream) {
     if (!a || !out || rows <= 0 || cols <= 0) return NR_EINVAL;
-    hipLaunchKernelGGL(nr_colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, rows, cols, out);
+    hipLaunchKernelGGL(nr_colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, a, rows, cols, out);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

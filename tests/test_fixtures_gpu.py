@@ -198,6 +198,7 @@ def test_configs3_full_size_step_runs_under_mean_flag():
     finite losses, invariance to a joint permutation of the pairs, total = weighted sum of the parts, the default
     "raise" flag still raises, and the three sims obey the exact-zero / range properties."""
     B, Nt, Nv, M, K = 128, 64, 64, 1024, 20
+    torch.manual_seed(3004)          # the model seeds its device noise stream (DPC-KNN tie-breaks) from torch's seed
     prob = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_problem(3004, B, Nt, Nv, M).items()}
     nz = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_noise(3004, B, Nt, Nv).items()}
     m = _model("bf16", K, centrality_multi_token="mean")
@@ -231,7 +232,9 @@ def test_configs3_full_size_step_runs_under_mean_flag():
     for t_ in (tf.grad, vf.grad, named["text_weight_fc.0.weight"].grad, named["video_weight_fc1.0.weight"].grad,
                named["text_ctm1.conv.conv.weight"].grad, m.clip.logit_scale.grad):
         assert t_ is not None and torch.isfinite(t_).all() and float(t_.abs().max()) > 0
-    assert abs(float(out[0]) - float(L[0])) < 0.5          # same batch, the bank moved on by one push
+    # same batch; the bank moved on by one push and the tie-break noise of the padded samples is drawn afresh (not `nz`):
+    # at this shape another draw moves the loss by a few per cent
+    assert abs(float(out[0].detach()) - float(L[0])) < 0.06 * float(L[0])
 
 
 def test_c4_b8_backward_matches_oracle_autograd_under_mean_flag():

@@ -48,6 +48,17 @@ def timeit(g, n=600):
     for _ in range(n): g.replay()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e6
+if "--random" in sys.argv[1:]:
+    import random
+    rng = random.Random(int(sys.argv[sys.argv.index("--random") + 1]))
+    SETTINGS = SETTINGS[:1]
+    for _ in range(40):
+        turns, c = [], 14
+        while c > 0:
+            a = rng.randint(1, min(7, c)); c -= a
+            turns.append((a, rng.randint(0, 9)))
+        turns.append((0, BIG))
+        SETTINGS.append((str(tuple(turns)).replace(str(BIG), "inf"), tuple(turns), 2))
 built = [(name, build(order, early)) for name, order, early in SETTINGS]
 for rnd in range(2):
     for name, (m, g) in built:
