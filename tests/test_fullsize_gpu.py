@@ -176,3 +176,21 @@ def test_grouped_products_equal_the_single_launches(B, M, all_groupable):
     assert hip.local_level_group_kind(8, 64, 8, 64, 512, hip.PREC_BF16) < 0
     got = ops.local_level_group([probs[0], odd])
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ops.local_level(*odd)[0])
+
+
+def test_chained_tile_pairs_with_ragged_edges():
+    """nr_sim_pair_kernel (two bank-shaped products through one K loop per workgroup) on grids whose last row / column blocks
+    hang over the operands (520 = 65 x 8 texts, 16.25 x 32 videos): bit-identical to one launch per product, in all three
+    output modes."""
+    n = 520
+    t, tm, wt = _tokens(31, n, 24)
+    v, vm, wv = _tokens(32, n, 12)
+    t2, tm2, wt2 = _tokens(33, n, 24)
+    v2, vm2, wv2 = _tokens(34, n, 12)
+    pt, pv, pt2, pv2 = (ops.prepare_tokens(a, b) for a, b in ((t, tm), (v, vm), (t2, tm2), (v2, vm2)))
+    for m0, m1 in ((hip.OUT_ROWSUM, hip.OUT_COLSUM), (hip.OUT_FULL, hip.OUT_ROWSUM), (hip.OUT_COLSUM, hip.OUT_FULL)):
+        probs = [(pt, pv2, wt, wv2, n, 24, n, 12, hip.PREC_BF16, m0), (pt2, pv, wt2, wv, n, 24, n, 12, hip.PREC_BF16, m1)]
+        assert all(hip.local_level_group_kind(n, 24, n, 12, 512, hip.PREC_BF16) == 0 for _ in probs)
+        got = ops.local_level_group(probs)
+        for q, g in zip(probs, got):
+            assert torch.equal(g, ops.local_level(*q)[0])
