@@ -392,6 +392,17 @@ struct NrGemmTile {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? r_al : r_bl, (nr_lds_ptr_t)(d + A_BYTES + B_BYTES), 16, voff, so, 0, 0);
             });
         };
+#ifndef NR_PP_MV
+#define NR_PP_MV 0
+#endif
+        // pieces per wave moved from a memory phase into the neighbouring MFMA phase (at most what every phase can spare)
+        constexpr int MV_CAP = (PB0 < PA1 ? (PB0 < PC1 ? PB0 : PC1) : (PA1 < PC1 ? PA1 : PC1)) - 1;
+        constexpr int MV = NR_PP_MV < MV_CAP ? NR_PP_MV : MV_CAP;
+        static_assert(MV >= 0 && MV < PB0 && MV < PA1 && MV < PC1, "not that many pieces in a memory phase");
+        using IMV = std::integral_constant<int, MV>;
+        using IA1 = std::integral_constant<int, PC1 + PA1 - MV>;
+        using IC1 = std::integral_constant<int, PC1 - MV>;
+        auto nothing = []() {};
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         using IPB0 = std::integral_constant<int, PB0>;
@@ -426,18 +437,20 @@ struct NrGemmTile {
 #ifdef NR_STAMP
         unsigned long long pp_t = __builtin_readcyclecounter(), pp_work = 0, pp_bar = 0, pp_mma = 0;
 #endif
-        auto mma = [&]() {
+        // `mid`: issued a third of the way through the phase's MFMAs (NR_PP_MV > 0: a few LDS-DMA pieces moved out of the
+        // wave's memory phases into its MFMA phases, where the matrix pipe still has the queued MFMAs to chew on)
+        auto mma = [&](auto&& mid) {
             __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int m = 0; m < MI; ++m)
-#pragma unroll
-                for (int n = 0; n < NI; ++n) {
-                    if constexpr (X3) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_l[m], fb_h[n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[m], fb_l[n], acc[m][n], 0, 0, 0);
-                    }
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[m], fb_h[n], acc[m][n], 0, 0, 0);
+            nr_static_for<0, MI * NI>([&](auto g_c) {
+                constexpr int g = decltype(g_c)::value;
+                constexpr int m = g / NI, n = g % NI;
+                if constexpr (X3) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_l[m], fb_h[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[m], fb_l[n], acc[m][n], 0, 0, 0);
                 }
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[m], fb_h[n], acc[m][n], 0, 0, 0);
+                if constexpr (g == (MI * NI) / 3) mid();
+            });
             __builtin_amdgcn_s_setprio(0);
 #ifdef NR_STAMP
             __builtin_amdgcn_sched_barrier(0);
@@ -458,7 +471,7 @@ struct NrGemmTile {
         auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
         // group 1 in phase C: everything but the PC1 pieces (x2 with split-bf16) it has just issued for slice kt+2
         auto landed_but = [&](bool newest_issued) {
-            if (newest_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PC1 * (X3 ? 2 : 1)) : "memory");
+            if (newest_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PC1 - MV) * (X3 ? 2 : 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
 
@@ -477,14 +490,14 @@ struct NrGemmTile {
             frags_in();
             for (int kt = 0; kt < KT; ++kt) {
                 const bool seam = NSEG > 1 && kt == KS - 1;
-                phase();                                                   // A: MFMA k-step 0
-                mma();
+                phase();                                                   // A: MFMA k-step 0 (+ MV of B's pieces)
+                mma([&]() { if (MV > 0 && kt + 1 < KT) issue(I0{}, I0{}, IMV{}, kt + 1); });
                 phase();                                                   // B: fragments of k-step 1, PB0 pieces of slice kt+1
                 load_frags(2 * kt + 1);
-                if (kt + 1 < KT) issue(I0{}, I0{}, IPB0{}, kt + 1);
+                if (kt + 1 < KT) issue(I0{}, IMV{}, IPB0{}, kt + 1);
                 frags_in();
                 phase();                                                   // C: MFMA k-step 1
-                mma();
+                mma(nothing);
                 landed();                                                  // this wave's pieces of slice kt+1
                 phase();                                                   // D: fragments of slice kt+1, PD0 pieces of slice kt+2
                 if (seam) {
@@ -503,17 +516,17 @@ struct NrGemmTile {
             for (int kt = 0; kt < KT; ++kt) {
                 phase();                                                   // A: fragments of k-step 0, PA1 pieces of slice kt+1
                 load_frags(2 * kt);
-                if (kt + 1 < KT) issue(I1{}, IPC1{}, IP1{}, kt + 1);
+                if (kt + 1 < KT) issue(I1{}, IPC1{}, IA1{}, kt + 1);
                 frags_in();
-                phase();                                                   // B: MFMA k-step 0
-                mma();
+                phase();                                                   // B: MFMA k-step 0 (+ the last MV of A's pieces)
+                mma([&]() { if (MV > 0 && kt + 1 < KT) issue(I1{}, IA1{}, IP1{}, kt + 1); });
                 phase();                                                   // C: fragments of k-step 1; then, the reads of this
                 load_frags(2 * kt + 1);                                    // stage done, its own strip's pieces of slice kt+2
                 frags_in();
-                if (kt + 2 < KT) issue(I1{}, I0{}, IPC1{}, kt + 2);
-                landed_but(kt + 2 < KT);                                   // pieces of slice kt+1 (the newest PC1 may fly)
-                phase();                                                   // D: MFMA k-step 1
-                mma();
+                if (kt + 2 < KT) issue(I1{}, I0{}, IC1{}, kt + 2);
+                landed_but(kt + 2 < KT);                                   // pieces of slice kt+1 (the newest PC1 - MV may fly)
+                phase();                                                   // D: MFMA k-step 1 (+ the last MV of C's pieces)
+                mma([&]() { if (MV > 0 && kt + 2 < KT) issue(I1{}, IC1{}, IPC1{}, kt + 2); });
                 if (NSEG > 1 && kt == KS - 1) {                            // the seam: see above
                     between(0);
                     zero();
