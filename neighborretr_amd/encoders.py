@@ -91,8 +91,17 @@ class VisualTransformer(nn.Module):
             p.requires_grad = False
 
     def forward(self, x):
-        x = self.conv1(x)                                           # [B, width, g, g]
-        x = x.flatten(2).transpose(1, 2)                            # [B, g*g, width]
+        # Patchify (module_clip.py:325: conv2d with stride = kernel, frozen) as ONE GEMM on the non-overlapping patches,
+        # [B g g, 3 p p] x [3 p p, width]: same arithmetic, no MIOpen solver search at the first call (seconds of naive /
+        # im2col trials) and no im2col pass per image.
+        p = self.conv1.kernel_size[0]
+        B, C, H, W = x.shape
+        if self.conv1.stride == self.conv1.kernel_size and H % p == 0 and W % p == 0 and self.conv1.bias is None:
+            g_h, g_w = H // p, W // p
+            patches = x.view(B, C, g_h, p, g_w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * g_h * g_w, C * p * p)
+            x = (patches @ self.conv1.weight.view(self.conv1.out_channels, -1).t().to(patches.dtype)).view(B, g_h * g_w, -1)
+        else:
+            x = self.conv1(x).flatten(2).transpose(1, 2)            # [B, g*g, width]
         cls = self.class_embedding.to(x.dtype).expand(x.shape[0], 1, -1)
         x = torch.cat((cls, x), dim=1) + self.positional_embedding.to(x.dtype)
         return self.transformer(self.ln_pre(x))
