@@ -306,10 +306,10 @@ def eval_epoch(args, model, test):
     they are the inputs), one packed all-gather + index scatter restores dataset order (evaluator.py:173-189), rank r
     computes rows [r N/W, (r+1) N/W) of the N x N similarity and the rank counts of its slab on the GPU, three small
     collectives complete them."""
-    from neighborretr_amd.evaluator import gather_eval_features, sharded_metrics
+    from neighborretr_amd.evaluator import gather_eval_features, rank_sample_indices, sharded_metrics
     model.eval()
     dev = args.device
-    mine = torch.arange(args.rank, test.n, args.world_size)
+    mine = rank_sample_indices(test.n, args.world_size, args.rank)     # equal counts on every rank (padded like DistributedSampler)
     if model.feature_mode:
         t, tm, v, vm = (x[mine].to(dev) for x in (test.t, test.tm, test.v, test.vm))
     else:                                                   # evaluator.py:162-171: features cached batch by batch

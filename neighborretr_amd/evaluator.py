@@ -22,6 +22,16 @@ def _world(args):
     return int(getattr(args, "world_size", 1))
 
 
+def rank_sample_indices(n, world, rank):
+    """Dataset indices rank `rank` extracts features for: rank, rank + W, ... PADDED to ceil(n / W) entries by wrapping around
+    to the start of the dataset -- torch's DistributedSampler(shuffle=False), which the reference's test loader uses
+    (dataloaders/data_dataloaders.py).  Every rank therefore hands the SAME number of rows to the packed all-gather (ranks
+    issuing a collective with different byte counts hang RCCL); the duplicates overwrite identical rows in dataset_order."""
+    import math
+    per = math.ceil(n / world)
+    return (torch.arange(rank, rank + per * world, world) % n)[:per]
+
+
 def gather_eval_features(text_feat, video_feat, idx, text_mask, video_mask, args):
     """evaluator.py:173-189: gather every rank's cached features and put them back into dataset order (`idx` = dataset
     index of every local sample; duplicates from a padded last batch overwrite each other with identical rows), trimmed to

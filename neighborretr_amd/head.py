@@ -324,39 +324,50 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         losses = torch.empty((5,), dtype=torch.float32, device=G.device)
         counter = ops.split_tail_counter(G.device)
         wts = (hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
-        ops.sinkhorn_uniform_rows_final(G, hp["beta"], hp["temperature"], rowloss, counter, *wts, losses, 50)
-        tgt_r = tgt_c = None
-        side, side2 = bank_streams[0], bank_streams[1]
-        push_stream = bank_streams[2] if len(bank_streams) > 2 else None
-        side.wait_stream(local_stream)
-        side2.wait_stream(local_stream)
-        with torch.cuda.stream(side2):
-            pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
-        with torch.cuda.stream(side):
-            pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
-            side.wait_stream(side2)
-            if pair_bank and early[0] is None:
-                for t_ in (pbt.hi, w_bt):
-                    t_.record_stream(side)
-                c1, c0 = ops.local_level_group([(L["pt"], pbv, L["w_t"], w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM),
-                                                (pbt, L["pv"], w_bt, L["w_v"], M, Nt, B, Nv, p_bank, hip.OUT_COLSUM)])
-            if bank_push is not None:
-                # both bank products have read the bank (and its prepared shadow): the batch may take the oldest rows'
-                # place -- on a stream of its own, beside the centrality weights and the row losses.  (A stream that
-                # has already been joined must not be forked again inside one capture: putting the push back on
-                # `side2` after `side.wait_stream(side2)` made the ROCm 7.2 runtime segfault at capture time.)
-                pst = push_stream if push_stream is not None else side
-                if push_stream is not None:
-                    push_stream.wait_stream(side)
-                with torch.cuda.stream(pst):
-                    for t_ in (pt.hi, pt.norm, pv.hi, pv.norm) + ((pt.lo, pv.lo) if pt.lo is not None else ()):
-                        t_.record_stream(pst)
-                    with torch.no_grad():
-                        bank_push()
-            side.wait_event(g_ready)
-            wc_t, wc_v, cw_aux = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
-            ops.row_losses_no_uniform_final(S, G, c0, c1, 1.0 / M, wc_t, wc_v, ls, K, hp["temperature"], rowloss, counter,
-                                            *wts, losses)
+        # The two self-finalizing launches share `counter`; only the one that finishes last resets it.  If anything raises
+        # between them (the push callable, an NR_E* status), the word would stay non-zero and every later step would finalize
+        # on incomplete row terms without an error: zero it before passing the exception on.
+        try:
+            ops.sinkhorn_uniform_rows_final(G, hp["beta"], hp["temperature"], rowloss, counter, *wts, losses, 50)
+            tgt_r = tgt_c = None
+            side, side2 = bank_streams[0], bank_streams[1]
+            push_stream = bank_streams[2] if len(bank_streams) > 2 else None
+            side.wait_stream(local_stream)
+            side2.wait_stream(local_stream)
+            with torch.cuda.stream(side2):
+                pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
+            with torch.cuda.stream(side):
+                pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
+                side.wait_stream(side2)
+                if pair_bank and early[0] is None:
+                    for t_ in (pbt.hi, w_bt):
+                        t_.record_stream(side)
+                    c1, c0 = ops.local_level_group([(L["pt"], pbv, L["w_t"], w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM),
+                                                    (pbt, L["pv"], w_bt, L["w_v"], M, Nt, B, Nv, p_bank, hip.OUT_COLSUM)])
+                if bank_push is not None:
+                    # both bank products have read the bank (and its prepared shadow): the batch may take the oldest rows'
+                    # place -- on a stream of its own, beside the centrality weights and the row losses.  (A stream that
+                    # has already been joined must not be forked again inside one capture: putting the push back on
+                    # `side2` after `side.wait_stream(side2)` made the ROCm 7.2 runtime segfault at capture time.)
+                    pst = push_stream if push_stream is not None else side
+                    if push_stream is not None:
+                        push_stream.wait_stream(side)
+                    with torch.cuda.stream(pst):
+                        for t_ in (pt.hi, pt.norm, pv.hi, pv.norm) + ((pt.lo, pv.lo) if pt.lo is not None else ()):
+                            t_.record_stream(pst)
+                        with torch.no_grad():
+                            bank_push()
+                side.wait_event(g_ready)
+                wc_t, wc_v, cw_aux = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
+                ops.row_losses_no_uniform_final(S, G, c0, c1, 1.0 / M, wc_t, wc_v, ls, K, hp["temperature"], rowloss, counter,
+                                                *wts, losses)
+        except BaseException:
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize(G.device)
+                counter.zero_()
+            else:
+                ops.forget_split_tail_counter(G.device)   # an aborted capture: the next step takes a fresh zeroed word
+            raise
         cur.wait_stream(side)
         if push_stream is not None:
             cur.wait_stream(push_stream)

@@ -225,6 +225,11 @@ def split_tail_counter(dev):
     return c
 
 
+def forget_split_tail_counter(dev):
+    """Drops the device's shared finalize word (the next split_tail_counter call allocates a zeroed one)."""
+    _COUNTERS.pop(("split_tail", dev), None)
+
+
 def sinkhorn_uniform_rows_final(G, beta, T, rowloss, counter, wu, wn, wkl, losses, iters=50):
     """nr_sinkhorn_uniform_rows_final: Sinkhorn + uniform-CE row terms into rowloss[:, 1, :], taking part in the shared
     finalize (see row_losses_no_uniform_final)."""

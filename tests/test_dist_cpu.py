@@ -96,3 +96,47 @@ def test_single_rank_is_identity():
     assert torch.equal(tf.grad, torch.ones_like(tf))
     x = torch.randn(3, 2, requires_grad=True)
     assert AllGather.apply(x, args) is x or torch.equal(AllGather.apply(x, args), x)
+
+
+def _eval_pad_worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from neighborretr_amd.evaluator import gather_eval_features, rank_sample_indices
+        args = SimpleNamespace(world_size=world, local_rank=rank)
+        Nt, Nv, d = 4, 3, 8
+        g = torch.Generator().manual_seed(3)
+        T, V = torch.randn(n, Nt, d, generator=g), torch.randn(n, Nv, d, generator=g)
+        TM, VM = (torch.rand(n, Nt, generator=g) > 0.3).long(), (torch.rand(n, Nv, generator=g) > 0.3).long()
+        mine = rank_sample_indices(n, world, rank)
+        assert len(mine) == -(-n // world)                     # the same row count on every rank
+        t, v, tm, vm = gather_eval_features(T[mine], V[mine], mine, TM[mine], VM[mine], args)
+        assert t.shape[0] == n and torch.equal(t, T) and torch.equal(v, V)
+        assert torch.equal(tm, TM.float()) and torch.equal(vm, VM.float())
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eval_gather_with_a_test_set_not_divisible_by_the_rank_count():
+    """N % W != 0 (e.g. the 1000-sample default on 3 ranks) must not issue a collective with unequal byte counts:
+    every rank pads its index list to ceil(N / W) by wrapping around (DistributedSampler's rule); dataset_order drops the
+    duplicates."""
+    from neighborretr_amd.evaluator import rank_sample_indices
+    assert rank_sample_indices(10, 3, 0).tolist() == [0, 3, 6, 9] and rank_sample_indices(10, 3, 1).tolist() == [1, 4, 7, 0]
+    assert rank_sample_indices(10, 3, 2).tolist() == [2, 5, 8, 1] and rank_sample_indices(8, 2, 1).tolist() == [1, 3, 5, 7]
+    assert rank_sample_indices(2, 3, 2).tolist() == [0]        # more ranks than samples
+    for world, n in ((3, 10), (2, 5)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_eval_pad_worker, args=(r, world, port, n, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=180) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+        assert all(r[1] == "ok" for r in res), res

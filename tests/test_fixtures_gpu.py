@@ -223,18 +223,26 @@ def test_configs3_full_size_step_runs_under_mean_flag():
         out = m(prob["text_feat"], prob["text_mask"], prob["video_feat"], prob["video_mask"], prob["idx"], 0)
     assert len(out) == 5 and all(torch.isfinite(o) for o in out)
     assert torch.equal(m.mb_ind[:B], prob["idx"]) and m.mb_feat_v.shape[0] == M
-    # ... and the TRAINING step at full size: finite gradients for the features, both scorer pairs and the clustering
+    # ... and the TRAINING step at full size: finite gradients for the features, both scorer pairs and the clustering.
+    # SAME inputs as the loss-only step above: explicit tie-break noise (`noise=nz`), the bank handed over as arguments (no
+    # push in between) -- so the training forward (prepare + scorer + products keeping their arg-max state, autograd-wrapped
+    # clustering) must reproduce the loss-only step's losses.  Both run the same kernels in the same precision plan; what
+    # differs is the summation order of the row terms (partial sums vs reduced centralities) and the clustering form
+    # (grouped no-grad kernels vs the training form): bar 2e-4 relative on every loss (measured deviation printed).
     tf = prob["text_feat"].clone().requires_grad_(True)
     vf = prob["video_feat"].clone().requires_grad_(True)
-    out = m(tf, prob["text_mask"], vf, prob["video_mask"], prob["idx"] + 1000, 0)
+    c = m.config
+    out = m._compute_losses(tf, vf, prob["text_mask"], prob["video_mask"], prob["mb_feat_t"], prob["mb_feat_v"], prob["mb_mask_t"],
+                            prob["mb_mask_v"], c.centrality_scale, c.beta, K, c.temperature, m.clip.logit_scale.exp(), noise=nz)
     out[0].backward()
     named = dict(m.named_parameters())
     for t_ in (tf.grad, vf.grad, named["text_weight_fc.0.weight"].grad, named["video_weight_fc1.0.weight"].grad,
                named["text_ctm1.conv.conv.weight"].grad, m.clip.logit_scale.grad):
         assert t_ is not None and torch.isfinite(t_).all() and float(t_.abs().max()) > 0
-    # same batch; the bank moved on by one push and the tie-break noise of the padded samples is drawn afresh (not `nz`):
-    # at this shape another draw moves the loss by a few per cent
-    assert abs(float(out[0].detach()) - float(L[0])) < 0.06 * float(L[0])
+    Lt = torch.stack([o.detach() for o in out]).cpu().numpy()
+    dev_rel = np.abs(Lt - L) / np.maximum(np.abs(L), 1e-6)
+    print(f"[configs[3] full size] training-form losses {Lt}  relative deviation from the loss-only step {dev_rel}")
+    assert dev_rel.max() < 2e-4, (Lt, L)
 
 
 def test_c4_b8_backward_matches_oracle_autograd_under_mean_flag():

@@ -59,32 +59,61 @@ def test_forward_losses_match_reference(name, precision, tol):
         assert mine["cols"] == ref["cols"] and mine["R1"] == ref["R1"]
 
 
+# Gradient bars per precision plan (relative to the reference's value; measured deviations are printed, pytest -s):
+#   "bf16x3": every product split-bf16 (16 mantissa bits), the MFMA backward with the tokens' low halves: <= 2e-3 on the
+#             gradient norms, <= 5e-3 of the largest element on slices / row sums / per-parameter norms;
+#   "bf16"  : the SHIPPING training plan (modeling.NeighborRetr default).  Forward: bank products + bank scorer in one bf16
+#             pass; backward: nr_sim_bwd_mfma rounds the routing coefficients (token weight x upstream gradient) and the other
+#             operand's tokens to bf16 = 2^-9 relative per term, accumulated in fp32 over <= B*Nv (or M*Nv) terms of mixed sign.
+#             Bar: 1e-2 on norms / logit-scale, 2e-2 of the largest element on slices / row sums, 2e-2 per parameter (measured
+#             values printed below are well inside; the bar is 4 x 2^-9 = 8e-3 rounded up, twice that element-wise).
+GRAD_BARS = {"bf16x3": dict(norm=2e-3, elem=5e-3, param=5e-3), "bf16": dict(norm=1e-2, elem=2e-2, param=2e-2)}
+
+
 @pytest.mark.parametrize("name", ["c1_b16", "c2_b128"])
-def test_backward_matches_reference(name):
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("fused", [False, True], ids=["traced-clustering", "fused-clustering"])
+def test_backward_matches_reference(name, precision, fused):
+    """Gradients of the total loss against the REFERENCE's own autograd (fixtures g_* / param_grad_norms captured from the
+    imported reference, oracle/capture_golden.py) for every training form that ships: precision plan {bf16x3, bf16 (default)}
+    x clustering {autograd-traced torch ops (captured steps), grouped HIP forward + hand-derived backward (eager / DDP steps)}."""
     g = golden(name)
+    bar = GRAD_BARS[precision]
     B, Nt, Nv, M, K = (int(g[k]) for k in ("B", "Nt", "Nv", "M", "K"))
     x = problem(int(g["seed"]), B, Nt, Nv, M, device=DEV)
     nz = noise(int(g["seed"]), B, Nt, Nv, device=DEV)
-    m = _model("bf16x3", K)
+    m = _model(precision, K)
+    m.fused_training_clustering = fused
     x["text_feat"].requires_grad_(True)
     x["video_feat"].requires_grad_(True)
     losses = _losses(m, x, nz, K)
+    dL = np.abs(torch.stack([l.detach() for l in losses]).cpu().numpy() - g["losses"])
+    assert dL.max() < (2e-4 if precision == "bf16x3" else 1e-3), dL
     losses[0].backward()
     gt, gv = x["text_feat"].grad, x["video_feat"].grad
-    assert abs(float(gt.norm()) - float(g["g_text_norm"])) < 2e-3 * float(g["g_text_norm"])
-    assert abs(float(gv.norm()) - float(g["g_video_norm"])) < 2e-3 * float(g["g_video_norm"])
-    scale_t = float(np.abs(g["g_text_slice"]).max())
-    scale_v = float(np.abs(g["g_video_slice"]).max())
-    assert maxdiff(gt[:2, :4, :64], g["g_text_slice"]) < 5e-3 * scale_t
-    assert maxdiff(gv[:2, :4, :64], g["g_video_slice"]) < 5e-3 * scale_v
-    assert maxdiff(gt.sum(-1), g["g_text_rowsum"]) < 5e-3 * float(np.abs(g["g_text_rowsum"]).max())
-    assert maxdiff(gv.sum(-1), g["g_video_rowsum"]) < 5e-3 * float(np.abs(g["g_video_rowsum"]).max())
-    ls_grad = float(m.clip.logit_scale.grad) / 100.0            # d/d(exp(p)) = d/dp / exp(p)
-    assert abs(ls_grad - float(g["g_logit_scale"])) < 2e-3 * abs(float(g["g_logit_scale"])) + 1e-7
+    rel = lambda mine, ref: abs(float(mine) - float(ref)) / max(abs(float(ref)), 1e-30)      # noqa: E731
+    dev = dict(
+        g_text_norm=rel(gt.norm(), g["g_text_norm"]), g_video_norm=rel(gv.norm(), g["g_video_norm"]),
+        g_text_slice=maxdiff(gt[:2, :4, :64], g["g_text_slice"]) / float(np.abs(g["g_text_slice"]).max()),
+        g_video_slice=maxdiff(gv[:2, :4, :64], g["g_video_slice"]) / float(np.abs(g["g_video_slice"]).max()),
+        g_text_rowsum=maxdiff(gt.sum(-1), g["g_text_rowsum"]) / float(np.abs(g["g_text_rowsum"]).max()),
+        g_video_rowsum=maxdiff(gv.sum(-1), g["g_video_rowsum"]) / float(np.abs(g["g_video_rowsum"]).max()),
+        g_logit_scale=rel(float(m.clip.logit_scale.grad) / 100.0, g["g_logit_scale"]))       # d/d(exp(p)) = d/dp / exp(p)
     named = dict(m.named_parameters())
+    worst = ("", 0.0)
     for n, ref in zip([str(s) for s in g["param_names"]], g["param_grad_norms"]):
         mine = 0.0 if named[n].grad is None else float(named[n].grad.norm())
-        assert abs(mine - ref) < 5e-3 * max(ref, 1e-3), (n, mine, ref)
+        e = abs(mine - ref) / max(ref, 1e-3)
+        if e > worst[1]:
+            worst = (n, e)
+    print(f"\n[{name} {precision} {'fused' if fused else 'traced'}] relative gradient deviations vs the reference: "
+          + ", ".join(f"{k} {v:.2e}" for k, v in dev.items()) + f"; worst parameter-gradient norm {worst[0]} {worst[1]:.2e}")
+    for k in ("g_text_norm", "g_video_norm"):
+        assert dev[k] < bar["norm"], (k, dev[k])
+    assert dev["g_logit_scale"] < bar["norm"] + 1e-7 / abs(float(g["g_logit_scale"])), dev["g_logit_scale"]
+    for k in ("g_text_slice", "g_video_slice", "g_text_rowsum", "g_video_rowsum"):
+        assert dev[k] < bar["elem"], (k, dev[k])
+    assert worst[1] < bar["param"], worst
 
 
 @pytest.mark.parametrize("B,Nt,Nv", [(16, 24, 12), (8, 64, 64), (6, 20, 9)])
@@ -275,3 +304,37 @@ def test_step_with_the_bank_products_as_chained_tile_pairs(bank_early):
         finally:
             head.PAIR_BANK_PRODUCTS = old
     assert torch.isfinite(out[0]).all() and torch.equal(out[0], out[1])
+
+
+def test_a_failing_bank_push_does_not_poison_later_steps():
+    """the split tail's two self-finalizing launches share one device counter.  A push that raises between them
+    must not leave it non-zero -- the following step has to return the same losses as a clean model."""
+    B, Nt, Nv, M, K = 32, 24, 12, 64, 8
+    x = problem(1005, B, Nt, Nv, M, device=DEV)
+    m = _model("bf16", K=K)
+    for k in ("mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v"):
+        setattr(m, k, x[k].clone().float() if "mask" in k else x[k].clone())
+    m.mb_ind = torch.arange(M, device=DEV)
+    m.bank_frozen = True
+
+    def run():
+        m._rng_state = None
+        torch.manual_seed(5)
+        with torch.no_grad():
+            return torch.stack(m(x["text_feat"], x["text_mask"], x["video_feat"], x["video_mask"], x["idx"], 0)).cpu()
+    clean = run()
+    assert torch.isfinite(clean).all()
+    m.bank_frozen = False
+    real = m.update_memory_bank
+
+    def boom(*a, **k):
+        raise RuntimeError("injected push failure")
+    m.update_memory_bank = boom
+    with pytest.raises(RuntimeError, match="injected"):
+        run()
+    m.update_memory_bank = real
+    m.bank_frozen = True
+    m._ring_advanced = False
+    torch.cuda.synchronize()
+    again = run()
+    assert torch.equal(again, clean), (again, clean)

@@ -88,7 +88,7 @@ def test_sharded_loss_equals_replicated_loss(tmp_path):
         assert res[0]["seen"]["after"][k] == res[1]["seen"]["after"][k] == res[1]["seen"]["local"][k]
 
 
-def _train_worker(rank, world, port, out_path):
+def _train_worker(rank, world, port, out_path, precision):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -100,7 +100,7 @@ def _train_worker(rank, world, port, out_path):
     torch.cuda.set_device(dev)
     B, Nt, Nv, M, K = 32, 24, 12, 64, 8
     b = B // world
-    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K, world_size=world, local_rank=rank), precision="bf16x3")
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K, world_size=world, local_rank=rank), precision=precision)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}, strict=False)
     m = m.to(dev).train()
     with torch.no_grad():
@@ -136,14 +136,18 @@ def _train_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_sharded_training_loss_gradients_equal_replicated(tmp_path):
-    """Training step, two ranks: losses, the gradient of this rank's features and the DDP-averaged parameter gradients of
+@pytest.mark.parametrize("precision,port", [("bf16x3", 29653), ("bf16", 29655)])
+def test_sharded_training_loss_gradients_equal_replicated(tmp_path, precision, port):
+    """(both precision plans: "bf16" is what `NeighborRetr()` trains in by default; the sharded and the replicated form then
+    round the same products to bf16 in different tile shapes, so the bars below are the looser of the two plans'.)
+    Training step, two ranks: losses, the gradient of this rank's features and the DDP-averaged parameter gradients of
     the sharded loss (neighborretr_amd.sharded: row slabs + differentiable collectives, reduce-scatter in the exchange
     step's backward) equal those of the reference's replicated loss."""
     import torch.multiprocessing as mp
-    world, port = 2, 29653
+    world = 2
     out = str(tmp_path / "res")
-    mp.spawn(_train_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_train_worker, args=(world, port, out, precision), nprocs=world, join=True)
+    fbar, pbar = (3e-3, 5e-3) if precision == "bf16x3" else (1e-2, 2e-2)
     for r in range(world):
         res = torch.load(f"{out}.{r}", weights_only=False)
         rep, sh = res["replicated"], res["sharded"]
@@ -151,10 +155,11 @@ def test_sharded_training_loss_gradients_equal_replicated(tmp_path):
         assert torch.allclose(sh["losses"], rep["losses"], rtol=1e-4, atol=1e-4), (sh["losses"], rep["losses"])
         for k in ("g_text", "g_video"):
             scale = float(rep[k].abs().max())
-            assert float((sh[k] - rep[k]).abs().max()) < 3e-3 * scale, (k, float((sh[k] - rep[k]).abs().max()), scale)
+            print(f"\n[sharded vs replicated, {precision}, rank {r}] {k}: max|d| / max|g| = {float((sh[k] - rep[k]).abs().max()) / scale:.2e}")
+            assert float((sh[k] - rep[k]).abs().max()) < fbar * scale, (k, float((sh[k] - rep[k]).abs().max()), scale)
         assert set(sh["params"]) >= {n for n, g in rep["params"].items() if float(g.abs().max()) > 0}
         for n, g in rep["params"].items():
             scale = float(g.abs().max())
             if scale == 0:
                 continue
-            assert float((sh["params"][n] - g).abs().max()) < 5e-3 * scale + 2e-6, (n, float((sh["params"][n] - g).abs().max()), scale)
+            assert float((sh["params"][n] - g).abs().max()) < pbar * scale + 2e-6, (n, float((sh["params"][n] - g).abs().max()), scale)
