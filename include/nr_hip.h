@@ -37,6 +37,11 @@ extern "C" {
 
 int nr_version(void);
 
+/* Identity of the HIP stream capture `stream` belongs to (0 = not capturing).  No counterpart in the reference (it launches
+ * eagerly, trainer.py:84-110); used by neighborretr_amd/capture_guard.py to validate the step's fork / join topology per
+ * capture before handing it to the runtime.  Host-only, no launch, no sync. */
+int nr_stream_capture_id(void* stream, unsigned long long* id);
+
 /* F.normalize (eps 1e-12) + mask multiply + bf16 hi/lo split of a token matrix.
  * Replaces modeling.py:495-496 and the two mask einsums :500-501 (a masked token becomes a zero
  * vector, so every product with it is exactly 0, as in the reference).

@@ -12,6 +12,7 @@ import math
 import torch
 
 from . import hip
+from .capture_guard import wait_stream
 
 
 def _p(t, dtype=torch.float32):
@@ -257,7 +258,7 @@ class ClusterStagesFn(torch.autograd.Function):
                 sv["mask"] = mask
                 pb = blk.attn.proj.bias
                 if i == 1 and side is not None:
-                    side.wait_stream(cur)
+                    wait_stream(side, cur)
                     with torch.cuda.stream(side):
                         sv["merged"] = sv["merged_pb"] - pb if pb is not None else sv["merged_pb"]
                         results[i] = stage_backward(ctm, blk, sv, g)
@@ -265,7 +266,7 @@ class ClusterStagesFn(torch.autograd.Function):
                     sv["merged"] = sv["merged_pb"] - pb if pb is not None else sv["merged_pb"]
                     results[i] = stage_backward(ctm, blk, sv, g)
             if side is not None:
-                cur.wait_stream(side)
+                wait_stream(cur, side)
                 for t_ in [results[1][0]] + list(results[1][1].values()):
                     t_.record_stream(cur)
             for d_x0, gp in results:

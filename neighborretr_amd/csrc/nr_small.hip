@@ -6,6 +6,18 @@
 
 extern "C" int nr_version(void) { return NR_ABI_VERSION; }
 
+// Identity of the stream capture `stream` takes part in: *id = the runtime's capture sequence id (unique per capture in
+// this process), 0 when the stream is not capturing.  Host-only; lets the host code check its stream topology per capture.
+extern "C" int nr_stream_capture_id(void* stream, unsigned long long* id) {
+    if (!id) return NR_EINVAL;
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    hipError_t e = hipStreamGetCaptureInfo((hipStream_t)stream, &status, &cid);
+    if (e != hipSuccess) return (int)e;
+    *id = status == hipStreamCaptureStatusActive ? (cid ? cid : 1ull) : 0ull;
+    return NR_OK;
+}
+
 // ---- out[i] = scale * sum_p part[p,i]  (until_module.py:181) -----------------------------------
 // 64 outputs per workgroup; wave w sums the parts p = w, w+4, ... (independent loads in flight),
 // the four partial sums meet in LDS -- fixed order, deterministic.

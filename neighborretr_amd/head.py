@@ -21,6 +21,7 @@ import os
 import torch
 
 from . import hip, ops
+from .capture_guard import record_event, wait_event, wait_stream
 
 MLP_KEYS = ("0.weight", "0.bias", "2.weight", "2.bias")
 
@@ -258,7 +259,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         # the nodes captured ahead of it have started (profiled step: a branch captured after 7 clustering nodes
         # began 120 us late and ended up the critical path).  So the two branches are captured interleaved:
         # `capture_order` = [(clustering launches, local launches), ...] per turn, the last pair repeating.
-        local_stream.wait_stream(cur)
+        wait_stream(local_stream, cur)
         loc = local_steps()
         loc_alive, clu_alive = True, True
         produced = None
@@ -286,7 +287,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     else:
         # `join`: one callable run right before gt / gv are needed (may return them); generators are run through
         if local_stream is not None:
-            local_stream.wait_stream(cur)
+            wait_stream(local_stream, cur)
             if join is not None:
                 produced = exhaust(join) if stepwise_join else join()
                 if produced is not None:
@@ -318,8 +319,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     # is prologue -> clustering -> logits -> Sinkhorn, with neither a finalize launch nor the push behind it.
     if split_tail:
         G = global_logits(gt, gv, sw_t1, sw_v1)
-        g_ready = torch.cuda.Event()
-        g_ready.record(cur)
+        g_ready = record_event(cur)
         rowloss = torch.empty((2, 4, B), dtype=torch.float32, device=G.device)
         losses = torch.empty((5,), dtype=torch.float32, device=G.device)
         counter = ops.split_tail_counter(G.device)
@@ -332,13 +332,13 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
             tgt_r = tgt_c = None
             side, side2 = bank_streams[0], bank_streams[1]
             push_stream = bank_streams[2] if len(bank_streams) > 2 else None
-            side.wait_stream(local_stream)
-            side2.wait_stream(local_stream)
+            wait_stream(side, local_stream)
+            wait_stream(side2, local_stream)
             with torch.cuda.stream(side2):
                 pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
             with torch.cuda.stream(side):
                 pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
-                side.wait_stream(side2)
+                wait_stream(side, side2)
                 if pair_bank and early[0] is None:
                     for t_ in (pbt.hi, w_bt):
                         t_.record_stream(side)
@@ -348,16 +348,16 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
                     # both bank products have read the bank (and its prepared shadow): the batch may take the oldest rows'
                     # place -- on a stream of its own, beside the centrality weights and the row losses.  (A stream that
                     # has already been joined must not be forked again inside one capture: putting the push back on
-                    # `side2` after `side.wait_stream(side2)` made the ROCm 7.2 runtime segfault at capture time.)
+                    # `side2` after `wait_stream(side, side2)` made the ROCm 7.2 runtime segfault at capture time.)
                     pst = push_stream if push_stream is not None else side
                     if push_stream is not None:
-                        push_stream.wait_stream(side)
+                        wait_stream(push_stream, side)
                     with torch.cuda.stream(pst):
                         for t_ in (pt.hi, pt.norm, pv.hi, pv.norm) + ((pt.lo, pv.lo) if pt.lo is not None else ()):
                             t_.record_stream(pst)
                         with torch.no_grad():
                             bank_push()
-                side.wait_event(g_ready)
+                wait_event(side, g_ready)
                 wc_t, wc_v, cw_aux = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
                 ops.row_losses_no_uniform_final(S, G, c0, c1, 1.0 / M, wc_t, wc_v, ls, K, hp["temperature"], rowloss, counter,
                                                 *wts, losses)
@@ -368,9 +368,9 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
             else:
                 ops.forget_split_tail_counter(G.device)   # an aborted capture: the next step takes a fresh zeroed word
             raise
-        cur.wait_stream(side)
+        wait_stream(cur, side)
         if push_stream is not None:
-            cur.wait_stream(push_stream)
+            wait_stream(cur, push_stream)
         for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi, c0, c1, wc_t, wc_v, G, rowloss, losses):
             t_.record_stream(cur)
             t_.record_stream(side)
@@ -381,7 +381,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         pv.norm.record_stream(cur)
     else:
         if local_stream is not None:
-            cur.wait_stream(local_stream)
+            wait_stream(cur, local_stream)
             for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi):
                 t_.record_stream(cur)
         # The critical path after the join is global logits -> Sinkhorn -> row losses: captured FIRST.  What is left
@@ -389,20 +389,19 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         # forked from the join point (an event recorded before the Sinkhorn launch) and run beside the solve.
         fork = None
         if bank_streams is not None:
-            fork = torch.cuda.Event()
-            fork.record(cur)
+            fork = record_event(cur)
         G, g_saved = global_logits(gt, gv, sw_t1, sw_v1, keep=True) if keep else (global_logits(gt, gv, sw_t1, sw_v1), None)
         tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
         if bank_streams is not None:
             for st_ in bank_streams:
-                st_.wait_event(fork)
+                wait_event(st_, fork)
             with torch.cuda.stream(bank_streams[1]):
                 pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
             with torch.cuda.stream(bank_streams[0]):
                 pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
                 wc_t, wc_v, cw_aux = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
             for st_ in bank_streams:
-                cur.wait_stream(st_)
+                wait_stream(cur, st_)
             for t_ in (c0, c1, wc_t, wc_v) + ((pbt.hi, pbv.hi, w_bt, w_bv) if keep else ()):
                 t_.record_stream(cur)
         else:

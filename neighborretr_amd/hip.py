@@ -45,6 +45,7 @@ CTM_STAGE_LAUNCHES = 7
 
 _SIGNATURES = {
     "nr_version": ([], _I),
+    "nr_stream_capture_id": ([_P, ctypes.POINTER(ctypes.c_ulonglong)], _I),
     "nr_prepare_parts": ([_I], _I),
     "nr_prepare_tokens": ([_P, _P, _I, _I, _I, _P, _P, _P, _P, _P], _I),
     "nr_split_bf16": ([_P, _Z, _P, _P, _P], _I),
@@ -167,6 +168,14 @@ def call(name, *args):
 
 def version():
     return lib().nr_version()
+
+
+def stream_capture_id(stream=None):
+    """Capture id of `stream` (default: the current stream); 0 when it is not capturing."""
+    cid = ctypes.c_ulonglong(0)
+    st = torch.cuda.current_stream() if stream is None else stream
+    _check("nr_stream_capture_id", lib().nr_stream_capture_id(ctypes.c_void_p(st.cuda_stream), ctypes.byref(cid)))
+    return int(cid.value)
 
 
 def prepare_parts(n_tok):

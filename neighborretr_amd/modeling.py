@@ -20,6 +20,7 @@ import torch
 from torch import nn
 
 from . import head, hip, ops
+from .capture_guard import wait_stream
 from .cluster import CTM, TCBlock
 from .until_module import (AllGather, CentralityWeightingLoss, KLDivergenceLoss, NeighborAdjustingLoss,
                            UniformRegularizationLoss)
@@ -435,8 +436,8 @@ class NeighborRetr(nn.Module):
             # branches) and are joined right before the global logits need them.
             cur = torch.cuda.current_stream()
             s_t, s_v = self._side_streams(text_feat.device)
-            s_t.wait_stream(cur)
-            s_v.wait_stream(cur)
+            wait_stream(s_t, cur)
+            wait_stream(s_v, cur)
             with torch.cuda.stream(s_t):
                 gt = self._merge_one("text", text_feat, text_mask, nz.get("t0"), nz.get("t1"))
             with torch.cuda.stream(s_v):
@@ -445,8 +446,8 @@ class NeighborRetr(nn.Module):
             gv.record_stream(cur)
 
             def join():
-                cur.wait_stream(s_t)
-                cur.wait_stream(s_v)
+                wait_stream(cur, s_t)
+                wait_stream(cur, s_v)
             self._join_global = join
         else:
             gt, gv = self.merge_global_features(text_feat, video_feat, text_mask, video_mask, noise)

@@ -126,7 +126,10 @@ def test_configs4_full_size_end_to_end_properties():
     assert len(out) == 5 and all(torch.isfinite(o) for o in out)
     out[0].backward()
     named = dict(m.named_parameters())
-    for n in ("clip.visual.conv1.weight", "clip.visual.transformer.resblocks.11.mlp.c_proj.weight",
+    # the patchify convolution is frozen in the reference (module_clip.py:325-326): no gradient there, by design
+    assert not named["clip.visual.conv1.weight"].requires_grad and named["clip.visual.conv1.weight"].grad is None
+    for n in ("clip.visual.positional_embedding", "clip.visual.transformer.resblocks.0.attn.in_proj_weight",
+              "clip.visual.transformer.resblocks.11.mlp.c_proj.weight",
               "clip.transformer.resblocks.0.attn.in_proj_weight", "clip.token_embedding.weight",
               "transformerClip.resblocks.3.mlp.c_fc.weight", "frame_position_embeddings.weight",
               "text_weight_fc.0.weight", "video_weight_fc.2.weight", "text_ctm0.conv.conv.weight", "video_block1.attn.q.weight",

@@ -64,10 +64,11 @@ def test_forward_losses_match_reference(name, precision, tol):
 #             gradient norms, <= 5e-3 of the largest element on slices / row sums / per-parameter norms;
 #   "bf16"  : the SHIPPING training plan (modeling.NeighborRetr default).  Forward: bank products + bank scorer in one bf16
 #             pass; backward: nr_sim_bwd_mfma rounds the routing coefficients (token weight x upstream gradient) and the other
-#             operand's tokens to bf16 = 2^-9 relative per term, accumulated in fp32 over <= B*Nv (or M*Nv) terms of mixed sign.
-#             Bar: 1e-2 on norms / logit-scale, 2e-2 of the largest element on slices / row sums, 2e-2 per parameter (measured
-#             values printed below are well inside; the bar is 4 x 2^-9 = 8e-3 rounded up, twice that element-wise).
-GRAD_BARS = {"bf16x3": dict(norm=2e-3, elem=5e-3, param=5e-3), "bf16": dict(norm=1e-2, elem=2e-2, param=2e-2)}
+#             operand's tokens to bf16 = 2^-9 relative per term, of mixed sign, accumulated in fp32.  Measured on the MI355X
+#             against both fixtures (round 3): norms <= 1.8e-5, logit scale <= 7.1e-5, slices / row sums <= 1.6e-3, worst
+#             per-parameter norm 5.9e-4 -- the split plan measures the same to within 2x except the text slice at c1_b16
+#             (3.3e-4 vs 1.6e-3).  So the bars are the SAME for both plans.
+GRAD_BARS = {"bf16x3": dict(norm=2e-3, elem=5e-3, param=5e-3), "bf16": dict(norm=2e-3, elem=5e-3, param=5e-3)}
 
 
 @pytest.mark.parametrize("name", ["c1_b16", "c2_b128"])
@@ -338,3 +339,60 @@ def test_a_failing_bank_push_does_not_poison_later_steps():
     torch.cuda.synchronize()
     again = run()
     assert torch.equal(again, clean), (again, clean)
+
+
+def test_capture_guard_fires_inside_a_real_capture_and_the_shipped_step_passes_it():
+    """The capture rules in code (neighborretr_amd/capture_guard.py): inside a REAL stream capture the guard refuses the
+    re-fork of a joined stream BEFORE the runtime sees the edge (so the capture goes on and ends cleanly -- the crashing
+    capture itself is never executed), and the shipped loss-only step, captured, goes through the guard edge by edge."""
+    from neighborretr_amd import capture_guard as CG
+    x = torch.zeros(1 << 12, device=DEV)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cur = torch.cuda.current_stream()
+        assert CG._topology(cur) is not None
+        CG.wait_stream(s1, cur)
+        CG.wait_stream(s2, cur)
+        with torch.cuda.stream(s2):
+            a = x + 1
+        with torch.cuda.stream(s1):
+            b = x + 2
+            CG.wait_stream(s1, s2)
+        with pytest.raises(CG.CaptureTopologyError, match="already joined"):
+            CG.wait_stream(s2, s1)                      # tools/capture_refork.py's crashing edge: refused, never issued
+        with torch.cuda.stream(s1):
+            c = a + b
+        CG.wait_stream(cur, s1)
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(c[0]) == 3.0
+    # the shipped step
+    B, Nt, Nv, M, K = 32, 24, 12, 64, 8
+    p = problem(1006, B, Nt, Nv, M, device=DEV)
+    m = _model("bf16", K=K)
+    for k in ("mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v"):
+        setattr(m, k, p[k].clone().float() if "mask" in k else p[k].clone())
+    m.mb_ind = torch.arange(M, device=DEV)
+    out = {}
+
+    def step():
+        with torch.no_grad():
+            out["l"] = torch.stack(m(p["text_feat"], p["text_mask"], p["video_feat"], p["video_mask"], p["idx"], 0))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    before = dict(CG.STATS)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        step()
+    assert CG.STATS["captures"] == before["captures"] + 1
+    assert CG.STATS["edges"] >= before["edges"] + 7, CG.STATS     # local fork, side x2, sibling join, push fork, logits event, 2+ joins
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["l"]).all()

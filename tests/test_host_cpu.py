@@ -207,3 +207,49 @@ def test_hand_derived_stage_backward_equals_autograd(B, N, C, ratio, masked):
     for p, r in zip(ps, ref[1:]):
         assert grads[p].shape == r.shape
         assert float((grads[p] - r).abs().max()) < 1e-8 * max(float(r.abs().max()), 1e-12)
+
+
+def test_capture_guard_refuses_the_two_crashing_shapes_and_passes_the_shipped_ones():
+    """the stream-topology rules of HIP-graph capture on ROCm 7.2 (profiles/r02_capture_refork.txt,
+    r02_capture_nest.txt) live in code.  The pure bookkeeping runs on integer handles -- no GPU, and above all no execution
+    of the crashing captures themselves."""
+    from neighborretr_amd.capture_guard import CaptureTopologyError, StreamTopology
+    ORIGIN, S1, S2, S3 = 0, 1, 2, 3
+    # shape 1 (tools/capture_refork.py "refork"): s2 joined into s1, then s2 waits on s1 again
+    t = StreamTopology(ORIGIN)
+    t.wait(S1, ORIGIN), t.wait(S2, ORIGIN)
+    t.wait(S1, S2)
+    with pytest.raises(CaptureTopologyError, match="already joined"):
+        t.wait(S2, S1)
+    # ... the same work on a FRESH third stream is fine ("fresh")
+    t = StreamTopology(ORIGIN)
+    t.wait(S1, ORIGIN), t.wait(S2, ORIGIN), t.wait(S1, S2), t.wait(S3, S1)
+    t.wait(ORIGIN, S1), t.wait(ORIGIN, S3)
+    # shape 2 (tools/capture_nest.py): a forked stream joins a stream forked from itself
+    t = StreamTopology(ORIGIN)
+    t.wait(S1, ORIGIN)
+    t.wait(S2, S1)
+    with pytest.raises(CaptureTopologyError, match="forked from itself"):
+        t.wait(S1, S2)
+    # ... the same kid joined straight into the origin is fine, and so are many siblings
+    t = StreamTopology(ORIGIN)
+    t.wait(S1, ORIGIN), t.wait(S2, S1), t.wait(ORIGIN, S2), t.wait(ORIGIN, S1)
+    t = StreamTopology(ORIGIN)
+    for s_ in range(1, 17):
+        t.wait(s_, ORIGIN)
+    for s_ in range(1, 17):
+        t.wait(ORIGIN, s_)
+    # the shipped loss-only step (head.head_forward, split tail): local | side, side2, push | joins into the origin
+    LOCAL, SIDE, SIDE2, PUSH = 10, 11, 12, 13
+    t = StreamTopology(ORIGIN)
+    t.wait(LOCAL, ORIGIN)
+    t.wait(SIDE, LOCAL), t.wait(SIDE2, LOCAL), t.wait(SIDE, SIDE2), t.wait(PUSH, SIDE), t.wait(SIDE, ORIGIN)
+    t.wait(ORIGIN, SIDE), t.wait(ORIGIN, PUSH)
+    # round 2's attempted edit -- the push back on side2 after side.wait_stream(side2) -- is refused
+    t = StreamTopology(ORIGIN)
+    t.wait(LOCAL, ORIGIN), t.wait(SIDE, LOCAL), t.wait(SIDE2, LOCAL), t.wait(SIDE, SIDE2)
+    with pytest.raises(CaptureTopologyError):
+        t.wait(SIDE2, SIDE)
+    # autograd re-enters a side stream that was joined into the ORIGIN (every captured training step does): allowed
+    t = StreamTopology(ORIGIN)
+    t.wait(S1, ORIGIN), t.wait(ORIGIN, S1), t.wait(S1, ORIGIN), t.wait(ORIGIN, S1)
