@@ -71,6 +71,17 @@ int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_lo, const fl
 int nr_token_softmax(const float* logit_part, int n_parts, const float* b2, const float* mask,
                      int n_samples, int N, float* w, float* logits, void* stream);
 
+/* The two calls above in ONE launch: scorer MLP + masked softmax over each sample's tokens (modeling.py:485-487 /
+ * :490-492).  The H/BN column blocks of a row tile add to the tile's counter once their partial logits are visible
+ * device-wide; the block that arrives last sums the parts, applies mask and softmax for the tile's samples and resets the
+ * counter.  counters [n_counters] u32, zero on entry (the kernel leaves them zero), n_counters >= ceil(n_samples*N / 64);
+ * launches that may run concurrently need separate counters.  NR_EUNSUPPORTED when no block shape holds whole samples
+ * (N must divide 96 or 192, or 64 / 128 -- the caller then issues the two calls above) or N > 256.                        */
+int nr_token_weights_fwd(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_samples, int N, int d,
+                         const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2, const float* b2,
+                         int H, int prec, const float* mask, float* logit_part, unsigned int* counters, int n_counters,
+                         float* w, float* logits, void* stream);
+
 /* Fused local_level (modeling.py:499-512): token-token cosine products on MFMA, max-pool over
  * each token axis, weighted sums, (t2v+v2t)/2.  The [A,Bv,Nt,Nv] tensor is never materialised.
  *   t_hi/lo [A*Nt,d], v_hi/lo [Bv*Nv,d] prepared tokens; w_t [A*Nt], w_v [Bv*Nv] token weights;

@@ -16,12 +16,25 @@
 //     ceil(workgroups / 256 CUs) * (BM + BN)
 // -- e.g. 96x128 for the 3072 batch text tokens (256 workgroups, one per CU) and 192x256 on 8 waves for the
 // 12288 bank text tokens (again 256) instead of 128x128 everywhere (192 resp. 768 workgroups).
+// The masked softmax over each sample's tokens folded into the scorer launch (counters != nullptr): the H/BN column
+// blocks of one row tile add to the tile's counter after their partial logits are visible device-wide; whichever arrives
+// last sums the parts of the tile's samples (BM % N == 0: whole samples per row tile), applies mask and softmax
+// (modeling.py:485-492) and resets the counter.  One launch less per scorer call (four per step) on the local chain.
+struct NrMlpSoftmax {
+    unsigned int* counters;      // [row tiles], zero on entry and on exit
+    const float* b2;
+    const float* mask;           // [n_tok] or nullptr
+    int N;                       // tokens per sample
+    float* w;                    // [n_tok] softmax weights
+    float* logits;               // [n_tok] or nullptr
+};
+
 template <int MI, int NI, int WC, bool X3, int STAGES>
 __global__ __launch_bounds__(128 * WC) void nr_mlp_kernel(const uint16_t* __restrict__ tok_hi, const uint16_t* __restrict__ tok_lo,
                                                           const float* __restrict__ norm, int n_tok, int d,
                                                           const uint16_t* __restrict__ w1_hi, const uint16_t* __restrict__ w1_lo,
                                                           const float* __restrict__ b1, const float* __restrict__ w2, int H,
-                                                          float* __restrict__ logit_part) {
+                                                          float* __restrict__ logit_part, NrMlpSoftmax sm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Tile = NrGemmTile<MI, NI, X3, 16, 16, STAGES, WC>;
     constexpr int BM = Tile::BM, BN = Tile::BN;
@@ -76,6 +89,52 @@ __global__ __launch_bounds__(128 * WC) void nr_mlp_kernel(const uint16_t* __rest
         for (int q = 0; q < WPP; ++q) v += sPart[(part * WPP + q) * BM + r];
         logit_part[(size_t)(bx * (BN / 128) + part) * n_tok + row0 + r] = v;
     }
+    if (sm.counters == nullptr) return;
+    // ---- fused softmax: the last column block of this row tile ----------------------------------------------------
+    int* s_last = reinterpret_cast<int*>(smem + 8192);          // behind sPart (<= 3 KiB); the ring is free
+    __threadfence();                                             // this block's partial logits are visible device-wide
+    __syncthreads();
+    if (tid == 0) *s_last = atomicAdd(&sm.counters[by], 1u) == (unsigned)(n_col - 1);
+    __syncthreads();
+    if (!*s_last) return;
+    __threadfence();
+    const int N = sm.N, n_parts = H / 128;
+    const int s_end = min(row0 + BM, n_tok) / N;
+    const float bias = sm.b2[0];
+    for (int s_ = row0 / N + wave; s_ < s_end; s_ += Tile::NW) {            // one wave per sample; N <= 256
+        float x[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = e * 64 + lane;
+            x[e] = -INFINITY;
+            if (t < N) {
+                const size_t idx = (size_t)s_ * N + t;
+                float v = bias;
+                for (int p_ = 0; p_ < n_parts; ++p_)             // other workgroups wrote these: read past the L1
+                    v += __hip_atomic_load(logit_part + (size_t)p_ * n_tok + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sm.logits) sm.logits[idx] = v;
+                if (sm.mask && sm.mask[idx] == 0.f) v = NR_NEG_BIG;          // masked_fill_(-9e15)
+                x[e] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = nr_wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[e] = (e * 64 + lane < N) ? expf(x[e] - mx) : 0.f;
+            sum += x[e];
+        }
+        sum = nr_wave_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = e * 64 + lane;
+            if (t < N) sm.w[(size_t)s_ * N + t] = x[e] * inv;
+        }
+    }
+    if (tid == 0) sm.counters[by] = 0;
 }
 
 namespace {
@@ -83,10 +142,12 @@ struct MlpShape { int mi, ni, wc; };
 
 template <int MI, int NI, int WC, bool X3, int STAGES>
 int mlp_launch(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d, const uint16_t* w1_hi,
-               const uint16_t* w1_lo, const float* b1, const float* w2, int H, float* logit_part, hipStream_t st) {
+               const uint16_t* w1_lo, const float* b1, const float* w2, int H, float* logit_part, hipStream_t st,
+               NrMlpSoftmax sm = NrMlpSoftmax{}) {
     using Tile = NrGemmTile<MI, NI, X3, 16, 16, STAGES, WC>;
     size_t lds = Tile::RING_BYTES;
-    const size_t epi = (size_t)WC * Tile::BM * sizeof(float);
+    const size_t epi = 8192 + 16;                                 // sPart (<= 3 KiB) + the last-block flag at 8192
+    static_assert((size_t)WC * Tile::BM * sizeof(float) <= 8192, "the flag sits behind sPart");
     if (lds < epi) lds = epi;
     auto kern = nr_mlp_kernel<MI, NI, WC, X3, STAGES>;
     if (lds > 64 * 1024) {
@@ -94,15 +155,15 @@ int mlp_launch(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid(nr_xcd_chunk_grid((H / Tile::BN) * ((n_tok + Tile::BM - 1) / Tile::BM)));
-    hipLaunchKernelGGL(kern, grid, dim3(128 * WC), lds, st, tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part);
+    hipLaunchKernelGGL(kern, grid, dim3(128 * WC), lds, st, tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, sm);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }
 }  // namespace
 
-extern "C" int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d,
-                                   const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2,
-                                   int H, int prec, float* logit_part, void* stream) {
+static int nr_token_logits_go(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d,
+                              const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2,
+                              int H, int prec, float* logit_part, void* stream, const NrMlpSoftmax& sm) {
     if (!tok_hi || !norm || !w1_hi || !b1 || !w2 || !logit_part) return NR_EINVAL;
     if (n_tok <= 0 || d <= 0 || (d % 64) != 0 || H <= 0 || (H % 128) != 0) return NR_EINVAL;
     if (prec != NR_PREC_BF16 && prec != NR_PREC_BF16X3) return NR_EINVAL;
@@ -118,13 +179,15 @@ extern "C" int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_l
         const int bm = 32 * cand[c].mi, bn = 16 * cand[c].wc * cand[c].ni;
         if (H % bn) continue;
         if (x3 && cand[c].wc == 4) continue;
+        if (sm.counters && (bm % sm.N) != 0) continue;            // fused softmax: whole samples per row tile
         const long wg = (long)((n_tok + bm - 1) / bm) * (H / bn);
         const long cost = ((wg + 255) / 256) * (bm + bn);
         if (best < 0 || cost < best_cost || (cost == best_cost && wg > best_wg)) { best = c; best_cost = cost; best_wg = wg; }
     }
     if (const char* e = nr_tune_env("NR_MLP_SHAPE")) {          // tuning hook: index into the candidate list
         int c = atoi(e);
-        if (c >= 0 && c < 5 && H % (16 * cand[c].wc * cand[c].ni) == 0 && !(x3 && cand[c].wc == 4)) {
+        if (c >= 0 && c < 5 && H % (16 * cand[c].wc * cand[c].ni) == 0 && !(x3 && cand[c].wc == 4) &&
+            !(sm.counters && (32 * cand[c].mi) % sm.N != 0)) {
             best = c;
             best_wg = (long)((n_tok + 32 * cand[c].mi - 1) / (32 * cand[c].mi)) * (H / (16 * cand[c].wc * cand[c].ni));
         }
@@ -136,17 +199,38 @@ extern "C" int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_l
     if (cand[best].mi == MI_ && cand[best].ni == NI_ && cand[best].wc == WC_) {                                               \
         if (x3) {                                                                                                             \
             if constexpr (WC_ == 2) {                                                                                         \
-                return two ? mlp_launch<MI_, NI_, WC_, true, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st) \
-                           : mlp_launch<MI_, NI_, WC_, true, 1>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st); \
+                return two ? mlp_launch<MI_, NI_, WC_, true, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st, sm) \
+                           : mlp_launch<MI_, NI_, WC_, true, 1>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st, sm); \
             }                                                                                                                 \
         } else {                                                                                                              \
-            return two ? mlp_launch<MI_, NI_, WC_, false, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st)    \
-                       : mlp_launch<MI_, NI_, WC_, false, 1>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st);   \
+            return two ? mlp_launch<MI_, NI_, WC_, false, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st, sm)    \
+                       : mlp_launch<MI_, NI_, WC_, false, 1>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st, sm);   \
         }                                                                                                                     \
     }
     NR_MLP_GO(2, 4, 2) NR_MLP_GO(3, 4, 2) NR_MLP_GO(4, 4, 2) NR_MLP_GO(4, 4, 4) NR_MLP_GO(6, 4, 4)
 #undef NR_MLP_GO
     return NR_EUNSUPPORTED;
+}
+
+extern "C" int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d,
+                                   const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2,
+                                   int H, int prec, float* logit_part, void* stream) {
+    return nr_token_logits_go(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, prec, logit_part, stream, NrMlpSoftmax{});
+}
+
+// Scorer MLP AND the masked softmax over each sample's tokens in ONE launch (see NrMlpSoftmax).  n_row_tiles_max: length
+// of `counters` (zeroed by the caller once; the kernel leaves it zeroed).  NR_EUNSUPPORTED: no block shape holds whole
+// samples (the caller then issues nr_token_logits_fwd + nr_token_softmax).
+extern "C" int nr_token_weights_fwd(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_samples, int N, int d,
+                                    const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2, const float* b2,
+                                    int H, int prec, const float* mask, float* logit_part, unsigned int* counters, int n_counters,
+                                    float* w, float* logits, void* stream) {
+    if (!counters || !b2 || !w || n_samples <= 0 || N <= 0) return NR_EINVAL;
+    if (N > 256) return NR_EUNSUPPORTED;
+    const long n_tok = (long)n_samples * N;
+    if (n_counters < (n_tok + 63) / 64) return NR_EINVAL;           // the smallest row tile is 64 tokens
+    NrMlpSoftmax sm{counters, b2, mask, N, w, logits};
+    return nr_token_logits_go(tok_hi, tok_lo, norm, (int)n_tok, d, w1_hi, w1_lo, b1, w2, H, prec, logit_part, stream, sm);
 }
 
 // one wave per sample; N <= 256 tokens

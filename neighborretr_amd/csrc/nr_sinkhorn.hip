@@ -58,8 +58,14 @@ __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel
                                                                               NrSkFinal fin) {
     constexpr int LPL = 128 / SK_EPT;
     NR_CRITICAL_PATH();
-    __shared__ __attribute__((aligned(16))) float s_a[128];
-    __shared__ __attribute__((aligned(16))) float s_b[128];
+    // The scaling vectors live in LDS with every SK_EPT-entry segment shifted by 4 floats: the 4 (2, 8) lanes of a line read
+    // DIFFERENT segments with the same ds_read_b128, and unpadded segments start 128 B apart = on the same banks every other
+    // segment (a 2-way conflict on every read: 512 of the ~650 cycles of a half-iteration were the LDS array, 64 KiB of
+    // redundant reads at 2 x 4 cycles per wave-instruction).  vx(o) = slot of entry o.
+    constexpr int SV_N = 128 + 4 * LPL;
+    auto vx = [](int o) { return o + 4 * (o / SK_EPT); };
+    __shared__ __attribute__((aligned(16))) float s_a[SV_N];
+    __shared__ __attribute__((aligned(16))) float s_b[SV_N];
     const int dir = blockIdx.x;                 // 0: problem on G, 1: problem on G^T
     float* tgt = dir == 0 ? tgt_rows : tgt_cols;
     const int tid = threadIdx.x;
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel
         pr[k] = ok ? xr : -INFINITY;
         pc[k] = ok ? xc : -INFINITY;
     }
-    if (tid < 128) { s_a[tid] = 0.f; s_b[tid] = 0.f; }
+    if (tid < SV_N) { s_a[tid] = 0.f; s_b[tid] = 0.f; }
     __syncthreads();
 
     if (iters > 0) {
@@ -110,14 +116,14 @@ __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) s += __expf(pr[k] - m);
             s = sk_group_sum<LPL>(s);
-            if (live && sub == 0) s_a[line] = norm - (m + __logf(s));
+            if (live && sub == 0) s_a[vx(line)] = norm - (m + __logf(s));
         }
         __syncthreads();
         {
             float x[SK_EPT], m = -INFINITY;
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) {
-                x[k] = pc[k] + s_a[sub * SK_EPT + k];
+                x[k] = pc[k] + s_a[vx(sub * SK_EPT) + k];
                 m = fmaxf(m, x[k]);
             }
             m = sk_group_max<LPL>(m);
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel
 #pragma unroll
             for (int k = 0; k < SK_EPT; ++k) s += __expf(x[k] - m);
             s = sk_group_sum<LPL>(s);
-            if (live && sub == 0) s_b[line] = norm - (m + __logf(s));
+            if (live && sub == 0) s_b[vx(line)] = norm - (m + __logf(s));
         }
         __syncthreads();
     }
@@ -133,16 +139,16 @@ __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel
     // From here on the plan is P_ij = a_i K_ij b_j with scaling vectors a, b (= 1 now): K stays in
     // registers untouched, one half-iteration is  a_i = e^mu / sum_j K_ij b_j  (16 FMAs per thread).
     {
-        const float ul = live ? s_a[line] : 0.f, vl = live ? s_b[line] : 0.f;
+        const float ul = live ? s_a[vx(line)] : 0.f, vl = live ? s_b[vx(line)] : 0.f;
 #pragma unroll
         for (int k = 0; k < SK_EPT; ++k) {
             int o = sub * SK_EPT + k;
-            pr[k] = __expf(pr[k] + ul + s_b[o]);      // -inf entries -> 0
-            pc[k] = __expf(pc[k] + s_a[o] + vl);
+            pr[k] = __expf(pr[k] + ul + s_b[vx(o)]);      // -inf entries -> 0
+            pc[k] = __expf(pc[k] + s_a[vx(o)] + vl);
         }
     }
     __syncthreads();
-    if (tid < 128) { s_a[tid] = 1.f; s_b[tid] = 1.f; }
+    if (tid < SV_N) { s_a[tid] = 1.f; s_b[tid] = 1.f; }
     __syncthreads();
     float a_own = 1.f, b_own = 1.f;
     for (int it = 1; it < iters; ++it) {
@@ -150,24 +156,24 @@ __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel
             float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
 #pragma unroll
             for (int k = 0; k < SK_EPT; k += 4) {
-                f32x4_t f = *reinterpret_cast<const f32x4_t*>(&s_b[sub * SK_EPT + k]);
+                f32x4_t f = *reinterpret_cast<const f32x4_t*>(&s_b[vx(sub * SK_EPT) + k]);
                 r0 += pr[k] * f[0]; r1 += pr[k + 1] * f[1]; r2 += pr[k + 2] * f[2]; r3 += pr[k + 3] * f[3];
             }
             float r = sk_group_sum<LPL>((r0 + r1) + (r2 + r3));
             a_own = live ? mass * __builtin_amdgcn_rcpf(r) : 0.f;
-            if (sub == 0) s_a[line] = a_own;
+            if (sub == 0) s_a[vx(line)] = a_own;
         }
         __syncthreads();
         {   // b_j = e^nu / sum_i K_ij a_i
             float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
 #pragma unroll
             for (int k = 0; k < SK_EPT; k += 4) {
-                f32x4_t f = *reinterpret_cast<const f32x4_t*>(&s_a[sub * SK_EPT + k]);
+                f32x4_t f = *reinterpret_cast<const f32x4_t*>(&s_a[vx(sub * SK_EPT) + k]);
                 c0 += pc[k] * f[0]; c1 += pc[k + 1] * f[1]; c2 += pc[k + 2] * f[2]; c3 += pc[k + 3] * f[3];
             }
             float c = sk_group_sum<LPL>((c0 + c1) + (c2 + c3));
             b_own = live ? mass * __builtin_amdgcn_rcpf(c) : 0.f;
-            if (sub == 0) s_b[line] = b_own;
+            if (sub == 0) s_b[vx(line)] = b_own;
         }
         __syncthreads();
     }
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel
         for (int k = 0; k < SK_EPT; ++k) {
             const int o = sub * SK_EPT + k;
             if (live && o < B) {
-                const float t = sc * pr[k] * s_b[o] + (o == line ? 1.0f - beta : 0.f);
+                const float t = sc * pr[k] * s_b[vx(o)] + (o == line ? 1.0f - beta : 0.f);
                 u -= t * (xg[k] - lse_u);
             }
         }
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel
             if (o < B) {
                 f32x4_t q;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) q[e] = sc * pr[k + e] * s_b[o + e] + (o + e == line ? 1.0f - beta : 0.f);
+                for (int e = 0; e < 4; ++e) q[e] = sc * pr[k + e] * s_b[vx(o) + e] + (o + e == line ? 1.0f - beta : 0.f);
                 *reinterpret_cast<f32x4_t*>(tgt + (size_t)line * B + o) = q;
             }
         }
@@ -319,16 +325,29 @@ static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* 
         // Nearly the whole LDS of the CU is requested (156 of 160 KiB; the static arrays take the rest), although B x 129 floats would do: the solve
         // is a latency chain on ONE workgroup per direction, and no LDS-using workgroup of another kernel (scorer, bank
         // products run beside it in the step) can then be placed on its CU to compete for issue slots and the LDS.
-        const size_t lds = 156 * 1024;                   // + the kernel's static arrays (< 4 KiB)
-        if ((size_t)B * 129 * sizeof(float) > lds) return NR_EUNSUPPORTED;
+        // (never more than the device grants a block, never less than the B x 129 floats the solve needs)
+        static int lds_cap = -1;
+        if (lds_cap < 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) v = 64 * 1024;
+            lds_cap = v;
+        }
+        const size_t need = (size_t)B * 129 * sizeof(float);
+        size_t lds = 156 * 1024;                         // + the kernel's static arrays (< 4 KiB)
+        if (lds + 4096 > (size_t)lds_cap) lds = lds_cap > 4096 ? (size_t)lds_cap - 4096 : 0;
+        if (lds < need) lds = need;
+        if (need + 4096 > (size_t)lds_cap) return NR_EUNSUPPORTED;
         // entries per thread: 16 (1024 threads) / 32 (512) / 64 (256); NR_SINKHORN_EPT overrides (tuning hook)
         int ept = 32;
         if (const char* e = nr_tune_env("NR_SINKHORN_EPT")) ept = atoi(e);
-        if (lds > 64 * 1024) {
+        static size_t attr_set[3] = {0, 0, 0};             // per kernel variant: the dynamic-LDS limit already granted
+        size_t& granted = attr_set[ept == 16 ? 0 : ept == 64 ? 2 : 1];
+        if (lds > 64 * 1024 && lds > granted) {
             const void* k = ept == 16 ? (const void*)nr_sinkhorn_small_kernel<16> : ept == 64 ? (const void*)nr_sinkhorn_small_kernel<64>
                                                                                              : (const void*)nr_sinkhorn_small_kernel<32>;
             hipError_t er = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (er != hipSuccess) return (int)er;
+            granted = lds;
         }
         if (ept == 16) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<16>, dim3(2), dim3(1024), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride, fin);
         else if (ept == 64) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<64>, dim3(2), dim3(256), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride, fin);

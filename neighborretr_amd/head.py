@@ -38,8 +38,7 @@ class ScorerWeights:
 
 def token_weights(prep, mask, sw, n, N, prec, want_logits=False, scale_override=None):
     p = prep if scale_override is None else prep._replace(norm=scale_override)
-    parts = ops.token_logit_parts(p, sw.w1_hi, sw.w1_lo, sw.b1, sw.w2, prec)
-    return ops.token_softmax(parts, sw.b2, mask, n, N, want_logits)
+    return ops.token_weights(p, sw.w1_hi, sw.w1_lo, sw.b1, sw.w2, sw.b2, mask, n, N, prec, want_logits)
 
 
 def similarity_matrix(text_feat, video_feat, text_mask, video_mask, sw_t, sw_v, prec=hip.PREC_BF16X3):
@@ -118,7 +117,7 @@ PAIR_BANK_PRODUCTS = os.environ.get("NR_PAIR_BANK", "0") == "1"
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                  gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None,
                  bank_streams=None, local_stream=None, bank_early=0,
-                 capture_order=((7, 9), (7, 1 << 30)), bank_prepared=None, prepared_out=None, bank_push=None):
+                 capture_order=((7, 7), (7, 1 << 30)), bank_prepared=None, prepared_out=None, bank_push=None):
     """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None).
 
     `join`: optional callable run right before the first use of gt / gv.  Either the caller produces the
@@ -172,13 +171,9 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         yield
         L["pv"] = pv_ = ops.prepare_tokens(video_feat, video_mask, want_lo=lo_b, want_colsum=True)
         yield
-        parts = ops.token_logit_parts(pt_, sw_t.w1_hi, sw_t.w1_lo, sw_t.b1, sw_t.w2, p_mlp)
+        L["w_t"], L["lg_t"] = token_weights(pt_, text_mask, sw_t, B, Nt, p_mlp, keep)
         yield
-        L["w_t"], L["lg_t"] = ops.token_softmax(parts, sw_t.b2, text_mask, B, Nt, keep)
-        yield
-        parts = ops.token_logit_parts(pv_, sw_v.w1_hi, sw_v.w1_lo, sw_v.b1, sw_v.w2, p_mlp)
-        yield
-        L["w_v"], L["lg_v"] = ops.token_softmax(parts, sw_v.b2, video_mask, B, Nv, keep)
+        L["w_v"], L["lg_v"] = token_weights(pv_, video_mask, sw_v, B, Nv, p_mlp, keep)
         yield
         L["S"], L["aux0"] = ops.local_level(pt_, pv_, L["w_t"], L["w_v"], B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
         yield
@@ -207,9 +202,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         else:
             pbv = ops.prepare_tokens(mb_feat_v, mb_mask_v, want_lo=lo_k)
             yield
-        parts = ops.token_logit_parts(pbv, sw_v.w1_hi, sw_v.w1_lo, sw_v.b1, sw_v.w2, p_bank)
-        yield
-        w_bv, lg_bv = ops.token_softmax(parts, sw_v.b2, mb_mask_v, M, Nv, keep)
+        w_bv, lg_bv = token_weights(pbv, mb_mask_v, sw_v, M, Nv, p_bank, keep)
         yield
         if pair_bank:
             return pbv, w_bv, lg_bv, None, None          # the product itself: one launch with the other chain's (below)
@@ -228,9 +221,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         else:
             pbt = ops.prepare_tokens(mb_feat_t, mb_mask_t, want_lo=lo_k)
             yield
-        parts = ops.token_logit_parts(pbt, sw_t.w1_hi, sw_t.w1_lo, sw_t.b1, sw_t.w2, p_bank)
-        yield
-        w_bt, lg_bt = ops.token_softmax(parts, sw_t.b2, mb_mask_t, M, Nt, keep)
+        w_bt, lg_bt = token_weights(pbt, mb_mask_t, sw_t, M, Nt, p_bank, keep)
         yield
         if pair_bank:
             return pbt, w_bt, lg_bt, None, None

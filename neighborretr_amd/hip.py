@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("NR_HIP_LIB") or os.path.join(_HERE, "libnr_hip.so")
 PREC_BF16 = 0
 PREC_BF16X3 = 1
 OUT_FULL, OUT_ROWSUM, OUT_COLSUM = 0, 1, 2
+NR_EINVAL, NR_EUNSUPPORTED = -1, -2          # status codes of include/nr_hip.h
 
 _lib = None
 
@@ -51,6 +52,7 @@ _SIGNATURES = {
     "nr_split_bf16": ([_P, _Z, _P, _P, _P], _I),
     "nr_token_logits_fwd": ([_P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     "nr_token_softmax": ([_P, _I, _P, _P, _I, _I, _P, _P, _P], _I),
+    "nr_token_weights_fwd": ([_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P], _I),
     "nr_local_level_tiles": ([_I, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)], _I),
     "nr_local_level_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),
     "nr_local_level_group_kind": ([_I, _I, _I, _I, _I, _I], _I),

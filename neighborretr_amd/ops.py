@@ -70,6 +70,51 @@ def token_softmax(parts, b2, mask, n_samples, N, want_logits=False):
     return w, logits
 
 
+FUSE_TOKEN_SOFTMAX = True      # scorer MLP + masked softmax in one launch (nr_token_weights_fwd); False: two launches (A/B)
+_SOFTMAX_SLOTS, _SOFTMAX_SLOT_LEN = 16, 4096
+
+
+def _softmax_counters(dev, n_tok):
+    """Zeroed per-row-tile counters for one nr_token_weights_fwd launch.  Scorer launches of one step may run side by side on
+    different streams, so consecutive calls take different slots of a per-device pool (16 slots: a step issues at most six
+    scorer launches; a slot comes round again only behind launches that are ordered after its previous user).  The kernel
+    leaves its counters zeroed."""
+    need = (n_tok + 63) // 64
+    if need > _SOFTMAX_SLOT_LEN:
+        return None
+    key = ("softmax", dev)
+    st = _COUNTERS.get(key)
+    if st is None:
+        st = _COUNTERS[key] = [torch.zeros((_SOFTMAX_SLOTS, _SOFTMAX_SLOT_LEN), dtype=torch.int32, device=dev), 0]
+    st[1] = (st[1] + 1) % _SOFTMAX_SLOTS
+    return st[0][st[1]]
+
+
+def token_weights(prep, w1_hi, w1_lo, b1, w2, b2, mask, n_samples, N, prec, want_logits=False):
+    """Token scorer + masked softmax (modeling.py:485-492): (w [n,N], logits or None).  One launch
+    (nr_token_weights_fwd: the last column block of every row tile does the tile's softmax) when a block shape holds whole
+    samples, else nr_token_logits_fwd + nr_token_softmax."""
+    dev = prep.hi.device
+    counters = _softmax_counters(dev, prep.n_tok) if FUSE_TOKEN_SOFTMAX else None
+    if counters is not None:
+        H = w1_hi.shape[0]
+        parts = torch.empty((H // 128, prep.n_tok), dtype=torch.float32, device=dev)
+        w = torch.empty((n_samples, N), dtype=torch.float32, device=dev)
+        logits = torch.empty((n_samples, N), dtype=torch.float32, device=dev) if want_logits else None
+        m = _f32(mask).contiguous() if mask is not None else None
+        rc = hip.lib().nr_token_weights_fwd(
+            hip.ptr(prep.hi), hip.ptr(prep.lo, allow_none=True), hip.ptr(prep.norm), n_samples, N, prep.d, hip.ptr(w1_hi),
+            hip.ptr(w1_lo, allow_none=True), hip.ptr(b1, torch.float32), hip.ptr(w2, torch.float32), hip.ptr(b2, torch.float32),
+            H, prec, hip.ptr(m, allow_none=True), hip.ptr(parts), hip.ptr(counters), counters.numel(), hip.ptr(w),
+            hip.ptr(logits, allow_none=True), hip.stream_ptr())
+        if rc == 0:
+            return w, logits
+        if rc != hip.NR_EUNSUPPORTED:
+            hip._check("nr_token_weights_fwd", rc)
+    parts = token_logit_parts(prep, w1_hi, w1_lo, b1, w2, prec)
+    return token_softmax(parts, b2, mask, n_samples, N, want_logits)
+
+
 def local_level(prep_t, prep_v, w_t, w_v, A, Nt, Bv, Nv, prec=hip.PREC_BF16, out_mode=hip.OUT_FULL, want_arg=False):
     """Fused token-token similarity (nr_local_level_fwd).  Returns (out, aux); aux = None or
     (arg_v, arg_t, pmax, qmax) kept for the backward pass."""
