@@ -87,17 +87,25 @@ __global__ __launch_bounds__(128 * WC) void nr_mlp_kernel(const uint16_t* __rest
         float v = 0.f;
 #pragma unroll
         for (int q = 0; q < WPP; ++q) v += sPart[(part * WPP + q) * BM + r];
-        logit_part[(size_t)(bx * (BN / 128) + part) * n_tok + row0 + r] = v;
+        float* dst = logit_part + (size_t)(bx * (BN / 128) + part) * n_tok + row0 + r;
+        // fused softmax: another workgroup reads these -> `sc1` stores (written through, no L2 write-back fence needed)
+        if (sm.counters) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = v;
     }
     if (sm.counters == nullptr) return;
     // ---- fused softmax: the last column block of this row tile ----------------------------------------------------
+    // Hand-off without cache-wide fences (a __threadfence() = buffer_wbl2 + buffer_inv costs 3.5-6.5 us per workgroup and
+    // serialises at the L2: measured +25 us per scorer launch): every byte handed off is stored `sc1` (above) and loaded `sc1`
+    // (below), every storing wave drains its stores (vmcnt 0) before the workgroup barrier behind which ONE lane adds to the
+    // tile's counter; the workgroup whose add returned n_col - 1 loads after a barrier that lane has joined
+    // (MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire, first row).
     int* s_last = reinterpret_cast<int*>(smem + 8192);          // behind sPart (<= 3 KiB); the ring is free
-    __threadfence();                                             // this block's partial logits are visible device-wide
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) *s_last = atomicAdd(&sm.counters[by], 1u) == (unsigned)(n_col - 1);
+    if (tid == 0)
+        *s_last = __hip_atomic_fetch_add(&sm.counters[by], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_col - 1);
     __syncthreads();
     if (!*s_last) return;
-    __threadfence();
     const int N = sm.N, n_parts = H / 128;
     const int s_end = min(row0 + BM, n_tok) / N;
     const float bias = sm.b2[0];
@@ -111,8 +119,15 @@ __global__ __launch_bounds__(128 * WC) void nr_mlp_kernel(const uint16_t* __rest
             if (t < N) {
                 const size_t idx = (size_t)s_ * N + t;
                 float v = bias;
-                for (int p_ = 0; p_ < n_parts; ++p_)             // other workgroups wrote these: read past the L1
-                    v += __hip_atomic_load(logit_part + (size_t)p_ * n_tok + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int p0 = 0; p0 < n_parts; p0 += 8) {        // other workgroups wrote these: `sc1` loads, 8 in flight
+                    float pv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        pv[q] = p0 + q < n_parts ? __hip_atomic_load(logit_part + (size_t)(p0 + q) * n_tok + idx, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v += pv[q];
+                }
                 if (sm.logits) sm.logits[idx] = v;
                 if (sm.mask && sm.mask[idx] == 0.f) v = NR_NEG_BIG;          // masked_fill_(-9e15)
                 x[e] = v;
@@ -134,7 +149,7 @@ __global__ __launch_bounds__(128 * WC) void nr_mlp_kernel(const uint16_t* __rest
             if (t < N) sm.w[(size_t)s_ * N + t] = x[e] * inv;
         }
     }
-    if (tid == 0) sm.counters[by] = 0;
+    if (tid == 0) __hip_atomic_store(&sm.counters[by], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 namespace {

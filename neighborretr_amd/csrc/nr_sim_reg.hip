@@ -157,18 +157,15 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
     }
 
     Tile tile;
-    tile.zero();
+    if constexpr (!PP) tile.zero();          // the ping-pong loop clears the accumulators itself, under its first DMA
 #ifdef NR_STAMP
     if (blockIdx.x == 0 && threadIdx.x == 0) nr_stamp_buf[5] = __builtin_readcyclecounter() - t_start;
 #endif
-    if constexpr (PP) tile.run_pp(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
-    else tile.run(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem, rot, p.dma_front != 0);
-#ifdef NR_STAMP
-    if (blockIdx.x == 0 && threadIdx.x == 0) nr_stamp_buf[6] = __builtin_readcyclecounter() - t_start;
-#endif
-    if constexpr (LATE_W) load_weights();
-
     float t2v = 0.f, v2t = 0.f;
+    // The pooling epilogue (registers only: max-pools, weighted sums; in the ARGS form also the arg-max stores).  In the
+    // ping-pong kernels the waves of group 0 (wave row 0) run it inside the K loop's last phase, beside group 1's final MFMAs.
+    auto pool = [&]() {
+    if constexpr (LATE_W) load_weights();
     if constexpr (!ARGS) {
         // Loss-only / evaluation form: only the pooled VALUES are needed, so the pools are plain max chains
         // (v_max3_f32) -- a fifth of the instructions of the arg-tracking form below, which spent ~1000 VALU
@@ -263,6 +260,21 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
     v2t = nr_lanes_sum<FPS>(v2t);
 
     }
+    };      // pool
+
+    if constexpr (PP && !ARGS) {
+        tile.run_pp_tail(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem, [&]() { pool(); });
+        if (wr == 1) pool();
+    } else if constexpr (PP) {               // the arg-tracking epilogue inside the loop would spill (256 VGPRs): behind it
+        tile.run_pp(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
+        pool();
+    } else {
+        tile.run(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem, rot, p.dma_front != 0);
+        pool();
+    }
+#ifdef NR_STAMP
+    if (blockIdx.x == 0 && threadIdx.x == 0) nr_stamp_buf[6] = __builtin_readcyclecounter() - t_start;
+#endif
 
     const float S = 0.5f * (t2v + v2t);
 #ifdef NR_STAMP
@@ -359,8 +371,7 @@ __device__ __forceinline__ void nr_sim_pair_body(const NrSimRegArgs& p0, const N
     park_weights(p0, bx0, by0, w_lds);
     park_weights(p1, bx1, by1, w_lds + WT_N + WV_N);
 
-    Tile tile;
-    tile.zero();
+    Tile tile;                                // cleared inside run_pp_segs
     // the loss-only epilogue of nr_sim_reg_body (pooled values by max chains), on the weights parked at `wl`
     auto epilogue = [&](const NrSimRegArgs& p, int bx, int by, const float* wl) {
         const int ag = by * TA + wr * TAW + al;
@@ -427,7 +438,7 @@ __device__ __forceinline__ void nr_sim_pair_body(const NrSimRegArgs& p0, const N
     const typename Tile::Seg sg[2] = {
         {p0.t_hi, p0.t_lo, by0 * TA * Nt, p0.A * Nt, p0.v_hi, p0.v_lo, bx0 * TB * Nv, p0.Bv * Nv},
         {p1.t_hi, p1.t_lo, by1 * TA * Nt, p1.A * Nt, p1.v_hi, p1.v_lo, bx1 * TB * Nv, p1.Bv * Nv}};
-    tile.template run_pp_segs<2>(sg, p0.K, smem, [&](int) { epilogue(p0, bx0, by0, w_lds); });
+    tile.template run_pp_segs<2>(sg, p0.K, smem, [&](int) { epilogue(p0, bx0, by0, w_lds); }, []() {});
     epilogue(p1, bx1, by1, w_lds + WT_N + WV_N);
 }
 

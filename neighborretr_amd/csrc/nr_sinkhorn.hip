@@ -208,7 +208,7 @@ __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel
             }
         }
         u = sk_group_sum<LPL>(u);
-        if (live && sub == 0) uniform_rows[(size_t)dir * uniform_stride + line] = u;
+        if (live && sub == 0) __hip_atomic_store(uniform_rows + (size_t)dir * uniform_stride + line, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // `sc1`: read by the finalizing workgroup
     }
     if (live && tgt) {
         const float sc = beta * (float)(2 * B) * a_own;
@@ -224,15 +224,14 @@ __global__ __launch_bounds__(128 * (128 / SK_EPT)) void nr_sinkhorn_small_kernel
         }
     }
     if (fin.counter == nullptr) return;
-    __shared__ int s_last;
-    __threadfence();                               // this workgroup's row terms are visible device-wide
+    __shared__ int s_last;                         // hand-off by sc1 stores / loads, no cache-wide fence: see nr_rowloss.hip
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(fin.counter, 1u) == fin.total - 1;
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fin.total - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     nr_loss_finalize_body<true>(uniform_rows - B, B, fin.wu, fin.wn, fin.wkl, fin.losses);
-    if (threadIdx.x == 0) *fin.counter = 0;
+    if (threadIdx.x == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- large-B path ---------------------------------------------------------------------------------
