@@ -227,6 +227,77 @@ int nr_ctm_stage_fwd(const NrCtmStageDesc* problems, int n_problems, void* strea
 #define NR_CTM_STAGE_LAUNCHES 7
 int nr_ctm_stage_fwd_range(const NrCtmStageDesc* problems, int n_problems, int first, int last, void* stream);
 
+/* As nr_ctm_stage_workspace_layout, plus the split-bf16 operands the forward GEMMs read and the backward's weight-gradient
+ * GEMMs need again: [8] kvn_hi [9] kvn_lo  [n*N, C]  norm1(xn);  [10] qn_hi [11] qn_lo  [n*cnum, C]  norm1(merged);
+ * [12] att_hi [13] att_lo  [n*cnum, C]  attention output (input of proj).  offsets: 14 entries.                          */
+int nr_ctm_stage_workspace_layout2(int n_samples, int N, int C, int cluster_num, size_t* offsets);
+
+/* ---- backward of the clustering stage (no counterpart in the reference: PyTorch autograd differentiates cluster.py:453-561,
+ * 689-717, 834-888 op by op; here the hand-derived backward of neighborretr_amd/cluster_backward.py runs as grouped kernels)
+ *
+ * nr_split_group: up to NR_SPLIT_MAX matrices in ONE launch.  mode 0: f32 src [rows, cols] -> bf16 hi/lo [rows, ld]
+ * (ld >= cols, same 64-column tile count; lo may be NULL); mode 1: the same split written TRANSPOSED [cols, ld], ld >= rows,
+ * entries [rows, ld) zero (K padding of a GEMM operand); mode 2: a bf16 PAIR src (hi) / src2 (lo) [rows, cols] -> transposed
+ * [cols, ld].  Used for the per-step re-split of every weight matrix and for the K = token-rows operands of the
+ * weight-gradient GEMMs.                                                                                                   */
+#define NR_SPLIT_MAX 48
+typedef struct NrSplitItem {
+    const void* src;
+    const void* src2;
+    uint16_t *hi, *lo;
+    int32_t rows, cols, mode, ld;
+} NrSplitItem;
+int nr_split_group(int n, const NrSplitItem* items, void* stream);
+
+/* nr_colsum_group: dst[c] = sum_r src[r, c] for up to NR_COLSUM_MAX f32 matrices in one launch (bias gradients, sums of
+ * per-sample partial parameter gradients); fixed summation order.                                                           */
+#define NR_COLSUM_MAX 16
+typedef struct NrColsumItem {
+    const float* src;
+    float* dst;
+    int32_t rows, cols;
+} NrColsumItem;
+int nr_colsum_group(int n, const NrColsumItem* items, void* stream);
+
+/* nr_linear_group: up to 8 independent problems Y = X W^T (+bias) (+residual) of nr_linear_x3's kind in one launch (every
+ * problem tiled with the same block shape; K % 64 == 0 each).                                                               */
+typedef struct NrLinearProblem {
+    const uint16_t *x_hi, *x_lo, *w_hi, *w_lo;
+    const float *bias, *residual;
+    float* out;
+    int32_t M, N, K;
+} NrLinearProblem;
+int nr_linear_group(int n, const NrLinearProblem* problems, void* stream);
+
+/* Score-biased attention backward (cluster.py:868-885) per sample for up to NR_CTM_MAX_GROUP problems: from q [n*cnum,C],
+ * kv [n*N,2C] (k | v), score [n,N] and d_att [n*cnum,C] (gradient of the attention output, = upstream x proj.weight) to
+ * d_q [n*cnum,C], d_kv [n*N,2C] (both also as bf16 pairs, operands of the next GEMMs) and d_score [n,N] (the gradient
+ * reaching the token scores through the attention bias).  N <= 64, C == 64 * heads, heads <= 16.                           */
+typedef struct NrCtmAttnBwdDesc {
+    int32_t n_samples, N, C, cnum, heads;
+    const float *q, *kv, *score, *d_att;
+    float *d_q, *d_kv, *d_score;
+    uint16_t *dq_hi, *dq_lo, *dkv_hi, *dkv_lo;
+} NrCtmAttnBwdDesc;
+int nr_ctm_attn_bwd(int n, const NrCtmAttnBwdDesc* problems, void* stream);
+
+/* The middle of the stage, backward, per sample: norm1 backward of the merged rows (d_qn) and of the token rows (d_kvn),
+ * the block's residual (g), weighted cluster means (cluster.py:536-556; cluster ids `assign` carry no gradient), score / exp
+ * (masked tokens: zero), LayerNorm(ctm) backward.  Writes d_y [n*N,C] (gradient of the conv output) and dcat [n*N,3C] as a
+ * bf16 pair with row m = d_y[m+1] | d_y[m] | d_y[m-1] (zeros across sample ends) -- the A operand of the transposed token
+ * convolution -- and partial [n,6,C]: per-sample sums of d norm1.weight, d norm1.bias, d ctm.norm.weight, d ctm.norm.bias,
+ * d score.weight, and d score.bias in [.,5,0].  merged_pb = cluster means + proj bias (what the forward keeps).            */
+typedef struct NrCtmMidBwdDesc {
+    int32_t n_samples, N, C, cnum;
+    float eps_ctm, eps_n1;
+    const float *d_qn, *d_kvn, *g, *merged_pb, *proj_b, *xn, *y, *tokw, *d_score, *mask, *n1_w, *ln_w, *sc_w;
+    const int64_t* assign;
+    float* d_y;
+    uint16_t *dcat_hi, *dcat_lo;
+    float* partial;
+} NrCtmMidBwdDesc;
+int nr_ctm_mid_bwd(int n, const NrCtmMidBwdDesc* problems, void* stream);
+
 /* Y[M,N] = X[M,K] W[N,K]^T (+ bias[N]) (+ residual[M,N]) in split-bf16 on the MFMA tile engine: the big
  * fp32 GEMMs of the clustering stage (token convolution cluster.py:664, kv projection :866).
  * x_hi/x_lo [M,K], w_hi/w_lo [N,K] bf16 pairs; out [M,N] f32; K % 64 == 0.

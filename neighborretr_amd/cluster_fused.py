@@ -19,30 +19,78 @@ def _p(t, dtype=torch.float32):
     return hip.ptr(t, dtype)
 
 
+def split_group(items):
+    """ONE launch of nr_split_group.  items: (src, src2 or None, hi, lo or None, rows, cols, mode, ld) with tensors."""
+    for lo in range(0, len(items), hip.SPLIT_MAX):
+        chunk = items[lo:lo + hip.SPLIT_MAX]
+        arr = (hip.SplitItem * len(chunk))()
+        for a, (src, src2, hi, lo_, rows, cols, mode, ld) in zip(arr, chunk):
+            for t in (src, src2, hi, lo_):
+                if t is not None and (not t.is_cuda or not t.is_contiguous()):
+                    raise hip.NrHipError("nr_split_group: contiguous GPU tensors only")
+            a.src, a.src2, a.hi, a.lo = _addr(src), _addr(src2), _addr(hi), _addr(lo_)
+            a.rows, a.cols, a.mode, a.ld = int(rows), int(cols), int(mode), int(ld)
+        hip.call("nr_split_group", len(chunk), arr, hip.stream_ptr())
+
+
 class _StageWeights:
-    """Per-stage derived weights (conv kernel as a [3C,C] matrix, transposed linears), rebuilt when
-    any parameter of the stage changed."""
+    """Per-stage derived weights, rebuilt when any parameter of the stage changed: the bf16 hi/lo pairs the split-bf16 GEMMs
+    read -- forward: the conv kernel as a [C, 3C] matrix, kv / q / proj weights [N, K]; backward (input-gradient GEMMs): the
+    TRANSPOSED linears and the transposed convolution [C_in, 3 C_out] -- all written by ONE nr_split_group launch
+    (`items`, issued by build_stage_weights for every stale stage of the step together)."""
 
     def __init__(self, ctm, blk):
-        from . import ops
-        w = ctm.conv.conv.weight.detach()
-        self.wcat = w.permute(2, 1, 0).reshape(3 * w.shape[1], w.shape[0]).contiguous()
-        # [C_out, 3*C_in] = the conv kernel as the W[N,K] operand of nr_linear_x3, split-bf16
-        self.wconv_hi, self.wconv_lo = ops.split_bf16(self.wcat.t().contiguous())
-        self.wkv_hi, self.wkv_lo = ops.split_bf16(blk.attn.kv.weight.detach())
-        self.wq_hi, self.wq_lo = ops.split_bf16(blk.attn.q.weight.detach())
-        self.wp_hi, self.wp_lo = ops.split_bf16(blk.attn.proj.weight.detach())
-        self.wq_t = blk.attn.q.weight.detach().t().contiguous()
-        self.wkv_t = blk.attn.kv.weight.detach().t().contiguous()
-        self.wp_t = blk.attn.proj.weight.detach().t().contiguous()
+        w = ctm.conv.conv.weight.detach()                                        # [C_out, C_in, 3]
+        Co, Ci = w.shape[0], w.shape[1]
+        dev = w.device
+        self.wcat = w.permute(2, 1, 0).reshape(3 * Ci, Co).contiguous()          # fp32 [3 C_in, C_out] (small stages: addmm)
+        wconv = w.permute(0, 2, 1).reshape(Co, 3 * Ci).contiguous()              # [C_out, 3 C_in]: tap k multiplies x[n+k-1]
+        wconv_bt = w.permute(1, 2, 0).reshape(Ci, 3 * Co).contiguous()           # [C_in, 3 C_out]: d x0 = d y + dcat Wbt^T
+        attn = blk.attn
+        wkv, wq, wp = attn.kv.weight.detach(), attn.q.weight.detach(), attn.proj.weight.detach()
+        self.wq_t = wq.t().contiguous()
+        self.wkv_t = wkv.t().contiguous()
+        self.wp_t = wp.t().contiguous()
+        self.items = []
+
+        def pair(name, src, rows, cols, mode):
+            shape = (rows, cols) if mode == 0 else (cols, rows)
+            hi = torch.empty(shape, dtype=torch.int16, device=dev)
+            lo = torch.empty(shape, dtype=torch.int16, device=dev)
+            setattr(self, name + "_hi", hi)
+            setattr(self, name + "_lo", lo)
+            self.items.append((src.contiguous(), None, hi, lo, rows, cols, mode, cols if mode == 0 else rows))
+        pair("wconv", wconv, Co, 3 * Ci, 0)
+        pair("wkv", wkv, wkv.shape[0], wkv.shape[1], 0)
+        pair("wq", wq, wq.shape[0], wq.shape[1], 0)
+        pair("wp", wp, wp.shape[0], wp.shape[1], 0)
+        pair("wconv_bt", wconv_bt, Ci, 3 * Co, 0)
+        pair("wkv_bt", wkv, wkv.shape[0], wkv.shape[1], 1)                       # [C, 2C]: d kvn = d kv Wkv
+        pair("wq_bt", wq, wq.shape[0], wq.shape[1], 1)
+        pair("wp_bt", wp, wp.shape[0], wp.shape[1], 1)
+
+
+def build_stage_weights(cache, stages):
+    """Refreshes the derived weights of several stages -- [(key, ctm, blk), ...] -- with ONE split launch for all that are
+    stale (in training every stage is, after every optimizer step)."""
+    fresh = []
+    for key, ctm, blk in stages:
+        params = list(ctm.parameters()) + list(blk.parameters())
+        ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+        hit = cache.get(key)
+        if hit is None or hit[0] != ver:
+            sw = _StageWeights(ctm, blk)
+            cache[key] = (ver, sw)
+            fresh.append(sw)
+    items = [it for sw in fresh for it in sw.items]
+    if items:
+        split_group(items)
+    for sw in fresh:
+        sw.items = None
 
 
 def _stage_weights(cache, key, ctm, blk):
-    params = list(ctm.parameters()) + list(blk.parameters())
-    ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
-    hit = cache.get(key)
-    if hit is None or hit[0] != ver:
-        cache[key] = (ver, _StageWeights(ctm, blk))
+    build_stage_weights(cache, [(key, ctm, blk)])
     return cache[key][1]
 
 
@@ -119,18 +167,24 @@ def _addr(t):
 
 
 def _workspace_views(ws, B, N, C, cnum):
-    """fp32 views of the intermediates a backward pass needs, inside a stage's workspace (nr_ctm_stage_workspace_layout)."""
+    """Views of the intermediates a backward pass needs, inside a stage's workspace (nr_ctm_stage_workspace_layout2): fp32
+    tensors, and the bf16 pairs (int16) of norm1(xn), norm1(merged) and the attention output the forward GEMMs read."""
     import ctypes
-    off = (ctypes.c_size_t * 8)()
-    hip.call("nr_ctm_stage_workspace_layout", B, N, C, cnum, off)
+    off = (ctypes.c_size_t * 14)()
+    hip.call("nr_ctm_stage_workspace_layout2", B, N, C, cnum, off)
     shapes = {"y": (B, N, C), "xn": (B, N, C), "score": (B, N), "w": (B, N), "merged_pb": (B, cnum, C), "q": (B * cnum, C),
               "kv": (B * N, 2 * C), "smax": (B,)}
+    pairs = {"kvn_hi": (B * N, C), "kvn_lo": (B * N, C), "qn_hi": (B * cnum, C), "qn_lo": (B * cnum, C),
+             "att_hi": (B * cnum, C), "att_lo": (B * cnum, C)}
     out = {}
-    for o, (name, shape) in zip(off, shapes.items()):
+    for o, (name, shape) in zip(off, list(shapes.items()) + list(pairs.items())):
         n = 1
         for k in shape:
             n *= k
-        out[name] = ws[int(o): int(o) + 4 * n].view(torch.float32).view(shape)
+        if name in shapes:
+            out[name] = ws[int(o): int(o) + 4 * n].view(torch.float32).view(shape)
+        else:
+            out[name] = ws[int(o): int(o) + 2 * n].view(torch.int16).view(shape)
     return out
 
 
@@ -209,7 +263,11 @@ def ctm_stage_group(problems, cache, stepwise=False, want_assign=False, want_sav
     return (outs, assigns) if want_assign else outs
 
 
-_SAVED = ("x0", "y", "xn", "score", "w", "assign", "merged_pb", "q", "kv")
+_SAVED = ("x0", "y", "xn", "score", "w", "assign", "merged_pb", "q", "kv", "kvn_hi", "kvn_lo", "qn_hi", "qn_lo", "att_hi", "att_lo")
+# The stage's backward: grouped HIP kernels (cluster_backward_hip.stage_backward_group: both modalities in the same nine
+# launches) or, False / shapes they do not cover, the same arithmetic as torch ops (cluster_backward.stage_backward, ~125
+# launches per modality) -- kept as the reference the kernels are tested against.
+HIP_BACKWARD = True
 # None: two streams inside a capture (6.3 -> 5.3 ms for the captured training step with the fused clustering), one when the
 # step is launched eagerly (the stream switches cost the host more than the overlap returns: 8.4 vs 9.2 ms)
 BACKWARD_ON_TWO_STREAMS = None
@@ -220,6 +278,33 @@ def _backward_stream(device):
     if device not in _BWD_STREAMS:
         _BWD_STREAMS[device] = torch.cuda.Stream(device=device)
     return _BWD_STREAMS[device]
+
+
+def _torch_backward(ctx, saved, g_t, g_v):
+    """cluster_backward.stage_backward (torch ops) for both modalities: the video stage's backward on a side stream beside the
+    text stage's when the step is being captured (~95 small launches each), forked from and joined back into the stream
+    autograd runs this node on."""
+    from .cluster_backward import stage_backward
+    cur = torch.cuda.current_stream()
+    two = BACKWARD_ON_TWO_STREAMS if BACKWARD_ON_TWO_STREAMS is not None else torch.cuda.is_current_stream_capturing()
+    side = _backward_stream(g_t.device) if (two and g_t.is_cuda) else None
+    results = [None, None]
+    with torch.no_grad():
+        for i, ((ctm, blk), sv, g) in enumerate(zip(ctx.modules, saved, (g_t, g_v))):
+            pb = blk.attn.proj.bias
+            if i == 1 and side is not None:
+                wait_stream(side, cur)
+                with torch.cuda.stream(side):
+                    sv["merged"] = sv["merged_pb"] - pb if pb is not None else sv["merged_pb"]
+                    results[i] = stage_backward(ctm, blk, sv, g)
+            else:
+                sv["merged"] = sv["merged_pb"] - pb if pb is not None else sv["merged_pb"]
+                results[i] = stage_backward(ctm, blk, sv, g)
+        if side is not None:
+            wait_stream(cur, side)
+            for t_ in [results[1][0]] + list(results[1][1].values()):
+                t_.record_stream(cur)
+    return results
 
 
 class ClusterStagesFn(torch.autograd.Function):
@@ -236,6 +321,7 @@ class ClusterStagesFn(torch.autograd.Function):
                                                  (keys[1], x_v, mask_v, ctm_v, blk_v, noise_v)], cache, want_saved=True,
                                                 exchange=exchange)
         ctx.modules = modules
+        ctx.cache, ctx.keys = cache, keys
         ctx.masks = tuple(sv["mask"] for sv in saved)
         ctx.n_params = len(params)
         ctx.save_for_backward(*[sv[k] for sv in saved for k in _SAVED])
@@ -243,36 +329,24 @@ class ClusterStagesFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_t, g_v):
-        from .cluster_backward import stage_backward
         tensors = ctx.saved_tensors
         grads_x, grads_p = [], {}
-        # the two modalities are independent: the video stage's backward runs on a side stream beside the text stage's
-        # (~95 small launches each), forked from and joined back into the stream autograd runs this node on
-        cur = torch.cuda.current_stream()
-        two = BACKWARD_ON_TWO_STREAMS if BACKWARD_ON_TWO_STREAMS is not None else torch.cuda.is_current_stream_capturing()
-        side = _backward_stream(g_t.device) if (two and g_t.is_cuda) else None
-        results = [None, None]
-        with torch.no_grad():
-            for i, ((ctm, blk), mask, g) in enumerate(zip(ctx.modules, ctx.masks, (g_t, g_v))):
-                sv = dict(zip(_SAVED, tensors[i * len(_SAVED): (i + 1) * len(_SAVED)]))
-                sv["mask"] = mask
-                pb = blk.attn.proj.bias
-                if i == 1 and side is not None:
-                    wait_stream(side, cur)
-                    with torch.cuda.stream(side):
-                        sv["merged"] = sv["merged_pb"] - pb if pb is not None else sv["merged_pb"]
-                        results[i] = stage_backward(ctm, blk, sv, g)
-                else:
-                    sv["merged"] = sv["merged_pb"] - pb if pb is not None else sv["merged_pb"]
-                    results[i] = stage_backward(ctm, blk, sv, g)
-            if side is not None:
-                wait_stream(cur, side)
-                for t_ in [results[1][0]] + list(results[1][1].values()):
-                    t_.record_stream(cur)
-            for d_x0, gp in results:
-                grads_x.append(d_x0)
-                for p_, gr in gp.items():
-                    grads_p[id(p_)] = gr
+        saved = []
+        for i, mask in enumerate(ctx.masks):
+            sv = dict(zip(_SAVED, tensors[i * len(_SAVED): (i + 1) * len(_SAVED)]))
+            sv["mask"] = mask
+            saved.append(sv)
+        from . import cluster_backward_hip as CBH
+        if HIP_BACKWARD and all(CBH.supported(sv) for sv in saved):
+            with torch.no_grad():
+                results = CBH.stage_backward_group([(ctx.keys[i], ctm, blk, saved[i], g)
+                                                    for i, ((ctm, blk), g) in enumerate(zip(ctx.modules, (g_t, g_v)))], ctx.cache)
+        else:
+            results = _torch_backward(ctx, saved, g_t, g_v)
+        for d_x0, gp in results:
+            grads_x.append(d_x0)
+            for p_, gr in gp.items():
+                grads_p[id(p_)] = gr
         ordered = []
         for ctm, blk in ctx.modules:
             for p_ in list(ctm.parameters()) + list(blk.parameters()):

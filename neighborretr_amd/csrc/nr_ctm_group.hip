@@ -138,6 +138,16 @@ extern "C" int nr_ctm_stage_workspace_layout(int n_samples, int N, int C, int cl
     return NR_OK;
 }
 
+extern "C" int nr_ctm_stage_workspace_layout2(int n_samples, int N, int C, int cluster_num, size_t* offsets) {
+    int rc = nr_ctm_stage_workspace_layout(n_samples, N, C, cluster_num, offsets);
+    if (rc != NR_OK) return rc;
+    char* const base = reinterpret_cast<char*>(4096);
+    const StageBuffers s = carve(base, n_samples, N, C, cluster_num);
+    const void* p[6] = {s.kvn_hi, s.kvn_lo, s.qn_hi, s.qn_lo, s.att_hi, s.att_lo};
+    for (int i = 0; i < 6; ++i) offsets[8 + i] = (size_t)(static_cast<const char*>(p[i]) - base);
+    return NR_OK;
+}
+
 extern "C" int nr_ctm_stage_fwd(const NrCtmStageDesc* d, int n, void* stream) {
     return nr_ctm_stage_fwd_range(d, n, 0, NR_CTM_STAGE_LAUNCHES, stream);
 }

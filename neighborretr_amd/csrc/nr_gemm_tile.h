@@ -328,23 +328,11 @@ struct NrGemmTile {
                                            const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
                                            int b_row0, int b_rows, int K, char* smem) {
         const Seg sg[1] = {{a_hi, a_lo, a_row0, a_rows, b_hi, b_lo, b_row0, b_rows}};
-        run_pp_segs<1>(sg, K, smem, [](int) {}, []() {});
+        run_pp_segs<1>(sg, K, smem, [](int) {});
     }
 
-    // `tail0`: run by the waves of group 0 in the loop's LAST phase, in which they have nothing left to fetch while group 1
-    // issues its final MFMAs -- the register part of group 0's epilogue goes there, beside the busy matrix pipe, instead of
-    // behind the final barrier (group 1 runs its own after the loop).  Must not touch the ring and must not hold a barrier.
-    template <typename Tail0>
-    __device__ __forceinline__ void run_pp_tail(const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
-                                                int a_row0, int a_rows,
-                                                const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
-                                                int b_row0, int b_rows, int K, char* smem, Tail0&& tail0) {
-        const Seg sg[1] = {{a_hi, a_lo, a_row0, a_rows, b_hi, b_lo, b_row0, b_rows}};
-        run_pp_segs<1>(sg, K, smem, [](int) {}, tail0);
-    }
-
-    template <int NSEG, typename Between, typename Tail0>
-    __device__ __forceinline__ void run_pp_segs(const Seg (&sg)[NSEG], int K, char* smem, Between&& between, Tail0&& tail0) {
+    template <int NSEG, typename Between>
+    __device__ __forceinline__ void run_pp_segs(const Seg (&sg)[NSEG], int K, char* smem, Between&& between) {
         static_assert(WC == 4 && STAGES == 2, "ping-pong loop: 2 x 4 waves, two-stage ring");
         static_assert(NSEG == 1 || NSEG == 2, "one tile, or two chained tiles");
         const int tid = threadIdx.x;
@@ -525,7 +513,6 @@ struct NrGemmTile {
                     if (kt + 2 < KT) issue(I0{}, IPB0{}, IP0{}, kt + 2);
                 }
                 frags_in();
-                if (kt + 1 == KT) tail0();                                 // the loop's last phase: group 0 is idle otherwise
             }
         } else {
             if (KT > 1) issue(I1{}, I0{}, IPC1{}, 1);                      // C(-1): own-strip pieces of slice 1

@@ -164,6 +164,8 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
     float t2v = 0.f, v2t = 0.f;
     // The pooling epilogue (registers only: max-pools, weighted sums; in the ARGS form also the arg-max stores).  In the
     // ping-pong kernels the waves of group 0 (wave row 0) run it inside the K loop's last phase, beside group 1's final MFMAs.
+    // (explicit fma in the weighted sums: S must not depend on how the compiler contracts them in one instantiation or
+    // another; tests/test_fullsize_gpu.py holds row / column permutations to bit equality)
     auto pool = [&]() {
     if constexpr (LATE_W) load_weights();
     if constexpr (!ARGS) {
@@ -179,7 +181,7 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
 #pragma unroll
                 for (int n = 1; n < NI; ++n) m = fmaxf(m, tile.acc[i][n][j]);
                 m = nr_lanes_max<FPS>(m);
-                t2v += m * wt[i][j];
+                t2v = __builtin_fmaf(m, wt[i][j], t2v);
             }
         if constexpr (GX >= 2) t2v += __shfl_xor(t2v, 16);
         if constexpr (GX >= 4) t2v += __shfl_xor(t2v, 32);
@@ -192,7 +194,7 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
                 for (int j = 0; j < 4; ++j) m = fmaxf(m, tile.acc[i][n][j]);
             if constexpr (GX >= 2) m = fmaxf(m, __shfl_xor(m, 16));
             if constexpr (GX >= 4) m = fmaxf(m, __shfl_xor(m, 32));
-            v2t += m * wv[n];
+            v2t = __builtin_fmaf(m, wv[n], v2t);
         }
         v2t = nr_lanes_sum<FPS>(v2t);
     } else {
@@ -219,7 +221,7 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
             } else {
                 m = nr_lanes_max<FPS>(m);
             }
-            t2v += m * wt[i][j];
+            t2v = __builtin_fmaf(m, wt[i][j], t2v);
         }
     if constexpr (GX >= 2) t2v += __shfl_xor(t2v, 16);
     if constexpr (GX >= 4) t2v += __shfl_xor(t2v, 32);
@@ -255,23 +257,18 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
                 p.qmax[o] = m;
             }
         }
-        v2t += m * wv[n];
+        v2t = __builtin_fmaf(m, wv[n], v2t);
     }
     v2t = nr_lanes_sum<FPS>(v2t);
 
     }
     };      // pool
 
-    if constexpr (PP && !ARGS) {
-        tile.run_pp_tail(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem, [&]() { pool(); });
-        if (wr == 1) pool();
-    } else if constexpr (PP) {               // the arg-tracking epilogue inside the loop would spill (256 VGPRs): behind it
-        tile.run_pp(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
-        pool();
-    } else {
-        tile.run(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem, rot, p.dma_front != 0);
-        pool();
-    }
+    // (group 0's pooling inside the loop's last phase, beside group 1's final MFMAs, was built and measured: 16.2 / 15.8 us
+    // against 16.1 / 15.4 for the bank products -- nothing; the epilogue stays behind the loop.)
+    if constexpr (PP) tile.run_pp(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
+    else tile.run(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem, rot, p.dma_front != 0);
+    pool();
 #ifdef NR_STAMP
     if (blockIdx.x == 0 && threadIdx.x == 0) nr_stamp_buf[6] = __builtin_readcyclecounter() - t_start;
 #endif
@@ -438,7 +435,7 @@ __device__ __forceinline__ void nr_sim_pair_body(const NrSimRegArgs& p0, const N
     const typename Tile::Seg sg[2] = {
         {p0.t_hi, p0.t_lo, by0 * TA * Nt, p0.A * Nt, p0.v_hi, p0.v_lo, bx0 * TB * Nv, p0.Bv * Nv},
         {p1.t_hi, p1.t_lo, by1 * TA * Nt, p1.A * Nt, p1.v_hi, p1.v_lo, bx1 * TB * Nv, p1.Bv * Nv}};
-    tile.template run_pp_segs<2>(sg, p0.K, smem, [&](int) { epilogue(p0, bx0, by0, w_lds); }, []() {});
+    tile.template run_pp_segs<2>(sg, p0.K, smem, [&](int) { epilogue(p0, bx0, by0, w_lds); });
     epilogue(p1, bx1, by1, w_lds + WT_N + WV_N);
 }
 

@@ -40,6 +40,36 @@ class LocalLevelProblem(ctypes.Structure):
                 + [(n, ctypes.c_int) for n in ("A", "Nt", "Bv", "Nv", "d", "prec", "out_mode")])
 
 
+class SplitItem(ctypes.Structure):
+    """NrSplitItem of include/nr_hip.h."""
+    _fields_ = [("src", _P), ("src2", _P), ("hi", _P), ("lo", _P)] + [(n, ctypes.c_int32) for n in ("rows", "cols", "mode", "ld")]
+
+
+class ColsumItem(ctypes.Structure):
+    """NrColsumItem of include/nr_hip.h."""
+    _fields_ = [("src", _P), ("dst", _P), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
+
+
+class LinearProblem(ctypes.Structure):
+    """NrLinearProblem of include/nr_hip.h."""
+    _fields_ = ([(n, _P) for n in ("x_hi", "x_lo", "w_hi", "w_lo", "bias", "residual", "out")]
+                + [(n, ctypes.c_int32) for n in ("M", "N", "K")])
+
+
+class CtmAttnBwdDesc(ctypes.Structure):
+    """NrCtmAttnBwdDesc of include/nr_hip.h."""
+    _fields_ = ([(n, ctypes.c_int32) for n in ("n_samples", "N", "C", "cnum", "heads")]
+                + [(n, _P) for n in ("q", "kv", "score", "d_att", "d_q", "d_kv", "d_score", "dq_hi", "dq_lo", "dkv_hi", "dkv_lo")])
+
+
+class CtmMidBwdDesc(ctypes.Structure):
+    """NrCtmMidBwdDesc of include/nr_hip.h."""
+    _fields_ = ([(n, ctypes.c_int32) for n in ("n_samples", "N", "C", "cnum")] + [("eps_ctm", _F), ("eps_n1", _F)]
+                + [(n, _P) for n in ("d_qn", "d_kvn", "g", "merged_pb", "proj_b", "xn", "y", "tokw", "d_score", "mask", "n1_w",
+                                     "ln_w", "sc_w", "assign", "d_y", "dcat_hi", "dcat_lo", "partial")])
+
+
+SPLIT_MAX, COLSUM_MAX, LINEAR_GROUP_MAX = 48, 16, 8
 LOCAL_LEVEL_GROUP_MAX = 4
 CTM_MAX_GROUP = 4
 CTM_STAGE_LAUNCHES = 7
@@ -73,6 +103,12 @@ _SIGNATURES = {
     "nr_ctm_back": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
     "nr_ctm_stage_workspace_bytes": ([_I, _I, _I, _I], _Z),
     "nr_ctm_stage_workspace_layout": ([_I, _I, _I, _I, ctypes.POINTER(_Z)], _I),
+    "nr_ctm_stage_workspace_layout2": ([_I, _I, _I, _I, ctypes.POINTER(_Z)], _I),
+    "nr_split_group": ([_I, ctypes.POINTER(SplitItem), _P], _I),
+    "nr_colsum_group": ([_I, ctypes.POINTER(ColsumItem), _P], _I),
+    "nr_linear_group": ([_I, ctypes.POINTER(LinearProblem), _P], _I),
+    "nr_ctm_attn_bwd": ([_I, ctypes.POINTER(CtmAttnBwdDesc), _P], _I),
+    "nr_ctm_mid_bwd": ([_I, ctypes.POINTER(CtmMidBwdDesc), _P], _I),
     "nr_ctm_stage_fwd": ([ctypes.POINTER(CtmStageDesc), _I, _P], _I),
     "nr_ctm_stage_fwd_range": ([ctypes.POINTER(CtmStageDesc), _I, _I, _I, _P], _I),
     "nr_sinkhorn_workspace_bytes": ([_I], _Z),
