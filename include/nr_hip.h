@@ -65,6 +65,19 @@ int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_lo, const fl
                         const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2, int H,
                         int prec, float* logit_part, void* stream);
 
+/* Backward of the token-weight MLP's hidden layer, fused (the reference's autograd does this in ~10 element-wise launches on
+ * [n_tok, H] tensors behind modeling.py:148-153): recomputes h = norm * (tok W1^T) + b1 like nr_token_logits_fwd and writes
+ *   dh = (h > 0) * dl[t] * w2 as bf16 pairs -- transposed into dhT [H, ldT] at columns [t0, t0 + n_tok) (the K = tokens operand
+ *   of dW1 = dh^T X) and, when dh_hi/lo are given, row-major [n_tok, H] (operand of dX = dh W1);
+ *   dw2_part / db1_part [2 * nr_token_mlp_bwd_row_tiles(n_tok), H]: partial column sums of dl * relu(h) and of dh;
+ *   dl_part [2 * row tiles] (may be NULL): partial sums of dl (the gradient of the output bias).
+ * dl [n_tok] f32 = gradient of the logits (0 on masked tokens).                                                            */
+int nr_token_mlp_bwd_row_tiles(int n_tok);
+int nr_token_mlp_bwd_hidden(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d,
+                            const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2, int H, int prec,
+                            const float* dl, uint16_t* dhT_hi, uint16_t* dhT_lo, int ldT, int t0, uint16_t* dh_hi, uint16_t* dh_lo,
+                            float* dw2_part, float* db1_part, float* dl_part, void* stream);
+
 /* masked_fill(-9e15) + softmax over the token axis (modeling.py:486-487 / :491-492).
  *   logit_part [n_parts, n_samples*N]; b2 [1] device; mask [n_samples*N] f32 or NULL;
  *   w [n_samples, N] out; logits [n_samples*N] out or NULL (pre-mask logits, kept for backward) */
@@ -237,7 +250,8 @@ int nr_ctm_stage_workspace_layout2(int n_samples, int N, int C, int cluster_num,
  *
  * nr_split_group: up to NR_SPLIT_MAX matrices in ONE launch.  mode 0: f32 src [rows, cols] -> bf16 hi/lo [rows, ld]
  * (ld >= cols, same 64-column tile count; lo may be NULL); mode 1: the same split written TRANSPOSED [cols, ld], ld >= rows,
- * entries [rows, ld) zero (K padding of a GEMM operand); mode 2: a bf16 PAIR src (hi) / src2 (lo) [rows, cols] -> transposed
+ * entries [rows, min(ld, rows rounded up to 64)) zero (K padding of a GEMM operand; hi / lo may point INTO a wider buffer of
+ * pitch ld at a 64-aligned column); mode 2: a bf16 PAIR src (hi) / src2 (lo) [rows, cols] -> transposed
  * [cols, ld].  Used for the per-step re-split of every weight matrix and for the K = token-rows operands of the
  * weight-gradient GEMMs.                                                                                                   */
 #define NR_SPLIT_MAX 48

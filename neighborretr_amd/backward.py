@@ -52,6 +52,82 @@ def _mlp_backward(feats, dlogits, w1, b1, w2, n_dx, exact):
     return dW1, db1, dW2, db2, dX
 
 
+FUSED_MLP_BACKWARD = True      # False: the torch-op form above (A/B and cross-check)
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def _mlp_backward_hip(jobs):
+    """Backward of the token scorers of BOTH modalities in eight launches (nr_token_mlp_bwd_hidden recomputes the hidden layer
+    like the forward and emits dh as bf16 pairs from its epilogue; the three GEMMs of each scorer run grouped on the tile
+    engine; bias gradients come out of one grouped column sum).  jobs: one dict per modality --
+        sw    head.ScorerWeights of the scorer
+        sets  [(prepared tokens, raw features [n, d] f32, dl [n] f32, precision the FORWARD ran this set in), ...]
+              the batch tokens first, then the bank tokens; dX is returned for the first set's rows
+    Returns [(dW1 [H,d], db1 [H], dW2 [1,H], db2 [1], dX [n_0, d]), ...]."""
+    from .cluster_backward_hip import _colsum_group, _linear_group
+    from .cluster_fused import split_group
+    J = []
+    items = []
+    for job in jobs:
+        sw = job["sw"]
+        H, d = sw.w1_hi.shape
+        dev = sw.w1_hi.device
+        offs, t0 = [], 0
+        for prep, feat, dl, prec in job["sets"]:
+            offs.append(t0)
+            t0 += _pad64(prep.n_tok)
+        ldT = t0
+        exact_fit = all(prep.n_tok % 64 == 0 for prep, _, _, _ in job["sets"])
+        i16 = dict(dtype=torch.int16, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        mk = torch.empty if exact_fit else torch.zeros            # the K padding between / behind the sets must be zeros
+        j = dict(job=job, H=H, d=d, ldT=ldT, offs=offs, dhT_hi=mk((H, ldT), **i16), dhT_lo=mk((H, ldT), **i16),
+                 XT_hi=torch.empty((d, ldT), **i16), XT_lo=torch.empty((d, ldT), **i16))
+        n0 = job["sets"][0][0].n_tok
+        j["dh_hi"], j["dh_lo"] = torch.empty((n0, H), **i16), torch.empty((n0, H), **i16)
+        rows = [2 * int(hip.lib().nr_token_mlp_bwd_row_tiles(prep.n_tok)) for prep, _, _, _ in job["sets"]]
+        j["rows"], R = rows, sum(rows)
+        j["dw2_part"], j["db1_part"], j["dl_part"] = torch.empty((R, H), **f32), torch.empty((R, H), **f32), torch.empty((R, 1), **f32)
+        for name, shape in (("dW1", (H, d)), ("db1", (H,)), ("dW2", (1, H)), ("db2", (1,)), ("dX", (n0, d))):
+            j[name] = torch.empty(shape, **f32)
+        for (prep, feat, dl, prec), off in zip(job["sets"], offs):
+            x = feat.detach().reshape(-1, d).float().contiguous()
+            # X^T of this set at columns [off, off + pad64(n)): the row tiles of the transposed form also write the zero padding
+            items.append((x, None, (j["XT_hi"], off), (j["XT_lo"], off), prep.n_tok, d, 1, ldT))
+        J.append(j)
+    split_group(items)
+    for j in J:
+        sw, r0 = j["job"]["sw"], 0
+        for k, ((prep, feat, dl, prec), off, rows) in enumerate(zip(j["job"]["sets"], j["offs"], j["rows"])):
+            dl = dl.detach().reshape(-1).float().contiguous()
+            first = k == 0
+            hip.call("nr_token_mlp_bwd_hidden", hip.ptr(prep.hi), hip.ptr(prep.lo, allow_none=True), hip.ptr(prep.norm), prep.n_tok,
+                     prep.d, hip.ptr(sw.w1_hi), hip.ptr(sw.w1_lo, allow_none=True), hip.ptr(sw.b1), hip.ptr(sw.w2), j["H"], int(prec),
+                     hip.ptr(dl), hip.ptr(j["dhT_hi"]), hip.ptr(j["dhT_lo"]), j["ldT"], off,
+                     hip.ptr(j["dh_hi"]) if first else None, hip.ptr(j["dh_lo"]) if first else None,
+                     ctypes_ptr(j["dw2_part"], r0 * j["H"]), ctypes_ptr(j["db1_part"], r0 * j["H"]), ctypes_ptr(j["dl_part"], r0),
+                     hip.stream_ptr())
+            r0 += rows
+    # dX = dh W1 (rows of the first set), dW1 = dh^T X (K = all tokens of the modality)
+    _linear_group([(j["dh_hi"], j["dh_lo"]) + j["job"]["sw"].w1_transposed() + (None, None, j["dX"], j["dX"].shape[0], j["d"], j["H"])
+                   for j in J])
+    _linear_group([(j["dhT_hi"], j["dhT_lo"], j["XT_hi"], j["XT_lo"], None, None, j["dW1"], j["H"], j["d"], j["ldT"]) for j in J])
+    cs = []
+    for j in J:
+        R = sum(j["rows"])
+        cs += [(j["dw2_part"], j["dW2"], R, j["H"]), (j["db1_part"], j["db1"], R, j["H"]), (j["dl_part"], j["db2"], R, 1)]
+    _colsum_group(cs)
+    return [(j["dW1"], j["db1"], j["dW2"], j["db2"], j["dX"]) for j in J]
+
+
+def ctypes_ptr(t, elem_offset):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + 4 * int(elem_offset))
+
+
 class HeadLossFn(torch.autograd.Function):
     """Fused _compute_losses (modeling.py:314-360) given the global tokens."""
 
@@ -69,6 +145,7 @@ class HeadLossFn(torch.autograd.Function):
                                        bank_streams=model._bank_streams(text_feat.device),
                                        **model._global_scorers(text_feat, video_feat))
         ctx.sv, ctx.hp, ctx.exact = sv, dict(hp), prec == hip.PREC_BF16X3
+        ctx.model, ctx.plan = model, head.precision_plan(prec)
         ctx.masks = (text_mask, video_mask)
         ctx.shapes = (text_feat.shape, video_feat.shape, mb_feat_t.shape, mb_feat_v.shape, gt.shape, gv.shape)
         sv["gt2"], sv["gv2"] = sv["gt2"].reshape(-1, sv["gt2"].shape[-1]), sv["gv2"].reshape(-1, sv["gv2"].shape[-1])
@@ -140,11 +217,19 @@ class HeadLossFn(torch.autograd.Function):
         dl_v = ops.token_softmax_bwd(sv["w_v"], d_wv.view(B, Nv))
         dl_bt = ops.token_softmax_bwd(sv["w_bt"], d_wbt.view(M, Nt))
         dl_bv = ops.token_softmax_bwd(sv["w_bv"], d_wbv.view(M, Nv))
-        dW1t, db1t, dW2t, db2t, dXt = _mlp_backward([text_feat, mb_feat_t], [dl_t, dl_bt], w1t, b1t, w2t, B * Nt, ctx.exact)
-        dW1v, db1v, dW2v, db2v, dXv = _mlp_backward([video_feat, mb_feat_v], [dl_v, dl_bv], w1v, b1v, w2v, B * Nv, ctx.exact)
+        if FUSED_MLP_BACKWARD:
+            _, p_mlp, p_bank = ctx.plan
+            (dW1t, db1t, dW2t, db2t, dXt), (dW1v, db1v, dW2v, db2v, dXv) = _mlp_backward_hip([
+                dict(sw=ctx.model.scorer_weights("text_weight_fc"),
+                     sets=[(pt, text_feat, dl_t, p_mlp), (pbt, mb_feat_t, dl_bt, p_bank)]),
+                dict(sw=ctx.model.scorer_weights("video_weight_fc"),
+                     sets=[(pv, video_feat, dl_v, p_mlp), (pbv, mb_feat_v, dl_bv, p_bank)])])
+        else:
+            dW1t, db1t, dW2t, db2t, dXt = _mlp_backward([text_feat, mb_feat_t], [dl_t, dl_bt], w1t, b1t, w2t, B * Nt, ctx.exact)
+            dW1v, db1v, dW2v, db2v, dXv = _mlp_backward([video_feat, mb_feat_v], [dl_v, dl_bv], w1v, b1v, w2v, B * Nv, ctx.exact)
         d_text = d_text + dXt.view_as(d_text)
         d_video = d_video + dXv.view_as(d_video)
-        ctx.sv = None
+        ctx.sv = ctx.model = None
         return (None, None, None, None, None, None, None, None,
                 d_text, d_video, d_gt, d_gv, d_ls,
                 dW1t, db1t, dW2t, db2t, dW1v, db1v, dW2v, db2v, *g1)

@@ -25,10 +25,15 @@ def split_group(items):
         chunk = items[lo:lo + hip.SPLIT_MAX]
         arr = (hip.SplitItem * len(chunk))()
         for a, (src, src2, hi, lo_, rows, cols, mode, ld) in zip(arr, chunk):
+            off = 0
+            if isinstance(hi, tuple):                    # (tensor, element offset): write into a wider buffer of pitch ld
+                (hi, off), lo_ = hi, (lo_[0] if lo_ is not None else None)
             for t in (src, src2, hi, lo_):
                 if t is not None and (not t.is_cuda or not t.is_contiguous()):
                     raise hip.NrHipError("nr_split_group: contiguous GPU tensors only")
-            a.src, a.src2, a.hi, a.lo = _addr(src), _addr(src2), _addr(hi), _addr(lo_)
+            a.src, a.src2 = _addr(src), _addr(src2)
+            a.hi = hi.data_ptr() + 2 * off
+            a.lo = None if lo_ is None else lo_.data_ptr() + 2 * off
             a.rows, a.cols, a.mode, a.ld = int(rows), int(cols), int(mode), int(ld)
         hip.call("nr_split_group", len(chunk), arr, hip.stream_ptr())
 

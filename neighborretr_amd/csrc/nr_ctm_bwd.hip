@@ -104,8 +104,10 @@ extern "C" int nr_split_group(int n, const NrSplitItem* items, void* stream) {
         if (it.mode ? it.ld < it.rows : it.ld < it.cols) return NR_EINVAL;
         g.it[i] = it;
         g.start[i] = total;
-        // transposed: row tiles cover [0, ld) so that the padding rows are written (zeros)
-        const int row_tiles = it.mode ? (it.ld + 63) / 64 : (it.rows + 63) / 64;
+        // transposed: the item's row tiles cover [0, rows rounded up to 64) of its destination columns -- the K padding of a
+        // GEMM operand, written as zeros (clipped at ld); a caller that packs several items side by side into one wide buffer
+        // gives each a 64-aligned start
+        const int row_tiles = (it.rows + 63) / 64;
         const int col_tiles = it.mode ? (it.cols + 63) / 64 : (it.ld + 63) / 64;
         total += row_tiles * col_tiles;
     }

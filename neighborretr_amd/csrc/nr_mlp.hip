@@ -248,6 +248,149 @@ extern "C" int nr_token_weights_fwd(const uint16_t* tok_hi, const uint16_t* tok_
     return nr_token_logits_go(tok_hi, tok_lo, norm, (int)n_tok, d, w1_hi, w1_lo, b1, w2, H, prec, logit_part, stream, sm);
 }
 
+// ---- backward of the scorer MLP, hidden layer (no counterpart in the reference: autograd differentiates modeling.py:148-153) ----
+// Recomputes h = ||x|| (x_hat W1^T) + b1 exactly as the forward did (same tile engine, same precision plan) and turns the
+// upstream gradient of the logits into the gradient of the hidden layer IN THE EPILOGUE -- the [n_tok, H] activations never
+// exist in fp32, and nothing element-wise is left for the host:
+//     dh[t, c]  = h > 0 ? dl[t] * w2[c] : 0          -> bf16 pair, TRANSPOSED [H, ldT] at column t0 + t (operand of dW1 = dh^T X,
+//                                                       K = tokens) and, for the rows that need dX = dh W1, row-major [n_tok, H]
+//     dW2[c]    = sum_t dl[t] * relu(h[t, c]),   db1[c] = sum_t dh[t, c]   as per-wave-row partial sums [2 * row tiles, H]
+template <int MI, int NI, int WC, bool X3, int STAGES>
+__global__ __launch_bounds__(128 * WC) void nr_mlp_bwd_hidden_kernel(const uint16_t* __restrict__ tok_hi, const uint16_t* __restrict__ tok_lo,
+                                                                     const float* __restrict__ norm, int n_tok, int d,
+                                                                     const uint16_t* __restrict__ w1_hi, const uint16_t* __restrict__ w1_lo,
+                                                                     const float* __restrict__ b1, const float* __restrict__ w2, int H,
+                                                                     const float* __restrict__ dl, uint16_t* __restrict__ dhT_hi,
+                                                                     uint16_t* __restrict__ dhT_lo, int ldT, int t0,
+                                                                     uint16_t* __restrict__ dh_hi, uint16_t* __restrict__ dh_lo,
+                                                                     float* __restrict__ dw2_part, float* __restrict__ db1_part,
+                                                                     float* __restrict__ dl_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Tile = NrGemmTile<MI, NI, X3, 16, 16, STAGES, WC>;
+    constexpr int BM = Tile::BM, BN = Tile::BN;
+    constexpr int WCOLS = 16 * NI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int n_col = H / BN;
+    const int tile_id = nr_xcd_chunk_tile(blockIdx.x, n_col * ((n_tok + BM - 1) / BM));
+    if (tile_id < 0) return;
+    const int bx = tile_id % n_col, by = tile_id / n_col;
+    const int row0 = by * BM, col0 = bx * BN;
+
+    Tile tile;
+    tile.zero();
+    tile.run(tok_hi, tok_lo, row0, n_tok, w1_hi, w1_lo, col0, H, d, smem);
+
+    float s_dl = 0.f;
+    float s_w2[NI], s_b1[NI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n) s_w2[n] = s_b1[n] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MI; ++m) {
+        const int rb = row0 + wr * 16 * MI + m * 16 + (lane >> 4) * 4;          // this lane's 4 consecutive rows
+        float sc[4], dlr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool on = rb + j < n_tok;
+            sc[j] = on ? norm[rb + j] : 0.f;
+            dlr[j] = on ? dl[rb + j] : 0.f;
+            s_dl += dlr[j];
+        }
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            const int c = col0 + wc * WCOLS + n * 16 + (lane & 15);
+            const float bb = b1[c], ww = w2[c];
+            uint16_t hb[4], lb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float h = tile.acc[m][n][j] * sc[j] + bb;
+                const float dh = h > 0.f ? dlr[j] * ww : 0.f;
+                s_w2[n] += dlr[j] * fmaxf(h, 0.f);
+                s_b1[n] += dh;
+                hb[j] = nr_f2bf(dh);
+                lb[j] = nr_f2bf(dh - nr_bf2f(hb[j]));
+                if (dh_hi && rb + j < n_tok) {
+                    dh_hi[(size_t)(rb + j) * H + c] = hb[j];
+                    dh_lo[(size_t)(rb + j) * H + c] = lb[j];
+                }
+            }
+            // four consecutive tokens of hidden unit c: one 8-byte store each into the transposed pair (rows past n_tok: zeros)
+            if (rb < n_tok) {
+                const size_t o = (size_t)c * ldT + t0 + rb;
+                if (rb + 3 < n_tok && ((t0 + rb) & 3) == 0) {
+                    *reinterpret_cast<uint2*>(dhT_hi + o) = uint2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)};
+                    *reinterpret_cast<uint2*>(dhT_lo + o) = uint2{(uint32_t)lb[0] | ((uint32_t)lb[1] << 16), (uint32_t)lb[2] | ((uint32_t)lb[3] << 16)};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (rb + j < n_tok) { dhT_hi[o + j] = hb[j]; dhT_lo[o + j] = lb[j]; }
+                }
+            }
+        }
+    }
+    // column sums over this wave's 16 * MI rows: lanes l, l+16, l+32, l+48 hold the same column
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+        float a = s_w2[n], b = s_b1[n];
+        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+        if (lane < 16) {
+            const int c = col0 + wc * WCOLS + n * 16 + lane;
+            dw2_part[(size_t)(2 * by + wr) * H + c] = a;
+            db1_part[(size_t)(2 * by + wr) * H + c] = b;
+        }
+    }
+    // d b2 = sum of dl: the first column block's first wave column adds up its rows (lanes 0, 16, 32, 48 hold distinct rows)
+    if (dl_part && bx == 0 && wc == 0) {
+        float a = (lane & 15) == 0 ? s_dl : 0.f;
+        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        if (lane == 0) dl_part[2 * by + wr] = a;
+    }
+}
+
+namespace {
+template <int MI, int NI, int WC, bool X3, int STAGES>
+int mlp_bwd_launch(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d, const uint16_t* w1_hi,
+                   const uint16_t* w1_lo, const float* b1, const float* w2, int H, const float* dl, uint16_t* dhT_hi, uint16_t* dhT_lo,
+                   int ldT, int t0, uint16_t* dh_hi, uint16_t* dh_lo, float* dw2_part, float* db1_part, float* dl_part, hipStream_t st) {
+    using Tile = NrGemmTile<MI, NI, X3, 16, 16, STAGES, WC>;
+    const size_t lds = Tile::RING_BYTES;
+    auto kern = nr_mlp_bwd_hidden_kernel<MI, NI, WC, X3, STAGES>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(nr_xcd_chunk_grid((H / Tile::BN) * ((n_tok + Tile::BM - 1) / Tile::BM)));
+    hipLaunchKernelGGL(kern, grid, dim3(128 * WC), lds, st, tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, dl, dhT_hi, dhT_lo,
+                       ldT, t0, dh_hi, dh_lo, dw2_part, db1_part, dl_part);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+}  // namespace
+
+// Row tiles of nr_token_mlp_bwd_hidden for n_tok tokens: dw2_part / db1_part hold 2 * this many rows of H floats.
+extern "C" int nr_token_mlp_bwd_row_tiles(int n_tok) { return n_tok > 0 ? (n_tok + 127) / 128 : 0; }
+
+extern "C" int nr_token_mlp_bwd_hidden(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d,
+                                       const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2, int H, int prec,
+                                       const float* dl, uint16_t* dhT_hi, uint16_t* dhT_lo, int ldT, int t0, uint16_t* dh_hi,
+                                       uint16_t* dh_lo, float* dw2_part, float* db1_part, float* dl_part, void* stream) {
+    if (!tok_hi || !norm || !w1_hi || !b1 || !w2 || !dl || !dhT_hi || !dhT_lo || !dw2_part || !db1_part) return NR_EINVAL;
+    if ((dh_hi == nullptr) != (dh_lo == nullptr)) return NR_EINVAL;
+    if (n_tok <= 0 || d <= 0 || (d % 64) != 0 || H <= 0 || (H % 128) != 0 || t0 < 0 || ldT < t0 + n_tok) return NR_EINVAL;
+    if (prec != NR_PREC_BF16 && prec != NR_PREC_BF16X3) return NR_EINVAL;
+    if (prec == NR_PREC_BF16X3 && (!tok_lo || !w1_lo)) return NR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // 128 x 128 blocks on 4 waves (the partial-sum layout is tied to BM = 128); two-deep ring unless the grid is crowded
+    const long wg = (long)((n_tok + 127) / 128) * (H / 128);
+    const bool two = wg < 3 * 256;
+    if (prec == NR_PREC_BF16X3)
+        return two ? mlp_bwd_launch<4, 4, 2, true, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, dl, dhT_hi, dhT_lo, ldT, t0, dh_hi, dh_lo, dw2_part, db1_part, dl_part, st)
+                   : mlp_bwd_launch<4, 4, 2, true, 1>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, dl, dhT_hi, dhT_lo, ldT, t0, dh_hi, dh_lo, dw2_part, db1_part, dl_part, st);
+    return two ? mlp_bwd_launch<4, 4, 2, false, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, dl, dhT_hi, dhT_lo, ldT, t0, dh_hi, dh_lo, dw2_part, db1_part, dl_part, st)
+               : mlp_bwd_launch<4, 4, 2, false, 1>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, dl, dhT_hi, dhT_lo, ldT, t0, dh_hi, dh_lo, dw2_part, db1_part, dl_part, st);
+}
+
 // one wave per sample; N <= 256 tokens
 __global__ __launch_bounds__(256) void nr_token_softmax_kernel(const float* __restrict__ logit_part, int n_parts,
                                                                const float* __restrict__ b2, const float* __restrict__ mask,

@@ -34,6 +34,19 @@ class ScorerWeights:
         self.b1 = b1.detach().float().contiguous()
         self.w2 = w2.detach().float().reshape(-1).contiguous()
         self.b2 = b2.detach().float().reshape(1).contiguous()
+        self._w1 = w1.detach()
+        self._w1t = None
+
+    def w1_transposed(self):
+        """bf16 pair of W1^T [d, H]: the operand of dX = dh W1 in the scorer's backward (built on first use per version)."""
+        if self._w1t is None:
+            from .cluster_fused import split_group
+            H, d = self._w1.shape
+            hi = torch.empty((d, H), dtype=torch.int16, device=self._w1.device)
+            lo = torch.empty((d, H), dtype=torch.int16, device=self._w1.device)
+            split_group([(self._w1.float().contiguous(), None, hi, lo, H, d, 1, H)])
+            self._w1t = (hi, lo)
+        return self._w1t
 
 
 def token_weights(prep, mask, sw, n, N, prec, want_logits=False, scale_override=None):

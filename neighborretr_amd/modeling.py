@@ -118,15 +118,12 @@ class NeighborRetr(nn.Module):
         self.bank_early = 2                 # bank chains started beside the clustering instead of the Sinkhorn (0..2)
         self.group_clustering = True        # text + video clustering in the same launches (no-grad forward)
         self.fuse_clustering = True
-        # training: fused clustering forward + recompute backward (cluster_fused.ClusterStagesFn).  Correct (gradient
-        # parity tests run it) but OFF by default: the recompute runs text and video one after the other on one stream,
-        # 7.0 ms per graph-captured training step against 4.1 ms with the autograd-traced forward on two side streams
-        # (tools/train_times.py, MI355X)
-        # Training step: clustering forward on the grouped HIP kernels + hand-derived backward (cluster_backward.py) or the
-        # autograd-traced torch ops on two side streams.  None = by how the step is launched: launched eagerly (DDP steps,
-        # whose collectives keep them out of a graph) the fused form is host-bound on ~50 launches less (8.3 vs 11.0 ms);
-        # replayed from a captured graph the traced form's two side streams overlap and win (4.2 vs 6.6 ms).
-        self.fused_training_clustering = None
+        # Training step: clustering forward on the grouped HIP kernels + the stage backward as grouped HIP kernels too
+        # (cluster_fused.ClusterStagesFn -> cluster_backward_hip: nine launches per stage for both modalities) -- the default,
+        # launched eagerly (5.3 ms against 11.8 with the autograd-traced torch ops) and replayed from a captured graph (3.6 against
+        # 4.2) alike (tools/train_times.py, MI355X, round 3).  False: the autograd-traced torch ops of cluster.py on two side
+        # streams, kept as the cross-check of the gradient tests.  (None is accepted as "default" for older callers.)
+        self.fused_training_clustering = True
         self.shard_clustering = True               # with the sharded loss: every rank clusters its own samples only
         self._ctm_cache = {}
 
@@ -419,8 +416,7 @@ class NeighborRetr(nn.Module):
 
             self._join_global = self._merge_grouped_steps(text_feat, video_feat, text_mask, video_mask, nz)
         elif (text_feat.is_cuda and self.fuse_clustering and torch.is_grad_enabled()
-              and (self.fused_training_clustering if self.fused_training_clustering is not None
-                   else not torch.cuda.is_current_stream_capturing())
+              and (self.fused_training_clustering is None or self.fused_training_clustering)
               and text_feat.shape[1] <= 64 and video_feat.shape[1] <= 64 and text_feat.shape[2] % 128 == 0):
             # training step: the clustering forward on the grouped HIP kernels, the backward hand-derived from what they
             # leave in their workspaces (cluster_fused.ClusterStagesFn, cluster_backward.stage_backward)
@@ -458,13 +454,12 @@ class NeighborRetr(nn.Module):
 
     @contextlib.contextmanager
     def graph_capture_mode(self):
-        """For the warm-up AND the capture of a training step as a HIP graph: pins the choices that otherwise follow the launch
-        mode (`fused_training_clustering` = None) to the captured form, so that the warm-up runs exactly the kernels -- and
-        initialises exactly the library handles -- the capture will record (hipBLASLt refuses to set itself up inside a
-        capture)."""
+        """For the warm-up AND the capture of a training step as a HIP graph: the warm-up must run exactly the kernels -- and
+        initialise exactly the library handles -- the capture will record (hipBLASLt refuses to set itself up inside a capture).
+        Every choice of the training step is now independent of the launch mode, so this only pins `fused_training_clustering`
+        against a change between warm-up and capture."""
         old = self.fused_training_clustering
-        if old is None:
-            self.fused_training_clustering = False
+        self.fused_training_clustering = True if old is None else old
         try:
             yield self
         finally:
