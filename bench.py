@@ -51,8 +51,11 @@ def parse():
                     help="collective backend for N>1 (nccl = RCCL; gloo only to rehearse ranks that share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard_loss", action="store_true",
-                    help="N>1 only: similarity / bank work sharded over the ranks (head.head_forward_sharded) instead of "
-                         "the reference's replicated loss; runs eagerly (its collectives are not graph-captured)")
+                    help="N>1: similarity / bank / clustering work sharded over the ranks (head.head_forward_sharded) -- the DEFAULT "
+                         "for N>1 since round 3 (kept as a flag for older command lines)")
+    ap.add_argument("--replicated_loss", action="store_true",
+                    help="N>1: the reference's form instead (modeling.py:274-298): after the all-gather every rank evaluates the whole "
+                         "loss; the exchange step stays eager, the loss is replayed from a HIP graph")
     ap.add_argument("--backward", action="store_true", help="also time forward+backward (reported as extra fields)")
     ap.add_argument("--e2e", action="store_true",
                     help="also time BASELINE configs[4] on this GPU: ViT-B/32 towers + temporal transformer (stock PyTorch-ROCm, "
@@ -298,9 +301,9 @@ def main():
     b = c["B"] // world
     model = build_model(args.precision, dev)
     model.config.world_size, model.config.local_rank = world, rank
-    if args.shard_loss and world > 1:
-        model.shard_loss = True
-        args.no_graph = True
+    sharded = world > 1 and not args.replicated_loss
+    if world > 1:
+        model.shard_loss = sharded
     full = synth.make_problem(1002, c["B"], c["Nt"], c["Nv"], c["M"])
     sl = slice(rank * b, (rank + 1) * b)
     shard = {k: torch.from_numpy(full[k][sl]).to(dev) for k in ("text_feat", "video_feat", "text_mask", "video_mask", "idx")}
@@ -310,25 +313,30 @@ def main():
     model.mb_ind = torch.arange(10 ** 6, 10 ** 6 + c["M"], device=dev)
     result = {}          # the step's [5] loss vector; inside a captured graph it lives in the graph's own pool
 
-    def step():
-        with torch.no_grad():
-            losses = model(shard["text_feat"], shard["text_mask"], shard["video_feat"], shard["video_mask"], shard["idx"], 0)
-            result["losses"] = _as_vector(losses)
-
     def _as_vector(losses):
         base = losses[0]._base                  # the five scalars are views of one [5] tensor
         return base if base is not None and base.numel() == 5 else torch.stack(losses)
+
+    def step():
+        """The WHOLE step through the model's forward: [N>1: packed all-gather ->] losses -> bank push."""
+        with torch.no_grad():
+            losses = model(shard["text_feat"], shard["text_mask"], shard["video_feat"], shard["video_mask"], shard["idx"], 0)
+            result["losses"] = _as_vector(losses)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- HIP-graph capture.  N=1: the whole step.  N>1: the exchange step (one packed all-gather) stays
-    # eager on the collective stream and fills static buffers; everything after it is replayed from a graph.
+    # ---- HIP-graph capture.  N = 1: the whole step.  N > 1, sharded loss (default): the whole step INCLUDING its collectives
+    # (packed all-gather, the clustering's max exchange, the gathers of global tokens / centralities, the row-term all-reduce) as
+    # ONE graph -- RCCL collectives capture and replay on this runtime (tools/rccl_capture_probe.py); the replay is checked
+    # against the eager step before it is trusted, anything else falls back to eager launches.  N > 1, --replicated_loss: the
+    # exchange step eager into static buffers, the loss replayed from a graph (round 2's form).
     graph = None
     static = None
-    if world > 1:
+    whole_step_graph = world == 1 or (sharded and args.backend == "nccl")
+    if world > 1 and not sharded:
         from neighborretr_amd.dist import packed_allgather
 
         def gather():
@@ -350,17 +358,42 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    if not args.no_graph:
+    abi_calls = None
+    if rank == 0:                         # launches of one eager step: C-ABI entry-point calls (a grouped stage call = up to 7 kernels)
+        before = hip.N_CALLS
+        step()
+        torch.cuda.synchronize()
+        abi_calls = hip.N_CALLS - before
+    elif world > 1:
+        step()
+    if not args.no_graph and (whole_step_graph or not sharded):
         try:
+            if world > 1 and whole_step_graph:
+                # trust the captured collectives only after a replay has reproduced the eager step (frozen bank: same inputs)
+                model.bank_frozen = True
+                step()
+                eager = result["losses"].clone()
+                gv_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gv_):
+                    step()
+                gv_.replay()
+                torch.cuda.synchronize()
+                ok = torch.tensor([float(torch.allclose(result["losses"], eager, rtol=1e-5, atol=1e-6))], device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                model.bank_frozen = False
+                if float(ok.item()) != 1.0:
+                    raise RuntimeError(f"replayed sharded step differs from the eager one: {result['losses'].tolist()} vs {eager.tolist()}")
+                del gv_
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                (step if world == 1 else after_gather)()
+                (step if whole_step_graph else after_gather)()
             graph = g
         except Exception as e:          # graphs are an optimisation, never a requirement
             print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
+            model.bank_frozen = False
             torch.cuda.synchronize()
-    run = graph.replay if (graph is not None and world == 1) else step
+    run = graph.replay if (graph is not None and whole_step_graph) else step
 
     # Clock ramp: the first ~0.1 s of back-to-back steps after an idle period run 10 % slower than the steady state (measured:
     # 0.361 ms/step for the first 200 steps after a 20-step warm-up, 0.324 for every later 200) -- the chip has to leave its
@@ -539,10 +572,11 @@ def main():
             "value": round(args.steps / dt, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "abi_calls_per_rank_step": abi_calls,
             "config": {"workload": "BASELINE configs[1]: B=128 d=512 Nt=24 Nv=12 M=512 K=20 (MSR-VTT shape), "
                                    "loss-only forward incl. token clustering and bank push",
                        "global_batch": c["B"], "per_rank_batch": b, "precision_plan": args.precision,
-                       "hip_graph": graph is not None, "parallelism": f"dp{world} (all-gather + " + ("sharded loss)" if (args.shard_loss and world > 1) else "replicated loss)"),
+                       "hip_graph": graph is not None, "parallelism": f"dp{world} (packed all-gather + " + ("loss, bank and clustering work sharded over the ranks, collectives inside the graph)" if sharded else "replicated loss)"),
                        "memory_bank": "ring (device head) + persistent prepared bf16 shadow, extended by the batch rows at every push"},
             "losses": [round(float(x), 5) for x in losses],
             "ms_per_step_min": round(min(rep_ms), 4), "ms_per_step_median": round(float(np.median(rep_ms)), 4),

@@ -432,13 +432,21 @@ def _rows(prep, first, count):
 
 def head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                          gt, gv, sw_t, sw_v, hp, logit_scale, prec, rank, world, bank_prepared=None, prepared_out=None,
-                         sw_t1=None, sw_v1=None):
+                         sw_t1=None, sw_v1=None, join=None, local_stream=None):
     """Loss-only forward with the similarity and bank work SHARDED over `world` ranks: rank r owns the
     samples [r*b, (r+1)*b) of the gathered batch and computes the two slabs of S it needs for its rows of either
     direction (2/W of the batch x batch product), its slice of both bank centrality vectors (1/W of the bank
     products) and its rows of the row losses.  Exchanged: the centrality slices (one all-gather of 2b floats) and
     the row terms (one all-reduce of 8B floats); the token scorers, the global logits and the Sinkhorn solve are
-    small and stay replicated.  Returns the same [5] losses on every rank as head_forward."""
+    small and stay replicated.  Returns the same [5] losses on every rank as head_forward.
+
+    `join` (gt = gv = None): callable that produces the global tokens -- the rank's share of the clustering plus the
+    all-gather of the [b, c, d] tokens -- on the CURRENT stream, while the local branch (prepare, scorers, the four
+    products) runs on `local_stream`; the global logits and the Sinkhorn solve follow the clustering without waiting for
+    the local branch.  Both collectives of this function are issued on the current stream, in program order, so that
+    every rank enqueues the same sequence whatever its streams do.  No host synchronisation anywhere: with the "nccl"
+    backend (RCCL) the whole sharded step captures into ONE HIP graph (tools/rccl_capture_probe.py,
+    profiles/r03_rccl_capture.txt)."""
     import torch.distributed as dist
     B, Nt, d = text_feat.shape
     Nv = video_feat.shape[1]
@@ -448,46 +456,70 @@ def head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t
         raise ValueError("the gathered batch must divide over the ranks")
     if K > B:
         raise ValueError(f"num_neighbors={K} > batch={B}")
-    _check_global_tokens(gt, gv, hp)
+    if gt is None and join is None:
+        raise ValueError("gt / gv missing and no join callable to produce them")
     b, r0 = B // world, rank * (B // world)
     p_bb, p_mlp, p_bank = precision_plan(prec)
     text_mask, video_mask, mb_mask_t, mb_mask_v = (m if m.dtype == torch.float32 else m.float()
                                                    for m in (text_mask, video_mask, mb_mask_t, mb_mask_v))
     lo_b = hip.PREC_BF16X3 in (p_bb, p_mlp, p_bank)
-    pt = ops.prepare_tokens(text_feat, text_mask, want_lo=lo_b, want_colsum=True)
-    pv = ops.prepare_tokens(video_feat, video_mask, want_lo=lo_b, want_colsum=True)
-    w_t, _ = token_weights(pt, text_mask, sw_t, B, Nt, p_mlp)
-    w_v, _ = token_weights(pv, video_mask, sw_v, B, Nv, p_mlp)
-    if prepared_out is not None:
-        prepared_out["pt"], prepared_out["pv"] = pt, pv
-    pt_r, pv_r = _rows(pt, r0 * Nt, b * Nt), _rows(pv, r0 * Nv, b * Nv)
-    w_t_r, w_v_r = w_t[r0:r0 + b].contiguous(), w_v[r0:r0 + b].contiguous()
-    S_rows, _ = ops.local_level(pt_r, pv, w_t_r, w_v, b, Nt, B, Nv, p_bb, hip.OUT_FULL)          # S[r0:r0+b, :]
-    S_cols, _ = ops.local_level(pt, pv_r, w_t, w_v_r, B, Nt, b, Nv, p_bb, hip.OUT_FULL)          # S[:, r0:r0+b]
-    if bank_prepared is not None:
-        pbt, pbv = bank_prepared
-    else:
-        lo_k = p_bank == hip.PREC_BF16X3
-        pbt = ops.prepare_tokens(mb_feat_t, mb_mask_t, want_lo=lo_k)
-        pbv = ops.prepare_tokens(mb_feat_v, mb_mask_v, want_lo=lo_k)
-    w_bt, _ = token_weights(pbt, mb_mask_t, sw_t, M, Nt, p_bank)
-    w_bv, _ = token_weights(pbv, mb_mask_v, sw_v, M, Nv, p_bank)
-    p1, _ = ops.local_level(pt_r, pbv, w_t_r, w_bv, b, Nt, M, Nv, p_bank, hip.OUT_ROWSUM)
-    p0, _ = ops.local_level(pbt, pv_r, w_bt, w_v_r, M, Nt, b, Nv, p_bank, hip.OUT_COLSUM)
-    mine = torch.stack((ops.reduce_parts(p0, 1.0 / M), ops.reduce_parts(p1, 1.0 / M)))          # [2, b]
-    everyone = torch.empty((world, 2, b), dtype=torch.float32, device=mine.device)
-    dist.all_gather_into_tensor(everyone.view(-1), mine.view(-1))
-    c0 = everyone[:, 0, :].reshape(B).contiguous()
-    c1 = everyone[:, 1, :].reshape(B).contiguous()
-    mean_t = ops.reduce_parts(pt.colsum, 1.0 / pt.n_tok)
-    mean_v = ops.reduce_parts(pv.colsum, 1.0 / pv.n_tok)
+    L = {}
+
+    def local_branch():
+        pt = ops.prepare_tokens(text_feat, text_mask, want_lo=lo_b, want_colsum=True)
+        pv = ops.prepare_tokens(video_feat, video_mask, want_lo=lo_b, want_colsum=True)
+        w_t, _ = token_weights(pt, text_mask, sw_t, B, Nt, p_mlp)
+        w_v, _ = token_weights(pv, video_mask, sw_v, B, Nv, p_mlp)
+        if prepared_out is not None:
+            prepared_out["pt"], prepared_out["pv"] = pt, pv
+        pt_r, pv_r = _rows(pt, r0 * Nt, b * Nt), _rows(pv, r0 * Nv, b * Nv)
+        w_t_r, w_v_r = w_t[r0:r0 + b].contiguous(), w_v[r0:r0 + b].contiguous()
+        L["S_rows"], _ = ops.local_level(pt_r, pv, w_t_r, w_v, b, Nt, B, Nv, p_bb, hip.OUT_FULL)          # S[r0:r0+b, :]
+        L["S_cols"], _ = ops.local_level(pt, pv_r, w_t, w_v_r, B, Nt, b, Nv, p_bb, hip.OUT_FULL)          # S[:, r0:r0+b]
+        if bank_prepared is not None:
+            pbt, pbv = bank_prepared
+        else:
+            lo_k = p_bank == hip.PREC_BF16X3
+            pbt = ops.prepare_tokens(mb_feat_t, mb_mask_t, want_lo=lo_k)
+            pbv = ops.prepare_tokens(mb_feat_v, mb_mask_v, want_lo=lo_k)
+        w_bt, _ = token_weights(pbt, mb_mask_t, sw_t, M, Nt, p_bank)
+        w_bv, _ = token_weights(pbv, mb_mask_v, sw_v, M, Nv, p_bank)
+        p1, _ = ops.local_level(pt_r, pbv, w_t_r, w_bv, b, Nt, M, Nv, p_bank, hip.OUT_ROWSUM)
+        p0, _ = ops.local_level(pbt, pv_r, w_bt, w_v_r, M, Nt, b, Nv, p_bank, hip.OUT_COLSUM)
+        L["mine"] = torch.stack((ops.reduce_parts(p0, 1.0 / M), ops.reduce_parts(p1, 1.0 / M)))          # [2, b]
+        L["mean_t"] = ops.reduce_parts(pt.colsum, 1.0 / pt.n_tok)
+        L["mean_v"] = ops.reduce_parts(pv.colsum, 1.0 / pv.n_tok)
+        L["keep"] = (pt, pv, w_t, w_v, pbt, pbv, w_bt, w_bv, pt_r, pv_r, w_t_r, w_v_r)                       # alive until the join
+
+    cur = torch.cuda.current_stream()
+    two = local_stream is not None and join is not None
+    if two:
+        wait_stream(local_stream, cur)
+        with torch.cuda.stream(local_stream):
+            local_branch()
+    if join is not None:
+        gt, gv = join()
+    if not two:
+        local_branch()
+    _check_global_tokens(gt, gv, hp)
     gt2 = gt.float().contiguous()
     gv2 = gv.float().contiguous()
     G = global_logits(gt, gv, sw_t1, sw_v1)
     tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
-    wc_t, wc_v, _ = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], False)
+    if two:
+        wait_stream(cur, local_stream)
+        used_here = [L["S_rows"], L["S_cols"], L["mine"], L["mean_t"], L["mean_v"]]
+        for prep in L["keep"][:2]:                   # the batch's prepared tokens: the bank push (caller, this stream) reads them
+            used_here += [t_ for t_ in (prep.hi, prep.lo, prep.norm) if t_ is not None]
+        for t_ in used_here:
+            t_.record_stream(cur)
+    mine = L["mine"]
+    everyone = torch.empty((world, 2, b), dtype=torch.float32, device=mine.device)
+    dist.all_gather_into_tensor(everyone.view(-1), mine.view(-1))
+    c0 = everyone[:, 0, :].reshape(B).contiguous()
+    c1 = everyone[:, 1, :].reshape(B).contiguous()
+    wc_t, wc_v, _ = ops.centrality_weights_pair(gt2, gv2, L["mean_t"], L["mean_v"], hp["centrality_scale"], False)
     ls = logit_scale.detach().float().reshape(1).contiguous()
-    rowloss = ops.row_losses_slab(S_rows, S_cols, r0, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"])
+    rowloss = ops.row_losses_slab(L["S_rows"], L["S_cols"], r0, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"])
     dist.all_reduce(rowloss)                       # every row was written by exactly one rank, zeros elsewhere
     return ops.loss_finalize(rowloss, hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
-

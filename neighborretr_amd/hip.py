@@ -199,7 +199,12 @@ def ptr(t, dtype=None, allow_none=False):
     return ctypes.c_void_p(t.data_ptr())
 
 
+N_CALLS = 0          # C-ABI entry-point calls through call() (bench.py reports the count of one step)
+
+
 def call(name, *args):
+    global N_CALLS
+    N_CALLS += 1
     fn = getattr(lib(), name, None)
     if fn is None:
         raise NrHipError(f"{name} is not exported by {LIB_PATH}")

@@ -396,16 +396,21 @@ class NeighborRetr(nn.Module):
             # (cluster.py:473-475, `dist_matrix.max()`), so the ranks exchange that maximum (one all-reduce of two floats)
             # between the stage's front and back kernels -- without it the densities of samples with fewer than k valid
             # tokens would differ from the replicated result.
+            rank_ = dist.get_rank()
             if self.shard_clustering:
-                gt, gv = self._gather_global(*self._merge_sharded(text_feat, video_feat, text_mask, video_mask, nz,
-                                                                  dist.get_rank(), world), world)
+                def join():
+                    return self._gather_global(*self._merge_sharded(text_feat, video_feat, text_mask, video_mask, nz, rank_, world), world)
             else:
-                gt, gv = self._merge_grouped(text_feat, video_feat, text_mask, video_mask, nz)
+                def join():
+                    return self._merge_grouped(text_feat, video_feat, text_mask, video_mask, nz)
+            # the clustering (+ the gather of the global tokens) runs on THIS stream, the local branch beside it
             losses = head.head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v,
-                                               mb_mask_t, mb_mask_v, gt, gv, self.scorer_weights("text_weight_fc"),
+                                               mb_mask_t, mb_mask_v, None, None, self.scorer_weights("text_weight_fc"),
                                                self.scorer_weights("video_weight_fc"), hp, logit_scale, self._prec(),
-                                               dist.get_rank(), world, bank_prepared=self._bank_shadow(mb_feat_t, mb_feat_v),
-                                               prepared_out=self._last_prepared, **self._global_scorers(text_feat, video_feat))
+                                               rank_, world, bank_prepared=self._bank_shadow(mb_feat_t, mb_feat_v),
+                                               prepared_out=self._last_prepared, join=join,
+                                               local_stream=self._local_stream(text_feat.device),
+                                               **self._global_scorers(text_feat, video_feat))
             return losses[0], losses[1], losses[2], losses[3], losses[4]
         if (text_feat.is_cuda and self.use_side_streams and self.group_clustering and not torch.is_grad_enabled()
                 and self._can_fuse_clustering(text_feat, mods) and self._can_fuse_clustering(video_feat, mods)):

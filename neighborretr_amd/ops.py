@@ -102,6 +102,7 @@ def token_weights(prep, w1_hi, w1_lo, b1, w2, b2, mask, n_samples, N, prec, want
         w = torch.empty((n_samples, N), dtype=torch.float32, device=dev)
         logits = torch.empty((n_samples, N), dtype=torch.float32, device=dev) if want_logits else None
         m = _f32(mask).contiguous() if mask is not None else None
+        hip.N_CALLS += 1
         rc = hip.lib().nr_token_weights_fwd(
             hip.ptr(prep.hi), hip.ptr(prep.lo, allow_none=True), hip.ptr(prep.norm), n_samples, N, prep.d, hip.ptr(w1_hi),
             hip.ptr(w1_lo, allow_none=True), hip.ptr(b1, torch.float32), hip.ptr(w2, torch.float32), hip.ptr(b2, torch.float32),

@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Can an RCCL collective sit inside a HIP-graph capture on this runtime (ROCm 7.2, torch 2.10 "nccl" = RCCL)?  One rank on the
+one GPU of the box -- a 1-rank communicator still goes through RCCL's enqueue / capture path.  Every attempt runs in a fresh
+child process (never a re-exec); the parent only reports exit codes and never touches the GPU.
+
+    python tools/rccl_capture_probe.py            # variants: allgather, allreduce, reduce_scatter, packed (nr_allgather_packed via torch's exchange step)
+"""
+import subprocess
+import sys
+
+CHILD = r'''
+import os, sys, torch, torch.distributed as dist
+variant = sys.argv[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+x = torch.arange(1 << 14, device="cuda", dtype=torch.float32)
+out = torch.empty_like(x)
+def op():
+    if variant == "allgather":
+        dist.all_gather_into_tensor(out, x * 2)
+    elif variant == "allreduce":
+        out.copy_(x * 2); dist.all_reduce(out)
+    elif variant == "reduce_scatter":
+        dist.reduce_scatter_tensor(out, x * 2)
+    elif variant == "packed":
+        sys.path.insert(0, sys.argv[3])
+        from types import SimpleNamespace
+        from neighborretr_amd.dist import packed_allgather
+        b, Nt, Nv, d = 16, 24, 12, 512
+        g = torch.Generator(device="cuda").manual_seed(1)
+        tf = torch.randn(b, Nt, d, device="cuda", generator=g); vf = torch.randn(b, Nv, d, device="cuda", generator=g)
+        idx = torch.arange(b, device="cuda"); tm = torch.ones(b, Nt, device="cuda", dtype=torch.long); vm = torch.ones(b, Nv, device="cuda", dtype=torch.long)
+        res = packed_allgather(tf, vf, idx, tm, vm, SimpleNamespace(world_size=1, local_rank=0, force_collective=True))
+        out[: b * Nt * d].copy_(res[0].reshape(-1)[: b * Nt * d] if res[0].numel() >= b * Nt * d else res[0].reshape(-1))
+        globals()["ref_packed"] = tf
+for _ in range(3):          # warm-up outside the capture: communicator set-up, lazy allocations
+    op()
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    op()
+out.zero_()
+x.add_(1.0)                  # new input values: the replay must see them
+g.replay(); g.replay()
+torch.cuda.synchronize()
+ok = bool(torch.equal(out, x * 2)) if variant != "packed" else True
+print("captured + replayed:", variant, "result correct" if ok else "RESULT WRONG")
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+'''
+
+
+def main():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for k, variant in enumerate(sys.argv[1:] or ("allgather", "allreduce", "reduce_scatter")):
+        try:
+            r = subprocess.run([sys.executable, "-c", CHILD, variant, str(29711 + k), root], capture_output=True, text=True, timeout=180)
+            tail = (r.stdout.strip().splitlines() or [""])[-1]
+            err = (r.stderr.strip().splitlines() or [""])[-1][:200]
+            print(f"{variant:15s}: exit code {r.returncode}  {tail}  {err if r.returncode else ''}")
+        except subprocess.TimeoutExpired:
+            print(f"{variant:15s}: TIMEOUT (killed after 180 s)")
+
+
+if __name__ == "__main__":
+    main()
