@@ -584,7 +584,12 @@ def main():
             "roofline": roofline,
         }
         line.update(extra)
-        line["parity"] = parity_gates(model, dev)
+        ws_, sl_ = model.config.world_size, model.shard_loss
+        model.config.world_size, model.shard_loss = 1, False       # rank 0 alone: the gate is a single-rank evaluation
+        try:
+            line["parity"] = parity_gates(model, dev)
+        finally:
+            model.config.world_size, model.shard_loss = ws_, sl_
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -198,7 +198,7 @@ int nr_ctm_back(const float* dist, const float* smax, const float* mask, const f
  * The step's form of the stage: CTM.forward (cluster.py:689-717) + TCBlock.forward (:938-965) of up to
  * NR_CTM_MAX_GROUP independent problems -- the text and the video tokens of modeling.py:446-481 -- in
  * seven launches that each carry the workgroups of every problem (conv GEMM, front, back, q+kv GEMMs,
- * attention, proj GEMM, preceded by the shift|split).  All GEMMs run split-bf16 (see nr_linear_x3); the
+ * attention, proj GEMM, preceded by the bf16 split of the token rows; the k=3 convolution reads the neighbour rows in place).  All GEMMs run split-bf16 (see nr_linear_x3); the
  * w*_hi/lo operands are the bf16 pairs (nr_split_bf16) of: the conv kernel as a [C, 3C] matrix with the
  * three taps side by side (tap k multiplies x[n+k-1]), q.weight [C,C], kv.weight [2C,C], proj.weight [C,C].
  * mask may be NULL (stage 1); conv_bias / q_bias / kv_bias may be NULL; assign (int64 [n_samples,N]) may
@@ -223,6 +223,10 @@ typedef struct NrCtmStageDesc {
     void* workspace;
     float* out;
     int64_t* assign;
+    /* optional (NULL): x as a bf16 pair [n_samples*N, C] (nr_split_bf16 of x) -- the stage then skips its own split launch;
+     * out_hi / out_lo [n_samples*cnum, C]: `out` also written as a bf16 pair by the proj GEMM (chain two stages with them). */
+    const uint16_t *x_hi, *x_lo;
+    uint16_t *out_hi, *out_lo;
 } NrCtmStageDesc;
 size_t nr_ctm_stage_workspace_bytes(int n_samples, int N, int C, int cluster_num);
 /* What the stage leaves in its workspace for a backward pass (neighborretr_amd/cluster_backward.py): byte offsets of

@@ -209,8 +209,12 @@ def ctm_stage_group(problems, cache, stepwise=False, want_assign=False, want_sav
     descs = (hip.CtmStageDesc * len(problems))()
     keep, outs, assigns, saved, smax = [], [], [], [], []
     for d, (key, x, mask, ctm, blk, noise) in zip(descs, problems):
+        # a previous stage's output carries its bf16 pair (written by that stage's proj GEMM): no split launch for it here
+        x_pair = getattr(x, "_nr_pair", None)
         x = x.detach().float().contiguous()
         B, N, C = x.shape
+        if x_pair is not None and (x_pair[0].shape != (B * N, C) or x_pair[0].device != x.device):
+            x_pair = None
         dev = x.device
         hip.ptr(x)                                           # device / contiguity check
         sw = _stage_weights(cache, key, ctm, blk)
@@ -225,6 +229,9 @@ def ctm_stage_group(problems, cache, stepwise=False, want_assign=False, want_sav
         nbytes = int(hip.lib().nr_ctm_stage_workspace_bytes(B, N, C, cnum))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         out = torch.empty((B, cnum, C), dtype=torch.float32, device=dev)
+        out_hi = torch.empty((B * cnum, C), dtype=torch.int16, device=dev)
+        out_lo = torch.empty((B * cnum, C), dtype=torch.int16, device=dev)
+        out._nr_pair = (out_hi, out_lo)
         assign = torch.empty((B, N), dtype=torch.int64, device=dev) if (want_assign or want_saved) else None
         assigns.append(assign)
         if want_saved or exchange is not None:
@@ -237,7 +244,8 @@ def ctm_stage_group(problems, cache, stepwise=False, want_assign=False, want_sav
                        ln_w=ctm.norm.weight, ln_b=ctm.norm.bias, sc_w=ctm.score.weight, sc_b=ctm.score.bias,
                        n1_w=blk.norm1.weight, n1_b=blk.norm1.bias, wq_hi=sw.wq_hi, wq_lo=sw.wq_lo, q_bias=attn.q.bias,
                        wkv_hi=sw.wkv_hi, wkv_lo=sw.wkv_lo, kv_bias=attn.kv.bias, wp_hi=sw.wp_hi, wp_lo=sw.wp_lo,
-                       proj_bias=attn.proj.bias, workspace=ws, out=out, assign=assign)
+                       proj_bias=attn.proj.bias, workspace=ws, out=out, assign=assign,
+                       x_hi=x_pair[0] if x_pair else None, x_lo=x_pair[1] if x_pair else None, out_hi=out_hi, out_lo=out_lo)
         d.n_samples, d.N, d.C, d.k, d.cnum, d.heads = B, N, C, int(ctm.k), cnum, int(attn.num_heads)
         d.eps_ctm, d.eps_n1 = float(ctm.norm.eps), float(blk.norm1.eps)
         for name, t in tensors.items():

@@ -491,10 +491,27 @@ struct NrShiftArgs {
     const float* x;
     int N, C;
     uint16_t *hi, *lo;
+    int plain;        // 1: the row itself as a bf16 pair, [rows, C] (the conv GEMM reads its neighbours in place)
 };
 
 __device__ __forceinline__ void nr_shift_split_body(const NrShiftArgs& a, const int row) {
     const int n = row % a.N, C = a.C;
+    if (a.plain) {
+        const float* src = a.x + (size_t)row * C;
+        const size_t o = (size_t)row * C;
+        for (int c = threadIdx.x * 4; c < C; c += 1024) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + c);
+            uint16_t h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = nr_f2bf(v[e]);
+                l[e] = nr_f2bf(v[e] - nr_bf2f(h[e]));
+            }
+            *reinterpret_cast<uint2*>(a.hi + o + c) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            *reinterpret_cast<uint2*>(a.lo + o + c) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+        }
+        return;
+    }
     for (int k = 0; k < 3; ++k) {
         const int nn = n + k - 1;
         const bool ok = nn >= 0 && nn < a.N;

@@ -172,27 +172,36 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
         front_lds = lds > front_lds ? lds : front_lds;
     }
     int rc;
-    // 1. x[n-1] | x[n] | x[n+1] as split-bf16 rows
-    if (first <= 0 && 0 < last) {
+    // 1. the token rows as bf16 pairs [rows, C] -- for the problems that do not bring them along (x_hi / x_lo: written by
+    //    the previous stage's proj GEMM).  The k=3 convolution reads its neighbour rows in place: no shifted copy.
+    bool all_split = true;
+    for (int i = 0; i < n; ++i) {
+        if ((d[i].x_hi == nullptr) != (d[i].x_lo == nullptr)) return NR_EINVAL;
+        all_split = all_split && d[i].x_hi != nullptr;
+    }
+    if (first <= 0 && 0 < last && !all_split) {
         NrGroupOf<NrShiftArgs> g;
-        g.n = n;
+        g.n = 0;
         int total = 0;
         for (int i = 0; i < n; ++i) {
-            g.p[i] = NrShiftArgs{d[i].x, d[i].N, d[i].C, w[i].cat_hi, w[i].cat_lo};
-            g.start[i] = total;
+            if (d[i].x_hi) continue;
+            g.p[g.n] = NrShiftArgs{d[i].x, d[i].N, d[i].C, w[i].cat_hi, w[i].cat_lo, 1};
+            g.start[g.n++] = total;
             total += d[i].n_samples * d[i].N;
         }
-        for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
+        for (int i = g.n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
         hipLaunchKernelGGL(nr_group_shift_kernel, dim3(total), dim3(256), 0, st, g);
         NR_LAUNCH_CHECK();
     }
-    // 2. y = x + conv(x)  (k=3 convolution as a [B*N, 3C] x [3C, C] product)
+    // 2. y = x + conv(x)  (k=3 convolution as a [B*N, 3C] x [3C, C] product whose A operand is read in place)
     if (first <= 1 && 1 < last) {
         NrLinearArgs p[NR_CTM_MAX_GROUP];
-        for (int i = 0; i < n; ++i)
-            p[i] = NrLinearArgs{w[i].cat_hi, w[i].cat_lo, d[i].wconv_hi, d[i].wconv_lo, d[i].conv_bias, d[i].x, w[i].y,
-                                d[i].n_samples * d[i].N, d[i].C, 3 * d[i].C};
-        if ((rc = nr_linear_group_launch(p, n, st)) != NR_OK) return rc;
+        for (int i = 0; i < n; ++i) {
+            p[i] = NrLinearArgs{d[i].x_hi ? d[i].x_hi : w[i].cat_hi, d[i].x_hi ? d[i].x_lo : w[i].cat_lo, d[i].wconv_hi, d[i].wconv_lo,
+                                d[i].conv_bias, d[i].x, w[i].y, d[i].n_samples * d[i].N, d[i].C, 3 * d[i].C};
+            p[i].conv_n = d[i].N;
+        }
+        if ((rc = nr_linear_group_launch(p, n, st, true)) != NR_OK) return rc;
     }
     // 3 + 4. front (LayerNorm, score, exp, norm1, pairwise distances) and back (DPC-KNN assignment, weighted cluster
     //        means, norm1).  Two launches when a problem carries a mask (the back half then needs the maximum
@@ -295,9 +304,12 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
     // 7. out = merged + proj(att) + proj.bias
     if (first <= 6 && 6 < last) {
         NrLinearArgs p[NR_CTM_MAX_GROUP];
-        for (int i = 0; i < n; ++i)
+        for (int i = 0; i < n; ++i) {
             p[i] = NrLinearArgs{w[i].att_hi, w[i].att_lo, d[i].wp_hi, d[i].wp_lo, nullptr, w[i].merged_pb, d[i].out,
                                 d[i].n_samples * d[i].cnum, d[i].C, d[i].C};
+            p[i].out_hi = d[i].out_hi;              // optional: the output also as a bf16 pair (the next stage's x_hi / x_lo)
+            p[i].out_lo = d[i].out_lo;
+        }
         if ((rc = nr_linear_group_launch(p, n, st)) != NR_OK) return rc;
     }
     return NR_OK;

@@ -51,6 +51,9 @@ struct NrPhaseClock {
 };
 #endif
 
+// a row of zeros for operand rows that do not exist (the k=3 token convolution read in place: run_conv3)
+static __device__ uint16_t nr_zero_row[1024];
+
 typedef __attribute__((address_space(3))) void* nr_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* nr_glb_ptr_t;
 
@@ -122,6 +125,25 @@ struct NrGemmTile {
                                         int a_row0, int a_rows,
                                         const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
                                         int b_row0, int b_rows, int K, char* smem, int rot = 0, bool dma_front = false) {
+        run_impl<false>(a_hi, a_lo, a_row0, a_rows, b_hi, b_lo, b_row0, b_rows, K, smem, rot, dma_front, 0);
+    }
+
+    // The k=3 token convolution read IN PLACE (cluster.py:664): A is the token matrix itself, [a_rows, K/3] (hi / lo), and
+    // the product is  sum_s A[row + s - 1, :] . B[:, s K/3 : (s+1) K/3]  with rows outside the sample of `conv_n` tokens
+    // reading as zeros -- the K loop walks three segments, each with its own (shifted, or zero-row) source pointers.
+    // No [rows, 3 K/3] shifted copy of the tokens exists any more: a third of the A bytes, one launch less.
+    __device__ __forceinline__ void run_conv3(const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
+                                              int a_row0, int a_rows,
+                                              const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
+                                              int b_row0, int b_rows, int K, char* smem, int conv_n) {
+        run_impl<true>(a_hi, a_lo, a_row0, a_rows, b_hi, b_lo, b_row0, b_rows, K, smem, 0, false, conv_n);
+    }
+
+    template <bool CONV3>
+    __device__ __forceinline__ void run_impl(const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
+                                             int a_row0, int a_rows,
+                                             const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
+                                             int b_row0, int b_rows, int K, char* smem, int rot, bool dma_front, int conv_n) {
         static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
         const int tid = threadIdx.x;
         const int lane = tid & 63;
@@ -130,17 +152,30 @@ struct NrGemmTile {
 
         // DMA piece i of an operand = LDS rows [8i, 8i+8); waves take pieces i = wave, wave+NW, ...
         // lane -> (row 8i + lane/8, LDS slot lane%8) which must receive global chunk slot ^ key(row)
-        const char* ga_h[PA];
+        constexpr int NSEG_A = CONV3 ? 3 : 1;                // source pointer sets of operand A
+        const char* ga_h[NSEG_A][PA];
         const char* gb_h[PB];
-        const char* ga_l[X3 ? PA : 1];
+        const char* ga_l[NSEG_A][X3 ? PA : 1];
         const char* gb_l[X3 ? PB : 1];
+        const int CA = CONV3 ? K / 3 : K;                    // row pitch of operand A
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             int r = (wave + NW * i) * 8 + (lane >> 3);
             int kc = (lane & 7) ^ row_key<TPS_A, MI>(r);
-            int gr = min(a_row0 + r, a_rows - 1);
-            ga_h[i] = reinterpret_cast<const char*>(a_hi + (size_t)gr * K + kc * 8);
-            if constexpr (X3) ga_l[i] = reinterpret_cast<const char*>(a_lo + (size_t)gr * K + kc * 8);
+            if constexpr (CONV3) {
+                const int gr = a_row0 + r, t = gr % conv_n;
+#pragma unroll
+                for (int sg = 0; sg < 3; ++sg) {
+                    const bool on = gr < a_rows && t + sg - 1 >= 0 && t + sg - 1 < conv_n;
+                    const size_t o = (size_t)(gr + sg - 1) * CA + kc * 8;
+                    ga_h[sg][i] = reinterpret_cast<const char*>(on ? a_hi + o : nr_zero_row + kc * 8);
+                    if constexpr (X3) ga_l[sg][i] = reinterpret_cast<const char*>(on ? a_lo + o : nr_zero_row + kc * 8);
+                }
+            } else {
+                int gr = min(a_row0 + r, a_rows - 1);
+                ga_h[0][i] = reinterpret_cast<const char*>(a_hi + (size_t)gr * K + kc * 8);
+                if constexpr (X3) ga_l[0][i] = reinterpret_cast<const char*>(a_lo + (size_t)gr * K + kc * 8);
+            }
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -164,11 +199,23 @@ struct NrGemmTile {
             // the loop is slice (kt + rot) mod KT of the operands): workgroups that share operand rows through one L2
             // then first-touch DIFFERENT slices and find the others' already there (see nr_sim_reg.hip)
             const int kr = kt + rot;
-            const int kb = (kr >= KT_ ? kr - KT_ : kr) * BK * 2;
+            int kb = (kr >= KT_ ? kr - KT_ : kr) * BK * 2;
             char* dst = st + (is_a ? 0 : A_BYTES) + (wave + NW * piece) * 1024 + (lo ? A_BYTES + B_BYTES : 0);
             const char* src;
-            if constexpr (is_a) src = lo ? ga_l[X3 ? piece : 0] : ga_h[piece];
-            else src = lo ? gb_l[X3 ? piece : 0] : gb_h[piece];
+            if constexpr (is_a) {
+                if constexpr (CONV3) {
+                    const int ks_ = KT_ / 3, sg = kt >= 2 * ks_ ? 2 : (kt >= ks_ ? 1 : 0);      // wave-uniform
+                    kb = (kt - sg * ks_) * BK * 2;
+                    const char* p0 = lo ? ga_l[0][X3 ? piece : 0] : ga_h[0][piece];
+                    const char* p1 = lo ? ga_l[1][X3 ? piece : 0] : ga_h[1][piece];
+                    const char* p2 = lo ? ga_l[2][X3 ? piece : 0] : ga_h[2][piece];
+                    src = sg == 0 ? p0 : (sg == 1 ? p1 : p2);
+                } else {
+                    src = lo ? ga_l[0][X3 ? piece : 0] : ga_h[0][piece];
+                }
+            } else {
+                src = lo ? gb_l[X3 ? piece : 0] : gb_h[piece];
+            }
             __builtin_amdgcn_global_load_lds((nr_glb_ptr_t)(src + kb), (nr_lds_ptr_t)dst, 16, 0, 0);
         };
         auto issue = [&](int kt) { nr_static_for<0, DMA_PER_STAGE>([&](auto i) { issue_one(kt, i); }); };
@@ -439,8 +486,14 @@ struct NrGemmTile {
 #endif
         // `mid`: issued a third of the way through the phase's MFMAs (NR_PP_MV > 0: a few LDS-DMA pieces moved out of the
         // wave's memory phases into its MFMA phases, where the matrix pipe still has the queued MFMAs to chew on)
+#ifndef NR_PP_PRIO
+#define NR_PP_PRIO 1
+#endif
+        // NR_PP_PRIO (A/B hook): 1 = the MFMA phase runs at raised issue priority (round 2); 0 = no priority changes; 2 = the
+        // MEMORY phase of the partner wave is the one raised (its few instructions get through between the MFMAs)
         auto mma = [&](auto&& mid) {
-            __builtin_amdgcn_s_setprio(1);
+            if constexpr (NR_PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+            if constexpr (NR_PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
             nr_static_for<0, MI * NI>([&](auto g_c) {
                 constexpr int g = decltype(g_c)::value;
                 constexpr int m = g / NI, n = g % NI;
@@ -451,7 +504,8 @@ struct NrGemmTile {
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[m], fb_h[n], acc[m][n], 0, 0, 0);
                 if constexpr (g == (MI * NI) / 3) mid();
             });
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr (NR_PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            if constexpr (NR_PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #ifdef NR_STAMP
             __builtin_amdgcn_sched_barrier(0);
             pp_mma += __builtin_readcyclecounter() - pp_t;

@@ -9,9 +9,15 @@ struct NrLinearArgs {
     const float *bias, *residual;
     float* out;
     int M, N, K;
+    // conv_n > 0 (only in launches made with conv = true): X is the token matrix [M, K/3] and the product the k=3 token
+    // convolution over samples of conv_n tokens, read in place (NrGemmTile::run_conv3)
+    int conv_n = 0;
+    // optional second form of the output: the bf16 pair of `out` (the A operand of a following GEMM)
+    uint16_t *out_hi = nullptr, *out_lo = nullptr;
 };
 
 #define NR_LINEAR_MAX_GROUP 8
 
 // All problems of a group are tiled with the same tile shape; K % 64 == 0 for each.
-int nr_linear_group_launch(const NrLinearArgs* probs, int n_probs, hipStream_t stream);
+// conv = true: every problem is a token convolution (conv_n > 0 each).
+int nr_linear_group_launch(const NrLinearArgs* probs, int n_probs, hipStream_t stream, bool conv = false);

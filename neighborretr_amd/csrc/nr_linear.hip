@@ -17,7 +17,7 @@ struct NrLinearGroup {
     int n;
 };
 
-template <int MI, int NI, int STAGES, int WC>
+template <int MI, int NI, int STAGES, int WC, bool CONV = false>
 __device__ __forceinline__ void nr_linear_tile(const NrLinearArgs& p, const int tile_row, const int tile_col, char* smem) {
     using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES, WC>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -25,7 +25,8 @@ __device__ __forceinline__ void nr_linear_tile(const NrLinearArgs& p, const int 
     const int row0 = tile_row * Tile::BM, col0 = tile_col * Tile::BN;
     Tile tile;
     tile.zero();
-    tile.run(p.x_hi, p.x_lo, row0, p.M, p.w_hi, p.w_lo, col0, p.N, p.K, smem);
+    if constexpr (CONV) tile.run_conv3(p.x_hi, p.x_lo, row0, p.M, p.w_hi, p.w_lo, col0, p.N, p.K, smem, p.conv_n);
+    else tile.run(p.x_hi, p.x_lo, row0, p.M, p.w_hi, p.w_lo, col0, p.N, p.K, smem);
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
         const int c = col0 + wc * 16 * NI + n * 16 + (lane & 15);
@@ -41,6 +42,11 @@ __device__ __forceinline__ void nr_linear_tile(const NrLinearArgs& p, const int 
                 float v = tile.acc[m][n][j] + bv;
                 if (p.residual) v += p.residual[o];
                 p.out[o] = v;
+                if (p.out_hi) {
+                    const uint16_t hb = nr_f2bf(v);
+                    p.out_hi[o] = hb;
+                    p.out_lo[o] = nr_f2bf(v - nr_bf2f(hb));
+                }
             }
     }
 }
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256) void nr_linear_kernel(NrLinearArgs p) {
 }
 
 // grouped: workgroup -> (problem, tile) through the prefix table; tiles of a problem are column-fastest
-template <int MI, int NI, int STAGES, int WC>
+template <int MI, int NI, int STAGES, int WC, bool CONV = false>
 __global__ __launch_bounds__(128 * WC) void nr_linear_group_kernel(NrLinearGroup g) {
     NR_CRITICAL_PATH();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(128 * WC) void nr_linear_group_kernel(NrLinearGroup
     const NrLinearArgs& p = g.p[gi];
     const int t = wg - g.tile_start[gi];
     const int ncol = (p.N + 16 * WC * NI - 1) / (16 * WC * NI);
-    nr_linear_tile<MI, NI, STAGES, WC>(p, t / ncol, t % ncol, smem);
+    nr_linear_tile<MI, NI, STAGES, WC, CONV>(p, t / ncol, t % ncol, smem);
 }
 
 template <int MI, int NI, int STAGES>
@@ -91,7 +97,7 @@ static int nr_linear_launch(NrLinearArgs& a, hipStream_t st) {
     return nr_linear_launch_s<MI, NI, 2>(a, st);
 }
 
-template <int MI, int NI, int STAGES, int WC = 2>
+template <int MI, int NI, int STAGES, int WC = 2, bool CONV = false>
 static int nr_linear_group_launch_s(const NrLinearArgs* probs, int n, hipStream_t st) {
     using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES, WC>;
     NrLinearGroup g;
@@ -105,17 +111,22 @@ static int nr_linear_group_launch_s(const NrLinearArgs* probs, int n, hipStream_
     for (int i = n; i <= NR_LINEAR_MAX_GROUP; ++i) g.tile_start[i] = total;
     size_t lds = Tile::RING_BYTES;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)nr_linear_group_kernel<MI, NI, STAGES, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)nr_linear_group_kernel<MI, NI, STAGES, WC, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((nr_linear_group_kernel<MI, NI, STAGES, WC>), dim3(nr_xcd_chunk_grid(total)), dim3(128 * WC), lds, st, g);
+    hipLaunchKernelGGL((nr_linear_group_kernel<MI, NI, STAGES, WC, CONV>), dim3(nr_xcd_chunk_grid(total)), dim3(128 * WC), lds, st, g);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }
 
 // Tile shape / ring depth of a grouped launch.  NR_LINEAR_TILE="MI,NI,STAGES" overrides (tuning only).
-int nr_linear_group_launch(const NrLinearArgs* probs, int n, hipStream_t st) {
+int nr_linear_group_launch(const NrLinearArgs* probs, int n, hipStream_t st, bool conv) {
     if (!probs || n <= 0 || n > NR_LINEAR_MAX_GROUP) return NR_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        if (conv != (probs[i].conv_n > 0)) return NR_EINVAL;
+        if (conv && (probs[i].K % 192) != 0) return NR_EINVAL;             // three segments of whole 64-wide slices
+        if ((probs[i].out_hi == nullptr) != (probs[i].out_lo == nullptr)) return NR_EINVAL;
+    }
     long t32x64 = 0, t128 = 0;
     for (int i = 0; i < n; ++i) {
         const NrLinearArgs& a = probs[i];
@@ -139,6 +150,13 @@ int nr_linear_group_launch(const NrLinearArgs* probs, int n, hipStream_t st) {
     if (const char* ov = nr_tune_env("NR_LINEAR_TILE")) {
         int a_, b_, c_, d_ = 2;
         if (sscanf(ov, "%d,%d,%d,%d", &a_, &b_, &c_, &d_) >= 3) { mi = a_; ni = b_; stg = c_; wcols = d_; }
+    }
+    if (conv) {                      // token convolutions: the two shapes the clustering stages use (and their neighbours)
+        if (wcols == 4 || mi > 2) { mi = 2; ni = 2; stg = 1; }
+#define NR_LGC_CASE(MI_, NI_, ST_) if (mi == MI_ && ni == NI_ && stg == ST_) return nr_linear_group_launch_s<MI_, NI_, ST_, 2, true>(probs, n, st)
+        NR_LGC_CASE(2, 2, 1); NR_LGC_CASE(2, 2, 2); NR_LGC_CASE(1, 2, 2); NR_LGC_CASE(1, 2, 4);
+#undef NR_LGC_CASE
+        return NR_EUNSUPPORTED;
     }
     if (wcols == 4) {
 #define NR_LG8_CASE(MI_, NI_, ST_) if (mi == MI_ && ni == NI_ && stg == ST_) return nr_linear_group_launch_s<MI_, NI_, ST_, 4>(probs, n, st)
@@ -174,7 +192,7 @@ __global__ __launch_bounds__(256) void nr_shift_concat_split_kernel(NrShiftArgs 
 
 extern "C" int nr_shift_concat_split(const float* x, int n_samples, int N, int C, uint16_t* hi, uint16_t* lo, void* stream) {
     if (!x || !hi || !lo || n_samples <= 0 || N <= 0 || C <= 0 || (C % 4) != 0) return NR_EINVAL;
-    NrShiftArgs a{x, N, C, hi, lo};
+    NrShiftArgs a{x, N, C, hi, lo, 0};
     hipLaunchKernelGGL(nr_shift_concat_split_kernel, dim3(n_samples * N), dim3(256), 0, (hipStream_t)stream, a);
     NR_LAUNCH_CHECK();
     return NR_OK;

@@ -31,7 +31,7 @@ class CtmStageDesc(ctypes.Structure):
                 + [("eps_ctm", _F), ("eps_n1", _F)]
                 + [(n, _P) for n in ("x", "mask", "noise", "wconv_hi", "wconv_lo", "conv_bias", "ln_w", "ln_b", "sc_w", "sc_b",
                                      "n1_w", "n1_b", "wq_hi", "wq_lo", "q_bias", "wkv_hi", "wkv_lo", "kv_bias", "wp_hi", "wp_lo",
-                                     "proj_bias", "workspace", "out", "assign")])
+                                     "proj_bias", "workspace", "out", "assign", "x_hi", "x_lo", "out_hi", "out_lo")])
 
 
 class LocalLevelProblem(ctypes.Structure):
