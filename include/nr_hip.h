@@ -385,6 +385,16 @@ int nr_row_losses_fwd_slab(const float* S_rows, const float* S_cols, int row0, i
                            const float* wc_text, const float* wc_video, const float* logit_scale, int B, int K,
                            float temperature, float* rowloss, void* stream);
 
+/* Backward of nr_row_losses_fwd_slab (the sharded TRAINING loss, neighborretr_amd/sharded.py): for the rows a rank owns,
+ * from upstream g_rowloss [2,4,B] (only the owned rows are read): dS_dir [2,n_rows,B] (direction 0: d S[row0+k, :],
+ * direction 1: d S[:, row0+k] as a row), dG_dir [2,n_rows,B] likewise, d_c_rows [2,n_rows,B] (gradient of the bank
+ * centrality vector a row's neighbour term read: direction 0 -> bank_c0, 1 -> bank_c1), d_wc / d_ls_rows [2,n_rows].       */
+int nr_row_losses_bwd_slab(const float* S_rows, const float* S_cols, int row0, int n_rows, const float* G,
+                           const float* tgt_rows, const float* tgt_cols, const float* bank_c0, const float* bank_c1,
+                           const float* wc_text, const float* wc_video, const float* logit_scale, int B, int K,
+                           float temperature, const float* g_rowloss, float* dS_dir, float* dG_dir, float* d_c_rows,
+                           float* d_wc, float* d_ls_rows, void* stream);
+
 /* nr_row_losses_fwd + nr_loss_finalize in one launch: the workgroup that finishes last reduces the row
  * terms (same arithmetic, bit-identical losses).  counter: one zero-initialised device word owned by the
  * caller; the kernel leaves it at zero again.                                                        */

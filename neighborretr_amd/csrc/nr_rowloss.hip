@@ -350,10 +350,12 @@ __global__ __launch_bounds__(256) void nr_row_losses_bwd_kernel(NrRowArgs a, con
                                                                 float* __restrict__ d_c_rows, float* __restrict__ d_wc,
                                                                 float* __restrict__ d_ls_rows) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int local = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = a.row0 + local;                 // slab form: rows [row0, row0 + n_rows) only (row0 = 0 in the full form)
     const int dir = blockIdx.y;
     const int B = a.B;
-    if (row >= B) return;
+    const int n_out = a.S_cols ? a.n_rows : B;      // rows of every output matrix
+    if (local >= n_out) return;
     NrRowState<NE> r;
     r.load(a, row, dir, lane);
     r.stats(a.K, lane);
@@ -416,9 +418,9 @@ __global__ __launch_bounds__(256) void nr_row_losses_bwd_kernel(NrRowArgs a, con
     Dmin_c = nr_wave_sum(Dmin_c); Dmax_c = nr_wave_sum(Dmax_c);
 
     // ---- pass 2: per-entry gradients --------------------------------------------------------------
-    float* dSr = dS_dir + ((size_t)dir * B + row) * B;
-    float* dGr = dG_dir + ((size_t)dir * B + row) * B;
-    float* dCr = d_c_rows + ((size_t)dir * B + row) * B;
+    float* dSr = dS_dir + ((size_t)dir * n_out + local) * B;
+    float* dGr = dG_dir + ((size_t)dir * n_out + local) * B;
+    float* dCr = d_c_rows + ((size_t)dir * n_out + local) * B;
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         if (!r.valid[e]) continue;
@@ -455,8 +457,8 @@ __global__ __launch_bounds__(256) void nr_row_losses_bwd_kernel(NrRowArgs a, con
         dCr[j] = gN * dc;
     }
     if (lane == 0) {
-        d_wc[(size_t)dir * B + row] = gC * -(r.s_ii * r.ls - r.lse_c);
-        d_ls_rows[(size_t)dir * B + row] = gC * -r.wci * (r.s_ii - pcs);
+        d_wc[(size_t)dir * n_out + local] = gC * -(r.s_ii * r.ls - r.lse_c);
+        d_ls_rows[(size_t)dir * n_out + local] = gC * -r.wci * (r.s_ii - pcs);
     }
 }
 
@@ -471,6 +473,32 @@ extern "C" int nr_row_losses_bwd(const float* S, const float* G, const float* tg
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;
     NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f};
     dim3 grid((B + 3) / 4, 2);
+    hipStream_t st = (hipStream_t)stream;
+#define NR_BWD_CASE(N_) \
+    case N_: hipLaunchKernelGGL(nr_row_losses_bwd_kernel<N_>, grid, dim3(256), 0, st, a, g_rowloss, dS_dir, dG_dir, d_c_rows, d_wc, d_ls_rows); break;
+    switch (nr_row_ne(B)) {
+        NR_BWD_CASE(2) NR_BWD_CASE(4) NR_BWD_CASE(8) NR_BWD_CASE(16) NR_BWD_CASE(32)
+        default: return NR_EUNSUPPORTED;
+    }
+#undef NR_BWD_CASE
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// Backward of nr_row_losses_fwd_slab: the rows [row0, row0 + n_rows) a rank owns, from the two slabs of S it holds.  Outputs
+// are slab-shaped, one row per owned row and direction: dS_dir [2, n_rows, B] (direction 0: d S[row0 + k, :]; direction 1:
+// d S[:, row0 + k] -- the caller transposes), dG_dir and d_c_rows likewise, d_wc / d_ls_rows [2, n_rows].
+extern "C" int nr_row_losses_bwd_slab(const float* S_rows, const float* S_cols, int row0, int n_rows, const float* G,
+                                      const float* tgt_rows, const float* tgt_cols, const float* bank_c0, const float* bank_c1,
+                                      const float* wc_text, const float* wc_video, const float* logit_scale, int B, int K,
+                                      float temperature, const float* g_rowloss, float* dS_dir, float* dG_dir, float* d_c_rows,
+                                      float* d_wc, float* d_ls_rows, void* stream) {
+    if (!S_rows || !S_cols || !G || !tgt_rows || !tgt_cols || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale ||
+        !g_rowloss || !dS_dir || !dG_dir || !d_c_rows || !d_wc || !d_ls_rows)
+        return NR_EINVAL;
+    if (B <= 0 || K < 0 || K > B || row0 < 0 || n_rows <= 0 || row0 + n_rows > B) return NR_EINVAL;
+    NrRowArgs a{S_rows, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, S_cols, row0, n_rows, 0, 0, 0.f};
+    dim3 grid((n_rows + 3) / 4, 2);
     hipStream_t st = (hipStream_t)stream;
 #define NR_BWD_CASE(N_) \
     case N_: hipLaunchKernelGGL(nr_row_losses_bwd_kernel<N_>, grid, dim3(256), 0, st, a, g_rowloss, dS_dir, dG_dir, d_c_rows, d_wc, d_ls_rows); break;

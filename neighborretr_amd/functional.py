@@ -40,7 +40,7 @@ def head_losses(model, text_feat, video_feat, text_mask, video_mask, mb_feat_t, 
                                   model.scorer_weights("video_weight_fc"), hp, logit_scale, model._prec(),
                                   join=model._take_join(), bank_streams=model._bank_streams(text_feat.device),
                                   local_stream=model._local_stream(text_feat.device) if gt is None else None,
-                                  bank_early=model.bank_early, capture_order=model.capture_order,
+                                  bank_early=model.bank_early, capture_order=model.capture_order, bb_late=getattr(model, "bb_late", False),
                                   bank_prepared=model._bank_shadow(mb_feat_t, mb_feat_v), prepared_out=model._last_prepared,
                                   bank_push=getattr(model, "_push_fn", None), **model._global_scorers(text_feat, video_feat))
     return losses

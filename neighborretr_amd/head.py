@@ -130,7 +130,7 @@ PAIR_BANK_PRODUCTS = os.environ.get("NR_PAIR_BANK", "0") == "1"
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                  gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None,
                  bank_streams=None, local_stream=None, bank_early=0,
-                 capture_order=((7, 7), (7, 1 << 30)), bank_prepared=None, prepared_out=None, bank_push=None):
+                 capture_order=((7, 7), (7, 1 << 30)), bank_prepared=None, prepared_out=None, bank_push=None, bb_late=False):
     """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None).
 
     `join`: optional callable run right before the first use of gt / gv.  Either the caller produces the
@@ -188,8 +188,9 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         yield
         L["w_v"], L["lg_v"] = token_weights(pv_, video_mask, sw_v, B, Nv, p_mlp, keep)
         yield
-        L["S"], L["aux0"] = ops.local_level(pt_, pv_, L["w_t"], L["w_v"], B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
-        yield
+        if not (bb_late and split_tail):
+            L["S"], L["aux0"] = ops.local_level(pt_, pv_, L["w_t"], L["w_v"], B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
+            yield
         # mean of the (unmasked) normalised tokens for the centrality weights -- still on the local branch
         L["mean_t"] = ops.reduce_parts(pt_.colsum, 1.0 / pt_.n_tok)
         yield
@@ -310,7 +311,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     pt, pv, w_t, w_v, lg_t, lg_v = L["pt"], L["pv"], L["w_t"], L["w_v"], L["lg_t"], L["lg_v"]
     if prepared_out is not None:
         prepared_out["pt"], prepared_out["pv"] = pt, pv
-    S, aux0, mean_t, mean_v = L["S"], L["aux0"], L["mean_t"], L["mean_v"]
+    S, aux0, mean_t, mean_v = L.get("S"), L.get("aux0"), L["mean_t"], L["mean_v"]
     _check_global_tokens(gt, gv, hp)
     gt2 = gt.float().contiguous()                  # [B, G, d]: G = 1 at the MSR-VTT token counts
     gv2 = gv.float().contiguous()
@@ -341,6 +342,10 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
             with torch.cuda.stream(side2):
                 pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
             with torch.cuda.stream(side):
+                if S is None:
+                    # `bb_late`: the batch x batch product runs HERE, beside the Sinkhorn solve (only the row losses read S)
+                    # -- one chip-filling launch less beside the clustering
+                    S, aux0 = ops.local_level(pt, pv, w_t, w_v, B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
                 pbv, w_bv, lg_bv, aux1, c1 = early[0] or bank_video()
                 wait_stream(side, side2)
                 if pair_bank and early[0] is None:

@@ -125,6 +125,7 @@ _SIGNATURES = {
     "nr_row_losses_fwd_final": ([_P] * 9 + [_I, _I, _F, _P, _P, _F, _F, _F, _P, _P], _I),
     "nr_loss_finalize": ([_P, _I, _F, _F, _F, _P, _P], _I),
     "nr_row_losses_bwd": ([_P] * 9 + [_I, _I, _F, _P, _P, _P, _P, _P, _P, _P], _I),
+    "nr_row_losses_bwd_slab": ([_P, _P, _I, _I] + [_P] * 8 + [_I, _I, _F, _P, _P, _P, _P, _P, _P, _P], _I),
     "nr_add_transposed": ([_P, _P, _I, _P, _P], _I),
     "nr_colsum": ([_P, _I, _I, _P, _P], _I),
     "nr_local_level_bwd_workspace_bytes": ([_I, _I, _I, _I, _I, _I], _Z),

@@ -328,6 +328,23 @@ def row_losses_slab(S_rows, S_cols, row0, G, tgt_rows, tgt_cols, bank_c0, bank_c
     return rowloss
 
 
+def row_losses_bwd_slab(S_rows, S_cols, row0, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, K, T, g_rowloss):
+    """Backward of row_losses_slab (nr_row_losses_bwd_slab) -> dS_dir, dG_dir, d_c_rows [2,n,B], d_wc, d_ls_rows [2,n]."""
+    n, B = S_rows.shape
+    dev = S_rows.device
+    dS = torch.empty((2, n, B), dtype=torch.float32, device=dev)
+    dG = torch.empty((2, n, B), dtype=torch.float32, device=dev)
+    dC = torch.empty((2, n, B), dtype=torch.float32, device=dev)
+    dwc = torch.empty((2, n), dtype=torch.float32, device=dev)
+    dls = torch.empty((2, n), dtype=torch.float32, device=dev)
+    hip.call("nr_row_losses_bwd_slab", hip.ptr(S_rows, torch.float32), hip.ptr(S_cols, torch.float32), int(row0), int(n),
+             hip.ptr(G, torch.float32), hip.ptr(tgt_rows), hip.ptr(tgt_cols), hip.ptr(bank_c0, torch.float32),
+             hip.ptr(bank_c1, torch.float32), hip.ptr(wc_text, torch.float32), hip.ptr(wc_video, torch.float32),
+             hip.ptr(logit_scale, torch.float32), B, int(K), float(T), hip.ptr(g_rowloss, torch.float32), hip.ptr(dS), hip.ptr(dG),
+             hip.ptr(dC), hip.ptr(dwc), hip.ptr(dls), hip.stream_ptr())
+    return dS, dG, dC, dwc, dls
+
+
 def row_losses_final(S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, K, T, wu, wn, wkl):
     """Row terms [2,4,B] AND the five losses from one launch (nr_row_losses_fwd_final)."""
     B = S.shape[0]

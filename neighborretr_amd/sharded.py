@@ -11,9 +11,10 @@ products, and gradients need no reduction because every rank differentiates the 
   sharded by samples as well: the token clustering of the rank's b samples (fused HIP forward, hand-derived backward).  Its
       masked stage uses the maximum distance over the WHOLE gathered batch (cluster.py:473-475): the ranks all-reduce that
       one number per modality between the stage's front and back kernels; the [b, d] global tokens are all-gathered
-  light, replicated or row-local, in torch ops on [b, B] slabs: global logits G = gt gv^T, Sinkhorn targets (no
-      gradient), centrality weights, and the four row-wise loss terms of the rank's 2 b rows
-      (until_module.py:56-359 restated row-wise).
+  row-local, on the HIP row-loss kernels (SlabRowLossFn: nr_row_losses_fwd_slab / nr_row_losses_bwd_slab -- the same per-row
+      code as the replicated loss): the four loss terms of the rank's 2 b rows (until_module.py:56-359);
+  light, replicated, in a few torch ops: global logits G = gt gv^T, Sinkhorn targets (HIP kernel, no gradient), centrality
+      weights.  (`_direction_terms` / `_neighbor_rows` below restate the row terms in torch ops: the cross-check of the tests.)
 
 Each rank's L_r is ITS rows' share of every term, so sum_r L_r = L (the reference's loss).  Cross-rank values enter
 through differentiable collectives whose backward is the matching reduction (all-gather <-> reduce-scatter(sum),
@@ -121,6 +122,40 @@ def _direction_terms(S, G, tgt, c, w, ls, K, T, diag_col):
     return cent, unif, neigh, kl
 
 
+class SlabRowLossFn(torch.autograd.Function):
+    """This rank's share of the four loss terms -- its rows of either direction, from the two slabs of S it owns -- on the HIP
+    row-loss kernels (nr_row_losses_fwd_slab / nr_row_losses_bwd_slab: the same per-row code as the replicated loss, top-K
+    by wave arg-max rounds, ties to the lowest column).  Returns the PARTIAL [5] losses (total, centrality, uniform,
+    neighbour, kl) of the rank's rows, normalised like the full loss (sum over ranks = the reference's values)."""
+
+    @staticmethod
+    def forward(ctx, S_rows, S_cols, G, tgt_r, tgt_c, c0, c1, wc_text, wc_video, logit_scale, hp, row0):
+        args = [t.detach().float().contiguous() for t in (S_rows, S_cols, G, tgt_r, tgt_c, c0, c1, wc_text, wc_video)]
+        ls = logit_scale.detach().float().reshape(1).contiguous()
+        K, T = int(hp["num_neighbors"]), float(hp["temperature"])
+        rowloss = ops.row_losses_slab(args[0], args[1], row0, *args[2:], ls, K, T)
+        ctx.save_for_backward(*args, ls)
+        ctx.hp, ctx.row0 = dict(hp), int(row0)
+        return ops.loss_finalize(rowloss, hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
+
+    @staticmethod
+    def backward(ctx, g):
+        from .backward import _coef_rowloss
+        S_rows, S_cols, G, tgt_r, tgt_c, c0, c1, wc_text, wc_video, ls = ctx.saved_tensors
+        hp, r0 = ctx.hp, ctx.row0
+        n, B = S_rows.shape
+        coef = _coef_rowloss(g.float().contiguous(), hp, B)
+        dS, dG_dir, dC, dwc, dls = ops.row_losses_bwd_slab(S_rows, S_cols, r0, G, tgt_r, tgt_c, c0, c1, wc_text, wc_video, ls,
+                                                           int(hp["num_neighbors"]), float(hp["temperature"]), coef)
+        dG = torch.zeros_like(G)
+        dG[r0:r0 + n] += dG_dir[0]                       # direction 0 read rows of G, direction 1 columns
+        dG[:, r0:r0 + n] += dG_dir[1].t()
+        d_wt, d_wv = torch.zeros_like(wc_text), torch.zeros_like(wc_video)
+        d_wt[r0:r0 + n], d_wv[r0:r0 + n] = dwc[0], dwc[1]
+        return (dS[0], dS[1].t().contiguous(), dG, None, None, dC[0].sum(0), dC[1].sum(0), d_wt, d_wv,
+                dls.sum().reshape(1), None, None)
+
+
 def sharded_training_losses(model, text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                             hp, logit_scale, rank, world, noise=None):
     """-> [5] tensor (total, centrality, uniform, neighbour, kl): full values, this rank's share of the gradient (x W)."""
@@ -168,15 +203,10 @@ def sharded_training_losses(model, text_feat, video_feat, text_mask, video_mask,
     mean_v = _AllReduceSum.apply(vn) / (B * video_feat.shape[1])
     w_text = torch.exp(hp["centrality_scale"] * (torch.nn.functional.normalize(gt[sl], dim=-1) @ mean_t))      # [b]
     w_video = torch.exp(hp["centrality_scale"] * (torch.nn.functional.normalize(gv[sl], dim=-1) @ mean_v))
-    # ---- the four terms on this rank's rows of either direction
-    ls = logit_scale.reshape(()).float()
-    diag = torch.arange(r0, r0 + b, device=text_feat.device)
-    c_t, u_t, n_t, k_t = _direction_terms(S_rows, G[sl], tgt_r[sl], c0, w_text, ls, K, T, diag)
-    c_v, u_v, n_v, k_v = _direction_terms(S_cols.t(), G.t()[sl], tgt_c[sl], c1, w_video, ls, K, T, diag)
-    cent, unif, neigh = ((x + y) / (2 * B) for x, y in ((c_t, c_v), (u_t, u_v), (n_t, n_v)))
-    kl = (k_t + k_v) / (2 * B * B)                                                     # kl_div 'mean' divides by B*B
-    total = cent + unif * hp["uniform_weight"] + neigh * hp["neighbor_weight"] + kl * hp["kl_weight"]
-    part = torch.stack((total, cent, unif, neigh, kl))
+    # ---- the four terms on this rank's rows of either direction: HIP row-loss kernels on the slabs (forward and backward)
+    wt_full = torch.zeros((B,), dtype=torch.float32, device=text_feat.device).index_add(0, torch.arange(r0, r0 + b, device=text_feat.device), w_text)
+    wv_full = torch.zeros((B,), dtype=torch.float32, device=text_feat.device).index_add(0, torch.arange(r0, r0 + b, device=text_feat.device), w_video)
+    part = SlabRowLossFn.apply(S_rows, S_cols, G, tgt_r, tgt_c, c0, c1, wt_full, wv_full, logit_scale.reshape(1).float(), hp, r0)
     full = part.detach().clone()
     dist.all_reduce(full)                                                              # the reference's (full) values
     # value: full;  gradient: W x this rank's share (DDP's mean over ranks then yields the full-loss gradient)

@@ -163,3 +163,47 @@ def test_sharded_training_loss_gradients_equal_replicated(tmp_path, precision, p
             if scale == 0:
                 continue
             assert float((sh["params"][n] - g).abs().max()) < pbar * scale + 2e-6, (n, float((sh["params"][n] - g).abs().max()), scale)
+
+
+def test_slab_row_losses_on_hip_match_the_torch_restatement():
+    """SlabRowLossFn (nr_row_losses_fwd_slab / nr_row_losses_bwd_slab) against sharded._direction_terms -- the row terms restated
+    in torch ops -- for one rank's slab: the partial losses and the gradients w.r.t. both S slabs, G, both bank centrality
+    vectors, the centrality weights and the logit scale.  Single process (no collective involved)."""
+    import numpy as np
+    from neighborretr_amd import ops, sharded, synth
+    dev = "cuda"
+    B, b, r0, K, T = 64, 16, 32, 8, 3.0
+    hp = dict(num_neighbors=K, temperature=T, uniform_weight=1.0, neighbor_weight=0.7, kl_weight=1.3, beta=0.7)
+    S = torch.from_numpy(synth.uniform(3, "slab_S", (B, B)).astype(np.float32) * 0.12).to(dev)
+    G = torch.from_numpy(synth.normal(3, "slab_G", (B, B)).astype(np.float32) * 6).to(dev)
+    c0 = torch.from_numpy(synth.uniform(3, "slab_c0", (B,)).astype(np.float32) * 0.1).to(dev)
+    c1 = torch.from_numpy(synth.uniform(3, "slab_c1", (B,)).astype(np.float32) * 0.1).to(dev)
+    w_t = torch.exp(torch.from_numpy(synth.normal(3, "slab_wt", (b,)).astype(np.float32) * 0.05)).to(dev)
+    w_v = torch.exp(torch.from_numpy(synth.normal(3, "slab_wv", (b,)).astype(np.float32) * 0.05)).to(dev)
+    tgt_r, tgt_c = ops.sinkhorn_targets(G, 0.7, 50)
+    sl = slice(r0, r0 + b)
+
+    def leaves():
+        return [t.clone().requires_grad_(True) for t in (S[sl].contiguous(), S[:, sl].contiguous(), G, c0, c1, w_t, w_v,
+                                                           torch.tensor([100.0], device=dev))]
+    # torch restatement (normalised like the full loss)
+    a = leaves()
+    diag = torch.arange(r0, r0 + b, device=dev)
+    ct, ut, nt, kt = sharded._direction_terms(a[0], a[2][sl], tgt_r[sl], a[3], a[5], a[7].reshape(()), K, T, diag)
+    cv, uv, nv, kv = sharded._direction_terms(a[1].t(), a[2].t()[sl], tgt_c[sl], a[4], a[6], a[7].reshape(()), K, T, diag)
+    cent, unif, neigh = ((x + y) / (2 * B) for x, y in ((ct, cv), (ut, uv), (nt, nv)))
+    kl = (kt + kv) / (2 * B * B)
+    ref = torch.stack((cent + unif * hp["uniform_weight"] + neigh * hp["neighbor_weight"] + kl * hp["kl_weight"], cent, unif, neigh, kl))
+    wts = torch.tensor([1.0, 0.3, -0.2, 0.5, 0.1], device=dev)
+    (ref * wts).sum().backward()
+    # HIP
+    h = leaves()
+    wt_full = torch.zeros(B, device=dev).index_add(0, diag, h[5])
+    wv_full = torch.zeros(B, device=dev).index_add(0, diag, h[6])
+    got = sharded.SlabRowLossFn.apply(h[0], h[1], h[2], tgt_r, tgt_c, h[3], h[4], wt_full, wv_full, h[7], hp, r0)
+    (got * wts).sum().backward()
+    assert torch.allclose(got, ref, rtol=2e-5, atol=1e-6), (got, ref)
+    for name, x, y in zip(("S_rows", "S_cols", "G", "c0", "c1", "w_text", "w_video", "logit_scale"), h, a):
+        scale = float(y.grad.abs().max())
+        err = float((x.grad - y.grad).abs().max())
+        assert err < 2e-4 * scale + 1e-9, (name, err, scale)

@@ -11,9 +11,14 @@ dev = torch.device("cuda")
 p = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_problem(1002, B, Nt, Nv, M).items()}
 BIG = 1 << 30
 SETTINGS = [
-    ("default ((7,9),(7,inf)) early=2", ((7, 9), (7, BIG)), 2),
-    ("early=1", ((7, 9), (7, BIG)), 1),
-    ("early=0", ((7, 9), (7, BIG)), 0),
+    ("default ((7,7),(7,inf)) early=2", ((7, 7), (7, BIG)), 2),
+    ("early=1", ((7, 7), (7, BIG)), 1),
+    ("early=0", ((7, 7), (7, BIG)), 0),
+    ("early=2 bb_late", ((7, 6), (7, BIG)), 2, True),
+    ("early=1 bb_late", ((7, 6), (7, BIG)), 1, True),
+    ("early=0 bb_late", ((7, 6), (7, BIG)), 0, True),
+    ("((7,5),(7,inf)) early=2", ((7, 5), (7, BIG)), 2),
+    ("((7,9),(7,inf)) early=2", ((7, 9), (7, BIG)), 2),
     ("((7,9),(3,4),(4,inf))", ((7, 9), (3, 4), (4, BIG)), 2),
     ("((4,5),(3,4),(7,inf))", ((4, 5), (3, 4), (7, BIG)), 2),
     ("((7,7),(7,inf))", ((7, 7), (7, BIG)), 2),
@@ -26,11 +31,11 @@ SETTINGS = [
     ("((14,0),(0,inf)) clustering first", ((14, 0), (0, BIG)), 2),
     ("((0,inf),(14,0)) local first", ((0, BIG), (14, 0)), 2),
 ]
-def build(order, early):
+def build(order, early, bb_late=False):
     m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K))
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}, strict=False)
     m = m.to(dev).train()
-    m.capture_order, m.bank_early = order, early
+    m.capture_order, m.bank_early, m.bb_late = order, early, bb_late
     m.mb_feat_t, m.mb_feat_v, m.mb_mask_t, m.mb_mask_v = (p[k].clone() for k in ("mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v"))
     m.mb_ind = torch.arange(M, device=dev)
     def step():
@@ -59,7 +64,7 @@ if "--random" in sys.argv[1:]:
             turns.append((a, rng.randint(0, 9)))
         turns.append((0, BIG))
         SETTINGS.append((str(tuple(turns)).replace(str(BIG), "inf"), tuple(turns), 2))
-built = [(name, build(order, early)) for name, order, early in SETTINGS]
+built = [(st[0], build(*st[1:])) for st in SETTINGS]
 for rnd in range(2):
     for name, (m, g) in built:
         print(f"round {rnd}  {name:40s} {timeit(g):7.1f} us", flush=True)
