@@ -541,16 +541,19 @@ def main():
         per_launch_s = e0.elapsed_time(e1) * 1e-3 / (n_launch * reps * inner)
         achieved = (f_sim / n_launch) / per_launch_s / 1e12
         traffic = mfma_busy = None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_sim.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_sim.json")
+        if not os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_sim.json")
+        pmc_name = "profiles/" + os.path.basename(pmc)
         if os.path.exists(pmc):     # PMC counters need rocprofv3 (separate passes): the committed passes are quoted here
             pj = json.load(open(pmc))
             traffic, mfma_busy = pj.get("bytes_per_launch_avg_over_step"), pj.get("mfma_busy_frac_flops_weighted")
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r02_pmc_sim.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 "
+                    "traffic_source": pmc_name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 "
                                       "correction on FETCH_SIZE; bytes per launch, mean over the step's similarity launches; not re-measured in this run)",
                     "mfma_busy_frac": mfma_busy,
-                    "mfma_busy_source": "profiles/r02_pmc_sim.json: SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / (SQ_BUSY_CYCLES / shader engines), "
+                    "mfma_busy_source": pmc_name + ": SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / (SQ_BUSY_CYCLES / shader engines), "
                                         "weighted by the MFMA flops each launch issues",
                     "kernel": ("nr_sim_pair_kernel (fused local_level: the 2 bank products as chained 192x384 tile pairs through one "
                                "ping-pong K loop) + nr_sim_reg_kernel (the split-bf16 batch product on 96x192 blocks), both on 2x4 "
@@ -576,7 +579,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: B=128 d=512 Nt=24 Nv=12 M=512 K=20 (MSR-VTT shape), "
                                    "loss-only forward incl. token clustering and bank push",
                        "global_batch": c["B"], "per_rank_batch": b, "precision_plan": args.precision,
-                       "hip_graph": graph is not None, "parallelism": f"dp{world} (packed all-gather + " + ("loss, bank and clustering work sharded over the ranks, collectives inside the graph)" if sharded else "replicated loss)"),
+                       "hip_graph": graph is not None, "parallelism": f"dp{world} (packed all-gather + " + (("loss, bank and clustering work sharded over the ranks; " + ("every collective inside the one HIP graph" if graph is not None else "launched eagerly") + ")") if sharded else "replicated loss; exchange step eager, loss from a HIP graph)"),
                        "memory_bank": "ring (device head) + persistent prepared bf16 shadow, extended by the batch rows at every push"},
             "losses": [round(float(x), 5) for x in losses],
             "ms_per_step_min": round(min(rep_ms), 4), "ms_per_step_median": round(float(np.median(rep_ms)), 4),

@@ -53,6 +53,11 @@ int nr_prepare_parts(int n_tok);
 int nr_prepare_tokens(const float* x, const float* mask, int n_tok, int d, int normalize,
                       uint16_t* hi, uint16_t* lo, float* norm, float* colsum_part, void* stream);
 
+/* nr_prepare_tokens for TWO token matrices of the same width (the batch's text and video tokens) in one launch. */
+int nr_prepare_tokens_pair(const float* x0, const float* mask0, int n_tok0, uint16_t* hi0, uint16_t* lo0, float* norm0,
+                           float* colsum_part0, const float* x1, const float* mask1, int n_tok1, uint16_t* hi1, uint16_t* lo1,
+                           float* norm1, float* colsum_part1, int d, int normalize, void* stream);
+
 /* plain f32 -> bf16 hi/lo split (MLP weight matrices). */
 int nr_split_bf16(const float* x, size_t n, uint16_t* hi, uint16_t* lo, void* stream);
 
@@ -267,13 +272,15 @@ typedef struct NrSplitItem {
 } NrSplitItem;
 int nr_split_group(int n, const NrSplitItem* items, void* stream);
 
-/* nr_colsum_group: dst[c] = sum_r src[r, c] for up to NR_COLSUM_MAX f32 matrices in one launch (bias gradients, sums of
+/* nr_colsum_group: dst[c] = scale * sum_r src[r, c] for up to NR_COLSUM_MAX f32 matrices in one launch (bias gradients, sums of
  * per-sample partial parameter gradients); fixed summation order.                                                           */
 #define NR_COLSUM_MAX 16
 typedef struct NrColsumItem {
     const float* src;
     float* dst;
     int32_t rows, cols;
+    float scale;       /* dst = scale * column sums */
+    int32_t pad_;
 } NrColsumItem;
 int nr_colsum_group(int n, const NrColsumItem* items, void* stream);
 

@@ -44,9 +44,12 @@ def _linear_group(problems):
 
 
 def _colsum_group(items):
+    """items: (src [rows, cols] f32, dst [cols], rows, cols[, scale])."""
     arr = (hip.ColsumItem * len(items))()
-    for a, (src, dst, rows, cols) in zip(arr, items):
+    for a, it in zip(arr, items):
+        src, dst, rows, cols = it[:4]
         a.src, a.dst, a.rows, a.cols = _addr(src), _addr(dst), int(rows), int(cols)
+        a.scale = float(it[4]) if len(it) > 4 else 1.0
     hip.call("nr_colsum_group", len(items), arr, hip.stream_ptr())
 
 

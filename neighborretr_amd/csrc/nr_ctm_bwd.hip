@@ -153,7 +153,7 @@ __global__ __launch_bounds__(1024) void nr_colsum_group_kernel(NrColsumGroup g) 
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) s += red[w][lane];
-        it.dst[c] = s;
+        it.dst[c] = s * it.scale;
     }
 }
 

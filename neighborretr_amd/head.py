@@ -130,7 +130,7 @@ PAIR_BANK_PRODUCTS = os.environ.get("NR_PAIR_BANK", "0") == "1"
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                  gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None,
                  bank_streams=None, local_stream=None, bank_early=0,
-                 capture_order=((7, 7), (7, 1 << 30)), bank_prepared=None, prepared_out=None, bank_push=None, bb_late=False):
+                 capture_order=((7, 5), (7, 1 << 30)), bank_prepared=None, prepared_out=None, bank_push=None, bb_late=False):
     """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None).
 
     `join`: optional callable run right before the first use of gt / gv.  Either the caller produces the
@@ -180,9 +180,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     early = [None, None]
 
     def local_steps():
-        L["pt"] = pt_ = ops.prepare_tokens(text_feat, text_mask, want_lo=lo_b, want_colsum=True)
-        yield
-        L["pv"] = pv_ = ops.prepare_tokens(video_feat, video_mask, want_lo=lo_b, want_colsum=True)
+        L["pt"], L["pv"] = pt_, pv_ = ops.prepare_tokens_pair(text_feat, text_mask, video_feat, video_mask, want_lo=lo_b, want_colsum=True)
         yield
         L["w_t"], L["lg_t"] = token_weights(pt_, text_mask, sw_t, B, Nt, p_mlp, keep)
         yield
@@ -191,10 +189,8 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         if not (bb_late and split_tail):
             L["S"], L["aux0"] = ops.local_level(pt_, pv_, L["w_t"], L["w_v"], B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
             yield
-        # mean of the (unmasked) normalised tokens for the centrality weights -- still on the local branch
-        L["mean_t"] = ops.reduce_parts(pt_.colsum, 1.0 / pt_.n_tok)
-        yield
-        L["mean_v"] = ops.reduce_parts(pv_.colsum, 1.0 / pv_.n_tok)
+        # mean of the (unmasked) normalised tokens for the centrality weights -- still on the local branch, both in one launch
+        L["mean_t"], L["mean_v"] = ops.colsum_pair(pt_.colsum, 1.0 / pt_.n_tok, pv_.colsum, 1.0 / pv_.n_tok)
         yield
         # `bank_early` chains (0..2) run right behind the batch products, i.e. beside the clustering; the rest is
         # forked after the join (beside the Sinkhorn solve)
@@ -471,8 +467,7 @@ def head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t
     L = {}
 
     def local_branch():
-        pt = ops.prepare_tokens(text_feat, text_mask, want_lo=lo_b, want_colsum=True)
-        pv = ops.prepare_tokens(video_feat, video_mask, want_lo=lo_b, want_colsum=True)
+        pt, pv = ops.prepare_tokens_pair(text_feat, text_mask, video_feat, video_mask, want_lo=lo_b, want_colsum=True)
         w_t, _ = token_weights(pt, text_mask, sw_t, B, Nt, p_mlp)
         w_v, _ = token_weights(pv, video_mask, sw_v, B, Nv, p_mlp)
         if prepared_out is not None:
@@ -492,8 +487,7 @@ def head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t
         p1, _ = ops.local_level(pt_r, pbv, w_t_r, w_bv, b, Nt, M, Nv, p_bank, hip.OUT_ROWSUM)
         p0, _ = ops.local_level(pbt, pv_r, w_bt, w_v_r, M, Nt, b, Nv, p_bank, hip.OUT_COLSUM)
         L["mine"] = torch.stack((ops.reduce_parts(p0, 1.0 / M), ops.reduce_parts(p1, 1.0 / M)))          # [2, b]
-        L["mean_t"] = ops.reduce_parts(pt.colsum, 1.0 / pt.n_tok)
-        L["mean_v"] = ops.reduce_parts(pv.colsum, 1.0 / pv.n_tok)
+        L["mean_t"], L["mean_v"] = ops.colsum_pair(pt.colsum, 1.0 / pt.n_tok, pv.colsum, 1.0 / pv.n_tok)
         L["keep"] = (pt, pv, w_t, w_v, pbt, pbv, w_bt, w_bv, pt_r, pv_r, w_t_r, w_v_r)                       # alive until the join
 
     cur = torch.cuda.current_stream()

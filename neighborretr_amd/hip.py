@@ -47,7 +47,7 @@ class SplitItem(ctypes.Structure):
 
 class ColsumItem(ctypes.Structure):
     """NrColsumItem of include/nr_hip.h."""
-    _fields_ = [("src", _P), ("dst", _P), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
+    _fields_ = [("src", _P), ("dst", _P), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("scale", _F), ("pad_", ctypes.c_int32)]
 
 
 class LinearProblem(ctypes.Structure):
@@ -79,6 +79,7 @@ _SIGNATURES = {
     "nr_stream_capture_id": ([_P, ctypes.POINTER(ctypes.c_ulonglong)], _I),
     "nr_prepare_parts": ([_I], _I),
     "nr_prepare_tokens": ([_P, _P, _I, _I, _I, _P, _P, _P, _P, _P], _I),
+    "nr_prepare_tokens_pair": ([_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P], _I),
     "nr_split_bf16": ([_P, _Z, _P, _P, _P], _I),
     "nr_token_logits_fwd": ([_P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     "nr_token_softmax": ([_P, _I, _P, _P, _I, _I, _P, _P, _P], _I),

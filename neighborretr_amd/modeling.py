@@ -114,7 +114,7 @@ class NeighborRetr(nn.Module):
         self._push_fn = None
         self._pushed = False
         # capture order of the loss-only step: (clustering launches, local-branch launches) per turn, last repeats
-        self.capture_order = ((7, 7), (7, 1 << 30))
+        self.capture_order = ((7, 5), (7, 1 << 30))
         self.bank_early = 2                 # bank chains started beside the clustering instead of the Sinkhorn (0..2)
         self.group_clustering = True        # text + video clustering in the same launches (no-grad forward)
         self.fuse_clustering = True

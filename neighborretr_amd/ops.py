@@ -42,6 +42,32 @@ def prepare_tokens(x, mask=None, normalize=True, want_lo=True, want_norm=True, w
     return Prepared(hi, lo, norm, colsum, n_tok, d)
 
 
+def prepare_tokens_pair(x0, mask0, x1, mask1, want_lo=True, want_colsum=False):
+    """prepare_tokens of two token tensors of the same width in ONE launch (nr_prepare_tokens_pair) -> (Prepared, Prepared)."""
+    x0, x1 = _f32(x0).contiguous(), _f32(x1).contiguous()
+    d = x0.shape[-1]
+    if x1.shape[-1] != d:
+        raise ValueError("both tensors must have the same feature width")
+    dev = x0.device
+    out, argv = [], []
+    for x, mask in ((x0, mask0), (x1, mask1)):
+        n_tok = x.numel() // d
+        hi = torch.empty((n_tok, d), dtype=torch.int16, device=dev)
+        lo = torch.empty((n_tok, d), dtype=torch.int16, device=dev) if want_lo else None
+        norm = torch.empty((n_tok,), dtype=torch.float32, device=dev)
+        colsum = torch.empty((hip.prepare_parts(n_tok), d), dtype=torch.float32, device=dev) if want_colsum else None
+        m = None
+        if mask is not None:
+            m = _f32(mask).contiguous()
+            if m.numel() != n_tok:
+                raise ValueError("mask does not match the token count")
+        argv += [hip.ptr(x, torch.float32), hip.ptr(m, allow_none=True), n_tok, hip.ptr(hi), hip.ptr(lo, allow_none=True), hip.ptr(norm),
+                 hip.ptr(colsum, allow_none=True)]
+        out.append((Prepared(hi, lo, norm, colsum, n_tok, d), m))
+    hip.call("nr_prepare_tokens_pair", *argv, d, 1, hip.stream_ptr())
+    return out[0][0], out[1][0]
+
+
 def split_bf16(w, want_lo=True):
     w = _f32(w).contiguous()
     hi = torch.empty(w.shape, dtype=torch.int16, device=w.device)
@@ -177,6 +203,15 @@ def reduce_parts(parts, scale):
     hip.call("nr_reduce_parts", hip.ptr(parts, torch.float32), parts.shape[0], parts.shape[1], float(scale), hip.ptr(out),
              hip.stream_ptr())
     return out
+
+
+def colsum_pair(a, scale_a, b, scale_b):
+    """(scale_a * column sums of a, scale_b * column sums of b) in one launch (nr_colsum_group); fixed summation order."""
+    from .cluster_backward_hip import _colsum_group
+    oa = torch.empty((a.shape[1],), dtype=torch.float32, device=a.device)
+    ob = torch.empty((b.shape[1],), dtype=torch.float32, device=b.device)
+    _colsum_group([(a, oa, a.shape[0], a.shape[1], scale_a), (b, ob, b.shape[0], b.shape[1], scale_b)])
+    return oa, ob
 
 
 def gemm_nt_f32(a, b):
