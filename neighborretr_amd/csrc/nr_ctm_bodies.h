@@ -23,12 +23,15 @@ struct NrCtmFrontArgs {
 // and the NEXT row of a wave is loaded before the current row's results are stored (vmcnt retires in order:
 // a load issued after stores waits for their acknowledgement -- with the loads placed between the LayerNorm
 // and norm1 halves of a row that was three dependent round trips per row).
-template <int CPL>
+// THREADS: the workgroup size the body is launched with (stages with a handful of tokens per sample -- stage 1 of the step:
+// 4 and 3 -- run 256-thread workgroups: a 1024-thread workgroup needs a CU of its own and waits for one while the MFMA
+// kernels of the other branch hold them, a small one slots in beside them).
+template <int CPL, int THREADS = CF_THREADS>
 __device__ __forceinline__ void nr_ctm_front_body(const NrCtmFrontArgs& p, const int b, float* sx) {
-    __shared__ float s_wmax[CF_THREADS / 64];
+    __shared__ float s_wmax[THREADS / 64];
     const int N = p.N, C = p.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = CF_THREADS / 64;
+    constexpr int NW = THREADS / 64;
     const int cpl = C / 64;
     const float* __restrict__ g_y = p.y;
     float* __restrict__ g_xn = p.xn;
@@ -180,14 +183,14 @@ typedef const __attribute__((address_space(1))) void* nr_bk_glb_ptr_t;
 // FUSED = called right behind nr_ctm_front_body by the same workgroup (unmasked stages only: without a mask the
 // global maximum of the distances is never used, so nothing has to come from other workgroups): sxn already holds
 // the rows (the front body's sx), p.smax is not read.
-template <bool FUSED = false>
+template <bool FUSED = false, int THREADS = BK_THREADS>
 __device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const int b, float* sxn) {
-    constexpr int NW = BK_THREADS / 64;
+    constexpr int NW = THREADS / 64;
     __shared__ float sd[64][65];
     __shared__ float s_density[64], s_score[64], s_share[64], s_tot[64], s_tokw[64], s_noise[64], s_mask[64];
     __shared__ int s_centre[64], s_assign[64];
-    __shared__ float s_red[2][NW];
-    __shared__ float s_psum[NW * BK_MAXJ], s_pvar[NW * BK_MAXJ];
+    __shared__ float s_red[2][BK_THREADS / 64];
+    __shared__ float s_psum[(BK_THREADS / 64) * BK_MAXJ], s_pvar[(BK_THREADS / 64) * BK_MAXJ];
     const int N = p.N, C = p.C, cnum = p.cnum;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef NR_STAMP
@@ -210,7 +213,7 @@ __device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const i
     float dreg[DPT];
 #pragma unroll
     for (int u = 0; u < DPT; ++u) {
-        const int e = tid + BK_THREADS * u;
+        const int e = tid + THREADS * u;
         dreg[u] = e < N * N ? db[e] : 0.f;
     }
     if (tid < N) {
@@ -234,7 +237,7 @@ __device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const i
     // global maximum over all samples (cluster.py:473-475)
     float g = 0.f;
     if constexpr (!FUSED)
-        for (int i = tid; i < p.n_samples; i += BK_THREADS) g = fmaxf(g, p.smax[i]);
+        for (int i = tid; i < p.n_samples; i += THREADS) g = fmaxf(g, p.smax[i]);
     g = nr_wave_max(g);
     if (lane == 0) s_red[0][wave] = g;
     __syncthreads();
@@ -247,7 +250,7 @@ __device__ __forceinline__ void nr_ctm_back_body(const NrCtmBackArgs& p, const i
     float lmax = 0.f;
 #pragma unroll
     for (int u = 0; u < DPT; ++u) {
-        const int e = tid + BK_THREADS * u;
+        const int e = tid + THREADS * u;
         if (e < N * N) {
             int i = e / N, j = e - i * N;
             float dv = dreg[u];
@@ -444,14 +447,14 @@ __device__ __forceinline__ void nr_tc_attention_body(const NrAttnArgs& a, const 
     const int ld = skv ? 2 * C + 4 : 2 * C;
     if (skv) {
         const int per_row = 2 * C / 4;                       // float4 per row
-        for (int e = threadIdx.x; e < N * per_row; e += 1024) {
+        for (int e = threadIdx.x; e < N * per_row; e += (int)blockDim.x) {
             const int n = e / per_row, c4 = e - n * per_row;
             *reinterpret_cast<f32x4_t*>(skv + n * ld + c4 * 4) = *reinterpret_cast<const f32x4_t*>(kvb + (size_t)n * 2 * C + c4 * 4);
         }
         __syncthreads();
     }
     const float* kvs = skv ? skv : kvb;
-    for (int job = wave; job < a.H * cnum; job += 16) {
+    for (int job = wave; job < a.H * cnum; job += (int)(blockDim.x >> 6)) {
         const int h = job / cnum, cl = job - h * cnum;
         const float* qr = a.q + ((size_t)b * cnum + cl) * C + h * 64;
         float logit = -INFINITY;

@@ -41,16 +41,16 @@ __global__ __launch_bounds__(CF_THREADS) void nr_group_front_kernel(NrGroupOf<Nr
 
 // front + back in one launch for stages without a mask (stage 1 of the step): the back half needs nothing from
 // other workgroups then, and the normalised rows it merges are the ones the front half left in LDS
-template <int CPL>
-__global__ __launch_bounds__(CF_THREADS) void nr_group_front_back_kernel(NrGroupOf<NrCtmFrontArgs> gf, NrGroupOf<NrCtmBackArgs> gb) {
+template <int CPL, int THREADS = CF_THREADS>
+__global__ __launch_bounds__(THREADS) void nr_group_front_back_kernel(NrGroupOf<NrCtmFrontArgs> gf, NrGroupOf<NrCtmBackArgs> gb) {
     NR_CRITICAL_PATH();
     extern __shared__ __attribute__((aligned(16))) float sx[];
     const int gi = gf.find(blockIdx.x);
     const int b = blockIdx.x - gf.start[gi];
-    nr_ctm_front_body<CPL>(gf.p[gi], b, sx);
+    nr_ctm_front_body<CPL, THREADS>(gf.p[gi], b, sx);
     __threadfence_block();                 // the distances / token weights this workgroup just stored are read back
     __syncthreads();
-    nr_ctm_back_body<true>(gb.p[gi], b, sx);
+    nr_ctm_back_body<true, THREADS>(gb.p[gi], b, sx);
 }
 
 __global__ __launch_bounds__(BK_THREADS) void nr_group_back_kernel(NrGroupOf<NrCtmBackArgs> g, int use_lds) {
@@ -228,7 +228,11 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
         bool small = true;                   // registers sized for C <= 512 unless a problem is wider
         for (int i = 0; i < n; ++i) small = small && d[i].C <= 512;
         if (first <= 2 && 2 < last) {
-            if (fusable) {
+            bool few = small;                    // a handful of tokens per sample (stage 1 of the step): 256-thread workgroups
+            for (int i = 0; i < n; ++i) few = few && d[i].N <= 8 && d[i].cnum * (d[i].C / 128) <= 4 * BK_MAXJ;
+            if (fusable && few) {
+                hipLaunchKernelGGL((nr_group_front_back_kernel<8, 256>), dim3(total), dim3(256), front_lds, st, gf, gb);
+            } else if (fusable) {
                 const void* k = small ? (const void*)nr_group_front_back_kernel<8> : (const void*)nr_group_front_back_kernel<CF_MAX_CPL>;
                 if (front_lds > 64 * 1024) {
                     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds);
@@ -298,7 +302,9 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
             hipError_t e = hipFuncSetAttribute((const void*)nr_group_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(nr_group_attention_kernel, dim3(total), dim3(1024), lds, st, g, use_lds);
+        int jobs_max = 0;                    // (head, query) jobs per sample: one wave each, 8 waves when that covers them
+        for (int i = 0; i < n; ++i) jobs_max = d[i].heads * d[i].cnum > jobs_max ? d[i].heads * d[i].cnum : jobs_max;
+        hipLaunchKernelGGL(nr_group_attention_kernel, dim3(total), dim3(jobs_max <= 8 ? 512 : 1024), lds, st, g, use_lds);
         NR_LAUNCH_CHECK();
     }
     // 7. out = merged + proj(att) + proj.bias
