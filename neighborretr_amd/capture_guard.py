@@ -84,10 +84,15 @@ def _topology(stream):
     return hit
 
 
+TRACE = bool(int(__import__("os").environ.get("NR_GUARD_TRACE", "0")))     # developer hook: print every guarded edge
+
+
 def wait_stream(waiter, on):
     """waiter.wait_stream(on), checked against the capture rules first."""
     hit = _topology(waiter)
     if hit is not None:
+        if TRACE:
+            print(f"[capture_guard] {waiter.cuda_stream:#x} waits on {on.cuda_stream:#x} (origin {hit[1].origin:#x})", file=__import__("sys").stderr, flush=True)
         hit[1].wait(waiter.cuda_stream, on.cuda_stream)
         STATS["edges"] += 1
     waiter.wait_stream(on)

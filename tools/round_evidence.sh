@@ -1,0 +1,21 @@
+#!/bin/bash
+# Everything profiles/rNN_* is made from, in one GPU session (run on the GPU box from the repo root):
+#   bash tools/round_evidence.sh r03        -> gpurun_out/r03/*
+tag="${1:-rNN}"; repo="$(pwd)"; out="$repo/gpurun_out/$tag"; mkdir -p "$out"
+q() { grep -v "amdgpu.ids" ; }
+python bench.py --steps 200 --backward 2> "$out/bench.err" > "$out/bench_final.json"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null > "$out/bench_20steps.json"
+python tools/chain_times.py 2>&1 | q > "$out/chain_times.txt"
+python tools/train_times.py 2>&1 | q > "$out/train_times.txt"
+python tools/scorer_ab.py 2>&1 | q > "$out/scorer_ab.txt"
+python tools/sched_sweep.py 2>&1 | q > "$out/sched_sweep.txt"
+python tools/rccl_capture_probe.py 2>&1 | q > "$out/rccl_capture.txt"
+python tools/microbench.py 2>&1 | q > "$out/microbench.txt"
+bash tools/bench_profile.sh "$tag/step" > /dev/null 2>&1
+bash tools/train_profile.sh 13 > "$out/train_profile.txt" 2>&1
+cp "$repo/gpurun_out/train_prof/tr_kernel_stats.csv" "$out/train_kernel_stats.csv" 2>/dev/null
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$out/roof" -o r -- python3 "$repo/tools/roofline_launches.py" > "$out/roofline_launches.txt" 2>&1 )
+cp "$(find "$out/roof" -name '*kernel_stats.csv' | head -1)" "$out/roofline_kernel_stats.csv" 2>/dev/null; rm -rf "$out/roof"
+bash tools/pmc_passes.sh "$out/pmc" && python tools/pmc_to_json.py "$out/pmc" > "$out/pmc_sim.json"; rm -rf "$out/pmc" "$out"/pmc.*.log
+python bench.py --steps 50 --no-cpu-baseline --e2e 2>/dev/null > "$out/bench_e2e.json"
+ls -la "$out"

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Training step (forward + backward, configs[1]) as one captured HIP graph, with the clustering forward fused or
-autograd-traced and the scorer-MLP backward GEMMs on the build's engine or the library: ms per step of each."""
+"""Training step (forward + backward, configs[1]) launched eagerly and replayed from one captured HIP graph, by how its two
+heaviest backward parts run: the token clustering (HIP forward + HIP backward | HIP forward + hand-derived torch-op backward |
+autograd-traced torch ops) and the scorer MLP (fused HIP backward | torch-op form with GEMMs on the tile engine): ms per step."""
 import os
 import sys
 import time
@@ -10,13 +11,13 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from neighborretr_amd import backward, modeling, synth  # noqa: E402
+from neighborretr_amd import backward, cluster_fused, modeling, synth  # noqa: E402
 
 DEV = "cuda"
 B, Nt, Nv, M, K = 128, 24, 12, 512, 20
 
 
-def main():
+def main(which):
     m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K))
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}, strict=False)
     m = m.to(DEV).train()
@@ -31,12 +32,19 @@ def main():
         tf.grad = vf.grad = None
         m(tf, p["text_mask"], vf, p["video_mask"], p["idx"], 0)[0].backward()
 
-    for fused, own, side_streams in ((True, True, True), (True, False, True), (False, True, True), (False, False, True),
-                                     (False, True, False)):
+    settings = (("clustering HIP fwd + HIP bwd      | scorer bwd fused HIP", True, True, True),
+                ("clustering HIP fwd + HIP bwd      | scorer bwd torch-op form", True, True, False),
+                ("clustering HIP fwd + torch-op bwd | scorer bwd fused HIP", True, False, True),
+                ("clustering autograd-traced torch  | scorer bwd fused HIP", False, True, True),
+                ("clustering autograd-traced torch  | scorer bwd torch-op form (round 2)", False, True, False))
+    # one setting per process: a process that captures several training graphs with DIFFERENT stream topologies on the same
+    # side-stream objects segfaults inside the ROCm 7.2 runtime at the fourth capture (each setting alone captures fine:
+    # tools/traced_capture_check.py) -- the parent starts a child per setting and never touches the GPU itself
+    for name, fused, hip_bwd, mlp_hip in settings[which:which + 1]:
         if True:
             m.fused_training_clustering = fused
-            m.use_side_streams = side_streams
-            backward.OWN_MLP_GEMMS = own
+            cluster_fused.HIP_BACKWARD = hip_bwd
+            backward.FUSED_MLP_BACKWARD = mlp_hip
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -62,10 +70,15 @@ def main():
             for _ in range(30):
                 g.replay()
             torch.cuda.synchronize()
-            print(f"clustering forward {'fused HIP ' if fused else 'torch ops '} | {'side streams' if side_streams else 'ONE stream  '} | "
-                  f"MLP backward GEMMs {'own split-bf16' if own else 'library      '}: "
-                  f"eager {eager:6.2f} ms   graph {(time.perf_counter() - t0) / 30 * 1e3:6.2f} ms", flush=True)
+            print(f"{name:75s}: eager {eager:6.2f} ms   graph {(time.perf_counter() - t0) / 30 * 1e3:6.2f} ms", flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:
+        main(int(sys.argv[1]))
+    else:
+        import subprocess
+        for k in range(5):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), str(k)], capture_output=True, text=True, timeout=600)
+            out = [l for l in r.stdout.splitlines() if " ms " in l]
+            print(out[-1] if out else f"setting {k}: exit code {r.returncode} {r.stderr.strip().splitlines()[-1:]}", flush=True)
