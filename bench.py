@@ -366,6 +366,9 @@ def main():
         abi_calls = hip.N_CALLS - before
     elif world > 1:
         step()
+    # with collectives inside the capture other threads of the process (the process group's watchdog) may touch the runtime
+    # while this thread captures: thread-local capture mode keeps their calls out of the capture's error checking
+    cap_kw = {"capture_error_mode": "thread_local"} if world > 1 else {}
     if not args.no_graph and (whole_step_graph or not sharded):
         try:
             if world > 1 and whole_step_graph:
@@ -374,7 +377,7 @@ def main():
                 step()
                 eager = result["losses"].clone()
                 gv_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gv_):
+                with torch.cuda.graph(gv_, **cap_kw):
                     step()
                 gv_.replay()
                 torch.cuda.synchronize()
@@ -385,7 +388,7 @@ def main():
                     raise RuntimeError(f"replayed sharded step differs from the eager one: {result['losses'].tolist()} vs {eager.tolist()}")
                 del gv_
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **cap_kw):
                 (step if whole_step_graph else after_gather)()
             graph = g
         except Exception as e:          # graphs are an optimisation, never a requirement

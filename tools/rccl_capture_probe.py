@@ -38,7 +38,7 @@ for _ in range(3):          # warm-up outside the capture: communicator set-up, 
     op()
 torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
+with torch.cuda.graph(g, capture_error_mode="thread_local"):
     op()
 out.zero_()
 x.add_(1.0)                  # new input values: the replay must see them
