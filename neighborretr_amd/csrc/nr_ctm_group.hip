@@ -7,6 +7,7 @@
 // streams: measured on MI355X, two clustering branches on two streams overlap to only ~0.68 of their
 // summed time, while a grid that holds both costs max(text, video).  All GEMMs run split-bf16 on the MFMA
 // tile engine (nr_linear.hip); their A operands are written hi/lo directly by the producing kernel.
+#include <cstdlib>
 #include "nr_ctm_bodies.h"
 #include "nr_linear.h"
 #include "../../include/nr_hip.h"
@@ -31,12 +32,12 @@ __global__ __launch_bounds__(256) void nr_group_shift_kernel(NrGroupOf<NrShiftAr
     nr_shift_split_body(g.p[gi], blockIdx.x - g.start[gi]);
 }
 
-template <int CPL>
-__global__ __launch_bounds__(CF_THREADS) void nr_group_front_kernel(NrGroupOf<NrCtmFrontArgs> g) {
+template <int CPL, int THREADS = CF_THREADS>
+__global__ __launch_bounds__(THREADS) void nr_group_front_kernel(NrGroupOf<NrCtmFrontArgs> g) {
     NR_CRITICAL_PATH();
     extern __shared__ __attribute__((aligned(16))) float sx[];
     const int gi = g.find(blockIdx.x);
-    nr_ctm_front_body<CPL>(g.p[gi], blockIdx.x - g.start[gi], sx);
+    nr_ctm_front_body<CPL, THREADS>(g.p[gi], blockIdx.x - g.start[gi], sx);
 }
 
 // front + back in one launch for stages without a mask (stage 1 of the step): the back half needs nothing from
@@ -53,11 +54,12 @@ __global__ __launch_bounds__(THREADS) void nr_group_front_back_kernel(NrGroupOf<
     nr_ctm_back_body<true, THREADS>(gb.p[gi], b, sx);
 }
 
-__global__ __launch_bounds__(BK_THREADS) void nr_group_back_kernel(NrGroupOf<NrCtmBackArgs> g, int use_lds) {
+template <int THREADS = BK_THREADS>
+__global__ __launch_bounds__(THREADS) void nr_group_back_kernel(NrGroupOf<NrCtmBackArgs> g, int use_lds) {
     NR_CRITICAL_PATH();
     extern __shared__ __attribute__((aligned(16))) float sxn[];
     const int gi = g.find(blockIdx.x);
-    nr_ctm_back_body(g.p[gi], blockIdx.x - g.start[gi], use_lds ? sxn : nullptr);
+    nr_ctm_back_body<false, THREADS>(g.p[gi], blockIdx.x - g.start[gi], use_lds ? sxn : nullptr);
 }
 
 __global__ __launch_bounds__(1024) void nr_group_attention_kernel(NrGroupOf<NrAttnArgs> g, int use_lds) {
@@ -246,7 +248,9 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds);
                     if (e != hipSuccess) return (int)e;
                 }
-                if (small) hipLaunchKernelGGL(nr_group_front_kernel<8>, dim3(total), dim3(CF_THREADS), front_lds, st, gf);
+                const char* te = nr_tune_env("NR_CTM_THREADS");          // tuning hook: 512-thread workgroups for front / back / attention
+                if (small && te && atoi(te) == 512) hipLaunchKernelGGL((nr_group_front_kernel<8, 512>), dim3(total), dim3(512), front_lds, st, gf);
+                else if (small) hipLaunchKernelGGL(nr_group_front_kernel<8>, dim3(total), dim3(CF_THREADS), front_lds, st, gf);
                 else hipLaunchKernelGGL(nr_group_front_kernel<CF_MAX_CPL>, dim3(total), dim3(CF_THREADS), front_lds, st, gf);
             }
             NR_LAUNCH_CHECK();
@@ -262,10 +266,13 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
             const int use_lds = fits && lds <= 96 * 1024;
             if (!use_lds) lds = 0;
             if (lds > 40 * 1024) {
-                hipError_t e = hipFuncSetAttribute((const void*)nr_group_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipError_t e = hipFuncSetAttribute((const void*)nr_group_back_kernel<BK_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nr_group_back_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return (int)e;
             }
-            hipLaunchKernelGGL(nr_group_back_kernel, dim3(total), dim3(BK_THREADS), lds, st, gb, use_lds);
+            const char* te = nr_tune_env("NR_CTM_THREADS");
+            if (te && atoi(te) == 512) hipLaunchKernelGGL(nr_group_back_kernel<512>, dim3(total), dim3(512), lds, st, gb, use_lds);
+            else hipLaunchKernelGGL(nr_group_back_kernel<BK_THREADS>, dim3(total), dim3(BK_THREADS), lds, st, gb, use_lds);
             NR_LAUNCH_CHECK();
         }
     }
@@ -304,7 +311,8 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
         }
         int jobs_max = 0;                    // (head, query) jobs per sample: one wave each, 8 waves when that covers them
         for (int i = 0; i < n; ++i) jobs_max = d[i].heads * d[i].cnum > jobs_max ? d[i].heads * d[i].cnum : jobs_max;
-        hipLaunchKernelGGL(nr_group_attention_kernel, dim3(total), dim3(jobs_max <= 8 ? 512 : 1024), lds, st, g, use_lds);
+        const char* te = nr_tune_env("NR_CTM_THREADS");
+        hipLaunchKernelGGL(nr_group_attention_kernel, dim3(total), dim3((jobs_max <= 8 || (te && atoi(te) == 512)) ? 512 : 1024), lds, st, g, use_lds);
         NR_LAUNCH_CHECK();
     }
     // 7. out = merged + proj(att) + proj.bias

@@ -209,7 +209,8 @@ static int nr_token_logits_go(const uint16_t* tok_hi, const uint16_t* tok_lo, co
     }
     if (best < 0) return NR_EUNSUPPORTED;
     // ring depth: workgroups that sit alone on their CU prefetch for themselves (2 stages); crowded grids run 1
-    const bool two = best_wg < 3 * 256;
+    bool two = best_wg < 3 * 256;
+    if (nr_tune_env("NR_MLP_ONE_STAGE")) two = false;          // tuning hook: smallest LDS footprint
 #define NR_MLP_GO(MI_, NI_, WC_)                                                                                              \
     if (cand[best].mi == MI_ && cand[best].ni == NI_ && cand[best].wc == WC_) {                                               \
         if (x3) {                                                                                                             \

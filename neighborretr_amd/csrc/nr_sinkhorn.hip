@@ -285,9 +285,174 @@ __global__ __launch_bounds__(256) void nr_sinkhorn_plan_kernel(const float* __re
     }
 }
 
+// ---- 128 < B <= 1024 (B % 64 == 0): one cooperative launch instead of 2 x iters + 2 --------------------------------------------
+// The large-B path above is launch-bound (103 graph nodes: 300 / 420 / 669 us at B = 256 / 512 / 1024 for 50 iterations).
+// Here B/32 workgroups per direction keep their 32 rows AND their 32 columns of the kernel matrix in registers (wave w: 4
+// lines, B/64 entries per lane each), exchange the scaling vectors through two [B] arrays in global memory (`sc1` stores and
+// loads) and meet at a counter barrier after every half-iteration.  Only blockIdx % 8 in {0, 1} works -- direction 0 on one
+// XCD, direction 1 on another (round-robin placement: the barrier's atomics and the vectors then stay inside one L2; a
+// different placement is slower, never wrong).  Every spin is bounded: if the workgroups of a direction cannot become
+// co-resident (something else holds the CUs for good) the kernel gives up and poisons its targets with NaN instead of hanging.
+struct NrSkCoopArgs {
+    const float* G;
+    int B, iters;
+    float beta;
+    float *tgt_rows, *tgt_cols;
+    float* vec;                  // [2 dir][2][B] scaling vectors
+    unsigned int* counter;       // [2 dir][32] (one 128-byte line each), zero on entry
+};
+
+template <int EPL>               // entries per lane = B / 64
+__global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
+    NR_CRITICAL_PATH();
+    const int dir = blockIdx.x & 7;
+    if (dir > 1) return;
+    const int wg = blockIdx.x >> 3, B = p.B, nwg = B / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* va = p.vec + (size_t)dir * 2 * B;          // u / a
+    float* vb = va + B;                               // v / b
+    unsigned int* cnt = p.counter + dir * 32;
+    __shared__ int s_dead;
+    if (tid == 0) s_dead = 0;
+    const float norm = -logf((float)(2 * B));
+    const float mass = 1.0f / (float)(2 * B);
+    // X[i][j] = G[i][j] (dir 0) or G[j][i] (dir 1);  pr[q][e] = X[line q][64 e + lane],  pc[q][e] = X[64 e + lane][line q]
+    const int l0 = 32 * wg + 4 * wave;
+    float pr[4][EPL], pc[4][EPL];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const size_t rowmaj = (size_t)(l0 + q) * B + e * 64 + lane, colmaj = (size_t)(e * 64 + lane) * B + l0 + q;
+            pr[q][e] = p.G[dir == 0 ? rowmaj : colmaj];
+            pc[q][e] = p.G[dir == 0 ? colmaj : rowmaj];
+        }
+    unsigned int phase = 0;
+    auto barrier = [&]() {                            // all stores of this workgroup visible, then every workgroup of the direction
+        ++phase;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int target = phase * (unsigned)nwg;
+            int spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 22)) { s_dead = 1; break; }          // ~seconds: never hang the chip
+            }
+        }
+        __syncthreads();
+    };
+    auto put = [&](float* v, int q, float x) { if (lane == 0) __hip_atomic_store(v + l0 + q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto get = [&](const float* v, int e) { return __hip_atomic_load(v + e * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    float a_own[4] = {1.f, 1.f, 1.f, 1.f};
+    float u_own[4] = {0.f, 0.f, 0.f, 0.f}, v_own[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.iters > 0) {
+        // iteration 1 in the log domain, exactly as the reference (until_module.py:249-258): u = norm - LSE_j(X), v = norm - LSE_i(X + u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) m = fmaxf(m, pr[q][e]);
+            m = nr_wave_max(m);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) t += __expf(pr[q][e] - m);
+            u_own[q] = norm - (m + __logf(nr_wave_sum(t)));
+            put(va, q, u_own[q]);
+        }
+        barrier();
+        {
+            float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const float uu = get(va, e);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { pc[q][e] += uu; mx[q] = fmaxf(mx[q], pc[q][e]); }      // pc <- X + u
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float m = nr_wave_max(mx[q]);
+                float t = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) t += __expf(pc[q][e] - m);
+                v_own[q] = norm - (m + __logf(nr_wave_sum(t)));
+                put(vb, q, v_own[q]);
+            }
+        }
+        barrier();
+        // the kernel matrix K = exp(X + u + v): fixed from here on, the plan is a_i K_ij b_j
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const float vv = get(vb, e);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                pr[q][e] = __expf(pr[q][e] + u_own[q] + vv);
+                pc[q][e] = __expf(pc[q][e] + v_own[q]);
+            }
+        }
+        // a = b = 1: publish b = 1 through vb's slots only after everybody has read v from them
+        barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) put(vb, q, 1.0f);
+        barrier();
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { pr[q][e] = __expf(pr[q][e]); pc[q][e] = __expf(pc[q][e]); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) put(vb, q, 1.0f);
+        barrier();
+    }
+    for (int it = 1; it < p.iters; ++it) {
+        {   // a_i = e^mu / sum_j K_ij b_j
+            float bb[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) bb[e] = get(vb, e);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float r = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) r += pr[q][e] * bb[e];
+                a_own[q] = mass * __builtin_amdgcn_rcpf(nr_wave_sum(r));
+                put(va, q, a_own[q]);
+            }
+        }
+        barrier();
+        {   // b_j = e^nu / sum_i K_ij a_i
+            float aa[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) aa[e] = get(va, e);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float c = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) c += pc[q][e] * aa[e];
+                put(vb, q, mass * __builtin_amdgcn_rcpf(nr_wave_sum(c)));
+            }
+        }
+        barrier();
+    }
+    // target = beta * Q + (1 - beta) I,  Q = 2B a_i K_ij b_j
+    float* tgt = dir == 0 ? p.tgt_rows : p.tgt_cols;
+    const bool dead = s_dead != 0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const float bbv = get(vb, e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = e * 64 + lane;
+            const float t = p.beta * (float)(2 * B) * a_own[q] * pr[q][e] * bbv + (j == l0 + q ? 1.0f - p.beta : 0.f);
+            tgt[(size_t)(l0 + q) * B + j] = dead ? __builtin_nanf("") : t;
+        }
+    }
+}
+
 extern "C" size_t nr_sinkhorn_workspace_bytes(int B) {
     if (B <= 128 && (B % 4) == 0) return 16;
-    return ((size_t)B * B + 4 * (size_t)B) * sizeof(float) + 64;
+    // (the cooperative form needs 4 B floats + 256 bytes of counters: less than the multi-launch form, which stays the fallback)
+    return ((size_t)B * B + 4 * (size_t)B) * sizeof(float) + 64 + 256;
 }
 
 static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols, float temperature,
@@ -355,6 +520,24 @@ static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* 
         return NR_OK;
     }
     if (!workspace || !tgt_rows || !tgt_cols || uniform_rows) return NR_EINVAL;
+    if (B <= 1024 && (B % 64) == 0 && !nr_tune_env("NR_SINKHORN_MULTI")) {
+        // cooperative form: vectors [2][2][B] f32, then the counters (zeroed by a memset node in front of the launch)
+        float* vec = reinterpret_cast<float*>(workspace);
+        unsigned int* counter = reinterpret_cast<unsigned int*>(vec + 4 * (size_t)B);
+        hipError_t e = hipMemsetAsync(counter, 0, 256, st);
+        if (e != hipSuccess) return (int)e;
+        NrSkCoopArgs a{G, B, iters, beta, tgt_rows, tgt_cols, vec, counter};
+        const dim3 grid(8 * (B / 32));
+        switch (B / 64) {
+#define NR_SKC(E_) case E_: hipLaunchKernelGGL(nr_sinkhorn_coop_kernel<E_>, grid, dim3(512), 0, st, a); break;
+            NR_SKC(3) NR_SKC(4) NR_SKC(5) NR_SKC(6) NR_SKC(7) NR_SKC(8) NR_SKC(9) NR_SKC(10) NR_SKC(11) NR_SKC(12) NR_SKC(13) NR_SKC(14)
+            NR_SKC(15) NR_SKC(16)
+#undef NR_SKC
+            default: return NR_EUNSUPPORTED;
+        }
+        NR_LAUNCH_CHECK();
+        return NR_OK;
+    }
     float* GT = reinterpret_cast<float*>(workspace);
     float* u = GT + (size_t)B * B;     // [2][B]
     float* v = u + 2 * (size_t)B;      // [2][B]

@@ -194,3 +194,20 @@ def test_chained_tile_pairs_with_ragged_edges():
         got = ops.local_level_group(probs)
         for q, g in zip(probs, got):
             assert torch.equal(g, ops.local_level(*q)[0])
+
+
+@pytest.mark.parametrize("B", [192, 256, 512, 960, 1024])
+def test_cooperative_sinkhorn_matches_the_oracle(B):
+    """128 < B <= 1024, B % 64 == 0: the one-launch cooperative Sinkhorn solve (B/32 workgroups per direction, scaling vectors
+    exchanged through global memory, a counter barrier per half-iteration) against the oracle's log-domain iteration
+    (until_module.py:235-266) in fp64, both directions; unit column sums; 1 and 50 iterations."""
+    g = torch.Generator().manual_seed(B)
+    G = torch.randn(B, B, generator=g) * 6 + torch.eye(B) * 8
+    for iters in (1, 50):
+        tr, tc = ops.sinkhorn_targets(G.to(DEV), 0.7, iters)
+        assert torch.isfinite(tr).all() and torch.isfinite(tc).all()
+        ref_r = O.sinkhorn_targets(G.double(), 0.7, iters)
+        ref_c = O.sinkhorn_targets(G.double().t(), 0.7, iters)
+        assert maxdiff(tr, ref_r) < 2e-5 and maxdiff(tc, ref_c) < 2e-5, (B, iters, maxdiff(tr, ref_r), maxdiff(tc, ref_c))
+    Q = (tr.cpu().double() - 0.3 * torch.eye(B, dtype=torch.float64)) / 0.7
+    assert maxdiff(Q.sum(0), torch.ones(B, dtype=torch.float64)) < 1e-4
