@@ -168,8 +168,7 @@ class HeadLossFn(torch.autograd.Function):
                                                                     sv["c1"], sv["wc_t"], sv["wc_v"], sv["ls"], K, T, coef)
         dS = ops.add_transposed(dS_dir[0], dS_dir[1])
         dG = ops.add_transposed(dG_dir[0], dG_dir[1])
-        d_c0 = ops.colsum(dC_rows[0])
-        d_c1 = ops.colsum(dC_rows[1])
+        d_c0, d_c1 = ops.colsum_pair(dC_rows[0], 1.0, dC_rows[1], 1.0)        # one grouped launch (was two serial column sums)
         d_ls = dls_rows.sum()
         g1 = [None] * 8
         if sv["g_saved"] is None:
@@ -201,13 +200,17 @@ class HeadLossFn(torch.autograd.Function):
         pt, pv, pbt, pbv = sv["pt"], sv["pv"], sv["pbt"], sv["pbv"]
         lo = ctx.exact
         aux0, aux1, aux2 = sv["aux"]
-        d_tn, d_wt = ops.local_level_bwd(0, dS, 0, 1.0, pv, sv["w_t"], sv["w_v"], aux0, B, Nt, B, Nv, use_lo=lo)
-        d_vn, d_wv = ops.local_level_bwd(1, dS, 0, 1.0, pt, sv["w_v"], sv["w_t"], aux0, B, Nt, B, Nv, use_lo=lo)
+        # the four "other" operands of the MFMA backward, transposed in one launch
+        T_pv = T_pt = T_pbv = T_pbt = None
+        if ops.USE_MFMA_BACKWARD and bool(hip.lib().nr_local_level_bwd_mfma_supported(Nt, Nv, d)):
+            T_pv, T_pt, T_pbv, T_pbt = ops.transpose_prepared([pv, pt, pbv, pbt], use_lo=lo)
+        d_tn, d_wt = ops.local_level_bwd(0, dS, 0, 1.0, pv, sv["w_t"], sv["w_v"], aux0, B, Nt, B, Nv, use_lo=lo, other_T=T_pv)
+        d_vn, d_wv = ops.local_level_bwd(1, dS, 0, 1.0, pt, sv["w_v"], sv["w_t"], aux0, B, Nt, B, Nv, use_lo=lo, other_T=T_pt)
         ops.local_level_bwd(0, d_c1, 1, 1.0 / M, pbv, sv["w_t"], sv["w_bv"], aux1, B, Nt, M, Nv, d_x=d_tn, d_w=d_wt,
-                            accumulate=True, use_lo=lo)
+                            accumulate=True, use_lo=lo, other_T=T_pbv)
         _, d_wbv = ops.local_level_bwd(1, d_c1, 1, 1.0 / M, pt, sv["w_bv"], sv["w_t"], aux1, B, Nt, M, Nv, want_dx=False)
         ops.local_level_bwd(1, d_c0, 2, 1.0 / M, pbt, sv["w_v"], sv["w_bt"], aux2, M, Nt, B, Nv, d_x=d_vn, d_w=d_wv,
-                            accumulate=True, use_lo=lo)
+                            accumulate=True, use_lo=lo, other_T=T_pbt)
         _, d_wbt = ops.local_level_bwd(0, d_c0, 2, 1.0 / M, pv, sv["w_bt"], sv["w_v"], aux2, M, Nt, B, Nv, want_dx=False)
         # normalise / mask / centrality-mean backward
         d_text = ops.normalize_bwd(text_feat, pt.norm, text_mask, d_tn, dmean_t)

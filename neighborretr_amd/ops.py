@@ -439,8 +439,26 @@ def colsum(a):
 USE_MFMA_BACKWARD = True        # False: the scalar arg-max walk for d_x too (reference for the MFMA path in the tests)
 
 
+def transpose_prepared(preps, use_lo=True):
+    """The [d, ldk] k-contiguous images of several Prepared token sets (what nr_local_level_bwd_mfma reads as the "other"
+    operand) in ONE launch (nr_split_group, bf16-pair transposes) -> [(hi_t, lo_t or None, ldk), ...]."""
+    from .cluster_fused import split_group
+    items, out = [], []
+    for p in preps:
+        n_tok, d = p.hi.view(-1, p.d).shape
+        ldk = (n_tok + 7) // 8 * 8
+        dev = p.hi.device
+        mk = torch.empty if ldk == n_tok else torch.zeros
+        hi_t = mk((d, ldk), dtype=torch.int16, device=dev)
+        lo_t = mk((d, ldk), dtype=torch.int16, device=dev) if (use_lo and p.lo is not None) else None
+        items.append((p.hi.view(-1, d), p.lo.view(-1, d) if lo_t is not None else None, hi_t, lo_t, n_tok, d, 2, ldk))
+        out.append((hi_t, lo_t, ldk))
+    split_group(items)
+    return out
+
+
 def local_level_bwd(side, dS, ds_mode, ds_scale, other, w_self, w_other, aux, A, Nt, Bv, Nv, d_x=None, d_w=None,
-                    want_dx=True, accumulate=False, use_lo=True):
+                    want_dx=True, accumulate=False, use_lo=True, other_T=None):
     """Arg-max-routed gradient for one operand (nr_local_level_bwd).  `other` is the Prepared
     token set of the opposite operand.  Returns (d_x [n_self*N, d] or None, d_w [n_self*N])."""
     arg_v, arg_t, pmax, qmax = aux
@@ -465,8 +483,13 @@ def local_level_bwd(side, dS, ds_mode, ds_scale, other, w_self, w_other, aux, A,
             out = torch.zeros((d, ldk), dtype=t.dtype, device=dev)
             out[:, :n_tok] = t.t()
             return out, ldk
-        o_hi_t, ldk = transposed(other.hi.view(-1, d))
-        o_lo_t = transposed(other.lo.view(-1, d))[0] if (use_lo and other.lo is not None) else None
+        if other_T is not None:                      # transposed up front, several operands in one launch (transpose_prepared)
+            o_hi_t, o_lo_t, ldk = other_T
+            if not use_lo:
+                o_lo_t = None
+        else:
+            o_hi_t, ldk = transposed(other.hi.view(-1, d))
+            o_lo_t = transposed(other.lo.view(-1, d))[0] if (use_lo and other.lo is not None) else None
         ws = torch.empty((int(hip.lib().nr_local_level_bwd_mfma_workspace_bytes(int(side), A, Nt, Bv, Nv, d)),),
                          dtype=torch.uint8, device=dev)
         hip.call("nr_local_level_bwd_mfma", int(side), hip.ptr(dS, torch.float32), int(ds_mode), float(ds_scale),
