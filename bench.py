@@ -285,6 +285,18 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit(launch_ranks(args.gpus))
     import torch.distributed as dist
+    watchdog = None
+    if world > 1:
+        # a multi-rank run that stops making progress (a collective one rank never joins) would otherwise sit there until the
+        # caller's own limit: give up loudly after ten minutes instead
+        import threading
+
+        def _give_up():
+            print(f"[bench] rank {rank}: no result after 600 s -- giving up (a collective that some rank never joined?)", file=sys.stderr, flush=True)
+            os._exit(5)
+        watchdog = threading.Timer(600.0, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -599,6 +611,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
+    if watchdog is not None:
+        watchdog.cancel()
     if world > 1:
         dist.destroy_process_group()
 
