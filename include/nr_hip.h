@@ -447,16 +447,71 @@ int nr_local_level_bwd(int side, const float* dS, int ds_mode, float ds_scale,
 /* The d_x half of nr_local_level_bwd as an MFMA GEMM: 96 x 96 blocks of the (sparse) routing matrix
  *   P[(s,n),(o,m)] = 0.5 dS(s,o) ( w_other[o,m] [scat(s,o,m) == n] + w_self[s,n] [gath(s,o,n) == m] )
  * are generated in LDS from the stored arg-max bytes and multiplied with the other operand's tokens.
- *   oT_hi / oT_lo: the other operand's prepared tokens TRANSPOSED, [d][ldk] bf16 (ldk >= its token count,
- *   multiple of 8, zero padded); oT_lo may be NULL (one pass).  Token counts must divide 96 (12 / 24),
- *   d % 256 == 0 (nr_local_level_bwd_mfma_supported); d_w is not produced -- call nr_local_level_bwd with
- *   d_x == NULL for it.  workspace: nr_local_level_bwd_mfma_workspace_bytes(...).                    */
+ *   oT_hi / oT_lo: the other operand's prepared tokens in the order the kernel reads them (fragment-major, written by
+ *   nr_sim_bwd_operand_group; ldk = the tokens they cover, whole slices of 96); oT_lo may be NULL (one pass).
+ *   Token counts: multiples of 4 that divide 96 with at most 32 sample pairs per block (24 x 12, 12 x 24, 24 x 24,
+ *   16 x 24, 24 x 16), d % 256 == 0 (nr_local_level_bwd_mfma_supported); d_w is not produced --
+ *   nr_pool_weight_bwd_group computes it.  workspace: nr_local_level_bwd_mfma_workspace_bytes(...).      */
 int nr_local_level_bwd_mfma_supported(int Nt, int Nv, int d);
 size_t nr_local_level_bwd_mfma_workspace_bytes(int side, int A, int Nt, int Bv, int Nv, int d);
 int nr_local_level_bwd_mfma(int side, const float* dS, int ds_mode, float ds_scale, const uint16_t* oT_hi,
                             const uint16_t* oT_lo, int ldk, const float* w_self, const float* w_other,
                             const uint8_t* arg_v, const uint8_t* arg_t, int A, int Nt, int Bv, int Nv, int d,
                             float* d_x, int accumulate, void* workspace, void* stream);
+
+/* Prepared tokens [n_tok][d] (bf16 hi, optional lo; nr_prepare_tokens) -> fragment-major
+ * [slice of 96 tokens][k-step of 32][d / 16][64 lanes][8]: element j of lane (kg, n) of block (slice, ks, dg) is token
+ * 96 slice + 32 ks + 8 kg + j, dim 16 dg + n -- one wave load of the backward kernel is then one contiguous KiB.
+ * out_hi / out_lo hold ceil(n_tok / 96) * 96 * d elements (tokens past n_tok are written as zeros); out_lo may be NULL.
+ * d % 64 == 0, n <= 4 operands per launch.                                                                */
+typedef struct NrSimBwdOperand {
+    const uint16_t* hi;
+    const uint16_t* lo;
+    uint16_t* out_hi;
+    uint16_t* out_lo;
+    int32_t n_tok, d;
+} NrSimBwdOperand;                               /* 40 bytes */
+int nr_sim_bwd_operand_group(int n, const NrSimBwdOperand* items, void* stream);
+
+/* Several of those products in ONE launch (+ one launch that sums the chunks): the loss step has four -- text and
+ * video gradient of the batch x batch product (modeling.py:331) and of the two memory-bank products
+ * (modeling.py:339-340).  Items with the same d_x are added together in item order (`accumulate` of the FIRST
+ * item of a d_x says whether its previous content is kept).  All items share d and have oT_lo either all set
+ * or all NULL.  n <= 4.  Fields as the arguments of nr_local_level_bwd_mfma.                            */
+typedef struct NrSimBwdItem {
+    const float* dS;
+    const uint16_t* oT_hi;
+    const uint16_t* oT_lo;
+    const float* w_self;
+    const float* w_other;
+    const uint8_t* arg_v;
+    const uint8_t* arg_t;
+    float* d_x;
+    float ds_scale;
+    int32_t side, ds_mode, ldk, A, Nt, Bv, Nv, d, accumulate;
+} NrSimBwdItem;                                  /* 104 bytes */
+size_t nr_local_level_bwd_group_workspace_bytes(int n, const NrSimBwdItem* items);
+int nr_local_level_bwd_group(int n, const NrSimBwdItem* items, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Gradient of the token weights of the fused product (modeling.py:505-512: the weighted sums of the pooled
+ * maxima are linear in the weights):   d_w[s,n] = sum_o 0.5 * ds_scale * dS(s,o) * pooled[s,o,n]
+ * summed over up to two products that use the same weights (batch x batch + one bank product).
+ *   side 0: s = row sample a, pooled = pmax [A,Bv,N];  side 1: s = column sample b, pooled = qmax [A,Bv,N]
+ *   (the arrays nr_local_level_fwd stores with want_arg).  dS / ds_mode / ds_scale as in nr_local_level_bwd.
+ *   The sources of a job share the differentiated operand (side 0: same A; side 1: same Bv).  n <= 8 jobs,
+ *   one launch, fixed summation order.                                                                */
+typedef struct NrPoolWSrc {
+    const float* dS;
+    const float* pool;
+    float ds_scale;
+    int32_t ds_mode, A, Bv;
+} NrPoolWSrc;                                    /* 32 bytes */
+typedef struct NrPoolWJob {
+    NrPoolWSrc src[2];
+    float* d_w;
+    int32_t n_src, side, N, accumulate;
+} NrPoolWJob;                                    /* 88 bytes */
+int nr_pool_weight_bwd_group(int n, const NrPoolWJob* jobs, void* stream);
 
 /* Backward of F.normalize + mask + the centrality mean (nr_prepare_tokens):
  *   g = mask*d_xn + dmean/n_tok;  dx = (g - xhat <xhat,g>) / ||x||,  xhat = x/||x||.

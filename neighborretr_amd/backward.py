@@ -200,18 +200,38 @@ class HeadLossFn(torch.autograd.Function):
         pt, pv, pbt, pbv = sv["pt"], sv["pv"], sv["pbt"], sv["pbv"]
         lo = ctx.exact
         aux0, aux1, aux2 = sv["aux"]
-        # the four "other" operands of the MFMA backward, transposed in one launch
-        T_pv = T_pt = T_pbv = T_pbt = None
+        f32 = dict(dtype=torch.float32, device=dS.device)
+        d_tn, d_vn = torch.empty((B * Nt, d), **f32), torch.empty((B * Nv, d), **f32)
+        d_wt, d_wv = torch.empty((B * Nt,), **f32), torch.empty((B * Nv,), **f32)
+        d_wbt, d_wbv = torch.empty((M * Nt,), **f32), torch.empty((M * Nv,), **f32)
         if ops.USE_MFMA_BACKWARD and bool(hip.lib().nr_local_level_bwd_mfma_supported(Nt, Nv, d)):
+            # token gradients: the four products' routing matrices on the matrix cores in ONE launch (their "other" operands
+            # transposed in one launch before it), the chunks of a gradient's two products summed by one more
             T_pv, T_pt, T_pbv, T_pbt = ops.transpose_prepared([pv, pt, pbv, pbt], use_lo=lo)
-        d_tn, d_wt = ops.local_level_bwd(0, dS, 0, 1.0, pv, sv["w_t"], sv["w_v"], aux0, B, Nt, B, Nv, use_lo=lo, other_T=T_pv)
-        d_vn, d_wv = ops.local_level_bwd(1, dS, 0, 1.0, pt, sv["w_v"], sv["w_t"], aux0, B, Nt, B, Nv, use_lo=lo, other_T=T_pt)
-        ops.local_level_bwd(0, d_c1, 1, 1.0 / M, pbv, sv["w_t"], sv["w_bv"], aux1, B, Nt, M, Nv, d_x=d_tn, d_w=d_wt,
-                            accumulate=True, use_lo=lo, other_T=T_pbv)
-        _, d_wbv = ops.local_level_bwd(1, d_c1, 1, 1.0 / M, pt, sv["w_bv"], sv["w_t"], aux1, B, Nt, M, Nv, want_dx=False)
-        ops.local_level_bwd(1, d_c0, 2, 1.0 / M, pbt, sv["w_v"], sv["w_bt"], aux2, M, Nt, B, Nv, d_x=d_vn, d_w=d_wv,
-                            accumulate=True, use_lo=lo, other_T=T_pbt)
-        _, d_wbt = ops.local_level_bwd(0, d_c0, 2, 1.0 / M, pv, sv["w_bt"], sv["w_v"], aux2, M, Nt, B, Nv, want_dx=False)
+            ops.local_level_bwd_group([
+                dict(side=0, dS=dS, ds_mode=0, ds_scale=1.0, other_T=T_pv, w_self=sv["w_t"], w_other=sv["w_v"], aux=aux0,
+                     A=B, Nt=Nt, Bv=B, Nv=Nv, d_x=d_tn),
+                dict(side=0, dS=d_c1, ds_mode=1, ds_scale=1.0 / M, other_T=T_pbv, w_self=sv["w_t"], w_other=sv["w_bv"], aux=aux1,
+                     A=B, Nt=Nt, Bv=M, Nv=Nv, d_x=d_tn),
+                dict(side=1, dS=dS, ds_mode=0, ds_scale=1.0, other_T=T_pt, w_self=sv["w_v"], w_other=sv["w_t"], aux=aux0,
+                     A=B, Nt=Nt, Bv=B, Nv=Nv, d_x=d_vn),
+                dict(side=1, dS=d_c0, ds_mode=2, ds_scale=1.0 / M, other_T=T_pbt, w_self=sv["w_v"], w_other=sv["w_bt"], aux=aux2,
+                     A=M, Nt=Nt, Bv=B, Nv=Nv, d_x=d_vn)], use_lo=lo)
+            # token-weight gradients of the batch and of the bank, all six sums in one launch
+            ops.pool_weight_bwd_group([
+                dict(side=0, N=Nt, d_w=d_wt, srcs=[(dS, 0, 1.0, aux0[2], B, B), (d_c1, 1, 1.0 / M, aux1[2], B, M)]),
+                dict(side=1, N=Nv, d_w=d_wv, srcs=[(dS, 0, 1.0, aux0[3], B, B), (d_c0, 2, 1.0 / M, aux2[3], M, B)]),
+                dict(side=1, N=Nv, d_w=d_wbv, srcs=[(d_c1, 1, 1.0 / M, aux1[3], B, M)]),
+                dict(side=0, N=Nt, d_w=d_wbt, srcs=[(d_c0, 2, 1.0 / M, aux2[2], M, B)])])
+        else:
+            ops.local_level_bwd(0, dS, 0, 1.0, pv, sv["w_t"], sv["w_v"], aux0, B, Nt, B, Nv, d_x=d_tn, d_w=d_wt, use_lo=lo)
+            ops.local_level_bwd(1, dS, 0, 1.0, pt, sv["w_v"], sv["w_t"], aux0, B, Nt, B, Nv, d_x=d_vn, d_w=d_wv, use_lo=lo)
+            ops.local_level_bwd(0, d_c1, 1, 1.0 / M, pbv, sv["w_t"], sv["w_bv"], aux1, B, Nt, M, Nv, d_x=d_tn, d_w=d_wt,
+                                accumulate=True, use_lo=lo)
+            ops.local_level_bwd(1, d_c1, 1, 1.0 / M, pt, sv["w_bv"], sv["w_t"], aux1, B, Nt, M, Nv, d_w=d_wbv, want_dx=False)
+            ops.local_level_bwd(1, d_c0, 2, 1.0 / M, pbt, sv["w_v"], sv["w_bt"], aux2, M, Nt, B, Nv, d_x=d_vn, d_w=d_wv,
+                                accumulate=True, use_lo=lo)
+            ops.local_level_bwd(0, d_c0, 2, 1.0 / M, pv, sv["w_bt"], sv["w_v"], aux2, M, Nt, B, Nv, d_w=d_wbt, want_dx=False)
         # normalise / mask / centrality-mean backward
         d_text = ops.normalize_bwd(text_feat, pt.norm, text_mask, d_tn, dmean_t)
         d_video = ops.normalize_bwd(video_feat, pv.norm, video_mask, d_vn, dmean_v)

@@ -69,7 +69,29 @@ class CtmMidBwdDesc(ctypes.Structure):
                                      "ln_w", "sc_w", "assign", "d_y", "dcat_hi", "dcat_lo", "partial")])
 
 
+class SimBwdItem(ctypes.Structure):
+    """NrSimBwdItem of include/nr_hip.h."""
+    _fields_ = ([(n, _P) for n in ("dS", "oT_hi", "oT_lo", "w_self", "w_other", "arg_v", "arg_t", "d_x")] + [("ds_scale", _F)]
+                + [(n, ctypes.c_int32) for n in ("side", "ds_mode", "ldk", "A", "Nt", "Bv", "Nv", "d", "accumulate")])
+
+
+class SimBwdOperand(ctypes.Structure):
+    """NrSimBwdOperand of include/nr_hip.h."""
+    _fields_ = [(n, _P) for n in ("hi", "lo", "out_hi", "out_lo")] + [("n_tok", ctypes.c_int32), ("d", ctypes.c_int32)]
+
+
+class PoolWSrc(ctypes.Structure):
+    """NrPoolWSrc of include/nr_hip.h."""
+    _fields_ = [("dS", _P), ("pool", _P), ("ds_scale", _F)] + [(n, ctypes.c_int32) for n in ("ds_mode", "A", "Bv")]
+
+
+class PoolWJob(ctypes.Structure):
+    """NrPoolWJob of include/nr_hip.h."""
+    _fields_ = [("src", PoolWSrc * 2), ("d_w", _P)] + [(n, ctypes.c_int32) for n in ("n_src", "side", "N", "accumulate")]
+
+
 SPLIT_MAX, COLSUM_MAX, LINEAR_GROUP_MAX = 48, 16, 8
+SIM_BWD_GROUP_MAX, POOLW_GROUP_MAX = 4, 8
 LOCAL_LEVEL_GROUP_MAX = 4
 CTM_MAX_GROUP = 4
 CTM_STAGE_LAUNCHES = 7
@@ -134,6 +156,10 @@ _SIGNATURES = {
     "nr_local_level_bwd_mfma_supported": ([_I, _I, _I], _I),
     "nr_local_level_bwd_mfma_workspace_bytes": ([_I, _I, _I, _I, _I, _I], _Z),
     "nr_local_level_bwd_mfma": ([_I, _P, _I, _F, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P], _I),
+    "nr_local_level_bwd_group_workspace_bytes": ([_I, ctypes.POINTER(SimBwdItem)], _Z),
+    "nr_local_level_bwd_group": ([_I, ctypes.POINTER(SimBwdItem), _P, _Z, _P], _I),
+    "nr_pool_weight_bwd_group": ([_I, ctypes.POINTER(PoolWJob), _P], _I),
+    "nr_sim_bwd_operand_group": ([_I, ctypes.POINTER(SimBwdOperand), _P], _I),
     "nr_normalize_bwd": ([_P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     "nr_token_softmax_bwd": ([_P, _P, _I, _I, _P, _P], _I),
     "nr_centrality_weights_bwd": ([_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P], _I),

@@ -440,27 +440,77 @@ USE_MFMA_BACKWARD = True        # False: the scalar arg-max walk for d_x too (re
 
 
 def transpose_prepared(preps, use_lo=True):
-    """The [d, ldk] k-contiguous images of several Prepared token sets (what nr_local_level_bwd_mfma reads as the "other"
-    operand) in ONE launch (nr_split_group, bf16-pair transposes) -> [(hi_t, lo_t or None, ldk), ...]."""
-    from .cluster_fused import split_group
-    items, out = [], []
-    for p in preps:
-        n_tok, d = p.hi.view(-1, p.d).shape
-        ldk = (n_tok + 7) // 8 * 8
-        dev = p.hi.device
-        mk = torch.empty if ldk == n_tok else torch.zeros
-        hi_t = mk((d, ldk), dtype=torch.int16, device=dev)
-        lo_t = mk((d, ldk), dtype=torch.int16, device=dev) if (use_lo and p.lo is not None) else None
-        items.append((p.hi.view(-1, d), p.lo.view(-1, d) if lo_t is not None else None, hi_t, lo_t, n_tok, d, 2, ldk))
-        out.append((hi_t, lo_t, ldk))
-    split_group(items)
+    """Several Prepared token sets in the order nr_local_level_bwd_group reads its "other" operand (fragment-major, whole
+    slices of 96 tokens) in ONE launch (nr_sim_bwd_operand_group) -> [(hi_f, lo_f or None, tokens covered), ...]."""
+    out = []
+    for k in range(0, len(preps), hip.SIM_BWD_GROUP_MAX):
+        chunk = preps[k:k + hip.SIM_BWD_GROUP_MAX]
+        arr = (hip.SimBwdOperand * len(chunk))()
+        for a, p in zip(arr, chunk):
+            n_tok, d = p.hi.view(-1, p.d).shape
+            ldk = (n_tok + 95) // 96 * 96
+            dev = p.hi.device
+            hi_f = torch.empty((ldk * d,), dtype=torch.int16, device=dev)
+            lo_f = torch.empty((ldk * d,), dtype=torch.int16, device=dev) if (use_lo and p.lo is not None) else None
+            a.hi, a.lo = p.hi.data_ptr(), (p.lo.data_ptr() if p.lo is not None else None)
+            a.out_hi, a.out_lo = hi_f.data_ptr(), (lo_f.data_ptr() if lo_f is not None else None)
+            a.n_tok, a.d = int(n_tok), int(d)
+            out.append((hi_f, lo_f, ldk))
+        hip.call("nr_sim_bwd_operand_group", len(chunk), arr, hip.stream_ptr())
     return out
 
 
+def local_level_bwd_group(items, use_lo=True):
+    """d_x of up to four fused products in one launch + one summing launch (nr_local_level_bwd_group).  items: dicts with
+        side, dS, ds_mode, ds_scale, other_T=(hi_t, lo_t, ldk) from transpose_prepared, w_self, w_other, aux, A, Nt, Bv, Nv,
+        d_x [n_self_tokens, d] f32 (items with the same d_x are summed), accumulate (first item of a d_x: keep its content)."""
+    if not 0 < len(items) <= hip.SIM_BWD_GROUP_MAX:
+        raise ValueError("1..%d products per launch" % hip.SIM_BWD_GROUP_MAX)
+    arr = (hip.SimBwdItem * len(items))()
+    keep = []
+    for a, it in zip(arr, items):
+        hi_t, lo_t, ldk = it["other_T"]
+        arg_v, arg_t = it["aux"][0], it["aux"][1]
+        dS = _f32(it["dS"]).contiguous()
+        w_s, w_o = _f32(it["w_self"]).contiguous(), _f32(it["w_other"]).contiguous()
+        keep += [dS, w_s, w_o]
+        a.dS, a.oT_hi, a.oT_lo = dS.data_ptr(), hi_t.data_ptr(), (lo_t.data_ptr() if (use_lo and lo_t is not None) else None)
+        a.w_self, a.w_other, a.arg_v, a.arg_t = w_s.data_ptr(), w_o.data_ptr(), arg_v.data_ptr(), arg_t.data_ptr()
+        a.d_x, a.ds_scale = it["d_x"].data_ptr(), float(it["ds_scale"])
+        a.side, a.ds_mode, a.ldk = int(it["side"]), int(it["ds_mode"]), int(ldk)
+        a.A, a.Nt, a.Bv, a.Nv, a.d = int(it["A"]), int(it["Nt"]), int(it["Bv"]), int(it["Nv"]), int(hi_t.numel() // ldk)
+        a.accumulate = 1 if it.get("accumulate") else 0
+    nbytes = int(hip.lib().nr_local_level_bwd_group_workspace_bytes(len(items), arr))
+    if nbytes == 0:
+        raise hip.NrHipError("nr_local_level_bwd_group: shape outside the matrix-core backward (nr_local_level_bwd_mfma_supported)")
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=items[0]["d_x"].device)
+    hip.call("nr_local_level_bwd_group", len(items), arr, hip.ptr(ws), nbytes, hip.stream_ptr())
+
+
+def pool_weight_bwd_group(jobs):
+    """d_w of several token-weight vectors in one launch (nr_pool_weight_bwd_group).  jobs: dicts with side, N, d_w [n_self*N]
+    f32, accumulate, srcs = [(dS, ds_mode, ds_scale, pooled [A,Bv,N] f32, A, Bv), ...] (one or two products)."""
+    if not 0 < len(jobs) <= hip.POOLW_GROUP_MAX:
+        raise ValueError("1..%d jobs per launch" % hip.POOLW_GROUP_MAX)
+    arr = (hip.PoolWJob * len(jobs))()
+    keep = []
+    for a, j in zip(arr, jobs):
+        a.n_src, a.side, a.N, a.accumulate = len(j["srcs"]), int(j["side"]), int(j["N"]), 1 if j.get("accumulate") else 0
+        a.d_w = j["d_w"].data_ptr()
+        for k, (dS, mode, scale, pool, A, Bv) in enumerate(j["srcs"]):
+            dS = _f32(dS).contiguous()
+            keep.append(dS)
+            a.src[k].dS, a.src[k].pool, a.src[k].ds_scale = dS.data_ptr(), pool.data_ptr(), float(scale)
+            a.src[k].ds_mode, a.src[k].A, a.src[k].Bv = int(mode), int(A), int(Bv)
+    hip.call("nr_pool_weight_bwd_group", len(jobs), arr, hip.stream_ptr())
+
+
 def local_level_bwd(side, dS, ds_mode, ds_scale, other, w_self, w_other, aux, A, Nt, Bv, Nv, d_x=None, d_w=None,
-                    want_dx=True, accumulate=False, use_lo=True, other_T=None):
-    """Arg-max-routed gradient for one operand (nr_local_level_bwd).  `other` is the Prepared
-    token set of the opposite operand.  Returns (d_x [n_self*N, d] or None, d_w [n_self*N])."""
+                    want_dx=True, accumulate=False, use_lo=True, other_T=None, scalar_dw=False):
+    """Arg-max-routed gradient for one operand.  `other` is the Prepared token set of the opposite operand.
+    d_x: nr_local_level_bwd_group (matrix cores) where the token counts allow, else nr_local_level_bwd's entry-by-entry walk;
+    d_w: nr_pool_weight_bwd_group (scalar_dw=True: the walk's own sum, kept as the cross-check of the tests).
+    Returns (d_x [n_self*N, d] or None, d_w [n_self*N])."""
     arg_v, arg_t, pmax, qmax = aux
     n_self = (A * Nt) if side == 0 else (Bv * Nv)
     d = other.d
@@ -473,37 +523,23 @@ def local_level_bwd(side, dS, ds_mode, ds_scale, other, w_self, w_other, aux, A,
         d_w = torch.empty((n_self,), dtype=torch.float32, device=dev)
     mfma = want_dx and USE_MFMA_BACKWARD and bool(hip.lib().nr_local_level_bwd_mfma_supported(Nt, Nv, d))
     if mfma:
-        # d_x on the matrix cores (routing-matrix blocks generated in LDS x the other operand's tokens, which the
-        # kernel wants k-contiguous: transposed here); d_w from the scalar kernel in its weights-only mode
-        def transposed(t):
-            n_tok = t.shape[0]
-            ldk = (n_tok + 7) // 8 * 8
-            if ldk == n_tok:
-                return t.t().contiguous(), ldk
-            out = torch.zeros((d, ldk), dtype=t.dtype, device=dev)
-            out[:, :n_tok] = t.t()
-            return out, ldk
-        if other_T is not None:                      # transposed up front, several operands in one launch (transpose_prepared)
-            o_hi_t, o_lo_t, ldk = other_T
-            if not use_lo:
-                o_lo_t = None
-        else:
-            o_hi_t, ldk = transposed(other.hi.view(-1, d))
-            o_lo_t = transposed(other.lo.view(-1, d))[0] if (use_lo and other.lo is not None) else None
-        ws = torch.empty((int(hip.lib().nr_local_level_bwd_mfma_workspace_bytes(int(side), A, Nt, Bv, Nv, d)),),
-                         dtype=torch.uint8, device=dev)
-        hip.call("nr_local_level_bwd_mfma", int(side), hip.ptr(dS, torch.float32), int(ds_mode), float(ds_scale),
-                 hip.ptr(o_hi_t), hip.ptr(o_lo_t, allow_none=True), int(ldk), hip.ptr(w_self, torch.float32),
-                 hip.ptr(w_other, torch.float32), hip.ptr(arg_v), hip.ptr(arg_t), A, Nt, Bv, Nv, d, hip.ptr(d_x),
-                 1 if accumulate else 0, hip.ptr(ws), hip.stream_ptr())
-    ws = torch.empty((int(hip.lib().nr_local_level_bwd_workspace_bytes(int(side), A, Nt, Bv, Nv, d)),), dtype=torch.uint8,
-                     device=dev)
+        if other_T is None:                          # else: transposed up front, several operands in one launch
+            other_T = transpose_prepared([other], use_lo=use_lo)[0]
+        local_level_bwd_group([dict(side=side, dS=dS, ds_mode=ds_mode, ds_scale=ds_scale, other_T=other_T, w_self=w_self,
+                                    w_other=w_other, aux=aux, A=A, Nt=Nt, Bv=Bv, Nv=Nv, d_x=d_x, accumulate=accumulate)],
+                              use_lo=use_lo)
     scalar_dx = want_dx and not mfma
-    hip.call("nr_local_level_bwd", int(side), hip.ptr(dS, torch.float32), int(ds_mode), float(ds_scale),
-             hip.ptr(other.hi), hip.ptr(other.lo if use_lo else None, allow_none=True), hip.ptr(w_self, torch.float32),
-             hip.ptr(w_other, torch.float32), hip.ptr(arg_v), hip.ptr(arg_t), hip.ptr(pmax), hip.ptr(qmax),
-             A, Nt, Bv, Nv, d, hip.ptr(d_x if scalar_dx else None, allow_none=True), hip.ptr(d_w),
-             1 if accumulate else 0, hip.ptr(ws), hip.stream_ptr())
+    if scalar_dx or scalar_dw:
+        ws = torch.empty((int(hip.lib().nr_local_level_bwd_workspace_bytes(int(side), A, Nt, Bv, Nv, d)),), dtype=torch.uint8,
+                         device=dev)
+        hip.call("nr_local_level_bwd", int(side), hip.ptr(dS, torch.float32), int(ds_mode), float(ds_scale),
+                 hip.ptr(other.hi), hip.ptr(other.lo if use_lo else None, allow_none=True), hip.ptr(w_self, torch.float32),
+                 hip.ptr(w_other, torch.float32), hip.ptr(arg_v), hip.ptr(arg_t), hip.ptr(pmax), hip.ptr(qmax),
+                 A, Nt, Bv, Nv, d, hip.ptr(d_x if scalar_dx else None, allow_none=True),
+                 hip.ptr(d_w if scalar_dw else None, allow_none=True), 1 if accumulate else 0, hip.ptr(ws), hip.stream_ptr())
+    if not scalar_dw:
+        pool_weight_bwd_group([dict(side=side, N=Nt if side == 0 else Nv, d_w=d_w, accumulate=accumulate,
+                                    srcs=[(dS, ds_mode, ds_scale, pmax if side == 0 else qmax, A, Bv)])])
     return (d_x if want_dx else None), d_w
 
 

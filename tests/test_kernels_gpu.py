@@ -388,13 +388,8 @@ def test_row_losses_final_is_bit_identical_to_two_launches(B):
         assert torch.equal(rl, rl2) and torch.equal(ref, fused)
 
 
-@pytest.mark.parametrize("side,mode,A,Bv,use_lo", [(0, 0, 40, 56, True), (1, 0, 40, 56, False), (0, 1, 16, 200, False),
-                                                    (1, 2, 200, 16, True), (0, 0, 3, 5, False)])
-def test_mfma_backward_matches_the_scalar_walk(side, mode, A, Bv, use_lo):
-    """nr_local_level_bwd_mfma (routing-matrix blocks on the matrix cores) against nr_sim_bwd_kernel's
-    entry-by-entry walk: same d_x to bf16-coefficient accuracy, d_w identical (same kernel)."""
-    Nt, Nv, d = 24, 12, 512
-    g = torch.Generator().manual_seed(A * 7 + Bv + side)
+def _bwd_problem(A, Bv, Nt, Nv, d, seed):
+    g = torch.Generator().manual_seed(seed)
     t = torch.randn(A, Nt, d, generator=g).to(DEV)
     v = torch.randn(Bv, Nv, d, generator=g).to(DEV)
     tm = (torch.arange(Nt)[None] < torch.randint(2, Nt + 1, (A, 1), generator=g)).float().to(DEV)
@@ -403,23 +398,80 @@ def test_mfma_backward_matches_the_scalar_walk(side, mode, A, Bv, use_lo):
     w_t = torch.softmax(torch.randn(A, Nt, generator=g), -1).to(DEV)
     w_v = torch.softmax(torch.randn(Bv, Nv, generator=g), -1).to(DEV)
     _, aux = ops.local_level(pt, pv, w_t, w_v, A, Nt, Bv, Nv, hip.PREC_BF16X3, hip.OUT_FULL, want_arg=True)
+    return pt, pv, w_t, w_v, aux, g
+
+
+@pytest.mark.parametrize("side,mode,A,Bv,use_lo,Nt,Nv,d", [
+    (0, 0, 40, 56, True, 24, 12, 512), (1, 0, 40, 56, False, 24, 12, 512), (0, 1, 16, 200, False, 24, 12, 512),
+    (1, 2, 200, 16, True, 24, 12, 512), (0, 0, 3, 5, False, 24, 12, 512), (1, 1, 130, 70, False, 24, 12, 512),
+    (0, 2, 37, 41, False, 12, 24, 512), (1, 0, 37, 41, True, 24, 24, 256), (0, 0, 21, 50, False, 16, 24, 768),
+    (1, 0, 9, 11, False, 12, 12, 512)])
+def test_mfma_backward_matches_the_scalar_walk(side, mode, A, Bv, use_lo, Nt, Nv, d):
+    """nr_local_level_bwd_group (routing-matrix blocks on the matrix cores, all three kernel variants: 512 dims per workgroup,
+    256 dims with / without the low halves) and nr_pool_weight_bwd_group against nr_sim_bwd_kernel's entry-by-entry walk:
+    same d_x to bf16-coefficient accuracy, same d_w to summation order.  12 x 12 tokens have too many sample pairs per block
+    for the matrix-core kernel and must fall back to the walk."""
+    pt, pv, w_t, w_v, aux, g = _bwd_problem(A, Bv, Nt, Nv, d, A * 7 + Bv + side)
     dS = (torch.randn(A, Bv, generator=g) if mode == 0 else torch.randn(A if mode == 1 else Bv, generator=g)).to(DEV)
     other, ws_, wo_ = (pv, w_t, w_v) if side == 0 else (pt, w_v, w_t)
+    assert bool(hip.lib().nr_local_level_bwd_mfma_supported(Nt, Nv, d)) == ((Nt, Nv) != (12, 12))
     try:
         ops.USE_MFMA_BACKWARD = False
-        dx_ref, dw_ref = ops.local_level_bwd(side, dS, mode, 0.37, other, ws_, wo_, aux, A, Nt, Bv, Nv, use_lo=use_lo)
+        dx_ref, dw_ref = ops.local_level_bwd(side, dS, mode, 0.37, other, ws_, wo_, aux, A, Nt, Bv, Nv, use_lo=use_lo, scalar_dw=True)
         ops.USE_MFMA_BACKWARD = True
         dx, dw = ops.local_level_bwd(side, dS, mode, 0.37, other, ws_, wo_, aux, A, Nt, Bv, Nv, use_lo=use_lo)
-        base = dx.clone()
-        dx2, _ = ops.local_level_bwd(side, dS, mode, 0.37, other, ws_, wo_, aux, A, Nt, Bv, Nv, d_x=base, d_w=dw.clone(),
-                                     accumulate=True, use_lo=use_lo)
+        base, wbase = dx.clone(), dw.clone()
+        dx2, dw2 = ops.local_level_bwd(side, dS, mode, 0.37, other, ws_, wo_, aux, A, Nt, Bv, Nv, d_x=base, d_w=wbase,
+                                       accumulate=True, use_lo=use_lo)
     finally:
         ops.USE_MFMA_BACKWARD = True
-    assert torch.equal(dw, dw_ref)
+    assert maxdiff(dw, dw_ref) < 2e-6 * max(float(dw_ref.abs().max()), 1e-6)
+    assert maxdiff(dw2, 2 * dw) < 2e-6 * max(float(dw_ref.abs().max()), 1e-6)
     scale = float(dx_ref.abs().max())
     assert maxdiff(dx, dx_ref) < 4e-3 * scale                 # coefficients rounded to bf16
     assert float((dx - dx_ref).abs().mean()) < 4e-4 * scale
     assert maxdiff(dx2, 2 * dx) < 1e-5 * scale
+
+
+@pytest.mark.parametrize("use_lo", [False, True])
+def test_grouped_backward_equals_the_products_one_by_one(use_lo):
+    """The loss step's four products in one nr_local_level_bwd_group launch (two gradients, two products each) and its six
+    weight sums in one nr_pool_weight_bwd_group launch == the same products launched one by one with accumulate."""
+    B, M, Nt, Nv, d = 20, 70, 24, 12, 512
+    pt, pv, w_t, w_v, aux0, g = _bwd_problem(B, B, Nt, Nv, d, 5)
+    _, pbv, _, w_bv, aux1, _ = _bwd_problem(B, M, Nt, Nv, d, 6)
+    pbt, _, w_bt, _, aux2, _ = _bwd_problem(M, B, Nt, Nv, d, 7)
+    # the bank products pair THIS batch with the bank: recompute their stored indices with the shared operands
+    _, aux1 = ops.local_level(pt, pbv, w_t, w_bv, B, Nt, M, Nv, hip.PREC_BF16X3, hip.OUT_FULL, want_arg=True)
+    _, aux2 = ops.local_level(pbt, pv, w_bt, w_v, M, Nt, B, Nv, hip.PREC_BF16X3, hip.OUT_FULL, want_arg=True)
+    dS, d_c1, d_c0 = torch.randn(B, B, generator=g).to(DEV), torch.randn(B, generator=g).to(DEV), torch.randn(B, generator=g).to(DEV)
+    # one by one
+    r_tn, r_wt = ops.local_level_bwd(0, dS, 0, 1.0, pv, w_t, w_v, aux0, B, Nt, B, Nv, use_lo=use_lo)
+    r_vn, r_wv = ops.local_level_bwd(1, dS, 0, 1.0, pt, w_v, w_t, aux0, B, Nt, B, Nv, use_lo=use_lo)
+    ops.local_level_bwd(0, d_c1, 1, 1.0 / M, pbv, w_t, w_bv, aux1, B, Nt, M, Nv, d_x=r_tn, d_w=r_wt, accumulate=True, use_lo=use_lo)
+    _, r_wbv = ops.local_level_bwd(1, d_c1, 1, 1.0 / M, pt, w_bv, w_t, aux1, B, Nt, M, Nv, want_dx=False)
+    ops.local_level_bwd(1, d_c0, 2, 1.0 / M, pbt, w_v, w_bt, aux2, M, Nt, B, Nv, d_x=r_vn, d_w=r_wv, accumulate=True, use_lo=use_lo)
+    _, r_wbt = ops.local_level_bwd(0, d_c0, 2, 1.0 / M, pv, w_bt, w_v, aux2, M, Nt, B, Nv, want_dx=False)
+    # grouped
+    f32 = dict(dtype=torch.float32, device=DEV)
+    d_tn, d_vn = torch.full((B * Nt, d), float("nan"), **f32), torch.full((B * Nv, d), float("nan"), **f32)
+    T_pv, T_pt, T_pbv, T_pbt = ops.transpose_prepared([pv, pt, pbv, pbt], use_lo=use_lo)
+    ops.local_level_bwd_group([
+        dict(side=0, dS=dS, ds_mode=0, ds_scale=1.0, other_T=T_pv, w_self=w_t, w_other=w_v, aux=aux0, A=B, Nt=Nt, Bv=B, Nv=Nv, d_x=d_tn),
+        dict(side=0, dS=d_c1, ds_mode=1, ds_scale=1.0 / M, other_T=T_pbv, w_self=w_t, w_other=w_bv, aux=aux1, A=B, Nt=Nt, Bv=M, Nv=Nv,
+             d_x=d_tn),
+        dict(side=1, dS=dS, ds_mode=0, ds_scale=1.0, other_T=T_pt, w_self=w_v, w_other=w_t, aux=aux0, A=B, Nt=Nt, Bv=B, Nv=Nv, d_x=d_vn),
+        dict(side=1, dS=d_c0, ds_mode=2, ds_scale=1.0 / M, other_T=T_pbt, w_self=w_v, w_other=w_bt, aux=aux2, A=M, Nt=Nt, Bv=B, Nv=Nv,
+             d_x=d_vn)], use_lo=use_lo)
+    d_wt, d_wv = torch.full((B * Nt,), float("nan"), **f32), torch.full((B * Nv,), float("nan"), **f32)
+    d_wbt, d_wbv = torch.full((M * Nt,), float("nan"), **f32), torch.full((M * Nv,), float("nan"), **f32)
+    ops.pool_weight_bwd_group([
+        dict(side=0, N=Nt, d_w=d_wt, srcs=[(dS, 0, 1.0, aux0[2], B, B), (d_c1, 1, 1.0 / M, aux1[2], B, M)]),
+        dict(side=1, N=Nv, d_w=d_wv, srcs=[(dS, 0, 1.0, aux0[3], B, B), (d_c0, 2, 1.0 / M, aux2[3], M, B)]),
+        dict(side=1, N=Nv, d_w=d_wbv, srcs=[(d_c1, 1, 1.0 / M, aux1[3], B, M)]),
+        dict(side=0, N=Nt, d_w=d_wbt, srcs=[(d_c0, 2, 1.0 / M, aux2[2], M, B)])])
+    for got, ref in ((d_tn, r_tn), (d_vn, r_vn), (d_wt, r_wt), (d_wv, r_wv), (d_wbt, r_wbt), (d_wbv, r_wbv)):
+        assert maxdiff(got, ref) < 2e-6 * float(ref.abs().max())
 
 
 def test_pack_and_unpack_of_the_exchange_step():
