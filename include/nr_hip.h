@@ -285,13 +285,17 @@ typedef struct NrColsumItem {
 int nr_colsum_group(int n, const NrColsumItem* items, void* stream);
 
 /* nr_linear_group: up to 8 independent problems Y = X W^T (+bias) (+residual) of nr_linear_x3's kind in one launch (every
- * problem tiled with the same block shape; K % 64 == 0 each).                                                               */
+ * problem tiled with the same block shape; K % 64 == 0 each).
+ *   x_lo == w_lo == NULL in EVERY problem: the one-pass bf16 product of the hi halves (a third of the matrix-core work).
+ *   ld > 0: X and W are K-slices of wider row-major matrices with row pitch ld elements (ld >= K, ld % 8 == 0) -- how a
+ *   weight-gradient GEMM with a long K (token rows) is cut into several problems whose outputs are added afterwards
+ *   (nr_slab_sum_group).  ld == 0: the rows are K long.                                                                     */
 typedef struct NrLinearProblem {
     const uint16_t *x_hi, *x_lo, *w_hi, *w_lo;
     const float *bias, *residual;
     float* out;
-    int32_t M, N, K;
-} NrLinearProblem;
+    int32_t M, N, K, ld;
+} NrLinearProblem;                               /* 72 bytes */
 int nr_linear_group(int n, const NrLinearProblem* problems, void* stream);
 
 /* Score-biased attention backward (cluster.py:868-885) per sample for up to NR_CTM_MAX_GROUP problems: from q [n*cnum,C],
@@ -492,6 +496,18 @@ typedef struct NrSimBwdItem {
 } NrSimBwdItem;                                  /* 104 bytes */
 size_t nr_local_level_bwd_group_workspace_bytes(int n, const NrSimBwdItem* items);
 int nr_local_level_bwd_group(int n, const NrSimBwdItem* items, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[i] = (accumulate ? out[i] : 0) + sum over sources k, slabs c < n_slabs[k] of part[k][c * n + i], in that fixed order
+ * (bitwise reproducible).  What nr_local_level_bwd_group ends with, exported for the weight-gradient GEMMs that are cut
+ * along their long K (token rows) into several nr_linear_group problems.  n % 4 == 0; <= 4 outputs, <= 4 sources each.     */
+typedef struct NrSlabSum {
+    float* out;
+    uint64_t n;
+    int32_t accumulate, n_src;
+    const float* part[4];
+    int32_t n_slabs[4];
+} NrSlabSum;                                     /* 72 bytes */
+int nr_slab_sum_group(int n, const NrSlabSum* items, void* stream);
 
 /* Gradient of the token weights of the fused product (modeling.py:505-512: the weighted sums of the pooled
  * maxima are linear in the weights):   d_w[s,n] = sum_o 0.5 * ds_scale * dS(s,o) * pooled[s,o,n]

@@ -114,13 +114,83 @@ def _mlp_backward_hip(jobs):
     # dX = dh W1 (rows of the first set), dW1 = dh^T X (K = all tokens of the modality)
     _linear_group([(j["dh_hi"], j["dh_lo"]) + j["job"]["sw"].w1_transposed() + (None, None, j["dX"], j["dX"].shape[0], j["d"], j["H"])
                    for j in J])
-    _linear_group([(j["dhT_hi"], j["dhT_lo"], j["XT_hi"], j["XT_lo"], None, None, j["dW1"], j["H"], j["d"], j["ldT"]) for j in J])
+    _weight_grad_sliced(J)
     cs = []
     for j in J:
         R = sum(j["rows"])
         cs += [(j["dw2_part"], j["dW2"], R, j["H"]), (j["db1_part"], j["db1"], R, j["H"]), (j["dl_part"], j["db2"], R, 1)]
     _colsum_group(cs)
     return [(j["dW1"], j["db1"], j["dW2"], j["db2"], j["dX"]) for j in J]
+
+
+ONE_PASS_WEIGHT_GRAD = True      # False: the scorers' dW1 in split-bf16 for every token set (cross-check of the one-pass product)
+
+
+def _apportion(weights, slots):
+    """Whole numbers >= 1 that add up to `slots` (or to len(weights) if that is more), proportional to `weights`."""
+    total = float(sum(weights))
+    want = [slots * w / total for w in weights]
+    got = [max(1, int(w)) for w in want]
+    while sum(got) < slots:
+        k = max(range(len(got)), key=lambda i: want[i] - got[i])
+        got[k] += 1
+    while sum(got) > slots and max(got) > 1:
+        k = min((i for i in range(len(got)) if got[i] > 1), key=lambda i: want[i] - got[i])
+        got[k] -= 1
+    return got
+
+
+def _weight_grad_sliced(J):
+    """dW1 = dh^T X of every scorer (K = all tokens of the modality: 15360 / 7680 at configs[1]) as K-SLICED problems -- a
+    [H, d] output is only 64..128 blocks, far fewer than CUs, so each set of tokens is cut into column ranges of the
+    transposed operands (nr_linear_group with a row pitch), every range writes its own slab and nr_slab_sum_group adds them
+    in fixed order.  Sets whose forward ran one-pass bf16 (the bank, on the mixed plan) take the one-pass GEMM here too: the
+    hi halves of dh and X, a third of the matrix-core work; the other sets stay split-bf16.  Two GEMM launches + one sum
+    (was one launch of 128 long-K blocks: 195 us at configs[1])."""
+    from .cluster_backward_hip import _linear_group
+    variants = {True: [], False: []}                       # exact (split-bf16) / one pass -> [(job index, set index), ...]
+    for ji, j in enumerate(J):
+        for si, (prep, feat, dl, prec) in enumerate(j["job"]["sets"]):
+            variants[int(prec) == hip.PREC_BF16X3 or not ONE_PASS_WEIGHT_GRAD].append((ji, si))
+    sums = [dict(out=j["dW1"], parts=[]) for j in J]
+    keep = []
+    for exact, members in variants.items():
+        if not members:
+            continue
+        cols = [_pad64(J[ji]["job"]["sets"][si][0].n_tok) for ji, si in members]
+        cuts = _apportion(cols, hip.LINEAR_GROUP_MAX)
+        n_prob = sum(cuts)
+        H, d = J[0]["H"], J[0]["d"]
+        slabs = torch.empty((n_prob, H, d), dtype=torch.float32, device=J[0]["dW1"].device)
+        keep.append(slabs)
+        probs, k, runs = [], 0, {}
+        for (ji, si), n_cols, n_cut in zip(members, cols, cuts):
+            j = J[ji]
+            if (j["H"], j["d"]) != (H, d):
+                raise hip.NrHipError("scorers of one backward launch share their shape")
+            step = _pad64(-(-n_cols // n_cut))
+            first = k
+            for c0 in range(0, n_cols, step):
+                kc = min(step, n_cols - c0)
+                off = 2 * (j["offs"][si] + c0)               # bytes: int16 elements
+                x_hi, w_hi = j["dhT_hi"].data_ptr() + off, j["XT_hi"].data_ptr() + off
+                x_lo = j["dhT_lo"].data_ptr() + off if exact else None
+                w_lo = j["XT_lo"].data_ptr() + off if exact else None
+                probs.append((x_hi, x_lo, w_hi, w_lo, None, None, slabs[k], H, d, kc, j["ldT"]))
+                k += 1
+            if ji in runs:                                   # the sets of a job are neighbours in `members`: one run of slabs
+                runs[ji][1] += k - first
+            else:
+                runs[ji] = [first, k - first]
+        for ji, (first, cnt) in runs.items():
+            sums[ji]["parts"].append((slabs[first], cnt))
+        _linear_group(probs)
+    arr = (hip.SlabSum * len(sums))()
+    for a, sm in zip(arr, sums):
+        a.out, a.n, a.accumulate, a.n_src = sm["out"].data_ptr(), sm["out"].numel(), 0, len(sm["parts"])
+        for i, (first, n) in enumerate(sm["parts"]):
+            a.part[i], a.n_slabs[i] = first.data_ptr(), n
+    hip.call("nr_slab_sum_group", len(sums), arr, hip.stream_ptr())
 
 
 def ctypes_ptr(t, elem_offset):

@@ -32,14 +32,16 @@ def _pad64(n):
 
 
 def _linear_group(problems):
-    """problems: (x_hi, x_lo, w_hi, w_lo, bias, residual, out, M, N, K)."""
+    """problems: (x_hi, x_lo, w_hi, w_lo, bias, residual, out, M, N, K[, ld]); operands may be tensors or raw addresses (a
+    K-slice of a wider matrix: address of its first column + ld)."""
     for lo in range(0, len(problems), hip.LINEAR_GROUP_MAX):
         chunk = problems[lo:lo + hip.LINEAR_GROUP_MAX]
         arr = (hip.LinearProblem * len(chunk))()
-        for a, (x_hi, x_lo, w_hi, w_lo, bias, res, out, M, N, K) in zip(arr, chunk):
+        for a, prob in zip(arr, chunk):
+            x_hi, x_lo, w_hi, w_lo, bias, res, out, M, N, K = prob[:10]
             a.x_hi, a.x_lo, a.w_hi, a.w_lo = _addr(x_hi), _addr(x_lo), _addr(w_hi), _addr(w_lo)
             a.bias, a.residual, a.out = _addr(bias), _addr(res), _addr(out)
-            a.M, a.N, a.K = int(M), int(N), int(K)
+            a.M, a.N, a.K, a.ld = int(M), int(N), int(K), int(prob[10]) if len(prob) > 10 else 0
         hip.call("nr_linear_group", len(chunk), arr, hip.stream_ptr())
 
 

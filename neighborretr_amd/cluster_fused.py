@@ -168,7 +168,8 @@ def ctm_stage_fused(x, mask, ctm, blk, noise, cache, key):
 
 
 def _addr(t):
-    return None if t is None else t.data_ptr()
+    """Device address of a tensor (None stays None; an int is taken as an address already)."""
+    return None if t is None else (t if isinstance(t, int) else t.data_ptr())
 
 
 def _workspace_views(ws, B, N, C, cnum):

@@ -550,6 +550,31 @@ extern "C" int nr_local_level_bwd_mfma(int side, const float* dS, int ds_mode, f
     return nr_local_level_bwd_group(1, &it, workspace, nr_local_level_bwd_group_workspace_bytes(1, &it), stream);
 }
 
+// The fixed-order slab sum on its own (weight-gradient GEMMs cut along K write one slab per cut)
+extern "C" int nr_slab_sum_group(int n, const NrSlabSum* items, void* stream) {
+    if (!items || n <= 0 || n > BW_MAX_GROUP) return NR_EINVAL;
+    NrBwdSumGroup sg;
+    sg.n = n;
+    size_t n_max = 0;
+    for (int i = 0; i < n; ++i) {
+        const NrSlabSum& it = items[i];
+        if (!it.out || it.n == 0 || (it.n % 4) != 0 || it.n_src < 1 || it.n_src > BW_MAX_GROUP) return NR_EINVAL;
+        sg.o[i].out = it.out;
+        sg.o[i].n = (size_t)it.n;
+        sg.o[i].accumulate = it.accumulate;
+        sg.o[i].n_src = it.n_src;
+        for (int k = 0; k < it.n_src; ++k) {
+            if (!it.part[k] || it.n_slabs[k] < 1) return NR_EINVAL;
+            sg.o[i].part[k] = it.part[k];
+            sg.o[i].n_chunks[k] = it.n_slabs[k];
+        }
+        if ((size_t)it.n > n_max) n_max = (size_t)it.n;
+    }
+    hipLaunchKernelGGL(nr_bwd_sum_group_kernel, dim3((unsigned)((n_max / 4 + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, sg);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
 // ---- the "other" operand in the order the kernel reads it ---------------------------------------------------------------------
 // Prepared tokens [n_tok][d] (bf16 hi, optional lo) -> fragment-major [slice][k-step][d / 16][64 lanes][8]: element j of lane
 // (kg, n) of block (slice, ks, dg) is token 96 slice + 32 ks + 8 kg + j, dim 16 dg + n; tokens past n_tok are zeros.

@@ -180,9 +180,11 @@ extern "C" int nr_linear_group(int n, const NrLinearProblem* probs, void* stream
     if (!probs || n <= 0) return NR_EINVAL;
     if (n > NR_LINEAR_MAX_GROUP) return NR_EUNSUPPORTED;
     NrLinearArgs a[NR_LINEAR_MAX_GROUP];
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < n; ++i) {
         a[i] = NrLinearArgs{probs[i].x_hi, probs[i].x_lo, probs[i].w_hi, probs[i].w_lo, probs[i].bias, probs[i].residual,
                             probs[i].out, probs[i].M, probs[i].N, probs[i].K};
+        a[i].ld = probs[i].ld;
+    }
     return nr_linear_group_launch(a, n, (hipStream_t)stream);
 }
 

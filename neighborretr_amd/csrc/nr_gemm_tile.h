@@ -124,8 +124,8 @@ struct NrGemmTile {
     __device__ __forceinline__ void run(const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
                                         int a_row0, int a_rows,
                                         const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
-                                        int b_row0, int b_rows, int K, char* smem, int rot = 0, bool dma_front = false) {
-        run_impl<false>(a_hi, a_lo, a_row0, a_rows, b_hi, b_lo, b_row0, b_rows, K, smem, rot, dma_front, 0);
+                                        int b_row0, int b_rows, int K, char* smem, int rot = 0, bool dma_front = false, int ld = 0) {
+        run_impl<false>(a_hi, a_lo, a_row0, a_rows, b_hi, b_lo, b_row0, b_rows, K, smem, rot, dma_front, 0, ld);
     }
 
     // The k=3 token convolution read IN PLACE (cluster.py:664): A is the token matrix itself, [a_rows, K/3] (hi / lo), and
@@ -143,8 +143,11 @@ struct NrGemmTile {
     __device__ __forceinline__ void run_impl(const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
                                              int a_row0, int a_rows,
                                              const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
-                                             int b_row0, int b_rows, int K, char* smem, int rot, bool dma_front, int conv_n) {
+                                             int b_row0, int b_rows, int K, char* smem, int rot, bool dma_front, int conv_n,
+                                             int ld = 0) {
         static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
+        // ld: row pitch of BOTH operands in elements when they are K-slices of wider matrices (0: the rows are K long)
+        const int LD = ld > 0 ? ld : K;
         const int tid = threadIdx.x;
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,7 +160,7 @@ struct NrGemmTile {
         const char* gb_h[PB];
         const char* ga_l[NSEG_A][X3 ? PA : 1];
         const char* gb_l[X3 ? PB : 1];
-        const int CA = CONV3 ? K / 3 : K;                    // row pitch of operand A
+        const int CA = CONV3 ? K / 3 : LD;                   // row pitch of operand A
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             int r = (wave + NW * i) * 8 + (lane >> 3);
@@ -173,8 +176,8 @@ struct NrGemmTile {
                 }
             } else {
                 int gr = min(a_row0 + r, a_rows - 1);
-                ga_h[0][i] = reinterpret_cast<const char*>(a_hi + (size_t)gr * K + kc * 8);
-                if constexpr (X3) ga_l[0][i] = reinterpret_cast<const char*>(a_lo + (size_t)gr * K + kc * 8);
+                ga_h[0][i] = reinterpret_cast<const char*>(a_hi + (size_t)gr * CA + kc * 8);
+                if constexpr (X3) ga_l[0][i] = reinterpret_cast<const char*>(a_lo + (size_t)gr * CA + kc * 8);
             }
         }
 #pragma unroll
@@ -182,8 +185,8 @@ struct NrGemmTile {
             int r = (wave + NW * i) * 8 + (lane >> 3);
             int kc = (lane & 7) ^ row_key<TPS_B, NI>(r);
             int gr = min(b_row0 + r, b_rows - 1);
-            gb_h[i] = reinterpret_cast<const char*>(b_hi + (size_t)gr * K + kc * 8);
-            if constexpr (X3) gb_l[i] = reinterpret_cast<const char*>(b_lo + (size_t)gr * K + kc * 8);
+            gb_h[i] = reinterpret_cast<const char*>(b_hi + (size_t)gr * LD + kc * 8);
+            if constexpr (X3) gb_l[i] = reinterpret_cast<const char*>(b_lo + (size_t)gr * LD + kc * 8);
         }
         const int KT_ = K / BK;
         // DMA instruction `idx` (0 .. DMA_PER_STAGE-1) of slice kt: A pieces first (hi, then lo), then B pieces

@@ -14,10 +14,13 @@ struct NrLinearArgs {
     int conv_n = 0;
     // optional second form of the output: the bf16 pair of `out` (the A operand of a following GEMM)
     uint16_t *out_hi = nullptr, *out_lo = nullptr;
+    // row pitch of X and W in elements when both are K-slices of wider matrices (0: rows are K long); not with conv
+    int ld = 0;
 };
 
 #define NR_LINEAR_MAX_GROUP 8
 
-// All problems of a group are tiled with the same tile shape; K % 64 == 0 for each.
+// All problems of a group are tiled with the same tile shape; K % 64 == 0 for each.  x_lo == w_lo == nullptr in EVERY problem
+// selects the one-pass bf16 product (hi halves only) instead of the three-pass split-bf16 one.
 // conv = true: every problem is a token convolution (conv_n > 0 each).
 int nr_linear_group_launch(const NrLinearArgs* probs, int n_probs, hipStream_t stream, bool conv = false);

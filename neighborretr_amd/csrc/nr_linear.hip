@@ -17,16 +17,16 @@ struct NrLinearGroup {
     int n;
 };
 
-template <int MI, int NI, int STAGES, int WC, bool CONV = false>
+template <int MI, int NI, int STAGES, int WC, bool CONV = false, bool X3 = true>
 __device__ __forceinline__ void nr_linear_tile(const NrLinearArgs& p, const int tile_row, const int tile_col, char* smem) {
-    using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES, WC>;
+    using Tile = NrGemmTile<MI, NI, X3, 16, 16, STAGES, WC>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave / WC, wc = wave % WC;
     const int row0 = tile_row * Tile::BM, col0 = tile_col * Tile::BN;
     Tile tile;
     tile.zero();
     if constexpr (CONV) tile.run_conv3(p.x_hi, p.x_lo, row0, p.M, p.w_hi, p.w_lo, col0, p.N, p.K, smem, p.conv_n);
-    else tile.run(p.x_hi, p.x_lo, row0, p.M, p.w_hi, p.w_lo, col0, p.N, p.K, smem);
+    else tile.run(p.x_hi, p.x_lo, row0, p.M, p.w_hi, p.w_lo, col0, p.N, p.K, smem, 0, false, p.ld);
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
         const int c = col0 + wc * 16 * NI + n * 16 + (lane & 15);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void nr_linear_kernel(NrLinearArgs p) {
 }
 
 // grouped: workgroup -> (problem, tile) through the prefix table; tiles of a problem are column-fastest
-template <int MI, int NI, int STAGES, int WC, bool CONV = false>
+template <int MI, int NI, int STAGES, int WC, bool CONV = false, bool X3 = true>
 __global__ __launch_bounds__(128 * WC) void nr_linear_group_kernel(NrLinearGroup g) {
     NR_CRITICAL_PATH();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(128 * WC) void nr_linear_group_kernel(NrLinearGroup
     const NrLinearArgs& p = g.p[gi];
     const int t = wg - g.tile_start[gi];
     const int ncol = (p.N + 16 * WC * NI - 1) / (16 * WC * NI);
-    nr_linear_tile<MI, NI, STAGES, WC, CONV>(p, t / ncol, t % ncol, smem);
+    nr_linear_tile<MI, NI, STAGES, WC, CONV, X3>(p, t / ncol, t % ncol, smem);
 }
 
 template <int MI, int NI, int STAGES>
@@ -97,9 +97,9 @@ static int nr_linear_launch(NrLinearArgs& a, hipStream_t st) {
     return nr_linear_launch_s<MI, NI, 2>(a, st);
 }
 
-template <int MI, int NI, int STAGES, int WC = 2, bool CONV = false>
+template <int MI, int NI, int STAGES, int WC = 2, bool CONV = false, bool X3 = true>
 static int nr_linear_group_launch_s(const NrLinearArgs* probs, int n, hipStream_t st) {
-    using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES, WC>;
+    using Tile = NrGemmTile<MI, NI, X3, 16, 16, STAGES, WC>;
     NrLinearGroup g;
     g.n = n;
     int total = 0;
@@ -111,10 +111,10 @@ static int nr_linear_group_launch_s(const NrLinearArgs* probs, int n, hipStream_
     for (int i = n; i <= NR_LINEAR_MAX_GROUP; ++i) g.tile_start[i] = total;
     size_t lds = Tile::RING_BYTES;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)nr_linear_group_kernel<MI, NI, STAGES, WC, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)nr_linear_group_kernel<MI, NI, STAGES, WC, CONV, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((nr_linear_group_kernel<MI, NI, STAGES, WC, CONV>), dim3(nr_xcd_chunk_grid(total)), dim3(128 * WC), lds, st, g);
+    hipLaunchKernelGGL((nr_linear_group_kernel<MI, NI, STAGES, WC, CONV, X3>), dim3(nr_xcd_chunk_grid(total)), dim3(128 * WC), lds, st, g);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }
@@ -128,9 +128,12 @@ int nr_linear_group_launch(const NrLinearArgs* probs, int n, hipStream_t st, boo
         if ((probs[i].out_hi == nullptr) != (probs[i].out_lo == nullptr)) return NR_EINVAL;
     }
     long t32x64 = 0, t128 = 0;
+    const bool one_pass = !probs[0].x_lo && !probs[0].w_lo;
     for (int i = 0; i < n; ++i) {
         const NrLinearArgs& a = probs[i];
-        if (!a.x_hi || !a.x_lo || !a.w_hi || !a.w_lo || !a.out || a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % 64) != 0) return NR_EINVAL;
+        if (!a.x_hi || !a.w_hi || !a.out || a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % 64) != 0) return NR_EINVAL;
+        if ((a.x_lo == nullptr) != one_pass || (a.w_lo == nullptr) != one_pass) return NR_EINVAL;       // one kernel variant per launch
+        if (a.ld < 0 || (a.ld > 0 && (a.ld < a.K || (a.ld % 8) != 0 || conv))) return NR_EINVAL;
         t32x64 += (long)((a.M + 31) / 32) * ((a.N + 63) / 64);
         t128 += (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     }
@@ -150,6 +153,22 @@ int nr_linear_group_launch(const NrLinearArgs* probs, int n, hipStream_t st, boo
     if (const char* ov = nr_tune_env("NR_LINEAR_TILE")) {
         int a_, b_, c_, d_ = 2;
         if (sscanf(ov, "%d,%d,%d,%d", &a_, &b_, &c_, &d_) >= 3) { mi = a_; ni = b_; stg = c_; wcols = d_; }
+    }
+    if (one_pass) {
+        // hi halves only (a third of the MFMAs, half the operand bytes): 64 x 128 blocks on 8 waves, or 64 x 64 on 4 for small
+        // grids; two-deep ring unless the grid brings >= 2 workgroups per CU.  (tools/scorer_bwd_times.py, NR_LINEAR_TILE)
+        if (conv) return NR_EUNSUPPORTED;
+        const long t64x128 = t32x64 / 4;
+        if (!nr_tune_env("NR_LINEAR_TILE")) {
+            mi = 2; ni = 2;
+            wcols = t64x128 >= 256 ? 4 : 2;
+            stg = (wcols == 4 ? t64x128 : t32x64 / 2) >= 512 ? 1 : 2;
+        }
+#define NR_LG1_CASE(MI_, NI_, ST_, WC_) if (mi == MI_ && ni == NI_ && stg == ST_ && wcols == WC_) return nr_linear_group_launch_s<MI_, NI_, ST_, WC_, false, false>(probs, n, st)
+        NR_LG1_CASE(2, 2, 1, 4); NR_LG1_CASE(2, 2, 2, 4); NR_LG1_CASE(2, 2, 1, 2); NR_LG1_CASE(2, 2, 2, 2);
+        NR_LG1_CASE(4, 2, 1, 4); NR_LG1_CASE(4, 2, 2, 4); NR_LG1_CASE(2, 4, 2, 2);
+#undef NR_LG1_CASE
+        return NR_EUNSUPPORTED;
     }
     if (conv) {                      // token convolutions: the two shapes the clustering stages use (and their neighbours)
         if (wcols == 4 || mi > 2) { mi = 2; ni = 2; stg = 1; }

@@ -53,7 +53,7 @@ class ColsumItem(ctypes.Structure):
 class LinearProblem(ctypes.Structure):
     """NrLinearProblem of include/nr_hip.h."""
     _fields_ = ([(n, _P) for n in ("x_hi", "x_lo", "w_hi", "w_lo", "bias", "residual", "out")]
-                + [(n, ctypes.c_int32) for n in ("M", "N", "K")])
+                + [(n, ctypes.c_int32) for n in ("M", "N", "K", "ld")])
 
 
 class CtmAttnBwdDesc(ctypes.Structure):
@@ -78,6 +78,12 @@ class SimBwdItem(ctypes.Structure):
 class SimBwdOperand(ctypes.Structure):
     """NrSimBwdOperand of include/nr_hip.h."""
     _fields_ = [(n, _P) for n in ("hi", "lo", "out_hi", "out_lo")] + [("n_tok", ctypes.c_int32), ("d", ctypes.c_int32)]
+
+
+class SlabSum(ctypes.Structure):
+    """NrSlabSum of include/nr_hip.h."""
+    _fields_ = [("out", _P), ("n", ctypes.c_uint64), ("accumulate", ctypes.c_int32), ("n_src", ctypes.c_int32),
+                ("part", _P * 4), ("n_slabs", ctypes.c_int32 * 4)]
 
 
 class PoolWSrc(ctypes.Structure):
@@ -160,6 +166,7 @@ _SIGNATURES = {
     "nr_local_level_bwd_group": ([_I, ctypes.POINTER(SimBwdItem), _P, _Z, _P], _I),
     "nr_pool_weight_bwd_group": ([_I, ctypes.POINTER(PoolWJob), _P], _I),
     "nr_sim_bwd_operand_group": ([_I, ctypes.POINTER(SimBwdOperand), _P], _I),
+    "nr_slab_sum_group": ([_I, ctypes.POINTER(SlabSum), _P], _I),
     "nr_normalize_bwd": ([_P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     "nr_token_softmax_bwd": ([_P, _P, _I, _I, _P, _P], _I),
     "nr_centrality_weights_bwd": ([_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P], _I),
