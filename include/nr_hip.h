@@ -261,15 +261,19 @@ int nr_ctm_stage_workspace_layout2(int n_samples, int N, int C, int cluster_num,
  * (ld >= cols, same 64-column tile count; lo may be NULL); mode 1: the same split written TRANSPOSED [cols, ld], ld >= rows,
  * entries [rows, min(ld, rows rounded up to 64)) zero (K padding of a GEMM operand; hi / lo may point INTO a wider buffer of
  * pitch ld at a 64-aligned column); mode 2: a bf16 PAIR src (hi) / src2 (lo) [rows, cols] -> transposed
- * [cols, ld].  Used for the per-step re-split of every weight matrix and for the K = token-rows operands of the
- * weight-gradient GEMMs.                                                                                                   */
+ * [cols, ld]; mode 3: f32 src [rows, cols] = token rows in samples of `group` tokens -> the transposed k=3 neighbourhood
+ * [3 cols, ld]: row 3 c + s holds src[r + s - 1, c] at column r (zero where r + s - 1 leaves the sample of r, and in the K
+ * padding) -- the operand that makes the token-convolution weight gradient (cluster.py:664) come out of its GEMM in the
+ * parameter's own [C_out, C_in, 3] order.  Used for the per-step re-split of every weight matrix and for the K = token-rows
+ * operands of the weight-gradient GEMMs.                                                                                   */
 #define NR_SPLIT_MAX 48
 typedef struct NrSplitItem {
     const void* src;
     const void* src2;
     uint16_t *hi, *lo;
     int32_t rows, cols, mode, ld;
-} NrSplitItem;
+    int32_t group, pad_;                         /* mode 3: tokens per sample */
+} NrSplitItem;                                   /* 56 bytes */
 int nr_split_group(int n, const NrSplitItem* items, void* stream);
 
 /* nr_colsum_group: dst[c] = scale * sum_r src[r, c] for up to NR_COLSUM_MAX f32 matrices in one launch (bias gradients, sums of
@@ -424,6 +428,13 @@ int nr_row_losses_bwd(const float* S, const float* G, const float* tgt_rows, con
                       const float* bank_c0, const float* bank_c1, const float* wc_text, const float* wc_video,
                       const float* logit_scale, int B, int K, float temperature, const float* g_rowloss,
                       float* dS_dir, float* dG_dir, float* d_c_rows, float* d_wc, float* d_ls_rows, void* stream);
+
+/* g_rowloss [2,4,B] for nr_row_losses_bwd from the gradients of the five losses nr_loss_finalize returns (device scalars; NULL =
+ * that loss has no gradient): coef[term] = (g_total * weight[term] + g_term) * 0.5 / B, the kl term divided by B once more.  One
+ * launch in place of a dozen element-wise ones on 5-element tensors at the start of every backward pass.                    */
+int nr_rowloss_coef(const float* g_total, const float* g_centrality, const float* g_uniform, const float* g_neighbor,
+                    const float* g_kl, float uniform_weight, float neighbor_weight, float kl_weight, int B,
+                    float* g_rowloss, void* stream);
 
 /* out[i,j] = a[i,j] + b[j,i]  (folds the direction-1 gradients back into the row-major frame);
  * colsum variant: out[j] = sum_i a[i,j].                                                        */

@@ -59,6 +59,14 @@ def _pad64(n):
     return (n + 63) // 64 * 64
 
 
+def _residual(j):
+    r = j["job"].get("add_to")
+    if r is None:
+        return None
+    r = r.detach().float().contiguous().view(j["dX"].shape)
+    return r
+
+
 def _mlp_backward_hip(jobs):
     """Backward of the token scorers of BOTH modalities in eight launches (nr_token_mlp_bwd_hidden recomputes the hidden layer
     like the forward and emits dh as bf16 pairs from its epilogue; the three GEMMs of each scorer run grouped on the tile
@@ -66,6 +74,7 @@ def _mlp_backward_hip(jobs):
         sw    head.ScorerWeights of the scorer
         sets  [(prepared tokens, raw features [n, d] f32, dl [n] f32, precision the FORWARD ran this set in), ...]
               the batch tokens first, then the bank tokens; dX is returned for the first set's rows
+        add_to  optional [n_0, d] tensor added to dX inside its GEMM
     Returns [(dW1 [H,d], db1 [H], dW2 [1,H], db2 [1], dX [n_0, d]), ...]."""
     from .cluster_backward_hip import _colsum_group, _linear_group
     from .cluster_fused import split_group
@@ -112,8 +121,8 @@ def _mlp_backward_hip(jobs):
                      hip.stream_ptr())
             r0 += rows
     # dX = dh W1 (rows of the first set), dW1 = dh^T X (K = all tokens of the modality)
-    _linear_group([(j["dh_hi"], j["dh_lo"]) + j["job"]["sw"].w1_transposed() + (None, None, j["dX"], j["dX"].shape[0], j["d"], j["H"])
-                   for j in J])
+    _linear_group([(j["dh_hi"], j["dh_lo"]) + j["job"]["sw"].w1_transposed()
+                   + (None, _residual(j), j["dX"], j["dX"].shape[0], j["d"], j["H"]) for j in J])
     _weight_grad_sliced(J)
     cs = []
     for j in J:
@@ -221,10 +230,15 @@ class HeadLossFn(torch.autograd.Function):
         sv["gt2"], sv["gv2"] = sv["gt2"].reshape(-1, sv["gt2"].shape[-1]), sv["gv2"].reshape(-1, sv["gv2"].shape[-1])
         ctx.save_for_backward(text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v,
                               g1_w1t, g1_b1t, g1_w2t, g1_w1v, g1_b1v, g1_w2v)
-        return losses
+        # five scalar outputs (total, centrality, uniform, neighbour, kl): a loss that is not differentiated brings no gradient
+        # (not a zero tensor), and backward() on one of them needs no select-backward fill / copy launches
+        ctx.set_materialize_grads(False)
+        return tuple(losses.unbind(0))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
+        if all(g is None for g in gs):
+            return (None,) * 29
         sv, hp = ctx.sv, ctx.hp
         (text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v,
          g1_w1t, g1_b1t, g1_w2t, g1_w1v, g1_b1v, g1_w2v) = ctx.saved_tensors
@@ -232,8 +246,7 @@ class HeadLossFn(torch.autograd.Function):
         Gt, Gv = gt_shape[1], gv_shape[1]
         text_mask, video_mask = ctx.masks
         K, T = int(hp["num_neighbors"]), hp["temperature"]
-        g = g.float().contiguous()
-        coef = _coef_rowloss(g, hp, B)
+        coef = ops.rowloss_coef(gs, hp, B)
         dS_dir, dG_dir, dC_rows, dwc, dls_rows = ops.row_losses_bwd(sv["S"], sv["G"], sv["tgt_r"], sv["tgt_c"], sv["c0"],
                                                                     sv["c1"], sv["wc_t"], sv["wc_v"], sv["ls"], K, T, coef)
         dS = ops.add_transposed(dS_dir[0], dS_dir[1])
@@ -242,9 +255,7 @@ class HeadLossFn(torch.autograd.Function):
         d_ls = dls_rows.sum()
         g1 = [None] * 8
         if sv["g_saved"] is None:
-            # global logits G = gt gv^T   (tiny plain GEMMs)
-            d_gt = dG @ sv["gv2"]
-            d_gv = dG.t() @ sv["gt2"]
+            d_gt = d_gv = None              # global logits G = gt gv^T: tiny plain GEMMs, folded into the centrality step below
         else:
             # several global tokens per sample: G is the fused product on the un-normalised global tokens with the
             # *_weight_fc1 softmax weights (modeling.py:516-539): arg-max-routed gradient + softmax + scorer-MLP backward
@@ -260,12 +271,16 @@ class HeadLossFn(torch.autograd.Function):
         # centrality weights: w_i = mean over the sample's global tokens of exp(c <g_hat, mean>)  (one token: the reference's)
         cs = hp["centrality_scale"]
         gn_t, gn_v, wtok_t, wtok_v = sv["cw_aux"]
-        dw_t = (dwc[0] / Gt)[:, None].expand(B, Gt).reshape(-1).contiguous()
-        dw_v = (dwc[1] / Gv)[:, None].expand(B, Gv).reshape(-1).contiguous()
+        dw_t = dwc[0] if Gt == 1 else (dwc[0] / Gt)[:, None].expand(B, Gt).reshape(-1).contiguous()
+        dw_v = dwc[1] if Gv == 1 else (dwc[1] / Gv)[:, None].expand(B, Gv).reshape(-1).contiguous()
         dg_t, dmean_t = ops.centrality_weights_bwd(sv["gt2"], gn_t, sv["mean_t"], wtok_t, dw_t, cs)
         dg_v, dmean_v = ops.centrality_weights_bwd(sv["gv2"], gn_v, sv["mean_v"], wtok_v, dw_v, cs)
-        d_gt = (d_gt + dg_t).reshape(gt_shape)
-        d_gv = (d_gv + dg_v).reshape(gv_shape)
+        if d_gt is None:                    # one token per sample: d gt = dG gv + (centrality part), the sum inside the GEMM
+            d_gt = torch.addmm(dg_t, dG, sv["gv2"]).reshape(gt_shape)
+            d_gv = torch.addmm(dg_v, dG.t(), sv["gt2"]).reshape(gv_shape)
+        else:
+            d_gt = (d_gt + dg_t).reshape(gt_shape)
+            d_gv = (d_gv + dg_v).reshape(gv_shape)
         # similarity kernels: batch x batch, text x bank-video (row mean), bank-text x video (col mean)
         pt, pv, pbt, pbv = sv["pt"], sv["pv"], sv["pbt"], sv["pbv"]
         lo = ctx.exact
@@ -312,16 +327,18 @@ class HeadLossFn(torch.autograd.Function):
         dl_bv = ops.token_softmax_bwd(sv["w_bv"], d_wbv.view(M, Nv))
         if FUSED_MLP_BACKWARD:
             _, p_mlp, p_bank = ctx.plan
-            (dW1t, db1t, dW2t, db2t, dXt), (dW1v, db1v, dW2v, db2v, dXv) = _mlp_backward_hip([
-                dict(sw=ctx.model.scorer_weights("text_weight_fc"),
+            # the scorer's input gradient is added to the similarity path's inside its GEMM (residual operand)
+            (dW1t, db1t, dW2t, db2t, d_text), (dW1v, db1v, dW2v, db2v, d_video) = _mlp_backward_hip([
+                dict(sw=ctx.model.scorer_weights("text_weight_fc"), add_to=d_text,
                      sets=[(pt, text_feat, dl_t, p_mlp), (pbt, mb_feat_t, dl_bt, p_bank)]),
-                dict(sw=ctx.model.scorer_weights("video_weight_fc"),
+                dict(sw=ctx.model.scorer_weights("video_weight_fc"), add_to=d_video,
                      sets=[(pv, video_feat, dl_v, p_mlp), (pbv, mb_feat_v, dl_bv, p_bank)])])
+            d_text, d_video = d_text.view(text_feat.shape), d_video.view(video_feat.shape)
         else:
             dW1t, db1t, dW2t, db2t, dXt = _mlp_backward([text_feat, mb_feat_t], [dl_t, dl_bt], w1t, b1t, w2t, B * Nt, ctx.exact)
             dW1v, db1v, dW2v, db2v, dXv = _mlp_backward([video_feat, mb_feat_v], [dl_v, dl_bv], w1v, b1v, w2v, B * Nv, ctx.exact)
-        d_text = d_text + dXt.view_as(d_text)
-        d_video = d_video + dXv.view_as(d_video)
+            d_text = d_text + dXt.view_as(d_text)
+            d_video = d_video + dXv.view_as(d_video)
         ctx.sv = ctx.model = None
         return (None, None, None, None, None, None, None, None,
                 d_text, d_video, d_gt, d_gv, d_ls,

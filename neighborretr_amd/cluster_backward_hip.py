@@ -72,10 +72,10 @@ def stage_backward_group(problems, cache):
                  sw=_stage_weights(cache, key, ctm, blk), g=g.detach().float().contiguous().view(Mc, C))
         for name, shape in (("g_hi", (Mc, C)), ("g_lo", (Mc, C)), ("gT_hi", (C, Mcp)), ("gT_lo", (C, Mcp)),
                             ("attT_hi", (C, Mcp)), ("attT_lo", (C, Mcp)), ("qnT_hi", (C, Mcp)), ("qnT_lo", (C, Mcp)),
-                            ("kvnT_hi", (C, Mp)), ("kvnT_lo", (C, Mp)), ("x0T_hi", (C, Mp)), ("x0T_lo", (C, Mp)),
+                            ("kvnT_hi", (C, Mp)), ("kvnT_lo", (C, Mp)), ("x0T3_hi", (3 * C, Mp)), ("x0T3_lo", (3 * C, Mp)),
                             ("dq_hi", (Mc, C)), ("dq_lo", (Mc, C)), ("dkv_hi", (M, 2 * C)), ("dkv_lo", (M, 2 * C)),
                             ("dcat_hi", (M, 3 * C)), ("dcat_lo", (M, 3 * C)), ("dqT_hi", (C, Mcp)), ("dqT_lo", (C, Mcp)),
-                            ("dkvT_hi", (2 * C, Mp)), ("dkvT_lo", (2 * C, Mp)), ("dcatT_hi", (3 * C, Mp)), ("dcatT_lo", (3 * C, Mp))):
+                            ("dkvT_hi", (2 * C, Mp)), ("dkvT_lo", (2 * C, Mp)), ("dyT_hi", (C, Mp)), ("dyT_lo", (C, Mp))):
             d[name] = torch.empty(shape, **i16)
         for name, shape in (("d_att", (Mc, C)), ("d_q", (Mc, C)), ("d_kv", (M, 2 * C)), ("d_score", (B, N)), ("d_qn", (Mc, C)),
                             ("d_kvn", (M, C)), ("d_y", (M, C)), ("partial", (B, 6 * C)), ("d_x0", (M, C)), ("dWp", (C, C)),
@@ -94,7 +94,9 @@ def stage_backward_group(problems, cache):
                   (sv["att_hi"], sv["att_lo"], d["attT_hi"], d["attT_lo"], Mc, C, 2, Mcp),
                   (sv["qn_hi"], sv["qn_lo"], d["qnT_hi"], d["qnT_lo"], Mc, C, 2, Mcp),
                   (sv["kvn_hi"], sv["kvn_lo"], d["kvnT_hi"], d["kvnT_lo"], M, C, 2, Mp),
-                  (d["x0"], None, d["x0T_hi"], d["x0T_lo"], M, C, 1, Mp)]
+                  # the k=3 token neighbourhood of x0, transposed (row 3 i + s = x0[n + s - 1, i]): with it the convolution's
+                  # weight gradient comes out of its GEMM as [C_out, C_in, 3], the parameter's own order
+                  (d["x0"], None, d["x0T3_hi"], d["x0T3_lo"], M, C, 3, Mp, d["N"])]
     split_group(items)
     # 2. d_att = g Wp
     _linear_group([(d["g_hi"], d["g_lo"], d["sw"].wp_bt_hi, d["sw"].wp_bt_lo, None, None, d["d_att"], d["Mc"], d["C"], d["C"])
@@ -134,7 +136,7 @@ def stage_backward_group(problems, cache):
         C, M, Mc, Mp, Mcp = d["C"], d["M"], d["Mc"], d["Mp"], d["Mcp"]
         items += [(d["d_q"], None, d["dqT_hi"], d["dqT_lo"], Mc, C, 1, Mcp),
                   (d["d_kv"], None, d["dkvT_hi"], d["dkvT_lo"], M, 2 * C, 1, Mp),
-                  (d["dcat_hi"], d["dcat_lo"], d["dcatT_hi"], d["dcatT_lo"], M, 3 * C, 2, Mp)]
+                  (d["d_y"], None, d["dyT_hi"], d["dyT_lo"], M, C, 1, Mp)]
     split_group(items)
     # 8. weight gradients: K = token rows (zero-padded to a multiple of 64)
     probs = []
@@ -143,7 +145,7 @@ def stage_backward_group(problems, cache):
         probs += [(d["gT_hi"], d["gT_lo"], d["attT_hi"], d["attT_lo"], None, None, d["dWp"], C, C, Mcp),
                   (d["dqT_hi"], d["dqT_lo"], d["qnT_hi"], d["qnT_lo"], None, None, d["dWq"], C, C, Mcp),
                   (d["dkvT_hi"], d["dkvT_lo"], d["kvnT_hi"], d["kvnT_lo"], None, None, d["dWkv"], 2 * C, C, Mp),
-                  (d["x0T_hi"], d["x0T_lo"], d["dcatT_hi"], d["dcatT_lo"], None, None, d["dWc"], C, 3 * C, Mp)]
+                  (d["dyT_hi"], d["dyT_lo"], d["x0T3_hi"], d["x0T3_lo"], None, None, d["dWc"], C, 3 * C, Mp)]
     _linear_group(probs)
     # 9. bias gradients and the per-sample partial sums
     items = []
@@ -160,8 +162,8 @@ def stage_backward_group(problems, cache):
         grads = {attn.proj.weight: d["dWp"], attn.q.weight: d["dWq"], attn.kv.weight: d["dWkv"],
                  n1.weight: ps[0:C], n1.bias: ps[C:2 * C], ctm.norm.weight: ps[2 * C:3 * C], ctm.norm.bias: ps[3 * C:4 * C],
                  ctm.score.weight: ps[4 * C:5 * C].reshape(1, C),
-                 # dWc[i, s C + o] = d W[o, i, s]
-                 wconv: d["dWc"].view(wconv.shape[1], 3, wconv.shape[0]).permute(2, 0, 1)}
+                 # dWc[o, 3 i + s] = d W[o, i, s]: already the parameter's layout
+                 wconv: d["dWc"].view(wconv.shape)}
         if attn.proj.bias is not None:
             grads[attn.proj.bias] = d["dbp"]
         if attn.q.bias is not None:

@@ -20,11 +20,14 @@ def _p(t, dtype=torch.float32):
 
 
 def split_group(items):
-    """ONE launch of nr_split_group.  items: (src, src2 or None, hi, lo or None, rows, cols, mode, ld) with tensors."""
+    """ONE launch of nr_split_group.  items: (src, src2 or None, hi, lo or None, rows, cols, mode, ld[, group]) with tensors
+    (group: tokens per sample, mode 3 only)."""
     for lo in range(0, len(items), hip.SPLIT_MAX):
         chunk = items[lo:lo + hip.SPLIT_MAX]
         arr = (hip.SplitItem * len(chunk))()
-        for a, (src, src2, hi, lo_, rows, cols, mode, ld) in zip(arr, chunk):
+        for a, item in zip(arr, chunk):
+            src, src2, hi, lo_, rows, cols, mode, ld = item[:8]
+            a.group = int(item[8]) if len(item) > 8 else 0
             off = 0
             if isinstance(hi, tuple):                    # (tensor, element offset): write into a wider buffer of pitch ld
                 (hi, off), lo_ = hi, (lo_[0] if lo_ is not None else None)

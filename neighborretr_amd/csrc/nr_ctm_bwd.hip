@@ -27,7 +27,8 @@ struct NrSplitGroup {
 };
 
 __global__ __launch_bounds__(256) void nr_split_group_kernel(NrSplitGroup g) {
-    __shared__ float t[64][65];
+    __shared__ float smem3[66 * 65];
+    float (*t)[65] = reinterpret_cast<float (*)[65]>(smem3);
     const int wg = blockIdx.x;
     int gi = 0;
     for (int i = 1; i < g.n; ++i)
@@ -57,6 +58,33 @@ __global__ __launch_bounds__(256) void nr_split_group_kernel(NrSplitGroup g) {
                 const uint32_t v = tu[c][cl];
                 it.hi[(size_t)cc * it.ld + r] = (uint16_t)(v & 0xFFFFu);
                 if (it.lo) it.lo[(size_t)cc * it.ld + r] = (uint16_t)(v >> 16);
+            }
+        }
+        return;
+    }
+    if (it.mode == 3) {                     // transposed k=3 neighbourhood: tile rows with a one-row halo on both sides
+        float (*th)[65] = reinterpret_cast<float (*)[65]>(smem3);
+        for (int e = threadIdx.x; e < 66 * 64; e += 256) {
+            const int k = e >> 6, cl = e & 63;
+            const int r = tr * 64 - 1 + k, cc = tc * 64 + cl;
+            th[k][cl] = (r >= 0 && r < it.rows && cc < it.cols) ? src[(size_t)r * it.cols + cc] : 0.f;
+        }
+        __syncthreads();
+        const int r = tr * 64 + c;
+        const int sample = r / it.group;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int cl = r0 + 4 * i, cc = tc * 64 + cl;
+            if (cc >= it.cols || r >= it.ld) continue;
+#pragma unroll
+            for (int sft = 0; sft < 3; ++sft) {
+                const int rr = r + sft - 1;
+                const bool on = r < it.rows && rr >= 0 && rr < it.rows && rr / it.group == sample;
+                const float v = on ? th[c + sft][cl] : 0.f;
+                const uint16_t h = nr_f2bf(v);
+                const size_t o = (size_t)(3 * cc + sft) * it.ld + r;
+                it.hi[o] = h;
+                if (it.lo) it.lo[o] = nr_f2bf(v - nr_bf2f(h));
             }
         }
         return;
@@ -100,7 +128,8 @@ extern "C" int nr_split_group(int n, const NrSplitItem* items, void* stream) {
     int total = 0;
     for (int i = 0; i < n; ++i) {
         const NrSplitItem& it = items[i];
-        if (!it.src || !it.hi || it.rows <= 0 || it.cols <= 0 || it.mode < 0 || it.mode > 2) return NR_EINVAL;
+        if (!it.src || !it.hi || it.rows <= 0 || it.cols <= 0 || it.mode < 0 || it.mode > 3) return NR_EINVAL;
+        if (it.mode == 3 && it.group <= 0) return NR_EINVAL;
         if (it.mode ? it.ld < it.rows : it.ld < it.cols) return NR_EINVAL;
         g.it[i] = it;
         g.start[i] = total;

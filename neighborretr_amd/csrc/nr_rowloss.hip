@@ -462,6 +462,30 @@ __global__ __launch_bounds__(256) void nr_row_losses_bwd_kernel(NrRowArgs a, con
     }
 }
 
+// g_rowloss [2,4,B] of the fused objective from the gradients of its five outputs (total, centrality, uniform, neighbour, kl;
+// any of them may be absent): the constants of nr_loss_finalize differentiated --
+//   coef[term] = (g_total * weight[term] + g_term) * 0.5 / B,  the kl term divided by B once more (batchmean).
+__global__ __launch_bounds__(256) void nr_rowloss_coef_kernel(const float* g0, const float* g1, const float* g2, const float* g3,
+                                                              const float* g4, float wu, float wn, float wkl, int B,
+                                                              float* __restrict__ coef) {
+    const float t = g0 ? g0[0] : 0.f;
+    const float h = 0.5f / (float)B;
+    const float c[4] = {(t + (g1 ? g1[0] : 0.f)) * h, (t * wu + (g2 ? g2[0] : 0.f)) * h, (t * wn + (g3 ? g3[0] : 0.f)) * h,
+                        (t * wkl + (g4 ? g4[0] : 0.f)) / (float)B * h};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 8 * B; i += gridDim.x * 256) coef[i] = c[(i / B) & 3];
+}
+
+extern "C" int nr_rowloss_coef(const float* g_total, const float* g_centrality, const float* g_uniform, const float* g_neighbor,
+                               const float* g_kl, float uniform_weight, float neighbor_weight, float kl_weight, int B,
+                               float* g_rowloss, void* stream) {
+    if (!g_rowloss || B <= 0) return NR_EINVAL;
+    hipLaunchKernelGGL(nr_rowloss_coef_kernel, dim3((8 * B + 255) / 256 > 64 ? 64 : (8 * B + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, g_total, g_centrality, g_uniform, g_neighbor, g_kl, uniform_weight, neighbor_weight,
+                       kl_weight, B, g_rowloss);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
 extern "C" int nr_row_losses_bwd(const float* S, const float* G, const float* tgt_rows, const float* tgt_cols,
                                  const float* bank_c0, const float* bank_c1, const float* wc_text, const float* wc_video,
                                  const float* logit_scale, int B, int K, float temperature, const float* g_rowloss,

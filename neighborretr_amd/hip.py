@@ -42,7 +42,8 @@ class LocalLevelProblem(ctypes.Structure):
 
 class SplitItem(ctypes.Structure):
     """NrSplitItem of include/nr_hip.h."""
-    _fields_ = [("src", _P), ("src2", _P), ("hi", _P), ("lo", _P)] + [(n, ctypes.c_int32) for n in ("rows", "cols", "mode", "ld")]
+    _fields_ = ([("src", _P), ("src2", _P), ("hi", _P), ("lo", _P)]
+                + [(n, ctypes.c_int32) for n in ("rows", "cols", "mode", "ld", "group", "pad_")])
 
 
 class ColsumItem(ctypes.Structure):
@@ -167,6 +168,7 @@ _SIGNATURES = {
     "nr_pool_weight_bwd_group": ([_I, ctypes.POINTER(PoolWJob), _P], _I),
     "nr_sim_bwd_operand_group": ([_I, ctypes.POINTER(SimBwdOperand), _P], _I),
     "nr_slab_sum_group": ([_I, ctypes.POINTER(SlabSum), _P], _I),
+    "nr_rowloss_coef": ([_P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P], _I),
     "nr_normalize_bwd": ([_P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     "nr_token_softmax_bwd": ([_P, _P, _I, _I, _P, _P], _I),
     "nr_centrality_weights_bwd": ([_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P], _I),

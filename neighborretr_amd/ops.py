@@ -421,6 +421,16 @@ def row_losses_bwd(S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video
     return dS, dG, dC, dwc, dls
 
 
+def rowloss_coef(gs, hp, B):
+    """g_rowloss [2,4,B] from the gradients of the five losses (tensors or None) in one launch (nr_rowloss_coef)."""
+    dev = next(g for g in gs if g is not None).device
+    gs = [None if g is None else _f32(g).contiguous() for g in gs]
+    coef = torch.empty((2, 4, B), dtype=torch.float32, device=dev)
+    hip.call("nr_rowloss_coef", *[hip.ptr(g, allow_none=True) for g in gs], float(hp["uniform_weight"]),
+             float(hp["neighbor_weight"]), float(hp["kl_weight"]), int(B), hip.ptr(coef), hip.stream_ptr())
+    return coef
+
+
 def add_transposed(a, b):
     """a + b.T for square fp32 matrices."""
     B = a.shape[0]
