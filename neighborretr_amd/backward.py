@@ -239,110 +239,208 @@ class HeadLossFn(torch.autograd.Function):
     def backward(ctx, *gs):
         if all(g is None for g in gs):
             return (None,) * 29
-        sv, hp = ctx.sv, ctx.hp
         (text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v,
          g1_w1t, g1_b1t, g1_w2t, g1_w1v, g1_b1v, g1_w2v) = ctx.saved_tensors
-        (B, Nt, d), (_, Nv, _), (M, _, _), _, gt_shape, gv_shape = ctx.shapes
-        Gt, Gv = gt_shape[1], gv_shape[1]
-        text_mask, video_mask = ctx.masks
-        K, T = int(hp["num_neighbors"]), hp["temperature"]
-        coef = ops.rowloss_coef(gs, hp, B)
-        dS_dir, dG_dir, dC_rows, dwc, dls_rows = ops.row_losses_bwd(sv["S"], sv["G"], sv["tgt_r"], sv["tgt_c"], sv["c0"],
-                                                                    sv["c1"], sv["wc_t"], sv["wc_v"], sv["ls"], K, T, coef)
-        dS = ops.add_transposed(dS_dir[0], dS_dir[1])
-        dG = ops.add_transposed(dG_dir[0], dG_dir[1])
-        d_c0, d_c1 = ops.colsum_pair(dC_rows[0], 1.0, dC_rows[1], 1.0)        # one grouped launch (was two serial column sums)
-        d_ls = dls_rows.sum()
-        g1 = [None] * 8
-        if sv["g_saved"] is None:
-            d_gt = d_gv = None              # global logits G = gt gv^T: tiny plain GEMMs, folded into the centrality step below
-        else:
-            # several global tokens per sample: G is the fused product on the un-normalised global tokens with the
-            # *_weight_fc1 softmax weights (modeling.py:516-539): arg-max-routed gradient + softmax + scorer-MLP backward
-            gs = sv["g_saved"]
-            d_gt, d_wgt = ops.local_level_bwd(0, dG, 0, 1.0, gs["pv"], gs["w_t"], gs["w_v"], gs["aux"], B, Gt, B, Gv, use_lo=True)
-            d_gv, d_wgv = ops.local_level_bwd(1, dG, 0, 1.0, gs["pt"], gs["w_v"], gs["w_t"], gs["aux"], B, Gt, B, Gv, use_lo=True)
-            dl_gt = ops.token_softmax_bwd(gs["w_t"], d_wgt.view(B, Gt))
-            dl_gv = ops.token_softmax_bwd(gs["w_v"], d_wgv.view(B, Gv))
-            gW1t, gb1t, gW2t, gb2t, gXt = _mlp_backward([sv["gt2"]], [dl_gt], g1_w1t, g1_b1t, g1_w2t, B * Gt, True)
-            gW1v, gb1v, gW2v, gb2v, gXv = _mlp_backward([sv["gv2"]], [dl_gv], g1_w1v, g1_b1v, g1_w2v, B * Gv, True)
-            d_gt, d_gv = d_gt + gXt, d_gv + gXv
-            g1 = [gW1t, gb1t, gW2t, gb2t, gW1v, gb1v, gW2v, gb2v]
-        # centrality weights: w_i = mean over the sample's global tokens of exp(c <g_hat, mean>)  (one token: the reference's)
-        cs = hp["centrality_scale"]
-        gn_t, gn_v, wtok_t, wtok_v = sv["cw_aux"]
-        dw_t = dwc[0] if Gt == 1 else (dwc[0] / Gt)[:, None].expand(B, Gt).reshape(-1).contiguous()
-        dw_v = dwc[1] if Gv == 1 else (dwc[1] / Gv)[:, None].expand(B, Gv).reshape(-1).contiguous()
-        dg_t, dmean_t = ops.centrality_weights_bwd(sv["gt2"], gn_t, sv["mean_t"], wtok_t, dw_t, cs)
-        dg_v, dmean_v = ops.centrality_weights_bwd(sv["gv2"], gn_v, sv["mean_v"], wtok_v, dw_v, cs)
-        if d_gt is None:                    # one token per sample: d gt = dG gv + (centrality part), the sum inside the GEMM
-            d_gt = torch.addmm(dg_t, dG, sv["gv2"]).reshape(gt_shape)
-            d_gv = torch.addmm(dg_v, dG.t(), sv["gt2"]).reshape(gv_shape)
-        else:
-            d_gt = (d_gt + dg_t).reshape(gt_shape)
-            d_gv = (d_gv + dg_v).reshape(gv_shape)
-        # similarity kernels: batch x batch, text x bank-video (row mean), bank-text x video (col mean)
-        pt, pv, pbt, pbv = sv["pt"], sv["pv"], sv["pbt"], sv["pbv"]
-        lo = ctx.exact
-        aux0, aux1, aux2 = sv["aux"]
-        f32 = dict(dtype=torch.float32, device=dS.device)
-        d_tn, d_vn = torch.empty((B * Nt, d), **f32), torch.empty((B * Nv, d), **f32)
-        d_wt, d_wv = torch.empty((B * Nt,), **f32), torch.empty((B * Nv,), **f32)
-        d_wbt, d_wbv = torch.empty((M * Nt,), **f32), torch.empty((M * Nv,), **f32)
-        if ops.USE_MFMA_BACKWARD and bool(hip.lib().nr_local_level_bwd_mfma_supported(Nt, Nv, d)):
-            # token gradients: the four products' routing matrices on the matrix cores in ONE launch (their "other" operands
-            # transposed in one launch before it), the chunks of a gradient's two products summed by one more
-            T_pv, T_pt, T_pbv, T_pbt = ops.transpose_prepared([pv, pt, pbv, pbt], use_lo=lo)
-            ops.local_level_bwd_group([
-                dict(side=0, dS=dS, ds_mode=0, ds_scale=1.0, other_T=T_pv, w_self=sv["w_t"], w_other=sv["w_v"], aux=aux0,
-                     A=B, Nt=Nt, Bv=B, Nv=Nv, d_x=d_tn),
-                dict(side=0, dS=d_c1, ds_mode=1, ds_scale=1.0 / M, other_T=T_pbv, w_self=sv["w_t"], w_other=sv["w_bv"], aux=aux1,
-                     A=B, Nt=Nt, Bv=M, Nv=Nv, d_x=d_tn),
-                dict(side=1, dS=dS, ds_mode=0, ds_scale=1.0, other_T=T_pt, w_self=sv["w_v"], w_other=sv["w_t"], aux=aux0,
-                     A=B, Nt=Nt, Bv=B, Nv=Nv, d_x=d_vn),
-                dict(side=1, dS=d_c0, ds_mode=2, ds_scale=1.0 / M, other_T=T_pbt, w_self=sv["w_v"], w_other=sv["w_bt"], aux=aux2,
-                     A=M, Nt=Nt, Bv=B, Nv=Nv, d_x=d_vn)], use_lo=lo)
-            # token-weight gradients of the batch and of the bank, all six sums in one launch
-            ops.pool_weight_bwd_group([
-                dict(side=0, N=Nt, d_w=d_wt, srcs=[(dS, 0, 1.0, aux0[2], B, B), (d_c1, 1, 1.0 / M, aux1[2], B, M)]),
-                dict(side=1, N=Nv, d_w=d_wv, srcs=[(dS, 0, 1.0, aux0[3], B, B), (d_c0, 2, 1.0 / M, aux2[3], M, B)]),
-                dict(side=1, N=Nv, d_w=d_wbv, srcs=[(d_c1, 1, 1.0 / M, aux1[3], B, M)]),
-                dict(side=0, N=Nt, d_w=d_wbt, srcs=[(d_c0, 2, 1.0 / M, aux2[2], M, B)])])
-        else:
-            ops.local_level_bwd(0, dS, 0, 1.0, pv, sv["w_t"], sv["w_v"], aux0, B, Nt, B, Nv, d_x=d_tn, d_w=d_wt, use_lo=lo)
-            ops.local_level_bwd(1, dS, 0, 1.0, pt, sv["w_v"], sv["w_t"], aux0, B, Nt, B, Nv, d_x=d_vn, d_w=d_wv, use_lo=lo)
-            ops.local_level_bwd(0, d_c1, 1, 1.0 / M, pbv, sv["w_t"], sv["w_bv"], aux1, B, Nt, M, Nv, d_x=d_tn, d_w=d_wt,
-                                accumulate=True, use_lo=lo)
-            ops.local_level_bwd(1, d_c1, 1, 1.0 / M, pt, sv["w_bv"], sv["w_t"], aux1, B, Nt, M, Nv, d_w=d_wbv, want_dx=False)
-            ops.local_level_bwd(1, d_c0, 2, 1.0 / M, pbt, sv["w_v"], sv["w_bt"], aux2, M, Nt, B, Nv, d_x=d_vn, d_w=d_wv,
-                                accumulate=True, use_lo=lo)
-            ops.local_level_bwd(0, d_c0, 2, 1.0 / M, pv, sv["w_bt"], sv["w_v"], aux2, M, Nt, B, Nv, d_w=d_wbt, want_dx=False)
-        # normalise / mask / centrality-mean backward
-        d_text = ops.normalize_bwd(text_feat, pt.norm, text_mask, d_tn, dmean_t)
-        d_video = ops.normalize_bwd(video_feat, pv.norm, video_mask, d_vn, dmean_v)
-        # token weights -> logits -> scorer MLPs
-        dl_t = ops.token_softmax_bwd(sv["w_t"], d_wt.view(B, Nt))
-        dl_v = ops.token_softmax_bwd(sv["w_v"], d_wv.view(B, Nv))
-        dl_bt = ops.token_softmax_bwd(sv["w_bt"], d_wbt.view(M, Nt))
-        dl_bv = ops.token_softmax_bwd(sv["w_bv"], d_wbv.view(M, Nv))
-        if FUSED_MLP_BACKWARD:
-            _, p_mlp, p_bank = ctx.plan
-            # the scorer's input gradient is added to the similarity path's inside its GEMM (residual operand)
-            (dW1t, db1t, dW2t, db2t, d_text), (dW1v, db1v, dW2v, db2v, d_video) = _mlp_backward_hip([
-                dict(sw=ctx.model.scorer_weights("text_weight_fc"), add_to=d_text,
-                     sets=[(pt, text_feat, dl_t, p_mlp), (pbt, mb_feat_t, dl_bt, p_bank)]),
-                dict(sw=ctx.model.scorer_weights("video_weight_fc"), add_to=d_video,
-                     sets=[(pv, video_feat, dl_v, p_mlp), (pbv, mb_feat_v, dl_bv, p_bank)])])
-            d_text, d_video = d_text.view(text_feat.shape), d_video.view(video_feat.shape)
-        else:
-            dW1t, db1t, dW2t, db2t, dXt = _mlp_backward([text_feat, mb_feat_t], [dl_t, dl_bt], w1t, b1t, w2t, B * Nt, ctx.exact)
-            dW1v, db1v, dW2v, db2v, dXv = _mlp_backward([video_feat, mb_feat_v], [dl_v, dl_bv], w1v, b1v, w2v, B * Nv, ctx.exact)
-            d_text = d_text + dXt.view_as(d_text)
-            d_video = d_video + dXv.view_as(d_video)
+        dS, d_c0, d_c1, dmean_t, dmean_v, d_gt, d_gv, d_ls, g1 = _global_backward(
+            ctx.sv, ctx.hp, ctx.shapes, gs, (g1_w1t, g1_b1t, g1_w2t, g1_w1v, g1_b1v, g1_w2v))
+        d_text, d_video, scorer = _local_backward(ctx.sv, ctx.shapes, ctx.masks, ctx.exact, ctx.plan, ctx.model, text_feat, video_feat,
+                                                  mb_feat_t, mb_feat_v, (w1t, b1t, w2t, w1v, b1v, w2v), dS, d_c0, d_c1, dmean_t,
+                                                  dmean_v)
         ctx.sv = ctx.model = None
-        return (None, None, None, None, None, None, None, None,
-                d_text, d_video, d_gt, d_gv, d_ls,
-                dW1t, db1t, dW2t, db2t, dW1v, db1v, dW2v, db2v, *g1)
+        return (None, None, None, None, None, None, None, None, d_text, d_video, d_gt, d_gv, d_ls, *scorer, *g1)
+
+
+def _global_backward(sv, hp, shapes, gs, g1_params):
+    """The part of the loss head's backward that does not touch the token features: from the gradients of the five losses
+    through the row terms (nr_row_losses_bwd) to  dS [B,B], d bank means d_c0 / d_c1 [B], d centrality means dmean_t / dmean_v
+    [d], d global tokens d_gt / d_gv, d logit scale, and the *_weight_fc1 gradients when a sample has several global tokens."""
+    (B, Nt, d), (_, Nv, _), (M, _, _), _, gt_shape, gv_shape = shapes
+    Gt, Gv = gt_shape[1], gv_shape[1]
+    K, T = int(hp["num_neighbors"]), hp["temperature"]
+    g1_w1t, g1_b1t, g1_w2t, g1_w1v, g1_b1v, g1_w2v = g1_params
+    coef = ops.rowloss_coef(gs, hp, B)
+    dS_dir, dG_dir, dC_rows, dwc, dls_rows = ops.row_losses_bwd(sv["S"], sv["G"], sv["tgt_r"], sv["tgt_c"], sv["c0"],
+                                                                sv["c1"], sv["wc_t"], sv["wc_v"], sv["ls"], K, T, coef)
+    dS = ops.add_transposed(dS_dir[0], dS_dir[1])
+    dG = ops.add_transposed(dG_dir[0], dG_dir[1])
+    d_c0, d_c1 = ops.colsum_pair(dC_rows[0], 1.0, dC_rows[1], 1.0)        # one grouped launch (was two serial column sums)
+    d_ls = dls_rows.sum()
+    g1 = [None] * 8
+    if sv["g_saved"] is None:
+        d_gt = d_gv = None              # global logits G = gt gv^T: tiny plain GEMMs, folded into the centrality step below
+    else:
+        # several global tokens per sample: G is the fused product on the un-normalised global tokens with the
+        # *_weight_fc1 softmax weights (modeling.py:516-539): arg-max-routed gradient + softmax + scorer-MLP backward
+        gs_ = sv["g_saved"]
+        d_gt, d_wgt = ops.local_level_bwd(0, dG, 0, 1.0, gs_["pv"], gs_["w_t"], gs_["w_v"], gs_["aux"], B, Gt, B, Gv, use_lo=True)
+        d_gv, d_wgv = ops.local_level_bwd(1, dG, 0, 1.0, gs_["pt"], gs_["w_v"], gs_["w_t"], gs_["aux"], B, Gt, B, Gv, use_lo=True)
+        dl_gt = ops.token_softmax_bwd(gs_["w_t"], d_wgt.view(B, Gt))
+        dl_gv = ops.token_softmax_bwd(gs_["w_v"], d_wgv.view(B, Gv))
+        gW1t, gb1t, gW2t, gb2t, gXt = _mlp_backward([sv["gt2"]], [dl_gt], g1_w1t, g1_b1t, g1_w2t, B * Gt, True)
+        gW1v, gb1v, gW2v, gb2v, gXv = _mlp_backward([sv["gv2"]], [dl_gv], g1_w1v, g1_b1v, g1_w2v, B * Gv, True)
+        d_gt, d_gv = d_gt + gXt, d_gv + gXv
+        g1 = [gW1t, gb1t, gW2t, gb2t, gW1v, gb1v, gW2v, gb2v]
+    # centrality weights: w_i = mean over the sample's global tokens of exp(c <g_hat, mean>)  (one token: the reference's)
+    cs = hp["centrality_scale"]
+    gn_t, gn_v, wtok_t, wtok_v = sv["cw_aux"]
+    dw_t = dwc[0] if Gt == 1 else (dwc[0] / Gt)[:, None].expand(B, Gt).reshape(-1).contiguous()
+    dw_v = dwc[1] if Gv == 1 else (dwc[1] / Gv)[:, None].expand(B, Gv).reshape(-1).contiguous()
+    dg_t, dmean_t = ops.centrality_weights_bwd(sv["gt2"], gn_t, sv["mean_t"], wtok_t, dw_t, cs)
+    dg_v, dmean_v = ops.centrality_weights_bwd(sv["gv2"], gn_v, sv["mean_v"], wtok_v, dw_v, cs)
+    if d_gt is None:                    # one token per sample: d gt = dG gv + (centrality part), the sum inside the GEMM
+        d_gt = torch.addmm(dg_t, dG, sv["gv2"]).reshape(gt_shape)
+        d_gv = torch.addmm(dg_v, dG.t(), sv["gt2"]).reshape(gv_shape)
+    else:
+        d_gt = (d_gt + dg_t).reshape(gt_shape)
+        d_gv = (d_gv + dg_v).reshape(gv_shape)
+    return dS, d_c0, d_c1, dmean_t, dmean_v, d_gt, d_gv, d_ls, g1
+
+
+def _local_backward(sv, shapes, masks, exact, plan, model, text_feat, video_feat, mb_feat_t, mb_feat_v, scorer_params,
+                    dS, d_c0, d_c1, dmean_t, dmean_v):
+    """The token side of the loss head's backward: the three fused products (batch x batch, text x bank-video, bank-text x video)
+    through their stored arg-max routes, normalisation / mask / centrality mean, token softmax and the scorer MLPs ->
+    d text_feat, d video_feat and the *_weight_fc gradients (dW1t, db1t, dW2t, db2t, dW1v, db1v, dW2v, db2v)."""
+    (B, Nt, d), (_, Nv, _), (M, _, _), _, _, _ = shapes
+    text_mask, video_mask = masks
+    w1t, b1t, w2t, w1v, b1v, w2v = scorer_params
+    pt, pv, pbt, pbv = sv["pt"], sv["pv"], sv["pbt"], sv["pbv"]
+    lo = exact
+    aux0, aux1, aux2 = sv["aux"]
+    f32 = dict(dtype=torch.float32, device=dS.device)
+    d_tn, d_vn = torch.empty((B * Nt, d), **f32), torch.empty((B * Nv, d), **f32)
+    d_wt, d_wv = torch.empty((B * Nt,), **f32), torch.empty((B * Nv,), **f32)
+    d_wbt, d_wbv = torch.empty((M * Nt,), **f32), torch.empty((M * Nv,), **f32)
+    if ops.USE_MFMA_BACKWARD and bool(hip.lib().nr_local_level_bwd_mfma_supported(Nt, Nv, d)):
+        # token gradients: the four products' routing matrices on the matrix cores in ONE launch (their "other" operands
+        # transposed in one launch before it), the chunks of a gradient's two products summed by one more
+        T_pv, T_pt, T_pbv, T_pbt = ops.transpose_prepared([pv, pt, pbv, pbt], use_lo=lo)
+        ops.local_level_bwd_group([
+            dict(side=0, dS=dS, ds_mode=0, ds_scale=1.0, other_T=T_pv, w_self=sv["w_t"], w_other=sv["w_v"], aux=aux0,
+                 A=B, Nt=Nt, Bv=B, Nv=Nv, d_x=d_tn),
+            dict(side=0, dS=d_c1, ds_mode=1, ds_scale=1.0 / M, other_T=T_pbv, w_self=sv["w_t"], w_other=sv["w_bv"], aux=aux1,
+                 A=B, Nt=Nt, Bv=M, Nv=Nv, d_x=d_tn),
+            dict(side=1, dS=dS, ds_mode=0, ds_scale=1.0, other_T=T_pt, w_self=sv["w_v"], w_other=sv["w_t"], aux=aux0,
+                 A=B, Nt=Nt, Bv=B, Nv=Nv, d_x=d_vn),
+            dict(side=1, dS=d_c0, ds_mode=2, ds_scale=1.0 / M, other_T=T_pbt, w_self=sv["w_v"], w_other=sv["w_bt"], aux=aux2,
+                 A=M, Nt=Nt, Bv=B, Nv=Nv, d_x=d_vn)], use_lo=lo)
+        # token-weight gradients of the batch and of the bank, all six sums in one launch
+        ops.pool_weight_bwd_group([
+            dict(side=0, N=Nt, d_w=d_wt, srcs=[(dS, 0, 1.0, aux0[2], B, B), (d_c1, 1, 1.0 / M, aux1[2], B, M)]),
+            dict(side=1, N=Nv, d_w=d_wv, srcs=[(dS, 0, 1.0, aux0[3], B, B), (d_c0, 2, 1.0 / M, aux2[3], M, B)]),
+            dict(side=1, N=Nv, d_w=d_wbv, srcs=[(d_c1, 1, 1.0 / M, aux1[3], B, M)]),
+            dict(side=0, N=Nt, d_w=d_wbt, srcs=[(d_c0, 2, 1.0 / M, aux2[2], M, B)])])
+    else:
+        ops.local_level_bwd(0, dS, 0, 1.0, pv, sv["w_t"], sv["w_v"], aux0, B, Nt, B, Nv, d_x=d_tn, d_w=d_wt, use_lo=lo)
+        ops.local_level_bwd(1, dS, 0, 1.0, pt, sv["w_v"], sv["w_t"], aux0, B, Nt, B, Nv, d_x=d_vn, d_w=d_wv, use_lo=lo)
+        ops.local_level_bwd(0, d_c1, 1, 1.0 / M, pbv, sv["w_t"], sv["w_bv"], aux1, B, Nt, M, Nv, d_x=d_tn, d_w=d_wt,
+                            accumulate=True, use_lo=lo)
+        ops.local_level_bwd(1, d_c1, 1, 1.0 / M, pt, sv["w_bv"], sv["w_t"], aux1, B, Nt, M, Nv, d_w=d_wbv, want_dx=False)
+        ops.local_level_bwd(1, d_c0, 2, 1.0 / M, pbt, sv["w_v"], sv["w_bt"], aux2, M, Nt, B, Nv, d_x=d_vn, d_w=d_wv,
+                            accumulate=True, use_lo=lo)
+        ops.local_level_bwd(0, d_c0, 2, 1.0 / M, pv, sv["w_bt"], sv["w_v"], aux2, M, Nt, B, Nv, d_w=d_wbt, want_dx=False)
+    # normalise / mask / centrality-mean backward
+    d_text = ops.normalize_bwd(text_feat, pt.norm, text_mask, d_tn, dmean_t)
+    d_video = ops.normalize_bwd(video_feat, pv.norm, video_mask, d_vn, dmean_v)
+    # token weights -> logits -> scorer MLPs
+    dl_t = ops.token_softmax_bwd(sv["w_t"], d_wt.view(B, Nt))
+    dl_v = ops.token_softmax_bwd(sv["w_v"], d_wv.view(B, Nv))
+    dl_bt = ops.token_softmax_bwd(sv["w_bt"], d_wbt.view(M, Nt))
+    dl_bv = ops.token_softmax_bwd(sv["w_bv"], d_wbv.view(M, Nv))
+    if FUSED_MLP_BACKWARD:
+        _, p_mlp, p_bank = plan
+        # the scorer's input gradient is added to the similarity path's inside its GEMM (residual operand)
+        (dW1t, db1t, dW2t, db2t, d_text), (dW1v, db1v, dW2v, db2v, d_video) = _mlp_backward_hip([
+            dict(sw=model.scorer_weights("text_weight_fc"), add_to=d_text,
+                 sets=[(pt, text_feat, dl_t, p_mlp), (pbt, mb_feat_t, dl_bt, p_bank)]),
+            dict(sw=model.scorer_weights("video_weight_fc"), add_to=d_video,
+                 sets=[(pv, video_feat, dl_v, p_mlp), (pbv, mb_feat_v, dl_bv, p_bank)])])
+        d_text, d_video = d_text.view(text_feat.shape), d_video.view(video_feat.shape)
+    else:
+        dW1t, db1t, dW2t, db2t, dXt = _mlp_backward([text_feat, mb_feat_t], [dl_t, dl_bt], w1t, b1t, w2t, B * Nt, exact)
+        dW1v, db1v, dW2v, db2v, dXv = _mlp_backward([video_feat, mb_feat_v], [dl_v, dl_bv], w1v, b1v, w2v, B * Nv, exact)
+        d_text = d_text + dXt.view_as(d_text)
+        d_video = d_video + dXv.view_as(d_video)
+    return d_text, d_video, (dW1t, db1t, dW2t, db2t, dW1v, db1v, dW2v, db2v)
+
+
+class HeadLocalFn(torch.autograd.Function):
+    """First of the TWO autograd nodes the loss head is split into so that the backward of its token side (this node: ~2/3 of
+    the head's backward time) can run BESIDE the backward of the token clustering, which only needs the gradients of the global
+    tokens that the second, short node (HeadGlobalFn) produces.  Autograd runs a node's backward on the stream its forward ran
+    on: with the clustering issued on a side stream in the forward (modeling._compute_losses), the two heavy backward chains
+    overlap, eagerly and as parallel branches of a captured training graph.
+
+    The forward runs the WHOLE fused head (head.head_forward, every kernel as in HeadLossFn) and hands the losses and the saved
+    state to HeadGlobalFn through `bridge`; its differentiable outputs are the five tensors through which the loss reaches the
+    token side: S [B,B], the bank column means c0 / c1 [B], the centrality means mean_t / mean_v [d]."""
+
+    @staticmethod
+    def forward(ctx, model, hp, bridge, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v, gt, gv, logit_scale,
+                g1, text_feat, video_feat, w1t, b1t, w2t, b2t, w1v, b1v, w2v, b2v):
+        prec = model._prec()
+        losses, sv = head.head_forward(text_feat.detach(), video_feat.detach(), text_mask, video_mask,
+                                       mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v, gt.detach(), gv.detach(),
+                                       model.scorer_weights("text_weight_fc"), model.scorer_weights("video_weight_fc"),
+                                       hp, logit_scale.detach(), prec, keep=True, join=model._take_join(),
+                                       bank_streams=model._bank_streams(text_feat.device),
+                                       **model._global_scorers(text_feat, video_feat))
+        ctx.sv, ctx.exact = sv, prec == hip.PREC_BF16X3
+        ctx.model, ctx.plan = model, head.precision_plan(prec)
+        ctx.masks = (text_mask, video_mask)
+        ctx.shapes = (text_feat.shape, video_feat.shape, mb_feat_t.shape, mb_feat_v.shape, gt.shape, gv.shape)
+        sv["gt2"], sv["gv2"] = sv["gt2"].reshape(-1, sv["gt2"].shape[-1]), sv["gv2"].reshape(-1, sv["gv2"].shape[-1])
+        ctx.save_for_backward(text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v)
+        bridge["losses"], bridge["sv"], bridge["shapes"] = losses, sv, ctx.shapes
+        ctx.set_materialize_grads(False)
+        return sv["S"], sv["c0"], sv["c1"], sv["mean_t"], sv["mean_v"]
+
+    @staticmethod
+    def backward(ctx, dS, d_c0, d_c1, dmean_t, dmean_v):
+        if dS is None:
+            return (None,) * 23
+        text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v = ctx.saved_tensors
+        d_text, d_video, scorer = _local_backward(ctx.sv, ctx.shapes, ctx.masks, ctx.exact, ctx.plan, ctx.model, text_feat, video_feat,
+                                                  mb_feat_t, mb_feat_v, (w1t, b1t, w2t, w1v, b1v, w2v), dS, d_c0, d_c1, dmean_t,
+                                                  dmean_v)
+        ctx.sv = ctx.model = None
+        return (None,) * 13 + (d_text, d_video, *scorer)
+
+
+class HeadGlobalFn(torch.autograd.Function):
+    """Second node of the split loss head (see HeadLocalFn): takes the losses HeadLocalFn's forward already computed and owns
+    the short first part of the backward -- row terms, global logits, centrality weights."""
+
+    @staticmethod
+    def forward(ctx, hp, bridge, S, c0, c1, mean_t, mean_v, gt, gv, logit_scale,
+                g1_w1t, g1_b1t, g1_w2t, g1_b2t, g1_w1v, g1_b1v, g1_w2v, g1_b2v):
+        ctx.sv, ctx.hp, ctx.shapes = bridge.pop("sv"), dict(hp), bridge.pop("shapes")
+        ctx.save_for_backward(g1_w1t, g1_b1t, g1_w2t, g1_w1v, g1_b1v, g1_w2v)
+        ctx.set_materialize_grads(False)
+        return tuple(bridge.pop("losses").unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        if all(g is None for g in gs):
+            return (None,) * 18
+        dS, d_c0, d_c1, dmean_t, dmean_v, d_gt, d_gv, d_ls, g1 = _global_backward(ctx.sv, ctx.hp, ctx.shapes, gs, ctx.saved_tensors)
+        ctx.sv = None
+        return (None, None, dS, d_c0, d_c1, dmean_t, dmean_v, d_gt, d_gv, d_ls, *g1)
+
+
+SPLIT_HEAD_NODES = True       # False: the head as ONE autograd node (HeadLossFn), its backward strictly before the clustering's
+
+
+def head_loss_nodes(model, hp, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v, text_feat, video_feat, gt, gv,
+                    logit_scale, scorer_params, g1_params):
+    """The differentiable fused head -> (total, centrality, uniform, neighbour, kl)."""
+    if not SPLIT_HEAD_NODES:
+        return HeadLossFn.apply(model, hp, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
+                                text_feat, video_feat, gt, gv, logit_scale, *scorer_params, *g1_params)
+    bridge = {}
+    S, c0, c1, mean_t, mean_v = HeadLocalFn.apply(model, hp, bridge, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t,
+                                                  mb_mask_v, gt, gv, logit_scale, None, text_feat, video_feat, *scorer_params)
+    return HeadGlobalFn.apply(hp, bridge, S, c0, c1, mean_t, mean_v, gt, gv, logit_scale, *g1_params)
 
 
 class LocalLevelFn(torch.autograd.Function):

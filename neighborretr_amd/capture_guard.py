@@ -98,6 +98,13 @@ def wait_stream(waiter, on):
     waiter.wait_stream(on)
 
 
+def may_fork(stream):
+    """False when `stream` is being captured and is NOT the capture's origin: a side stream forked from it would have to be
+    joined back into a non-origin stream (shape 2 above).  True outside a capture."""
+    hit = _topology(stream)
+    return hit is None or hit[1].origin == stream.cuda_stream
+
+
 def record_event(stream=None):
     """A new event recorded on `stream` (default: current); remembered so that wait_event knows where it came from."""
     st = torch.cuda.current_stream() if stream is None else stream

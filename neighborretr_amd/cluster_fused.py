@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import hip
-from .capture_guard import wait_stream
+from .capture_guard import may_fork, wait_stream
 
 
 def _p(t, dtype=torch.float32):
@@ -304,6 +304,8 @@ def _torch_backward(ctx, saved, g_t, g_v):
     from .cluster_backward import stage_backward
     cur = torch.cuda.current_stream()
     two = BACKWARD_ON_TWO_STREAMS if BACKWARD_ON_TWO_STREAMS is not None else torch.cuda.is_current_stream_capturing()
+    # on the clustering's own stream (modeling._cluster_stream) this node is itself a fork of the step's stream: no nested fork
+    two = two and g_t.is_cuda and may_fork(cur)
     side = _backward_stream(g_t.device) if (two and g_t.is_cuda) else None
     results = [None, None]
     with torch.no_grad():
@@ -347,6 +349,9 @@ class ClusterStagesFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_t, g_v):
         tensors = ctx.saved_tensors
+        if g_t.is_cuda:                      # produced on the head's stream, consumed on this node's (modeling._cluster_stream)
+            g_t.record_stream(torch.cuda.current_stream())
+            g_v.record_stream(torch.cuda.current_stream())
         grads_x, grads_p = [], {}
         saved = []
         for i, mask in enumerate(ctx.masks):

@@ -104,6 +104,8 @@ class NeighborRetr(nn.Module):
         self._scorer_cache = {}
         self._streams = None
         self._join_global = None
+        self._cstream = None
+        self.cluster_side_stream = True      # training step: clustering (forward + backward) on its own stream, see _compute_losses
         # side streams inside the step (and inside its capture).  With ONE hardware queue (GPU_MAX_HW_QUEUES=1) any capture
         # that forks a stream segfaults in the ROCm 7.2 runtime (tools/capture_one_queue.py: plain torch ops): one stream then
         self.use_side_streams = os.environ.get("GPU_MAX_HW_QUEUES", "") != "1"
@@ -426,11 +428,31 @@ class NeighborRetr(nn.Module):
             # training step: the clustering forward on the grouped HIP kernels, the backward hand-derived from what they
             # leave in their workspaces (cluster_fused.ClusterStagesFn, cluster_backward.stage_backward)
             from .cluster_fused import cluster_stages_train
-            t, v = cluster_stages_train(((self.text_ctm0, self.text_block0), (self.video_ctm0, self.video_block0)),
-                                        self._ctm_cache, ("text0", "video0"), text_feat, text_mask, nz.get("t0"),
-                                        video_feat, video_mask, nz.get("v0"))
-            gt, gv = cluster_stages_train(((self.text_ctm1, self.text_block1), (self.video_ctm1, self.video_block1)),
-                                          self._ctm_cache, ("text1", "video1"), t, None, nz.get("t1"), v, None, nz.get("v1"))
+
+            def stages():
+                t, v = cluster_stages_train(((self.text_ctm0, self.text_block0), (self.video_ctm0, self.video_block0)),
+                                            self._ctm_cache, ("text0", "video0"), text_feat, text_mask, nz.get("t0"),
+                                            video_feat, video_mask, nz.get("v0"))
+                return cluster_stages_train(((self.text_ctm1, self.text_block1), (self.video_ctm1, self.video_block1)),
+                                            self._ctm_cache, ("text1", "video1"), t, None, nz.get("t1"), v, None, nz.get("v1"))
+            side = self._cluster_stream(text_feat.device)
+            if side is None:
+                gt, gv = stages()
+            else:
+                # The clustering is issued on its own stream: in the forward it runs beside the head's local branch (joined
+                # right before the global logits), and -- what matters more -- autograd runs its BACKWARD on that stream too,
+                # beside the backward of the head's token side (backward.HeadLocalFn), once the short HeadGlobalFn node has
+                # produced the gradients of the global tokens.  Fork from / join into the step's stream only.
+                cur = torch.cuda.current_stream()
+                wait_stream(side, cur)
+                with torch.cuda.stream(side):
+                    gt, gv = stages()
+                gt.record_stream(cur)
+                gv.record_stream(cur)
+
+                def join():
+                    wait_stream(cur, side)
+                self._join_global = join
         elif text_feat.is_cuda and self.use_side_streams:
             # three independent branches: text clustering | video clustering | local products.
             # The two clustering branches run on side streams (in a captured HIP graph: parallel
@@ -631,6 +653,14 @@ class NeighborRetr(nn.Module):
             # default priority: high-priority side streams made the captured graph 1.8x SLOWER on ROCm 7.2
             self._streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
         return self._streams
+
+    def _cluster_stream(self, device):
+        """Stream of the training step's token clustering (forward and, through autograd, backward), or None."""
+        if not (self.use_side_streams and self.cluster_side_stream and device.type == "cuda"):
+            return None
+        if self._cstream is None or self._cstream.device != device:
+            self._cstream = torch.cuda.Stream(device=device)
+        return self._cstream
 
     def _local_stream(self, device):
         if not (self.use_side_streams and device.type == "cuda"):

@@ -117,6 +117,66 @@ def test_backward_matches_reference(name, precision, fused):
     assert worst[1] < bar["param"], worst
 
 
+def test_split_head_nodes_and_the_clustering_stream_change_nothing_but_the_schedule():
+    """The training step with the head as two autograd nodes and the clustering on its own stream (the shipped form: the two
+    backward chains overlap) against the head as ONE node with everything on the step's stream: identical losses and
+    gradients (same kernels, same order per chain).  Then the shipped form captured as one HIP graph: the replay reproduces
+    the eager gradients bit for bit."""
+    from neighborretr_amd import backward
+    g = golden("c1_b16")
+    B, Nt, Nv, M, K = (int(g[k]) for k in ("B", "Nt", "Nv", "M", "K"))
+    x = problem(int(g["seed"]), B, Nt, Nv, M, device=DEV)
+    nz = noise(int(g["seed"]), B, Nt, Nv, device=DEV)
+    m = _model("bf16", K)
+    tf, vf = x["text_feat"].requires_grad_(True), x["video_feat"].requires_grad_(True)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        tf.grad = vf.grad = None
+        losses = _losses(m, x, nz, K)
+        losses[0].backward()
+        return torch.stack([l.detach() for l in losses])
+
+    def grads():
+        out = {"text": tf.grad.clone(), "video": vf.grad.clone()}
+        out.update({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+        return out
+    try:
+        backward.SPLIT_HEAD_NODES, m.cluster_side_stream = False, False
+        l_one = step()
+        g_one = grads()
+    finally:
+        backward.SPLIT_HEAD_NODES, m.cluster_side_stream = True, True
+    l_two = step()
+    g_two = grads()
+    torch.cuda.synchronize()
+    assert torch.equal(l_one, l_two)
+    assert g_one.keys() == g_two.keys() and len(g_two) > 40
+    for k in g_one:
+        assert torch.equal(g_one[k], g_two[k]), k
+    # captured
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), m.graph_capture_mode():
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    m.zero_grad(set_to_none=True)
+    tf.grad = vf.grad = None
+    gr = torch.cuda.CUDAGraph()
+    with m.graph_capture_mode(), torch.cuda.graph(gr):
+        losses = _losses(m, x, nz, K)
+        losses[0].backward()
+    for _ in range(2):
+        gr.replay()
+    torch.cuda.synchronize()
+    g_rep = grads()
+    assert torch.equal(torch.stack([l.detach() for l in losses]), l_two)
+    for k in g_two:
+        assert torch.equal(g_rep[k], g_two[k]), k
+
+
 @pytest.mark.parametrize("B,Nt,Nv", [(16, 24, 12), (8, 64, 64), (6, 20, 9)])
 def test_fused_clustering_matches_oracle_and_torch_path(B, Nt, Nv):
     """The no-grad fused kernels (cluster_fused.py), the autograd torch-op path (cluster.py) and the

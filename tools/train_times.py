@@ -33,6 +33,7 @@ def main(which):
         m(tf, p["text_mask"], vf, p["video_mask"], p["idx"], 0)[0].backward()
 
     settings = (("clustering HIP fwd + HIP bwd      | scorer bwd fused HIP", True, True, True),
+                ("  same, head as ONE autograd node, clustering on the step's stream (no overlap of the two backward chains)", True, True, True),
                 ("clustering HIP fwd + HIP bwd      | scorer bwd torch-op form", True, True, False),
                 ("clustering HIP fwd + torch-op bwd | scorer bwd fused HIP", True, False, True),
                 ("clustering autograd-traced torch  | scorer bwd fused HIP", False, True, True),
@@ -42,6 +43,9 @@ def main(which):
     # tools/traced_capture_check.py) -- the parent starts a child per setting and never touches the GPU itself
     for name, fused, hip_bwd, mlp_hip in settings[which:which + 1]:
         if True:
+            if which == 1:
+                backward.SPLIT_HEAD_NODES = False
+                m.cluster_side_stream = False
             m.fused_training_clustering = fused
             cluster_fused.HIP_BACKWARD = hip_bwd
             backward.FUSED_MLP_BACKWARD = mlp_hip
@@ -78,7 +82,7 @@ if __name__ == "__main__":
         main(int(sys.argv[1]))
     else:
         import subprocess
-        for k in range(5):
+        for k in range(6):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), str(k)], capture_output=True, text=True, timeout=600)
             out = [l for l in r.stdout.splitlines() if " ms " in l]
             print(out[-1] if out else f"setting {k}: exit code {r.returncode} {r.stderr.strip().splitlines()[-1:]}", flush=True)
