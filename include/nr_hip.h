@@ -264,7 +264,9 @@ int nr_ctm_stage_workspace_layout2(int n_samples, int N, int C, int cluster_num,
  * [cols, ld]; mode 3: f32 src [rows, cols] = token rows in samples of `group` tokens -> the transposed k=3 neighbourhood
  * [3 cols, ld]: row 3 c + s holds src[r + s - 1, c] at column r (zero where r + s - 1 leaves the sample of r, and in the K
  * padding) -- the operand that makes the token-convolution weight gradient (cluster.py:664) come out of its GEMM in the
- * parameter's own [C_out, C_in, 3] order.  Used for the per-step re-split of every weight matrix and for the K = token-rows
+ * parameter's own [C_out, C_in, 3] order; modes 4 / 5: the two matrix forms of a k=3 convolution kernel W [C_out, C_in, 3] read
+ * in place, row-major like mode 0 -- 4: dst[o, s C_in + i] = W[o, i, s] (rows C_out, cols 3 C_in, group C_in), 5: dst[i, s C_out + o]
+ * = W[o, i, s] (rows C_in, cols 3 C_out, group C_out).  Used for the per-step re-split of every weight matrix and for the K = token-rows
  * operands of the weight-gradient GEMMs.                                                                                   */
 #define NR_SPLIT_MAX 48
 typedef struct NrSplitItem {
@@ -272,7 +274,7 @@ typedef struct NrSplitItem {
     const void* src2;
     uint16_t *hi, *lo;
     int32_t rows, cols, mode, ld;
-    int32_t group, pad_;                         /* mode 3: tokens per sample */
+    int32_t group, pad_;                         /* mode 3: tokens per sample; modes 4 / 5: C_in / C_out */
 } NrSplitItem;                                   /* 56 bytes */
 int nr_split_group(int n, const NrSplitItem* items, void* stream);
 

@@ -48,34 +48,43 @@ class _StageWeights:
     (`items`, issued by build_stage_weights for every stale stage of the step together)."""
 
     def __init__(self, ctm, blk):
-        w = ctm.conv.conv.weight.detach()                                        # [C_out, C_in, 3]
+        w = ctm.conv.conv.weight.detach().contiguous()                           # [C_out, C_in, 3]
         Co, Ci = w.shape[0], w.shape[1]
         dev = w.device
-        self.wcat = w.permute(2, 1, 0).reshape(3 * Ci, Co).contiguous()          # fp32 [3 C_in, C_out] (small stages: addmm)
-        wconv = w.permute(0, 2, 1).reshape(Co, 3 * Ci).contiguous()              # [C_out, 3 C_in]: tap k multiplies x[n+k-1]
-        wconv_bt = w.permute(1, 2, 0).reshape(Ci, 3 * Co).contiguous()           # [C_in, 3 C_out]: d x0 = d y + dcat Wbt^T
         attn = blk.attn
         wkv, wq, wp = attn.kv.weight.detach(), attn.q.weight.detach(), attn.proj.weight.detach()
-        self.wq_t = wq.t().contiguous()
-        self.wkv_t = wkv.t().contiguous()
-        self.wp_t = wp.t().contiguous()
+        self._src = (w, wq, wkv, wp)
+        self._f32 = {}
         self.items = []
 
-        def pair(name, src, rows, cols, mode):
-            shape = (rows, cols) if mode == 0 else (cols, rows)
+        def pair(name, src, rows, cols, mode, group=0):
+            shape = (cols, rows) if mode == 1 else (rows, cols)
             hi = torch.empty(shape, dtype=torch.int16, device=dev)
             lo = torch.empty(shape, dtype=torch.int16, device=dev)
             setattr(self, name + "_hi", hi)
             setattr(self, name + "_lo", lo)
-            self.items.append((src.contiguous(), None, hi, lo, rows, cols, mode, cols if mode == 0 else rows))
-        pair("wconv", wconv, Co, 3 * Ci, 0)
+            self.items.append((src.contiguous(), None, hi, lo, rows, cols, mode, rows if mode == 1 else cols, group))
+        # both matrix forms of the convolution kernel are read straight from the parameter by the split launch (no permuted
+        # fp32 copies: the six torch copies per stage and modality were ~200 us of small launches at the head of every step)
+        pair("wconv", w, Co, 3 * Ci, 4, Ci)                                      # [C_out, 3 C_in]: tap k multiplies x[n+k-1]
         pair("wkv", wkv, wkv.shape[0], wkv.shape[1], 0)
         pair("wq", wq, wq.shape[0], wq.shape[1], 0)
         pair("wp", wp, wp.shape[0], wp.shape[1], 0)
-        pair("wconv_bt", wconv_bt, Ci, 3 * Co, 0)
+        pair("wconv_bt", w, Ci, 3 * Co, 5, Co)                                   # [C_in, 3 C_out]: d x0 = d y + dcat Wbt^T
         pair("wkv_bt", wkv, wkv.shape[0], wkv.shape[1], 1)                       # [C, 2C]: d kvn = d kv Wkv
         pair("wq_bt", wq, wq.shape[0], wq.shape[1], 1)
         pair("wp_bt", wp, wp.shape[0], wp.shape[1], 1)
+
+    def _lazy(self, name, make):
+        if name not in self._f32:
+            self._f32[name] = make()
+        return self._f32[name]
+
+    # fp32 forms for the library-GEMM fallback of the one-stage forward (ctm_stage_fused, small stages); built on first use
+    wcat = property(lambda self: self._lazy("wcat", lambda: self._src[0].permute(2, 1, 0).reshape(-1, self._src[0].shape[0]).contiguous()))
+    wq_t = property(lambda self: self._lazy("wq_t", lambda: self._src[1].t().contiguous()))
+    wkv_t = property(lambda self: self._lazy("wkv_t", lambda: self._src[2].t().contiguous()))
+    wp_t = property(lambda self: self._lazy("wp_t", lambda: self._src[3].t().contiguous()))
 
 
 def build_stage_weights(cache, stages):
@@ -212,6 +221,7 @@ def ctm_stage_group(problems, cache, stepwise=False, want_assign=False, want_sav
         raise hip.NrHipError(f"1..{hip.CTM_MAX_GROUP} problems per grouped stage")
     descs = (hip.CtmStageDesc * len(problems))()
     keep, outs, assigns, saved, smax = [], [], [], [], []
+    build_stage_weights(cache, [(key, ctm, blk) for key, _, _, ctm, blk, _ in problems])       # one split launch, if stale
     for d, (key, x, mask, ctm, blk, noise) in zip(descs, problems):
         # a previous stage's output carries its bf16 pair (written by that stage's proj GEMM): no split launch for it here
         x_pair = getattr(x, "_nr_pair", None)
@@ -221,7 +231,7 @@ def ctm_stage_group(problems, cache, stepwise=False, want_assign=False, want_sav
             x_pair = None
         dev = x.device
         hip.ptr(x)                                           # device / contiguity check
-        sw = _stage_weights(cache, key, ctm, blk)
+        sw = cache[key][1]
         attn = blk.attn
         cnum = max(math.ceil(N * ctm.sample_ratio), 1)
         m = None

@@ -89,12 +89,17 @@ __global__ __launch_bounds__(256) void nr_split_group_kernel(NrSplitGroup g) {
         }
         return;
     }
-    if (it.mode == 0) {
+    if (it.mode == 0 || it.mode >= 4) {
+        // modes 4 / 5: the two matrix forms of a k=3 convolution kernel W [C_out, C_in, 3] read in place --
+        //   4: dst[o, s C_in + i] = W[o, i, s]   (group = C_in)        5: dst[i, s C_out + o] = W[o, i, s]   (group = C_out)
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
             const int r = tr * 64 + r0 + 4 * i, cc = tc * 64 + c;
             if (r < it.rows && cc < it.ld) {
-                const float v = cc < it.cols ? src[(size_t)r * it.cols + cc] : 0.f;
+                size_t o = (size_t)r * it.cols + cc;
+                if (it.mode == 4) o = (size_t)r * it.cols + (size_t)(cc % it.group) * 3 + cc / it.group;
+                else if (it.mode == 5) o = (size_t)(cc % it.group) * (3 * (size_t)it.rows) + (size_t)r * 3 + cc / it.group;
+                const float v = cc < it.cols ? src[o] : 0.f;
                 const uint16_t h = nr_f2bf(v);
                 it.hi[(size_t)r * it.ld + cc] = h;
                 if (it.lo) it.lo[(size_t)r * it.ld + cc] = nr_f2bf(v - nr_bf2f(h));
@@ -128,22 +133,24 @@ extern "C" int nr_split_group(int n, const NrSplitItem* items, void* stream) {
     int total = 0;
     for (int i = 0; i < n; ++i) {
         const NrSplitItem& it = items[i];
-        if (!it.src || !it.hi || it.rows <= 0 || it.cols <= 0 || it.mode < 0 || it.mode > 3) return NR_EINVAL;
-        if (it.mode == 3 && it.group <= 0) return NR_EINVAL;
-        if (it.mode ? it.ld < it.rows : it.ld < it.cols) return NR_EINVAL;
+        if (!it.src || !it.hi || it.rows <= 0 || it.cols <= 0 || it.mode < 0 || it.mode > 5) return NR_EINVAL;
+        if (it.mode >= 3 && it.group <= 0) return NR_EINVAL;
+        if (it.mode >= 4 && it.cols != 3 * it.group) return NR_EINVAL;
+        const bool transposed = it.mode >= 1 && it.mode <= 3;
+        if (transposed ? it.ld < it.rows : it.ld < it.cols) return NR_EINVAL;
         g.it[i] = it;
         g.start[i] = total;
         // transposed: the item's row tiles cover [0, rows rounded up to 64) of its destination columns -- the K padding of a
         // GEMM operand, written as zeros (clipped at ld); a caller that packs several items side by side into one wide buffer
         // gives each a 64-aligned start
         const int row_tiles = (it.rows + 63) / 64;
-        const int col_tiles = it.mode ? (it.cols + 63) / 64 : (it.ld + 63) / 64;
+        const int col_tiles = transposed ? (it.cols + 63) / 64 : (it.ld + 63) / 64;
         total += row_tiles * col_tiles;
     }
     for (int i = n; i <= NR_SPLIT_MAX; ++i) g.start[i] = total;
     // the kernel derives the column-tile count from `cols`: for the row-major form ld == cols rounded up to 64 at most
     for (int i = 0; i < n; ++i)
-        if (!items[i].mode && (items[i].ld + 63) / 64 != (items[i].cols + 63) / 64) return NR_EUNSUPPORTED;
+        if ((items[i].mode == 0 || items[i].mode >= 4) && (items[i].ld + 63) / 64 != (items[i].cols + 63) / 64) return NR_EUNSUPPORTED;
     hipLaunchKernelGGL(nr_split_group_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
     NR_LAUNCH_CHECK();
     return NR_OK;

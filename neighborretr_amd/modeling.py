@@ -427,9 +427,12 @@ class NeighborRetr(nn.Module):
               and text_feat.shape[1] <= 64 and video_feat.shape[1] <= 64 and text_feat.shape[2] % 128 == 0):
             # training step: the clustering forward on the grouped HIP kernels, the backward hand-derived from what they
             # leave in their workspaces (cluster_fused.ClusterStagesFn, cluster_backward.stage_backward)
-            from .cluster_fused import cluster_stages_train
+            from .cluster_fused import build_stage_weights, cluster_stages_train
 
             def stages():
+                # the bf16 pairs of all four stages' weights (stale after every optimizer step) in ONE split launch
+                build_stage_weights(self._ctm_cache, [("text0", self.text_ctm0, self.text_block0), ("video0", self.video_ctm0, self.video_block0),
+                                                      ("text1", self.text_ctm1, self.text_block1), ("video1", self.video_ctm1, self.video_block1)])
                 t, v = cluster_stages_train(((self.text_ctm0, self.text_block0), (self.video_ctm0, self.video_block0)),
                                             self._ctm_cache, ("text0", "video0"), text_feat, text_mask, nz.get("t0"),
                                             video_feat, video_mask, nz.get("v0"))
