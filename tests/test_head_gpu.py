@@ -407,10 +407,16 @@ def test_capture_guard_fires_inside_a_real_capture_and_the_shipped_step_passes_i
     capture itself is never executed), and the shipped loss-only step, captured, goes through the guard edge by edge."""
     from neighborretr_amd import capture_guard as CG
     x = torch.zeros(1 << 12, device=DEV)
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    # three DIFFERENT streams: torch hands out its streams round-robin from a pool of 32, so after enough models a "new"
+    # stream can be the very stream the capture runs on (the guard then rightly sees a stream waiting on itself)
+    pool = {}
+    while len(pool) < 3:
+        st = torch.cuda.Stream()
+        pool.setdefault(st.cuda_stream, st)
+    cap, s1, s2 = pool.values()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=cap):
         cur = torch.cuda.current_stream()
         assert CG._topology(cur) is not None
         CG.wait_stream(s1, cur)
