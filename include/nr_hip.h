@@ -549,6 +549,20 @@ int nr_pool_weight_bwd_group(int n, const NrPoolWJob* jobs, void* stream);
 int nr_normalize_bwd(const float* x, const float* norm, const float* mask, const float* d_xn, const float* dmean,
                      int n_tok, int d, float* dx, void* stream);
 
+/* The short head of the loss backward (everything between nr_row_losses_bwd and the two long chains) in three launches:
+ *   nr_rowloss_bwd_finish: dS = dS_dir[0] + dS_dir[1]^T, dG likewise, d_c0 / d_c1 [B] = column sums of d_c_rows[0] / [1],
+ *     d_ls [1] = sum of d_ls_rows [2,B]  (fixed order);
+ *   nr_centrality_weights_bwd_pair: nr_centrality_weights_bwd for the text and the video global tokens together;
+ *   nr_global_logits_bwd: gradient of G = gt gv^T (one global token per sample, modeling.py:333) with the centrality part added:
+ *     d_gt [B,d] = dG gv + add_t,  d_gv [B,d] = dG^T gt + add_v   (fp32).                                                  */
+int nr_rowloss_bwd_finish(const float* dS_dir, const float* dG_dir, const float* d_c_rows, const float* d_ls_rows, int B,
+                          float* dS, float* dG, float* d_c0, float* d_c1, float* d_ls, void* stream);
+int nr_centrality_weights_bwd_pair(const float* g_t, const float* gnorm_t, const float* mean_t, const float* w_t, const float* dw_t,
+                                   const float* g_v, const float* gnorm_v, const float* mean_v, const float* w_v, const float* dw_v,
+                                   int B, int d, float scale, float* dg_t, float* dmean_t, float* dg_v, float* dmean_v, void* stream);
+int nr_global_logits_bwd(const float* dG, const float* gt, const float* gv, const float* add_t, const float* add_v, int B, int d,
+                         float* d_gt, float* d_gv, void* stream);
+
 /* Backward of nr_token_softmax: dlogit = w * (dw - sum_t w dw) per sample ([n_samples,N]). */
 int nr_token_softmax_bwd(const float* w, const float* dw, int n_samples, int N, float* dlogit, void* stream);
 

@@ -261,10 +261,7 @@ def _global_backward(sv, hp, shapes, gs, g1_params):
     coef = ops.rowloss_coef(gs, hp, B)
     dS_dir, dG_dir, dC_rows, dwc, dls_rows = ops.row_losses_bwd(sv["S"], sv["G"], sv["tgt_r"], sv["tgt_c"], sv["c0"],
                                                                 sv["c1"], sv["wc_t"], sv["wc_v"], sv["ls"], K, T, coef)
-    dS = ops.add_transposed(dS_dir[0], dS_dir[1])
-    dG = ops.add_transposed(dG_dir[0], dG_dir[1])
-    d_c0, d_c1 = ops.colsum_pair(dC_rows[0], 1.0, dC_rows[1], 1.0)        # one grouped launch (was two serial column sums)
-    d_ls = dls_rows.sum()
+    dS, dG, d_c0, d_c1, d_ls = ops.rowloss_bwd_finish(dS_dir, dG_dir, dC_rows, dls_rows)     # one launch (was four)
     g1 = [None] * 8
     if sv["g_saved"] is None:
         d_gt = d_gv = None              # global logits G = gt gv^T: tiny plain GEMMs, folded into the centrality step below
@@ -285,11 +282,15 @@ def _global_backward(sv, hp, shapes, gs, g1_params):
     gn_t, gn_v, wtok_t, wtok_v = sv["cw_aux"]
     dw_t = dwc[0] if Gt == 1 else (dwc[0] / Gt)[:, None].expand(B, Gt).reshape(-1).contiguous()
     dw_v = dwc[1] if Gv == 1 else (dwc[1] / Gv)[:, None].expand(B, Gv).reshape(-1).contiguous()
-    dg_t, dmean_t = ops.centrality_weights_bwd(sv["gt2"], gn_t, sv["mean_t"], wtok_t, dw_t, cs)
-    dg_v, dmean_v = ops.centrality_weights_bwd(sv["gv2"], gn_v, sv["mean_v"], wtok_v, dw_v, cs)
-    if d_gt is None:                    # one token per sample: d gt = dG gv + (centrality part), the sum inside the GEMM
-        d_gt = torch.addmm(dg_t, dG, sv["gv2"]).reshape(gt_shape)
-        d_gv = torch.addmm(dg_v, dG.t(), sv["gt2"]).reshape(gv_shape)
+    if sv["gt2"].shape == sv["gv2"].shape:
+        dg_t, dmean_t, dg_v, dmean_v = ops.centrality_weights_bwd_pair(sv["gt2"], gn_t, sv["mean_t"], wtok_t, dw_t,
+                                                                       sv["gv2"], gn_v, sv["mean_v"], wtok_v, dw_v, cs)
+    else:
+        dg_t, dmean_t = ops.centrality_weights_bwd(sv["gt2"], gn_t, sv["mean_t"], wtok_t, dw_t, cs)
+        dg_v, dmean_v = ops.centrality_weights_bwd(sv["gv2"], gn_v, sv["mean_v"], wtok_v, dw_v, cs)
+    if d_gt is None:                    # one token per sample: d gt = dG gv + (centrality part), one launch for both
+        d_gt, d_gv = ops.global_logits_bwd(dG, sv["gt2"], sv["gv2"], dg_t, dg_v)
+        d_gt, d_gv = d_gt.reshape(gt_shape), d_gv.reshape(gv_shape)
     else:
         d_gt = (d_gt + dg_t).reshape(gt_shape)
         d_gv = (d_gv + dg_v).reshape(gv_shape)

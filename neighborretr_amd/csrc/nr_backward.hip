@@ -262,6 +262,189 @@ extern "C" int nr_centrality_weights_bwd(const float* g, const float* gnorm, con
     return NR_OK;
 }
 
+// ---- the short head of the loss backward in three launches ----------------------------------------------------------------
+// (1) what follows nr_row_losses_bwd: both direction frames folded back (dS = dS_dir[0] + dS_dir[1]^T, same for dG), the bank
+//     column sums d_c0 / d_c1 and the logit-scale gradient -- was four launches (2 x add-transposed, grouped column sum, reduce).
+__global__ __launch_bounds__(256) void nr_rowloss_bwd_finish_kernel(const float* __restrict__ dS_dir, const float* __restrict__ dG_dir,
+                                                                    const float* __restrict__ dC_rows, const float* __restrict__ dls_rows,
+                                                                    int B, float* __restrict__ dS, float* __restrict__ dG,
+                                                                    float* __restrict__ d_c0, float* __restrict__ d_c1,
+                                                                    float* __restrict__ d_ls) {
+    __shared__ float t[32][33];
+    __shared__ float red[4][64];
+    const int T = (B + 31) / 32, CB = (B + 63) / 64;
+    int blk = blockIdx.x;
+    const size_t BB = (size_t)B * B;
+    if (blk < 2 * T * T) {                       // out = a + b^T, tile (ti, tj) of out needs tile (tj, ti) of b
+        const bool second = blk >= T * T;
+        if (second) blk -= T * T;
+        const float* a = second ? dG_dir : dS_dir;
+        const float* b = a + BB;
+        float* out = second ? dG : dS;
+        const int ti = blk / T, tj = blk - ti * T;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int r = ty; r < 32; r += 8) {
+            const int bi = tj * 32 + r, bj = ti * 32 + tx;
+            if (bi < B && bj < B) t[r][tx] = b[(size_t)bi * B + bj];
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int i = ti * 32 + r, j = tj * 32 + tx;
+            if (i < B && j < B) out[(size_t)i * B + j] = a[(size_t)i * B + j] + t[tx][r];
+        }
+        return;
+    }
+    blk -= 2 * T * T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blk < 2 * CB) {                          // d_c[dir][j] = sum_i dC_rows[dir][i][j]
+        const int dir = blk / CB, c = (blk - dir * CB) * 64 + lane;
+        const float* a = dC_rows + (size_t)dir * BB;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (c < B) {
+            int r = wave;
+            for (; r + 12 < B; r += 16) {
+                s0 += a[(size_t)r * B + c];
+                s1 += a[(size_t)(r + 4) * B + c];
+                s2 += a[(size_t)(r + 8) * B + c];
+                s3 += a[(size_t)(r + 12) * B + c];
+            }
+            for (; r < B; r += 4) s0 += a[(size_t)r * B + c];
+        }
+        red[wave][lane] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (wave == 0 && c < B) (dir == 0 ? d_c0 : d_c1)[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        return;
+    }
+    float s = 0.f;                               // d logit_scale = sum of the per-row terms of both directions
+    for (int i = threadIdx.x; i < 2 * B; i += 256) s += dls_rows[i];
+    s = nr_wave_sum(s);
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) d_ls[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+}
+
+extern "C" int nr_rowloss_bwd_finish(const float* dS_dir, const float* dG_dir, const float* d_c_rows, const float* d_ls_rows, int B,
+                                     float* dS, float* dG, float* d_c0, float* d_c1, float* d_ls, void* stream) {
+    if (!dS_dir || !dG_dir || !d_c_rows || !d_ls_rows || !dS || !dG || !d_c0 || !d_c1 || !d_ls || B <= 0) return NR_EINVAL;
+    const int T = (B + 31) / 32, CB = (B + 63) / 64;
+    hipLaunchKernelGGL(nr_rowloss_bwd_finish_kernel, dim3(2 * T * T + 2 * CB + 1), dim3(256), 0, (hipStream_t)stream, dS_dir, dG_dir,
+                       d_c_rows, d_ls_rows, B, dS, dG, d_c0, d_c1, d_ls);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// (2) nr_centrality_weights_bwd for the text AND the video tokens in one launch (was four)
+struct NrCentBwdPair {
+    const float *g[2], *gnorm[2], *mean[2], *w[2], *dw[2];
+    float *dg[2], *dmean[2];
+    int B, d;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void nr_centrality_bwd_pair_kernel(NrCentBwdPair p) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int RB = (p.B + 3) / 4, DB = (p.d + 63) / 64;
+    int blk = blockIdx.x;
+    if (blk < 2 * RB) {
+        const int m = blk / RB, i = (blk - m * RB) * 4 + wave;
+        if (i >= p.B) return;
+        const float inv = 1.0f / p.gnorm[m][i];
+        const float a = p.dw[m][i] * p.w[m][i] * p.scale;
+        const float* gi = p.g[m] + (size_t)i * p.d;
+        const float* mean = p.mean[m];
+        float dot = 0.f;
+        for (int c = lane; c < p.d; c += 64) dot += gi[c] * inv * mean[c];
+        dot = nr_wave_sum(dot);
+        for (int c = lane; c < p.d; c += 64) p.dg[m][(size_t)i * p.d + c] = a * (mean[c] - gi[c] * inv * dot) * inv;
+        return;
+    }
+    blk -= 2 * RB;
+    const int m = blk / DB, c = (blk - m * DB) * 64 + lane;
+    const float *g = p.g[m], *gnorm = p.gnorm[m], *w = p.w[m], *dw = p.dw[m];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < p.d) {
+        auto term = [&](int i) { return dw[i] * w[i] * p.scale * g[(size_t)i * p.d + c] / gnorm[i]; };
+        int i = wave;
+        for (; i + 12 < p.B; i += 16) {
+            s0 += term(i);
+            s1 += term(i + 4);
+            s2 += term(i + 8);
+            s3 += term(i + 12);
+        }
+        for (; i < p.B; i += 4) s0 += term(i);
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && c < p.d) p.dmean[m][c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+extern "C" int nr_centrality_weights_bwd_pair(const float* g_t, const float* gnorm_t, const float* mean_t, const float* w_t,
+                                              const float* dw_t, const float* g_v, const float* gnorm_v, const float* mean_v,
+                                              const float* w_v, const float* dw_v, int B, int d, float scale, float* dg_t,
+                                              float* dmean_t, float* dg_v, float* dmean_v, void* stream) {
+    if (!g_t || !gnorm_t || !mean_t || !w_t || !dw_t || !g_v || !gnorm_v || !mean_v || !w_v || !dw_v || !dg_t || !dmean_t || !dg_v ||
+        !dmean_v || B <= 0 || d <= 0)
+        return NR_EINVAL;
+    NrCentBwdPair p{{g_t, g_v}, {gnorm_t, gnorm_v}, {mean_t, mean_v}, {w_t, w_v}, {dw_t, dw_v}, {dg_t, dg_v}, {dmean_t, dmean_v}, B, d, scale};
+    hipLaunchKernelGGL(nr_centrality_bwd_pair_kernel, dim3(2 * ((B + 3) / 4) + 2 * ((d + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
+// (3) gradient of the global logits G = gt gv^T with the centrality part added in:  d_gt = dG gv + add_t,  d_gv = dG^T gt + add_v
+//     (fp32 FMA; B x B x d is a few MFLOP -- was two library GEMMs and two copies)
+__global__ __launch_bounds__(256) void nr_global_logits_bwd_kernel(const float* __restrict__ dG, const float* __restrict__ gt,
+                                                                   const float* __restrict__ gv, const float* __restrict__ add_t,
+                                                                   const float* __restrict__ add_v, int B, int d,
+                                                                   float* __restrict__ d_gt, float* __restrict__ d_gv) {
+    __shared__ float sA[32][33], sX[32][33];
+    const int TB = (B + 31) / 32, TD = (d + 31) / 32;
+    int blk = blockIdx.x;
+    const bool video = blk >= TB * TD;
+    if (video) blk -= TB * TD;
+    const int ti = blk / TD, tc = blk - ti * TD;
+    const float* X = video ? gt : gv;
+    const float* add = video ? add_v : add_t;
+    float* out = video ? d_gv : d_gt;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;         // thread: column tx, rows ty, ty+8, ty+16, ty+24
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < B; k0 += 32) {
+        for (int r = ty; r < 32; r += 8) {
+            const int i = ti * 32 + r, k = k0 + tx;
+            // A[i][k] = dG[i][k] (text) or dG[k][i] (video): staged as sA[row][k]
+            float a = 0.f;
+            if (i < B && k < B) a = video ? dG[(size_t)k * B + i] : dG[(size_t)i * B + k];
+            sA[r][tx] = a;
+            const int kk = k0 + r, c = tc * 32 + tx;
+            sX[r][tx] = (kk < B && c < d) ? X[(size_t)kk * d + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float x = sX[k][tx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(sA[ty + 8 * j][k], x, acc[j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = ti * 32 + ty + 8 * j, c = tc * 32 + tx;
+        if (i < B && c < d) out[(size_t)i * d + c] = acc[j] + add[(size_t)i * d + c];
+    }
+}
+
+extern "C" int nr_global_logits_bwd(const float* dG, const float* gt, const float* gv, const float* add_t, const float* add_v, int B,
+                                    int d, float* d_gt, float* d_gv, void* stream) {
+    if (!dG || !gt || !gv || !add_t || !add_v || !d_gt || !d_gv || B <= 0 || d <= 0) return NR_EINVAL;
+    const int TB = (B + 31) / 32, TD = (d + 31) / 32;
+    hipLaunchKernelGGL(nr_global_logits_bwd_kernel, dim3(2 * TB * TD), dim3(256), 0, (hipStream_t)stream, dG, gt, gv, add_t, add_v, B, d,
+                       d_gt, d_gv);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
 // ---- layout helpers ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nr_add_transposed_kernel(const float* __restrict__ a, const float* __restrict__ b, int B,
                                                                 float* __restrict__ out) {

@@ -169,6 +169,9 @@ _SIGNATURES = {
     "nr_sim_bwd_operand_group": ([_I, ctypes.POINTER(SimBwdOperand), _P], _I),
     "nr_slab_sum_group": ([_I, ctypes.POINTER(SlabSum), _P], _I),
     "nr_rowloss_coef": ([_P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P], _I),
+    "nr_rowloss_bwd_finish": ([_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], _I),
+    "nr_centrality_weights_bwd_pair": ([_P] * 10 + [_I, _I, _F, _P, _P, _P, _P, _P], _I),
+    "nr_global_logits_bwd": ([_P, _P, _P, _P, _P, _I, _I, _P, _P, _P], _I),
     "nr_normalize_bwd": ([_P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     "nr_token_softmax_bwd": ([_P, _P, _I, _I, _P, _P], _I),
     "nr_centrality_weights_bwd": ([_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P], _I),

@@ -431,6 +431,42 @@ def rowloss_coef(gs, hp, B):
     return coef
 
 
+def rowloss_bwd_finish(dS_dir, dG_dir, dC_rows, dls_rows):
+    """-> dS [B,B], dG [B,B], d_c0 [B], d_c1 [B], d_ls [] in one launch (nr_rowloss_bwd_finish)."""
+    B = dS_dir.shape[1]
+    f32 = dict(dtype=torch.float32, device=dS_dir.device)
+    dS, dG = torch.empty((B, B), **f32), torch.empty((B, B), **f32)
+    dc = torch.empty((2, B), **f32)
+    d_ls = torch.empty((1,), **f32)
+    hip.call("nr_rowloss_bwd_finish", hip.ptr(dS_dir, torch.float32), hip.ptr(dG_dir, torch.float32), hip.ptr(dC_rows, torch.float32),
+             hip.ptr(dls_rows, torch.float32), B, hip.ptr(dS), hip.ptr(dG), hip.ptr(dc[0]), hip.ptr(dc[1]), hip.ptr(d_ls),
+             hip.stream_ptr())
+    return dS, dG, dc[0], dc[1], d_ls[0]
+
+
+def centrality_weights_bwd_pair(g_t, gnorm_t, mean_t, w_t, dw_t, g_v, gnorm_v, mean_v, w_v, dw_v, scale):
+    """centrality_weights_bwd for both modalities in one launch -> dg_t, dmean_t, dg_v, dmean_v."""
+    B, d = g_t.shape
+    if g_v.shape != g_t.shape:
+        raise ValueError("text and video global tokens of one batch have the same shape")
+    dg_t, dg_v = torch.empty_like(g_t), torch.empty_like(g_v)
+    dmean = torch.empty((2, d), dtype=torch.float32, device=g_t.device)
+    hip.call("nr_centrality_weights_bwd_pair", hip.ptr(g_t, torch.float32), hip.ptr(gnorm_t), hip.ptr(mean_t), hip.ptr(w_t),
+             hip.ptr(dw_t.contiguous(), torch.float32), hip.ptr(g_v, torch.float32), hip.ptr(gnorm_v), hip.ptr(mean_v), hip.ptr(w_v),
+             hip.ptr(dw_v.contiguous(), torch.float32), B, d, float(scale), hip.ptr(dg_t), hip.ptr(dmean[0]), hip.ptr(dg_v),
+             hip.ptr(dmean[1]), hip.stream_ptr())
+    return dg_t, dmean[0], dg_v, dmean[1]
+
+
+def global_logits_bwd(dG, gt2, gv2, add_t, add_v):
+    """d_gt = dG gv + add_t, d_gv = dG^T gt + add_v in one launch (nr_global_logits_bwd)."""
+    B, d = gt2.shape
+    d_gt, d_gv = torch.empty_like(gt2), torch.empty_like(gv2)
+    hip.call("nr_global_logits_bwd", hip.ptr(dG, torch.float32), hip.ptr(gt2, torch.float32), hip.ptr(gv2, torch.float32),
+             hip.ptr(add_t, torch.float32), hip.ptr(add_v, torch.float32), B, d, hip.ptr(d_gt), hip.ptr(d_gv), hip.stream_ptr())
+    return d_gt, d_gv
+
+
 def add_transposed(a, b):
     """a + b.T for square fp32 matrices."""
     B = a.shape[0]

@@ -474,6 +474,34 @@ def test_grouped_backward_equals_the_products_one_by_one(use_lo):
         assert maxdiff(got, ref) < 2e-6 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("B,d", [(128, 512), (37, 96)])
+def test_the_three_launches_of_the_backward_head(B, d):
+    """nr_rowloss_bwd_finish, nr_centrality_weights_bwd_pair and nr_global_logits_bwd against their plain torch forms (and the
+    one-modality centrality kernel they replace)."""
+    g = torch.Generator().manual_seed(B + d)
+    r = lambda *sh: torch.randn(*sh, generator=g).to(DEV)       # noqa: E731
+    dS_dir, dG_dir, dC = r(2, B, B), r(2, B, B), r(2, B, B)
+    dls = r(2, B)
+    dS, dG, d_c0, d_c1, d_ls = ops.rowloss_bwd_finish(dS_dir, dG_dir, dC, dls)
+    assert torch.equal(dS, dS_dir[0] + dS_dir[1].T) and torch.equal(dG, dG_dir[0] + dG_dir[1].T)
+    assert maxdiff(d_c0, dC[0].double().sum(0).float()) < 1e-5 * B ** 0.5 and maxdiff(d_c1, dC[1].double().sum(0).float()) < 1e-5 * B ** 0.5
+    assert abs(float(d_ls) - float(dls.double().sum())) < 1e-5 * B ** 0.5
+    gt, gv = r(B, d), r(B, d)
+    gn_t, gn_v = gt.norm(dim=-1), gv.norm(dim=-1)
+    mean_t, mean_v = r(d) * 0.1, r(d) * 0.1
+    w_t, w_v = torch.rand(B, generator=g).to(DEV) + 0.5, torch.rand(B, generator=g).to(DEV) + 0.5
+    dw_t, dw_v = r(B), r(B)
+    dg_t, dm_t, dg_v, dm_v = ops.centrality_weights_bwd_pair(gt, gn_t, mean_t, w_t, dw_t, gv, gn_v, mean_v, w_v, dw_v, 0.3)
+    for (gg, gn, mean, w, dw, dg, dm) in ((gt, gn_t, mean_t, w_t, dw_t, dg_t, dm_t), (gv, gn_v, mean_v, w_v, dw_v, dg_v, dm_v)):
+        rdg, rdm = ops.centrality_weights_bwd(gg, gn, mean, w, dw, 0.3)
+        assert torch.equal(dg, rdg) and torch.equal(dm, rdm)
+    d_gt, d_gv = ops.global_logits_bwd(dG, gt, gv, dg_t, dg_v)
+    ref_t = (dG.double() @ gv.double() + dg_t.double()).float()
+    ref_v = (dG.double().T @ gt.double() + dg_v.double()).float()
+    assert maxdiff(d_gt, ref_t) < 2e-6 * float(ref_t.abs().max()) * B ** 0.5
+    assert maxdiff(d_gv, ref_v) < 2e-6 * float(ref_v.abs().max()) * B ** 0.5
+
+
 def test_pack_and_unpack_of_the_exchange_step():
     """nr_pack_shard / nr_unpack_gathered: two ranks' shards packed, concatenated as the all-gather would, unpacked
     rank-major with the u8 masks turned into fp32 multipliers."""
