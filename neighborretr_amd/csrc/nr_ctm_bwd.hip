@@ -26,6 +26,24 @@ struct NrSplitGroup {
     int n;
 };
 
+// Four consecutive destination columns r .. r + 3 of one transposed row as ONE 8-byte store per half (the rows of the transposed
+// operands are K-contiguous: 16 lanes x 8 B = a whole 128-byte line per row and wave store; the 2-byte stores this replaces put
+// a quarter of the bytes into four times the store instructions).  Falls back to element stores at a ragged end.
+__device__ __forceinline__ void nr_store_t4(uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, size_t o, int r, int ld,
+                                            const uint16_t (&h)[4], const uint16_t (&l)[4]) {
+    if (r + 3 < ld && ((o | (size_t)ld) & 3) == 0 && ((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 7) == 0) {
+        *reinterpret_cast<uint2*>(hi + o) = uint2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+        if (lo) *reinterpret_cast<uint2*>(lo + o) = uint2{(uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16)};
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r + j < ld) {
+                hi[o + j] = h[j];
+                if (lo) lo[o + j] = l[j];
+            }
+    }
+}
+
 __global__ __launch_bounds__(256) void nr_split_group_kernel(NrSplitGroup g) {
     __shared__ float smem3[66 * 65];
     float (*t)[65] = reinterpret_cast<float (*)[65]>(smem3);
@@ -51,13 +69,18 @@ __global__ __launch_bounds__(256) void nr_split_group_kernel(NrSplitGroup g) {
             tu[r0 + 4 * i][c] = on ? ((uint32_t)sh[o] | ((uint32_t)(sl ? sl[o] : 0) << 16)) : 0u;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int cl = r0 + 4 * i, cc = tc * 64 + cl, r = tr * 64 + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cl = (threadIdx.x >> 4) + 16 * i, cc = tc * 64 + cl, rl = 4 * (threadIdx.x & 15), r = tr * 64 + rl;
             if (cc < it.cols && r < it.ld) {
-                const uint32_t v = tu[c][cl];
-                it.hi[(size_t)cc * it.ld + r] = (uint16_t)(v & 0xFFFFu);
-                if (it.lo) it.lo[(size_t)cc * it.ld + r] = (uint16_t)(v >> 16);
+                uint16_t h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t v = tu[rl + j][cl];
+                    h[j] = (uint16_t)(v & 0xFFFFu);
+                    l[j] = (uint16_t)(v >> 16);
+                }
+                nr_store_t4(it.hi, it.lo, (size_t)cc * it.ld + r, r, it.ld, h, l);
             }
         }
         return;
@@ -70,21 +93,23 @@ __global__ __launch_bounds__(256) void nr_split_group_kernel(NrSplitGroup g) {
             th[k][cl] = (r >= 0 && r < it.rows && cc < it.cols) ? src[(size_t)r * it.cols + cc] : 0.f;
         }
         __syncthreads();
-        const int r = tr * 64 + c;
-        const int sample = r / it.group;
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int cl = r0 + 4 * i, cc = tc * 64 + cl;
+        const int rl = 4 * (threadIdx.x & 15), r = tr * 64 + rl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cl = (threadIdx.x >> 4) + 16 * i, cc = tc * 64 + cl;
             if (cc >= it.cols || r >= it.ld) continue;
 #pragma unroll
             for (int sft = 0; sft < 3; ++sft) {
-                const int rr = r + sft - 1;
-                const bool on = r < it.rows && rr >= 0 && rr < it.rows && rr / it.group == sample;
-                const float v = on ? th[c + sft][cl] : 0.f;
-                const uint16_t h = nr_f2bf(v);
-                const size_t o = (size_t)(3 * cc + sft) * it.ld + r;
-                it.hi[o] = h;
-                if (it.lo) it.lo[o] = nr_f2bf(v - nr_bf2f(h));
+                uint16_t h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rj = r + j, rr = rj + sft - 1;
+                    const bool on = rj < it.rows && rr >= 0 && rr < it.rows && rr / it.group == rj / it.group;
+                    const float v = on ? th[rl + j + sft][cl] : 0.f;
+                    h[j] = nr_f2bf(v);
+                    l[j] = nr_f2bf(v - nr_bf2f(h[j]));
+                }
+                nr_store_t4(it.hi, it.lo, (size_t)(3 * cc + sft) * it.ld + r, r, it.ld, h, l);
             }
         }
         return;
@@ -113,14 +138,18 @@ __global__ __launch_bounds__(256) void nr_split_group_kernel(NrSplitGroup g) {
         t[r0 + 4 * i][c] = (r < it.rows && cc < it.cols) ? src[(size_t)r * it.cols + cc] : 0.f;
     }
     __syncthreads();
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const int cl = r0 + 4 * i, cc = tc * 64 + cl, r = tr * 64 + c;      // rows past `rows` (up to ld) are zeros
-        if (cc < it.cols && r < it.ld) {
-            const float v = t[c][cl];
-            const uint16_t h = nr_f2bf(v);
-            it.hi[(size_t)cc * it.ld + r] = h;
-            if (it.lo) it.lo[(size_t)cc * it.ld + r] = nr_f2bf(v - nr_bf2f(h));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cl = (threadIdx.x >> 4) + 16 * i, cc = tc * 64 + cl, rl = 4 * (threadIdx.x & 15), r = tr * 64 + rl;
+        if (cc < it.cols && r < it.ld) {                                    // rows past `rows` (up to ld) are zeros
+            uint16_t h[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = t[rl + j][cl];
+                h[j] = nr_f2bf(v);
+                l[j] = nr_f2bf(v - nr_bf2f(h[j]));
+            }
+            nr_store_t4(it.hi, it.lo, (size_t)cc * it.ld + r, r, it.ld, h, l);
         }
     }
 }

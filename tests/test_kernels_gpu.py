@@ -502,6 +502,53 @@ def test_the_three_launches_of_the_backward_head(B, d):
     assert maxdiff(d_gv, ref_v) < 2e-6 * float(ref_v.abs().max()) * B ** 0.5
 
 
+def _bf(t):
+    """bf16 round-to-nearest-even of an fp32 tensor, as int16 bit patterns (what the split kernels store)."""
+    return t.to(torch.bfloat16).view(torch.int16)
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(200, 96, 256), (64, 64, 64), (130, 70, 132)])
+def test_split_group_modes(rows, cols, ld):
+    """nr_split_group, every mode, against torch: 0 row-major split, 1 transposed split (zero K padding), 2 bf16-pair transpose,
+    3 transposed k=3 token neighbourhood, 4 / 5 the two matrix forms of a convolution kernel."""
+    from neighborretr_amd.cluster_fused import split_group
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g).to(DEV)
+    i16 = dict(dtype=torch.int16, device=DEV)
+    hi_ref = x.to(torch.bfloat16)
+    lo_ref = (x - hi_ref.float()).to(torch.bfloat16)
+    # mode 1 and mode 2
+    t_hi, t_lo = torch.full((cols, ld), 7, **i16), torch.full((cols, ld), 7, **i16)
+    p_hi, p_lo = torch.full((cols, ld), 7, **i16), torch.full((cols, ld), 7, **i16)
+    split_group([(x, None, t_hi, t_lo, rows, cols, 1, ld),
+                 (hi_ref.view(torch.int16).contiguous(), lo_ref.view(torch.int16).contiguous(), p_hi, p_lo, rows, cols, 2, ld)])
+    pad = min(ld, (rows + 63) // 64 * 64)
+    for got_hi, got_lo in ((t_hi, t_lo), (p_hi, p_lo)):
+        assert torch.equal(got_hi[:, :rows], hi_ref.view(torch.int16).T) and torch.equal(got_lo[:, :rows], lo_ref.view(torch.int16).T)
+        assert int(got_hi[:, rows:pad].abs().max() if pad > rows else 0) == 0          # the K padding is written as zeros
+    # mode 3: samples of `n` tokens
+    n = 10 if rows % 10 == 0 else (13 if rows % 13 == 0 else 8)
+    n_rows = rows // n * n
+    xs = x[:n_rows].contiguous()
+    h3, l3 = torch.full((3 * cols, ld), 7, **i16), torch.full((3 * cols, ld), 7, **i16)
+    split_group([(xs, None, h3, l3, n_rows, cols, 3, ld, n)])
+    xv = xs.view(-1, n, cols)
+    z = torch.zeros_like(xv[:, :1])
+    shifted = torch.stack([torch.cat([z, xv[:, :-1]], 1), xv, torch.cat([xv[:, 1:], z], 1)], -1).reshape(n_rows, 3 * cols)   # [r, 3c + s]
+    assert torch.equal(h3[:, :n_rows], _bf(shifted).T)
+    assert torch.equal(l3[:, :n_rows], _bf(shifted - shifted.to(torch.bfloat16).float()).T)
+    # modes 4 / 5: W [C_out, C_in, 3]
+    Co, Ci = 48, 40
+    w = torch.randn(Co, Ci, 3, generator=g).to(DEV)
+    a_hi, a_lo = torch.empty((Co, 3 * Ci), **i16), torch.empty((Co, 3 * Ci), **i16)
+    b_hi, b_lo = torch.empty((Ci, 3 * Co), **i16), torch.empty((Ci, 3 * Co), **i16)
+    split_group([(w, None, a_hi, a_lo, Co, 3 * Ci, 4, 3 * Ci, Ci), (w, None, b_hi, b_lo, Ci, 3 * Co, 5, 3 * Co, Co)])
+    wa = w.permute(0, 2, 1).reshape(Co, 3 * Ci)
+    wb = w.permute(1, 2, 0).reshape(Ci, 3 * Co)
+    assert torch.equal(a_hi, _bf(wa)) and torch.equal(b_hi, _bf(wb))
+    assert torch.equal(a_lo, _bf(wa - wa.to(torch.bfloat16).float())) and torch.equal(b_lo, _bf(wb - wb.to(torch.bfloat16).float()))
+
+
 def test_pack_and_unpack_of_the_exchange_step():
     """nr_pack_shard / nr_unpack_gathered: two ranks' shards packed, concatenated as the all-gather would, unpacked
     rank-major with the u8 masks turned into fp32 multipliers."""
