@@ -36,6 +36,9 @@ extern "C" {
 #define NR_OUT_COLSUM 2 /* partial[n_row_tiles, Bv] : sum over the tile's rows (texts)      */
 
 int nr_version(void);
+/* sizeof of one of this header's descriptor structs by name ("NrSplitItem", ...; 0: unknown name): lets a foreign-language
+ * binding verify its mirror of the layout at load time. */
+size_t nr_struct_size(const char* name);
 
 /* Identity of the HIP stream capture `stream` belongs to (0 = not capturing).  No counterpart in the reference (it launches
  * eagerly, trainer.py:84-110); used by neighborretr_amd/capture_guard.py to validate the step's fork / join topology per

@@ -3,8 +3,21 @@
 #include <dlfcn.h>
 #include "nr_common.h"
 #include "../../include/nr_hip.h"
+#include <string.h>
 
 extern "C" int nr_version(void) { return NR_ABI_VERSION; }
+
+// sizeof of a descriptor struct of include/nr_hip.h by name (0: unknown) -- a binding checks its own layout against the library's
+// before the first grouped call (neighborretr_amd/hip.py does at load time; tests/test_host_cpu.py asserts it)
+extern "C" size_t nr_struct_size(const char* name) {
+    if (!name) return 0;
+#define NR_SIZE_OF(T) if (!strcmp(name, #T)) return sizeof(T)
+    NR_SIZE_OF(NrCtmStageDesc); NR_SIZE_OF(NrLocalLevelProblem); NR_SIZE_OF(NrSplitItem); NR_SIZE_OF(NrColsumItem);
+    NR_SIZE_OF(NrLinearProblem); NR_SIZE_OF(NrCtmAttnBwdDesc); NR_SIZE_OF(NrCtmMidBwdDesc); NR_SIZE_OF(NrSimBwdItem);
+    NR_SIZE_OF(NrSimBwdOperand); NR_SIZE_OF(NrSlabSum); NR_SIZE_OF(NrPoolWSrc); NR_SIZE_OF(NrPoolWJob);
+#undef NR_SIZE_OF
+    return 0;
+}
 
 // Identity of the stream capture `stream` takes part in: *id = the runtime's capture sequence id (unique per capture in
 // this process), 0 when the stream is not capturing.  Host-only; lets the host code check its stream topology per capture.

@@ -97,6 +97,10 @@ class PoolWJob(ctypes.Structure):
     _fields_ = [("src", PoolWSrc * 2), ("d_w", _P)] + [(n, ctypes.c_int32) for n in ("n_src", "side", "N", "accumulate")]
 
 
+STRUCTS = {"NrCtmStageDesc": CtmStageDesc, "NrLocalLevelProblem": LocalLevelProblem, "NrSplitItem": SplitItem,
+           "NrColsumItem": ColsumItem, "NrLinearProblem": LinearProblem, "NrCtmAttnBwdDesc": CtmAttnBwdDesc,
+           "NrCtmMidBwdDesc": CtmMidBwdDesc, "NrSimBwdItem": SimBwdItem, "NrSimBwdOperand": SimBwdOperand, "NrSlabSum": SlabSum,
+           "NrPoolWSrc": PoolWSrc, "NrPoolWJob": PoolWJob}
 SPLIT_MAX, COLSUM_MAX, LINEAR_GROUP_MAX = 48, 16, 8
 SIM_BWD_GROUP_MAX, POOLW_GROUP_MAX = 4, 8
 LOCAL_LEVEL_GROUP_MAX = 4
@@ -105,6 +109,7 @@ CTM_STAGE_LAUNCHES = 7
 
 _SIGNATURES = {
     "nr_version": ([], _I),
+    "nr_struct_size": ([ctypes.c_char_p], _Z),
     "nr_stream_capture_id": ([_P, ctypes.POINTER(ctypes.c_ulonglong)], _I),
     "nr_prepare_parts": ([_I], _I),
     "nr_prepare_tokens": ([_P, _P, _I, _I, _I, _P, _P, _P, _P, _P], _I),
@@ -207,6 +212,14 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = restype
+        # the descriptor structs mirrored above must have the library's layout: a stale .so against a newer header (or the
+        # other way round) is refused here instead of corrupting a grouped launch's arguments
+        if hasattr(handle, "nr_struct_size"):
+            for cname, cls in STRUCTS.items():
+                want = int(handle.nr_struct_size(cname.encode()))
+                if want != ctypes.sizeof(cls):
+                    raise NrHipError(f"{LIB_PATH}: sizeof({cname}) is {want}, the Python mirror has {ctypes.sizeof(cls)} "
+                                     "-- rebuild the extension (python -m neighborretr_amd.build --force)")
         _lib = handle
     return _lib
 

@@ -58,6 +58,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.nr_prepare_parts(10) == 1 and lib.nr_prepare_parts(10 ** 6) == 64
 
 
+def test_descriptor_structs_have_the_layout_the_library_was_built_with():
+    """Every descriptor struct of include/nr_hip.h that hip.py mirrors in ctypes: same size as the compiled one (nr_struct_size),
+    and the sizes the header's comments state."""
+    lib = hip.lib()                                        # load-time check: raises on any mismatch
+    header = open(os.path.join(ROOT, "include", "nr_hip.h")).read()
+    typedefs = set(re.findall(r"^\}\s*(Nr\w+);", header, flags=re.M))
+    assert typedefs == set(hip.STRUCTS), typedefs ^ set(hip.STRUCTS)
+    for name, cls in hip.STRUCTS.items():
+        assert int(lib.nr_struct_size(name.encode())) == ctypes.sizeof(cls) > 0, name
+        stated = re.search(r"\}\s*" + name + r";\s*/\*\s*(\d+) bytes", header)
+        if stated:
+            assert int(stated.group(1)) == ctypes.sizeof(cls), name
+    assert int(lib.nr_struct_size(b"NrNoSuchStruct")) == 0
+
+
 def test_tile_query_no_gpu_needed():
     assert hip.local_level_tiles(128, 24, 128, 12) == (32, 16)      # 4 texts x 8 videos per 96x96 block
     assert hip.local_level_tiles(128, 64, 1024, 64) == (64, 256)    # one pass: 2 x 4 per 128x256 block on 8 waves

@@ -14,6 +14,11 @@ python tools/microbench.py 2>&1 | q > "$out/microbench.txt"
 bash tools/bench_profile.sh "$tag/step" > /dev/null 2>&1
 bash tools/train_profile.sh 13 > "$out/train_profile.txt" 2>&1
 cp "$repo/gpurun_out/train_prof/tr_kernel_stats.csv" "$out/train_kernel_stats.csv" 2>/dev/null
+bash tools/train_graph_timeline.sh > "$out/train_graph_timeline.txt" 2>&1
+python tools/sim_bwd_times.py 2>&1 | q > "$out/sim_bwd_times.txt"
+python tools/sim_bwd_times.py bf16x3 2>&1 | q >> "$out/sim_bwd_times.txt"
+python tools/scorer_bwd_times.py 2>&1 | q > "$out/scorer_bwd_times.txt"
+python tools/sinkhorn_large_times.py 2>&1 | q > "$out/sinkhorn_large.txt"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$out/roof" -o r -- python3 "$repo/tools/roofline_launches.py" > "$out/roofline_launches.txt" 2>&1 )
 cp "$(find "$out/roof" -name '*kernel_stats.csv' | head -1)" "$out/roofline_kernel_stats.csv" 2>/dev/null; rm -rf "$out/roof"
 bash tools/pmc_passes.sh "$out/pmc" && python tools/pmc_to_json.py "$out/pmc" > "$out/pmc_sim.json"; rm -rf "$out/pmc" "$out"/pmc.*.log
