@@ -283,6 +283,7 @@ __device__ __forceinline__ float nr_rl(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+#define NR_ATT_LD 129
 // NCH token chunks of 32 (N <= 32 * NCH).  NCH == 1: the head's k | v rows are staged in the wave's own LDS slice first
 // ([n][128] floats: every later read is a ds_read at an immediate offset); read straight from global memory they cost a
 // 64-bit address pair per row and the kernel spilled.  NCH == 2 (ActivityNet token counts) keeps the global reads: its slices
@@ -292,16 +293,20 @@ __device__ __forceinline__ void nr_attn_bwd_body(const NrAttnBwdArgs& a, const i
     const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
     const int N = a.N, C = a.C, c = a.cnum;
     const size_t kvb = (size_t)b * N * 2 * C + (size_t)h * 64 + lane;
-    float* sk = s_kv + (size_t)h * N * 128 + lane;            // NCH == 1 only
+    // NCH == 1: this wave's LDS slice = N rows of k | v (NR_ATT_LD floats apart: an odd stride, so that lanes that hold
+    // different TOKENS read a column without bank conflicts) + q and d_att of the current query (128 floats)
+    float* slice = s_kv + (size_t)h * (N * NR_ATT_LD + 128);
+    float* sk = slice + lane;
+    float* sqd = slice + N * NR_ATT_LD;
     if constexpr (NCH == 1) {
         for (int n = 0; n < N; ++n) {
-            sk[n * 128] = a.kv[kvb + (size_t)n * 2 * C];
-            sk[n * 128 + 64] = a.kv[kvb + (size_t)n * 2 * C + C];
+            sk[n * NR_ATT_LD] = a.kv[kvb + (size_t)n * 2 * C];
+            sk[n * NR_ATT_LD + 64] = a.kv[kvb + (size_t)n * 2 * C + C];
         }
         // (the slice is private to this wave: no barrier)
     }
-    auto K_ = [&](int n) -> float { if constexpr (NCH == 1) return sk[n * 128]; else return a.kv[kvb + (size_t)n * 2 * C]; };
-    auto V_ = [&](int n) -> float { if constexpr (NCH == 1) return sk[n * 128 + 64]; else return a.kv[kvb + (size_t)n * 2 * C + C]; };
+    auto K_ = [&](int n) -> float { if constexpr (NCH == 1) return sk[n * NR_ATT_LD]; else return a.kv[kvb + (size_t)n * 2 * C]; };
+    auto V_ = [&](int n) -> float { if constexpr (NCH == 1) return sk[n * NR_ATT_LD + 64]; else return a.kv[kvb + (size_t)n * 2 * C + C]; };
     float dk[NCH][32], dv[NCH][32];
 #pragma unroll
     for (int u = 0; u < NCH; ++u)
@@ -313,14 +318,34 @@ __device__ __forceinline__ void nr_attn_bwd_body(const NrAttnBwdArgs& a, const i
         const size_t qo = ((size_t)b * c + ci) * C + (size_t)h * 64 + lane;
         const float qv = a.q[qo], da = a.d_att[qo];
         float lg = -INFINITY, dp = 0.f;    // lane n: logit / d_p of token n
+        if constexpr (NCH == 1) {
+            // lane = (token, half of the head's 64 dims): 32 multiply-adds per lane and one exchange between the halves instead
+            // of two 64-lane reductions per token (48 reductions per query at 24 tokens: that was most of this kernel's time)
+            sqd[lane] = qv;
+            sqd[64 + lane] = da;
+            const int tok = lane & 31, d0 = (lane >> 5) * 32;
+            float l_ = 0.f, d_ = 0.f;
+            if (tok < N) {
+                const float* kr = slice + tok * NR_ATT_LD + d0;
+#pragma unroll 8
+                for (int j = 0; j < 32; ++j) {
+                    l_ = __builtin_fmaf(sqd[d0 + j], kr[j], l_);
+                    d_ = __builtin_fmaf(sqd[64 + d0 + j], kr[64 + j], d_);
+                }
+            }
+            l_ += __shfl_xor(l_, 32);
+            d_ += __shfl_xor(d_, 32);
+            if (lane < N) { lg = l_ * a.scale; dp = d_; }
+        } else {
 #pragma unroll
-        for (int u = 0; u < NCH; ++u) {
+            for (int u = 0; u < NCH; ++u) {
 #pragma unroll
-            for (int n = 0; n < 32; ++n) {
-                if (u * 32 + n < N) {
-                    const float l_ = nr_wave_sum(qv * K_(u * 32 + n)) * a.scale;
-                    const float d_ = nr_wave_sum(da * V_(u * 32 + n));
-                    if (lane == u * 32 + n) { lg = l_; dp = d_; }
+                for (int n = 0; n < 32; ++n) {
+                    if (u * 32 + n < N) {
+                        const float l_ = nr_wave_sum(qv * K_(u * 32 + n)) * a.scale;
+                        const float d_ = nr_wave_sum(da * V_(u * 32 + n));
+                        if (lane == u * 32 + n) { lg = l_; dp = d_; }
+                    }
                 }
             }
         }
@@ -378,7 +403,7 @@ __device__ __forceinline__ void nr_attn_bwd_body(const NrAttnBwdArgs& a, const i
 template <int NCH>
 __global__ __launch_bounds__(512) void nr_attn_bwd_group_kernel(NrBwdGroupOf<NrAttnBwdArgs> g) {   // <= 8 heads: 256 VGPRs per lane
     __shared__ float s_ds[8 * 64];
-    extern __shared__ __attribute__((aligned(16))) float s_kv[];        // NCH == 1: [heads][N][128]
+    extern __shared__ __attribute__((aligned(16))) float s_kv[];        // NCH == 1: [heads][N * NR_ATT_LD + 128]
     const int gi = g.find(blockIdx.x);
     nr_attn_bwd_body<NCH>(g.p[gi], blockIdx.x - g.start[gi], s_ds, s_kv);
 }
@@ -404,7 +429,7 @@ extern "C" int nr_ctm_attn_bwd(int n, const NrCtmAttnBwdDesc* d, void* stream) {
     }
     for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
     if (nmax <= 32) {
-        const size_t lds = (size_t)heads * nmax * 128 * sizeof(float);             // <= 128 KiB
+        const size_t lds = (size_t)heads * (nmax * NR_ATT_LD + 128) * sizeof(float);   // <= 133 KiB
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)nr_attn_bwd_group_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;

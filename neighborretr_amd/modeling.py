@@ -247,7 +247,8 @@ class NeighborRetr(nn.Module):
     def scorer_weights(self, name):
         """bf16 hi/lo images of one scorer MLP, re-split when the parameters were updated."""
         mlp = getattr(self, name)
-        ver = tuple(p._version for p in mlp.parameters()) + tuple(p.data_ptr() for p in mlp.parameters())
+        ps = (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)          # Sequential(Linear, ReLU, Linear)
+        ver = tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps)
         hit = self._scorer_cache.get(name)
         if hit is None or hit[0] != ver:
             sw = head.ScorerWeights(mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
