@@ -269,7 +269,8 @@ int nr_ctm_stage_workspace_layout2(int n_samples, int N, int C, int cluster_num,
  * padding) -- the operand that makes the token-convolution weight gradient (cluster.py:664) come out of its GEMM in the
  * parameter's own [C_out, C_in, 3] order; modes 4 / 5: the two matrix forms of a k=3 convolution kernel W [C_out, C_in, 3] read
  * in place, row-major like mode 0 -- 4: dst[o, s C_in + i] = W[o, i, s] (rows C_out, cols 3 C_in, group C_in), 5: dst[i, s C_out + o]
- * = W[o, i, s] (rows C_in, cols 3 C_out, group C_out).  Used for the per-step re-split of every weight matrix and for the K = token-rows
+ * = W[o, i, s] (rows C_in, cols 3 C_out, group C_out), 6: as 5 with the taps reversed, dst[i, s C_out + o] = W[o, i, 2 - s] (the
+ * kernel of the TRANSPOSED convolution in nr_linear_group's in-place form).  Used for the per-step re-split of every weight matrix and for the K = token-rows
  * operands of the weight-gradient GEMMs.                                                                                   */
 #define NR_SPLIT_MAX 48
 typedef struct NrSplitItem {
@@ -304,7 +305,10 @@ typedef struct NrLinearProblem {
     const float *bias, *residual;
     float* out;
     int32_t M, N, K, ld;
-} NrLinearProblem;                               /* 72 bytes */
+    int32_t conv_n, pad_;                        /* conv_n > 0: X is the token matrix [M, K/3] of samples of conv_n rows and the
+                                                    product the k=3 token convolution read in place: sum_s X[r+s-1] W[:, s K/3..]
+                                                    (rows outside r's sample read as zeros); every problem of the launch then is */
+} NrLinearProblem;                               /* 80 bytes */
 int nr_linear_group(int n, const NrLinearProblem* problems, void* stream);
 
 /* Score-biased attention backward (cluster.py:868-885) per sample for up to NR_CTM_MAX_GROUP problems: from q [n*cnum,C],
@@ -321,9 +325,9 @@ int nr_ctm_attn_bwd(int n, const NrCtmAttnBwdDesc* problems, void* stream);
 
 /* The middle of the stage, backward, per sample: norm1 backward of the merged rows (d_qn) and of the token rows (d_kvn),
  * the block's residual (g), weighted cluster means (cluster.py:536-556; cluster ids `assign` carry no gradient), score / exp
- * (masked tokens: zero), LayerNorm(ctm) backward.  Writes d_y [n*N,C] (gradient of the conv output) and dcat [n*N,3C] as a
- * bf16 pair with row m = d_y[m+1] | d_y[m] | d_y[m-1] (zeros across sample ends) -- the A operand of the transposed token
- * convolution -- and partial [n,6,C]: per-sample sums of d norm1.weight, d norm1.bias, d ctm.norm.weight, d ctm.norm.bias,
+ * (masked tokens: zero), LayerNorm(ctm) backward.  Writes d_y [n*N,C] (gradient of the conv output), the same as a bf16 pair
+ * dy_hi / dy_lo [n*N,C] -- the A operand of the transposed token convolution, which nr_linear_group reads in place
+ * (conv_n) -- and partial [n,6,C]: per-sample sums of d norm1.weight, d norm1.bias, d ctm.norm.weight, d ctm.norm.bias,
  * d score.weight, and d score.bias in [.,5,0].  merged_pb = cluster means + proj bias (what the forward keeps).            */
 typedef struct NrCtmMidBwdDesc {
     int32_t n_samples, N, C, cnum;
@@ -331,7 +335,7 @@ typedef struct NrCtmMidBwdDesc {
     const float *d_qn, *d_kvn, *g, *merged_pb, *proj_b, *xn, *y, *tokw, *d_score, *mask, *n1_w, *ln_w, *sc_w;
     const int64_t* assign;
     float* d_y;
-    uint16_t *dcat_hi, *dcat_lo;
+    uint16_t *dy_hi, *dy_lo;
     float* partial;
 } NrCtmMidBwdDesc;
 int nr_ctm_mid_bwd(int n, const NrCtmMidBwdDesc* problems, void* stream);

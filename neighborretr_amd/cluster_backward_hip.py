@@ -7,8 +7,8 @@ AND the video problem of a stage in the same launches -- nine per stage instead 
     kernel   score-biased attention backward per sample                          (nr_ctm_attn_bwd)
     GEMM     d_qn = d_q Wq,  d_kvn = d_kv Wkv
     kernel   norm1 x2, residual, weighted cluster means, score, LayerNorm(ctm)   (nr_ctm_mid_bwd)
-    GEMM     d_x0 = d_y + dcat Wbt                                                (transposed token convolution)
-    split    transposes of d_q, d_kv, dcat
+    GEMM     d_x0 = d_y + conv^T(d_y)                                  (transposed token convolution, read in place)
+    split    transposes of d_q, d_kv, d_y
     GEMM     dWproj, dWq, dWkv, dWconv                                            (eight problems, one launch)
     colsum   bias gradients + sums of the per-sample LayerNorm / score parameter gradients
 
@@ -32,8 +32,8 @@ def _pad64(n):
 
 
 def _linear_group(problems):
-    """problems: (x_hi, x_lo, w_hi, w_lo, bias, residual, out, M, N, K[, ld]); operands may be tensors or raw addresses (a
-    K-slice of a wider matrix: address of its first column + ld)."""
+    """problems: (x_hi, x_lo, w_hi, w_lo, bias, residual, out, M, N, K[, ld[, conv_n]]); operands may be tensors or raw addresses
+    (a K-slice of a wider matrix: address of its first column + ld).  conv_n: see NrLinearProblem."""
     for lo in range(0, len(problems), hip.LINEAR_GROUP_MAX):
         chunk = problems[lo:lo + hip.LINEAR_GROUP_MAX]
         arr = (hip.LinearProblem * len(chunk))()
@@ -42,6 +42,7 @@ def _linear_group(problems):
             a.x_hi, a.x_lo, a.w_hi, a.w_lo = _addr(x_hi), _addr(x_lo), _addr(w_hi), _addr(w_lo)
             a.bias, a.residual, a.out = _addr(bias), _addr(res), _addr(out)
             a.M, a.N, a.K, a.ld = int(M), int(N), int(K), int(prob[10]) if len(prob) > 10 else 0
+            a.conv_n = int(prob[11]) if len(prob) > 11 else 0
         hip.call("nr_linear_group", len(chunk), arr, hip.stream_ptr())
 
 
@@ -74,7 +75,7 @@ def stage_backward_group(problems, cache):
                             ("attT_hi", (C, Mcp)), ("attT_lo", (C, Mcp)), ("qnT_hi", (C, Mcp)), ("qnT_lo", (C, Mcp)),
                             ("kvnT_hi", (C, Mp)), ("kvnT_lo", (C, Mp)), ("x0T3_hi", (3 * C, Mp)), ("x0T3_lo", (3 * C, Mp)),
                             ("dq_hi", (Mc, C)), ("dq_lo", (Mc, C)), ("dkv_hi", (M, 2 * C)), ("dkv_lo", (M, 2 * C)),
-                            ("dcat_hi", (M, 3 * C)), ("dcat_lo", (M, 3 * C)), ("dqT_hi", (C, Mcp)), ("dqT_lo", (C, Mcp)),
+                            ("dy_hi", (M, C)), ("dy_lo", (M, C)), ("dqT_hi", (C, Mcp)), ("dqT_lo", (C, Mcp)),
                             ("dkvT_hi", (2 * C, Mp)), ("dkvT_lo", (2 * C, Mp)), ("dyT_hi", (C, Mp)), ("dyT_lo", (C, Mp))):
             d[name] = torch.empty(shape, **i16)
         for name, shape in (("d_att", (Mc, C)), ("d_q", (Mc, C)), ("d_kv", (M, 2 * C)), ("d_score", (B, N)), ("d_qn", (Mc, C)),
@@ -125,11 +126,12 @@ def stage_backward_group(problems, cache):
         a.d_score, a.mask = _addr(d["d_score"]), _addr(sv.get("mask"))
         a.n1_w, a.ln_w, a.sc_w = _addr(blk.norm1.weight), _addr(ctm.norm.weight), _addr(ctm.score.weight)
         a.assign, a.d_y = _addr(sv["assign"]), _addr(d["d_y"])
-        a.dcat_hi, a.dcat_lo, a.partial = _addr(d["dcat_hi"]), _addr(d["dcat_lo"]), _addr(d["partial"])
+        a.dy_hi, a.dy_lo, a.partial = _addr(d["dy_hi"]), _addr(d["dy_lo"]), _addr(d["partial"])
     hip.call("nr_ctm_mid_bwd", len(P), arr, hip.stream_ptr())
-    # 6. d_x0 = d_y + dcat Wbt   (transposed k=3 token convolution + the residual path)
-    _linear_group([(d["dcat_hi"], d["dcat_lo"], d["sw"].wconv_bt_hi, d["sw"].wconv_bt_lo, None, d["d_y"], d["d_x0"], d["M"], d["C"],
-                    3 * d["C"]) for d in P])
+    # 6. d_x0 = d_y + conv^T(d_y): the transposed k=3 token convolution read in place from d_y's bf16 pair (the kernel with its
+    #    taps reversed: tap s meets row n + s - 1), the residual path as the GEMM's residual operand
+    _linear_group([(d["dy_hi"], d["dy_lo"], d["sw"].wconv_bt_hi, d["sw"].wconv_bt_lo, None, d["d_y"], d["d_x0"], d["M"], d["C"],
+                    3 * d["C"], 0, d["N"]) for d in P])
     # 7. transposes of what the backward produced
     items = []
     for d in P:

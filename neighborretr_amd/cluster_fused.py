@@ -70,7 +70,8 @@ class _StageWeights:
         pair("wkv", wkv, wkv.shape[0], wkv.shape[1], 0)
         pair("wq", wq, wq.shape[0], wq.shape[1], 0)
         pair("wp", wp, wp.shape[0], wp.shape[1], 0)
-        pair("wconv_bt", w, Ci, 3 * Co, 5, Co)                                   # [C_in, 3 C_out]: d x0 = d y + dcat Wbt^T
+        pair("wconv_bt", w, Ci, 3 * Co, 6, Co)                                   # [C_in, 3 C_out], taps reversed: the transposed
+        #                                                                          convolution d x0 = d y + conv^T(d y), in place
         pair("wkv_bt", wkv, wkv.shape[0], wkv.shape[1], 1)                       # [C, 2C]: d kvn = d kv Wkv
         pair("wq_bt", wq, wq.shape[0], wq.shape[1], 1)
         pair("wp_bt", wp, wp.shape[0], wp.shape[1], 1)

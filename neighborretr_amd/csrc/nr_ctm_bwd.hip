@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void nr_split_group_kernel(NrSplitGroup g) {
     if (it.mode == 0 || it.mode >= 4) {
         // modes 4 / 5: the two matrix forms of a k=3 convolution kernel W [C_out, C_in, 3] read in place --
         //   4: dst[o, s C_in + i] = W[o, i, s]   (group = C_in)        5: dst[i, s C_out + o] = W[o, i, s]   (group = C_out)
+        //   6: dst[i, s C_out + o] = W[o, i, 2 - s]: the TRANSPOSED convolution's kernel for the in-place form (tap s meets row n+s-1)
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
             const int r = tr * 64 + r0 + 4 * i, cc = tc * 64 + c;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void nr_split_group_kernel(NrSplitGroup g) {
                 size_t o = (size_t)r * it.cols + cc;
                 if (it.mode == 4) o = (size_t)r * it.cols + (size_t)(cc % it.group) * 3 + cc / it.group;
                 else if (it.mode == 5) o = (size_t)(cc % it.group) * (3 * (size_t)it.rows) + (size_t)r * 3 + cc / it.group;
+                else if (it.mode == 6) o = (size_t)(cc % it.group) * (3 * (size_t)it.rows) + (size_t)r * 3 + (2 - cc / it.group);
                 const float v = cc < it.cols ? src[o] : 0.f;
                 const uint16_t h = nr_f2bf(v);
                 it.hi[(size_t)r * it.ld + cc] = h;
@@ -162,7 +164,7 @@ extern "C" int nr_split_group(int n, const NrSplitItem* items, void* stream) {
     int total = 0;
     for (int i = 0; i < n; ++i) {
         const NrSplitItem& it = items[i];
-        if (!it.src || !it.hi || it.rows <= 0 || it.cols <= 0 || it.mode < 0 || it.mode > 5) return NR_EINVAL;
+        if (!it.src || !it.hi || it.rows <= 0 || it.cols <= 0 || it.mode < 0 || it.mode > 6) return NR_EINVAL;
         if (it.mode >= 3 && it.group <= 0) return NR_EINVAL;
         if (it.mode >= 4 && it.cols != 3 * it.group) return NR_EINVAL;
         const bool transposed = it.mode >= 1 && it.mode <= 3;
@@ -245,12 +247,16 @@ extern "C" int nr_linear_group(int n, const NrLinearProblem* probs, void* stream
     if (!probs || n <= 0) return NR_EINVAL;
     if (n > NR_LINEAR_MAX_GROUP) return NR_EUNSUPPORTED;
     NrLinearArgs a[NR_LINEAR_MAX_GROUP];
+    bool conv = false;
     for (int i = 0; i < n; ++i) {
         a[i] = NrLinearArgs{probs[i].x_hi, probs[i].x_lo, probs[i].w_hi, probs[i].w_lo, probs[i].bias, probs[i].residual,
                             probs[i].out, probs[i].M, probs[i].N, probs[i].K};
         a[i].ld = probs[i].ld;
+        if (probs[i].conv_n < 0) return NR_EINVAL;
+        a[i].conv_n = probs[i].conv_n;
+        conv = conv || probs[i].conv_n > 0;
     }
-    return nr_linear_group_launch(a, n, (hipStream_t)stream);
+    return nr_linear_group_launch(a, n, (hipStream_t)stream, conv);      // conv: EVERY problem must be one (checked there)
 }
 
 // ---- score-biased attention backward, one workgroup per sample, one wave per head ------------------------------------------------
@@ -449,7 +455,7 @@ struct NrMidBwdArgs {
     int N, C, cnum;
     float eps_ctm, eps_n1;
     float* d_y;                   // [B*N, C]
-    uint16_t *dcat_hi, *dcat_lo;  // [B*N, 3C]: row n = d_y[n+1] | d_y[n] | d_y[n-1] (zeros across the sample's ends)
+    uint16_t *dy_hi, *dy_lo;      // [B*N, C]: d_y as a bf16 pair (A operand of the transposed convolution, read in place)
     float* partial;               // [B, 6, C]: d norm1.weight, d norm1.bias, d ctm.norm.weight, d ctm.norm.bias, d score.weight, [d score.bias, 0...]
 };
 
@@ -593,13 +599,9 @@ __device__ __forceinline__ void nr_mid_bwd_body(const NrMidBwdArgs& a, const int
                 const float v = dx[q];
                 a.d_y[row + ch] = v;
                 const uint16_t hb = nr_f2bf(v), lb = nr_f2bf(v - nr_bf2f(hb));
-                // d_y[r] is column block 1 of row r, block 0 of row r-1, block 2 of row r+1 (inside the sample)
-                a.dcat_hi[tok * 3 * C + C + ch] = hb;
-                a.dcat_lo[tok * 3 * C + C + ch] = lb;
-                if (r > 0) { a.dcat_hi[(tok - 1) * 3 * C + ch] = hb; a.dcat_lo[(tok - 1) * 3 * C + ch] = lb; }
-                if (r + 1 < N) { a.dcat_hi[(tok + 1) * 3 * C + 2 * C + ch] = hb; a.dcat_lo[(tok + 1) * 3 * C + 2 * C + ch] = lb; }
-                if (r == N - 1) { a.dcat_hi[tok * 3 * C + ch] = 0; a.dcat_lo[tok * 3 * C + ch] = 0; }
-                if (r == 0) { a.dcat_hi[tok * 3 * C + 2 * C + ch] = 0; a.dcat_lo[tok * 3 * C + 2 * C + ch] = 0; }
+                // the bf16 pair of d_y: the transposed convolution reads it in place (three shifted row sets, like the forward's)
+                a.dy_hi[row + ch] = hb;
+                a.dy_lo[row + ch] = lb;
             }
     }
     // ---- C: the waves' partial parameter gradients meet in LDS, one vector at a time (fixed order) ---------------------
@@ -649,7 +651,7 @@ extern "C" int nr_ctm_mid_bwd(int n, const NrCtmMidBwdDesc* d, void* stream) {
     for (int i = 0; i < n; ++i) {
         const NrCtmMidBwdDesc& s = d[i];
         if (!s.d_qn || !s.d_kvn || !s.g || !s.merged_pb || !s.proj_b || !s.xn || !s.y || !s.tokw || !s.d_score || !s.n1_w || !s.ln_w ||
-            !s.sc_w || !s.assign || !s.d_y || !s.dcat_hi || !s.dcat_lo || !s.partial)
+            !s.sc_w || !s.assign || !s.d_y || !s.dy_hi || !s.dy_lo || !s.partial)
             return NR_EINVAL;
         if (s.n_samples <= 0 || s.N <= 0 || s.cnum <= 0 || s.cnum > s.N) return NR_EINVAL;
         if (s.N > 64 || s.C <= 0 || (s.C % 64) != 0 || s.C > 64 * CF_MAX_CPL) return NR_EUNSUPPORTED;
@@ -658,7 +660,7 @@ extern "C" int nr_ctm_mid_bwd(int n, const NrCtmMidBwdDesc* d, void* stream) {
         lds = need > lds ? need : lds;
         small = small && s.C <= 512;
         g.p[i] = NrMidBwdArgs{s.d_qn, s.d_kvn, s.g, s.merged_pb, s.proj_b, s.xn, s.y, s.tokw, s.d_score, s.mask, s.n1_w, s.ln_w, s.sc_w,
-                              s.assign, s.N, s.C, s.cnum, s.eps_ctm, s.eps_n1, s.d_y, s.dcat_hi, s.dcat_lo, s.partial};
+                              s.assign, s.N, s.C, s.cnum, s.eps_ctm, s.eps_n1, s.d_y, s.dy_hi, s.dy_lo, s.partial};
         g.start[i] = total;
         total += s.n_samples;
     }

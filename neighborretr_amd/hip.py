@@ -54,7 +54,7 @@ class ColsumItem(ctypes.Structure):
 class LinearProblem(ctypes.Structure):
     """NrLinearProblem of include/nr_hip.h."""
     _fields_ = ([(n, _P) for n in ("x_hi", "x_lo", "w_hi", "w_lo", "bias", "residual", "out")]
-                + [(n, ctypes.c_int32) for n in ("M", "N", "K", "ld")])
+                + [(n, ctypes.c_int32) for n in ("M", "N", "K", "ld", "conv_n", "pad_")])
 
 
 class CtmAttnBwdDesc(ctypes.Structure):
@@ -67,7 +67,7 @@ class CtmMidBwdDesc(ctypes.Structure):
     """NrCtmMidBwdDesc of include/nr_hip.h."""
     _fields_ = ([(n, ctypes.c_int32) for n in ("n_samples", "N", "C", "cnum")] + [("eps_ctm", _F), ("eps_n1", _F)]
                 + [(n, _P) for n in ("d_qn", "d_kvn", "g", "merged_pb", "proj_b", "xn", "y", "tokw", "d_score", "mask", "n1_w",
-                                     "ln_w", "sc_w", "assign", "d_y", "dcat_hi", "dcat_lo", "partial")])
+                                     "ln_w", "sc_w", "assign", "d_y", "dy_hi", "dy_lo", "partial")])
 
 
 class SimBwdItem(ctypes.Structure):

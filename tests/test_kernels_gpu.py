@@ -510,7 +510,7 @@ def _bf(t):
 @pytest.mark.parametrize("rows,cols,ld", [(200, 96, 256), (64, 64, 64), (130, 70, 132)])
 def test_split_group_modes(rows, cols, ld):
     """nr_split_group, every mode, against torch: 0 row-major split, 1 transposed split (zero K padding), 2 bf16-pair transpose,
-    3 transposed k=3 token neighbourhood, 4 / 5 the two matrix forms of a convolution kernel."""
+    3 transposed k=3 token neighbourhood, 4 / 5 / 6 the matrix forms of a convolution kernel."""
     from neighborretr_amd.cluster_fused import split_group
     g = torch.Generator().manual_seed(rows + cols)
     x = torch.randn(rows, cols, generator=g).to(DEV)
@@ -542,10 +542,13 @@ def test_split_group_modes(rows, cols, ld):
     w = torch.randn(Co, Ci, 3, generator=g).to(DEV)
     a_hi, a_lo = torch.empty((Co, 3 * Ci), **i16), torch.empty((Co, 3 * Ci), **i16)
     b_hi, b_lo = torch.empty((Ci, 3 * Co), **i16), torch.empty((Ci, 3 * Co), **i16)
-    split_group([(w, None, a_hi, a_lo, Co, 3 * Ci, 4, 3 * Ci, Ci), (w, None, b_hi, b_lo, Ci, 3 * Co, 5, 3 * Co, Co)])
+    c_hi, c_lo = torch.empty((Ci, 3 * Co), **i16), torch.empty((Ci, 3 * Co), **i16)
+    split_group([(w, None, a_hi, a_lo, Co, 3 * Ci, 4, 3 * Ci, Ci), (w, None, b_hi, b_lo, Ci, 3 * Co, 5, 3 * Co, Co),
+                 (w, None, c_hi, c_lo, Ci, 3 * Co, 6, 3 * Co, Co)])
     wa = w.permute(0, 2, 1).reshape(Co, 3 * Ci)
     wb = w.permute(1, 2, 0).reshape(Ci, 3 * Co)
-    assert torch.equal(a_hi, _bf(wa)) and torch.equal(b_hi, _bf(wb))
+    wc = w.flip(-1).permute(1, 2, 0).reshape(Ci, 3 * Co)          # mode 6: taps reversed
+    assert torch.equal(a_hi, _bf(wa)) and torch.equal(b_hi, _bf(wb)) and torch.equal(c_hi, _bf(wc))
     assert torch.equal(a_lo, _bf(wa - wa.to(torch.bfloat16).float())) and torch.equal(b_lo, _bf(wb - wb.to(torch.bfloat16).float()))
 
 
