@@ -73,6 +73,42 @@ def test_descriptor_structs_have_the_layout_the_library_was_built_with():
     assert int(lib.nr_struct_size(b"NrNoSuchStruct")) == 0
 
 
+def test_similarity_backward_planning_no_gpu_needed():
+    """Host-only parts of the grouped similarity backward: which token counts the matrix-core kernel takes (blocks of at most 32
+    sample pairs), and the workspace planner on the step's four products (no device call: 256 CUs assumed)."""
+    lib = hip.lib()
+    ok = {(24, 12), (12, 24), (24, 24), (16, 24), (24, 16)}
+    for nt in (4, 8, 12, 16, 24, 32, 20):
+        for nv in (4, 8, 12, 16, 24):
+            assert bool(lib.nr_local_level_bwd_mfma_supported(nt, nv, 512)) == ((nt, nv) in ok), (nt, nv)
+    assert not lib.nr_local_level_bwd_mfma_supported(24, 12, 320)            # d % 256
+    B, M, Nt, Nv, d = 128, 512, 24, 12, 512
+    items = (hip.SimBwdItem * 4)()
+    dummy = ctypes.create_string_buffer(64)
+    ptr = ctypes.addressof(dummy)
+    for it, (side, A, Bv) in zip(items, ((0, B, B), (0, B, M), (1, B, B), (1, M, B))):
+        for f in ("dS", "oT_hi", "w_self", "w_other", "arg_v", "arg_t", "d_x"):
+            setattr(it, f, ptr)
+        it.side, it.A, it.Nt, it.Bv, it.Nv, it.d, it.ds_scale = side, A, Nt, Bv, Nv, d, 1.0
+        n_other = (Bv * Nv) if side == 0 else (A * Nt)
+        it.ldk = (n_other + 95) // 96 * 96
+    nbytes = int(lib.nr_local_level_bwd_group_workspace_bytes(4, items))
+    text, video = B * Nt * d * 4, B * Nv * d * 4
+    assert nbytes > 2 * (text + video)                     # at least one slab per product
+    assert nbytes <= 32 * 2 * (text + video) + 256         # and never more than 32 chunks each
+    items[1].ldk -= 96                                      # operand that does not cover the product's tokens: refused
+    assert int(lib.nr_local_level_bwd_group_workspace_bytes(4, items)) == 0
+
+
+def test_k_slicing_of_a_weight_gradient():
+    from neighborretr_amd.backward import _apportion
+    assert _apportion([3072, 1536], 8) == [5, 3]
+    assert _apportion([12288, 6144], 8) == [5, 3]
+    assert _apportion([100, 1, 1], 8) == [6, 1, 1]
+    assert _apportion([1, 1, 1], 2) == [1, 1, 1]            # never fewer than one problem per set
+    assert sum(_apportion([7, 5, 3, 2], 8)) == 8
+
+
 def test_tile_query_no_gpu_needed():
     assert hip.local_level_tiles(128, 24, 128, 12) == (32, 16)      # 4 texts x 8 videos per 96x96 block
     assert hip.local_level_tiles(128, 64, 1024, 64) == (64, 256)    # one pass: 2 x 4 per 128x256 block on 8 waves
