@@ -76,11 +76,15 @@ int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_lo, const fl
 /* Backward of the token-weight MLP's hidden layer, fused (the reference's autograd does this in ~10 element-wise launches on
  * [n_tok, H] tensors behind modeling.py:148-153): recomputes h = norm * (tok W1^T) + b1 like nr_token_logits_fwd and writes
  *   dh = (h > 0) * dl[t] * w2 as bf16 pairs -- transposed into dhT [H, ldT] at columns [t0, t0 + n_tok) (the K = tokens operand
- *   of dW1 = dh^T X) and, when dh_hi/lo are given, row-major [n_tok, H] (operand of dX = dh W1);
- *   dw2_part / db1_part [2 * nr_token_mlp_bwd_row_tiles(n_tok), H]: partial column sums of dl * relu(h) and of dh;
- *   dl_part [2 * row tiles] (may be NULL): partial sums of dl (the gradient of the output bias).
+ *   of dW1 = dh^T X; columns up to the next multiple of 64, as far as ldT reaches, are written as zeros: the K padding;
+ *   t0 % 8 == 0, ldT % 8 == 0; dhT_lo may be NULL when the weight-gradient GEMM is one-pass) and, when dh_hi/lo are given,
+ *   row-major [n_tok, H] (operand of dX = dh W1);
+ *   dw2_part / db1_part [nr_token_mlp_bwd_part_rows(n_tok, H, prec, hi_only), H] (hi_only: the call passes dhT_lo = dh_hi =
+ *   dh_lo = NULL, which lets the large one-pass sets run a bigger block): partial column sums of dl * relu(h) and of dh;
+ *   dl_part [the same number of rows] (may be NULL): partial sums of dl (the gradient of the output bias).
  * dl [n_tok] f32 = gradient of the logits (0 on masked tokens).                                                            */
 int nr_token_mlp_bwd_row_tiles(int n_tok);
+int nr_token_mlp_bwd_part_rows(int n_tok, int H, int prec, int hi_only);
 int nr_token_mlp_bwd_hidden(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d,
                             const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2, int H, int prec,
                             const float* dl, uint16_t* dhT_hi, uint16_t* dhT_lo, int ldT, int t0, uint16_t* dh_hi, uint16_t* dh_lo,

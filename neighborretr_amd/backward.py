@@ -97,7 +97,10 @@ def _mlp_backward_hip(jobs):
                  XT_hi=torch.empty((d, ldT), **i16), XT_lo=torch.empty((d, ldT), **i16))
         n0 = job["sets"][0][0].n_tok
         j["dh_hi"], j["dh_lo"] = torch.empty((n0, H), **i16), torch.empty((n0, H), **i16)
-        rows = [2 * int(hip.lib().nr_token_mlp_bwd_row_tiles(prep.n_tok)) for prep, _, _, _ in job["sets"]]
+        # (set k > 0 with a one-pass weight gradient asks for the hi halves of dh^T only: see the calls below)
+        rows = [int(hip.lib().nr_token_mlp_bwd_part_rows(prep.n_tok, H, int(prec),
+                                                         int(k > 0 and int(prec) != hip.PREC_BF16X3 and ONE_PASS_WEIGHT_GRAD)))
+                for k, (prep, _, _, prec) in enumerate(job["sets"])]
         j["rows"], R = rows, sum(rows)
         j["dw2_part"], j["db1_part"], j["dl_part"] = torch.empty((R, H), **f32), torch.empty((R, H), **f32), torch.empty((R, 1), **f32)
         for name, shape in (("dW1", (H, d)), ("db1", (H,)), ("dW2", (1, H)), ("db2", (1,)), ("dX", (n0, d))):
@@ -105,7 +108,9 @@ def _mlp_backward_hip(jobs):
         for (prep, feat, dl, prec), off in zip(job["sets"], offs):
             x = feat.detach().reshape(-1, d).float().contiguous()
             # X^T of this set at columns [off, off + pad64(n)): the row tiles of the transposed form also write the zero padding
-            items.append((x, None, (j["XT_hi"], off), (j["XT_lo"], off), prep.n_tok, d, 1, ldT))
+            # (a set whose weight-gradient GEMM is one-pass gets the hi halves only)
+            want_lo = int(prec) == hip.PREC_BF16X3 or not ONE_PASS_WEIGHT_GRAD
+            items.append((x, None, (j["XT_hi"], off), (j["XT_lo"], off) if want_lo else None, prep.n_tok, d, 1, ldT))
         J.append(j)
     split_group(items)
     for j in J:
@@ -113,9 +118,11 @@ def _mlp_backward_hip(jobs):
         for k, ((prep, feat, dl, prec), off, rows) in enumerate(zip(j["job"]["sets"], j["offs"], j["rows"])):
             dl = dl.detach().reshape(-1).float().contiguous()
             first = k == 0
+            # a set whose weight-gradient GEMM is one-pass (below) has no use for the low halves of its dh^T
+            want_lo = int(prec) == hip.PREC_BF16X3 or not ONE_PASS_WEIGHT_GRAD
             hip.call("nr_token_mlp_bwd_hidden", hip.ptr(prep.hi), hip.ptr(prep.lo, allow_none=True), hip.ptr(prep.norm), prep.n_tok,
                      prep.d, hip.ptr(sw.w1_hi), hip.ptr(sw.w1_lo, allow_none=True), hip.ptr(sw.b1), hip.ptr(sw.w2), j["H"], int(prec),
-                     hip.ptr(dl), hip.ptr(j["dhT_hi"]), hip.ptr(j["dhT_lo"]), j["ldT"], off,
+                     hip.ptr(dl), hip.ptr(j["dhT_hi"]), hip.ptr(j["dhT_lo"]) if want_lo else None, j["ldT"], off,
                      hip.ptr(j["dh_hi"]) if first else None, hip.ptr(j["dh_lo"]) if first else None,
                      ctypes_ptr(j["dw2_part"], r0 * j["H"]), ctypes_ptr(j["db1_part"], r0 * j["H"]), ctypes_ptr(j["dl_part"], r0),
                      hip.stream_ptr())

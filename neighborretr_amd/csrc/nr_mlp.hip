@@ -256,7 +256,7 @@ extern "C" int nr_token_weights_fwd(const uint16_t* tok_hi, const uint16_t* tok_
 //     dh[t, c]  = h > 0 ? dl[t] * w2[c] : 0          -> bf16 pair, TRANSPOSED [H, ldT] at column t0 + t (operand of dW1 = dh^T X,
 //                                                       K = tokens) and, for the rows that need dX = dh W1, row-major [n_tok, H]
 //     dW2[c]    = sum_t dl[t] * relu(h[t, c]),   db1[c] = sum_t dh[t, c]   as per-wave-row partial sums [2 * row tiles, H]
-template <int MI, int NI, int WC, bool X3, int STAGES>
+template <int MI, int NI, int WC, bool X3, int STAGES, bool LO_OUT = true>
 __global__ __launch_bounds__(128 * WC) void nr_mlp_bwd_hidden_kernel(const uint16_t* __restrict__ tok_hi, const uint16_t* __restrict__ tok_lo,
                                                                      const float* __restrict__ norm, int n_tok, int d,
                                                                      const uint16_t* __restrict__ w1_hi, const uint16_t* __restrict__ w1_lo,
@@ -286,6 +286,11 @@ __global__ __launch_bounds__(128 * WC) void nr_mlp_bwd_hidden_kernel(const uint1
     float s_w2[NI], s_b1[NI];
 #pragma unroll
     for (int n = 0; n < NI; ++n) s_w2[n] = s_b1[n] = 0.f;
+    // dh of this lane's 4 x MI x NI accumulator entries as bf16 pairs: [m][n] = rows rb(m) .. rb(m)+3 of column c(n)
+    // LO_OUT = false (only the hi halves of dh^T are wanted): the packed values go straight into the LDS image, no register copy
+    uint2 ph[LO_OUT ? MI : 1][LO_OUT ? NI : 1], pl[LO_OUT ? MI : 1][LO_OUT ? NI : 1];
+    uint16_t* sT = reinterpret_cast<uint16_t*>(smem);
+    constexpr int TLD = BM + 8, RLD = BN + 8;                            // row pitches of the two images (16-byte multiples)
 #pragma unroll
     for (int m = 0; m < MI; ++m) {
         const int rb = row0 + wr * 16 * MI + m * 16 + (lane >> 4) * 4;          // this lane's 4 consecutive rows
@@ -305,28 +310,78 @@ __global__ __launch_bounds__(128 * WC) void nr_mlp_bwd_hidden_kernel(const uint1
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float h = tile.acc[m][n][j] * sc[j] + bb;
-                const float dh = h > 0.f ? dlr[j] * ww : 0.f;
+                const float dh = h > 0.f ? dlr[j] * ww : 0.f;                   // rows past n_tok: dl = 0 -> 0
                 s_w2[n] += dlr[j] * fmaxf(h, 0.f);
                 s_b1[n] += dh;
                 hb[j] = nr_f2bf(dh);
                 lb[j] = nr_f2bf(dh - nr_bf2f(hb[j]));
-                if (dh_hi && rb + j < n_tok) {
-                    dh_hi[(size_t)(rb + j) * H + c] = hb[j];
-                    dh_lo[(size_t)(rb + j) * H + c] = lb[j];
-                }
             }
-            // four consecutive tokens of hidden unit c: one 8-byte store each into the transposed pair (rows past n_tok: zeros)
-            if (rb < n_tok) {
-                const size_t o = (size_t)c * ldT + t0 + rb;
-                if (rb + 3 < n_tok && ((t0 + rb) & 3) == 0) {
-                    *reinterpret_cast<uint2*>(dhT_hi + o) = uint2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)};
-                    *reinterpret_cast<uint2*>(dhT_lo + o) = uint2{(uint32_t)lb[0] | ((uint32_t)lb[1] << 16), (uint32_t)lb[2] | ((uint32_t)lb[3] << 16)};
-                } else {
+            const uint2 packed_hi = uint2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)};
+            if constexpr (LO_OUT) {
+                ph[m][n] = packed_hi;
+                pl[m][n] = uint2{(uint32_t)lb[0] | ((uint32_t)lb[1] << 16), (uint32_t)lb[2] | ((uint32_t)lb[3] << 16)};
+            } else {
+                const int cl = wc * WCOLS + n * 16 + (lane & 15), tl = wr * 16 * MI + m * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<uint2*>(sT + cl * TLD + tl) = packed_hi;       // (the ring is free: run() ended with a barrier)
+            }
+        }
+    }
+    // The tile leaves through LDS (the ring is free: run() ended with a barrier), one image at a time, so that global memory
+    // sees whole 16-byte pieces of contiguous rows: the TRANSPOSED pair [unit][token] (a unit's 128 tokens = 256 contiguous
+    // bytes of its row of dhT; written straight from the accumulator layout they were 8-byte pieces at a row pitch of tens of
+    // KB, and this kernel spent more time storing than multiplying), then -- for the token set whose dX is wanted -- the
+    // row-major pair [token][unit].  Columns [n_tok, n_tok rounded up to 64) of dhT get the zeros they need as K padding.
+    const int lim = min((n_tok + 63) / 64 * 64, ldT - t0) - row0;        // tokens of this tile that belong to the set's columns
+    auto flush = [&](uint16_t* __restrict__ dst, const bool transposed) {
+        __syncthreads();                                                 // image complete
+        if (transposed) {                                                // [BN units][BM tokens]
+            for (int e = threadIdx.x; e < BN * (BM / 8); e += 128 * WC) {
+                const int r = e / (BM / 8), k = e - r * (BM / 8);        // unit, 16-byte piece (8 tokens)
+                const uint4 v = *reinterpret_cast<const uint4*>(sT + r * TLD + 8 * k);
+                if (8 * k < lim) *reinterpret_cast<uint4*>(dst + (size_t)(col0 + r) * ldT + t0 + row0 + 8 * k) = v;
+            }
+        } else {                                                         // [BM tokens][BN units]
+            for (int e = threadIdx.x; e < BM * (BN / 8); e += 128 * WC) {
+                const int r = e / (BN / 8), k = e - r * (BN / 8);
+                const uint4 v = *reinterpret_cast<const uint4*>(sT + r * RLD + 8 * k);
+                if (row0 + r < n_tok) *reinterpret_cast<uint4*>(dst + (size_t)(row0 + r) * H + col0 + 8 * k) = v;
+            }
+        }
+        __syncthreads();                                                 // image consumed
+    };
+    auto image_t = [&](const uint2 (&p)[MI][NI]) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (rb + j < n_tok) { dhT_hi[o + j] = hb[j]; dhT_lo[o + j] = lb[j]; }
-                }
+        for (int m = 0; m < MI; ++m)
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                const int cl = wc * WCOLS + n * 16 + (lane & 15), tl = wr * 16 * MI + m * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<uint2*>(sT + cl * TLD + tl) = p[m][n];
             }
+    };
+    auto image_r = [&](const uint2 (&p)[MI][NI]) {
+#pragma unroll
+        for (int m = 0; m < MI; ++m)
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                const int cl = wc * WCOLS + n * 16 + (lane & 15), tl = wr * 16 * MI + m * 16 + (lane >> 4) * 4;
+                sT[(tl + 0) * RLD + cl] = (uint16_t)(p[m][n].x & 0xffffu);
+                sT[(tl + 1) * RLD + cl] = (uint16_t)(p[m][n].x >> 16);
+                sT[(tl + 2) * RLD + cl] = (uint16_t)(p[m][n].y & 0xffffu);
+                sT[(tl + 3) * RLD + cl] = (uint16_t)(p[m][n].y >> 16);
+            }
+    };
+    if constexpr (LO_OUT) image_t(ph);
+    flush(dhT_hi, true);
+    if constexpr (LO_OUT) {
+        if (dhT_lo) {
+            image_t(pl);
+            flush(dhT_lo, true);
+        }
+        if (dh_hi) {
+            image_r(ph);
+            flush(dh_hi, false);
+            image_r(pl);
+            flush(dh_lo, false);
         }
     }
     // column sums over this wave's 16 * MI rows: lanes l, l+16, l+32, l+48 hold the same column
@@ -350,13 +405,18 @@ __global__ __launch_bounds__(128 * WC) void nr_mlp_bwd_hidden_kernel(const uint1
 }
 
 namespace {
-template <int MI, int NI, int WC, bool X3, int STAGES>
+template <int MI, int NI, int WC, bool X3, int STAGES, bool LO_OUT = true>
 int mlp_bwd_launch(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d, const uint16_t* w1_hi,
                    const uint16_t* w1_lo, const float* b1, const float* w2, int H, const float* dl, uint16_t* dhT_hi, uint16_t* dhT_lo,
                    int ldT, int t0, uint16_t* dh_hi, uint16_t* dh_lo, float* dw2_part, float* db1_part, float* dl_part, hipStream_t st) {
     using Tile = NrGemmTile<MI, NI, X3, 16, 16, STAGES, WC>;
-    const size_t lds = Tile::RING_BYTES;
-    auto kern = nr_mlp_bwd_hidden_kernel<MI, NI, WC, X3, STAGES>;
+    // the epilogue's LDS images: [BN][BM + 8] (transposed) and, only with dh_hi, [BM][BN + 8] (row-major)
+    size_t image = (size_t)Tile::BN * (Tile::BM + 8) * sizeof(uint16_t);
+    if (dh_hi && (size_t)Tile::BM * (Tile::BN + 8) * sizeof(uint16_t) > image) image = (size_t)Tile::BM * (Tile::BN + 8) * sizeof(uint16_t);
+    const size_t lds = Tile::RING_BYTES > image ? Tile::RING_BYTES : image;
+    if (lds > 160 * 1024) return NR_EUNSUPPORTED;
+    if (!LO_OUT && (dhT_lo || dh_hi)) return NR_EINVAL;
+    auto kern = nr_mlp_bwd_hidden_kernel<MI, NI, WC, X3, STAGES, LO_OUT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -369,16 +429,29 @@ int mlp_bwd_launch(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* 
 }
 }  // namespace
 
-// Row tiles of nr_token_mlp_bwd_hidden for n_tok tokens: dw2_part / db1_part hold 2 * this many rows of H floats.
+// Block of nr_token_mlp_bwd_hidden for a token set: 192 x 256 on 8 waves for the large one-pass sets (the memory bank: one
+// block per CU at 12 288 tokens, 43 -> 25 us against 128 x 128 on 4 waves), 128 x 128 on 4 waves otherwise.
+static bool mlp_bwd_big(int n_tok, int H, int prec, bool hi_only) { return hi_only && prec == NR_PREC_BF16 && n_tok >= 4096 && (H % 256) == 0; }
+
+// Rows of dw2_part / db1_part / dl_part that nr_token_mlp_bwd_hidden writes for n_tok tokens in precision `prec` with H hidden
+// units: two (wave rows) per row block of the variant it will run (hi_only: the call will pass dhT_lo = dh_hi = dh_lo = NULL).
+extern "C" int nr_token_mlp_bwd_part_rows(int n_tok, int H, int prec, int hi_only) {
+    if (n_tok <= 0) return 0;
+    const int bm = mlp_bwd_big(n_tok, H, prec, hi_only != 0) ? 192 : 128;
+    return 2 * ((n_tok + bm - 1) / bm);
+}
+
+// (kept: the row blocks of the 128-row variant; nr_token_mlp_bwd_part_rows is what sizes the partial-sum buffers)
 extern "C" int nr_token_mlp_bwd_row_tiles(int n_tok) { return n_tok > 0 ? (n_tok + 127) / 128 : 0; }
 
 extern "C" int nr_token_mlp_bwd_hidden(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d,
                                        const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2, int H, int prec,
                                        const float* dl, uint16_t* dhT_hi, uint16_t* dhT_lo, int ldT, int t0, uint16_t* dh_hi,
                                        uint16_t* dh_lo, float* dw2_part, float* db1_part, float* dl_part, void* stream) {
-    if (!tok_hi || !norm || !w1_hi || !b1 || !w2 || !dl || !dhT_hi || !dhT_lo || !dw2_part || !db1_part) return NR_EINVAL;
+    if (!tok_hi || !norm || !w1_hi || !b1 || !w2 || !dl || !dhT_hi || !dw2_part || !db1_part) return NR_EINVAL;
     if ((dh_hi == nullptr) != (dh_lo == nullptr)) return NR_EINVAL;
     if (n_tok <= 0 || d <= 0 || (d % 64) != 0 || H <= 0 || (H % 128) != 0 || t0 < 0 || ldT < t0 + n_tok) return NR_EINVAL;
+    if ((t0 % 8) != 0 || (ldT % 8) != 0) return NR_EUNSUPPORTED;          // 16-byte pieces of the transposed rows
     if (prec != NR_PREC_BF16 && prec != NR_PREC_BF16X3) return NR_EINVAL;
     if (prec == NR_PREC_BF16X3 && (!tok_lo || !w1_lo)) return NR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -388,6 +461,11 @@ extern "C" int nr_token_mlp_bwd_hidden(const uint16_t* tok_hi, const uint16_t* t
     if (prec == NR_PREC_BF16X3)
         return two ? mlp_bwd_launch<4, 4, 2, true, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, dl, dhT_hi, dhT_lo, ldT, t0, dh_hi, dh_lo, dw2_part, db1_part, dl_part, st)
                    : mlp_bwd_launch<4, 4, 2, true, 1>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, dl, dhT_hi, dhT_lo, ldT, t0, dh_hi, dh_lo, dw2_part, db1_part, dl_part, st);
+    if (mlp_bwd_big(n_tok, H, prec, !dhT_lo && !dh_hi))
+        return mlp_bwd_launch<6, 4, 4, false, 2, false>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, dl, dhT_hi, dhT_lo, ldT, t0, dh_hi, dh_lo, dw2_part, db1_part, dl_part, st);
+    // one pass: the two-deep ring is 64 KB, and the 256 registers of the epilogue allow two workgroups per CU either way
+    if (nr_tune_env("NR_MLP_BWD_ONE_STAGE") == nullptr)
+        return mlp_bwd_launch<4, 4, 2, false, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, dl, dhT_hi, dhT_lo, ldT, t0, dh_hi, dh_lo, dw2_part, db1_part, dl_part, st);
     return two ? mlp_bwd_launch<4, 4, 2, false, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, dl, dhT_hi, dhT_lo, ldT, t0, dh_hi, dh_lo, dw2_part, db1_part, dl_part, st)
                : mlp_bwd_launch<4, 4, 2, false, 1>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, dl, dhT_hi, dhT_lo, ldT, t0, dh_hi, dh_lo, dw2_part, db1_part, dl_part, st);
 }
