@@ -164,6 +164,10 @@ int nr_linear_group_launch(const NrLinearArgs* probs, int n, hipStream_t st, boo
             wcols = t64x128 >= 256 ? 4 : 2;
             stg = (wcols == 4 ? t64x128 : t32x64 / 2) >= 512 ? 1 : 2;
         }
+        if (const char* ov = nr_tune_env("NR_LINEAR_TILE1")) {       // the one-pass launches only
+            int a_, b_, c_, d_;
+            if (sscanf(ov, "%d,%d,%d,%d", &a_, &b_, &c_, &d_) == 4) { mi = a_; ni = b_; stg = c_; wcols = d_; }
+        }
 #define NR_LG1_CASE(MI_, NI_, ST_, WC_) if (mi == MI_ && ni == NI_ && stg == ST_ && wcols == WC_) return nr_linear_group_launch_s<MI_, NI_, ST_, WC_, false, false>(probs, n, st)
         NR_LG1_CASE(2, 2, 1, 4); NR_LG1_CASE(2, 2, 2, 4); NR_LG1_CASE(2, 2, 1, 2); NR_LG1_CASE(2, 2, 2, 2);
         NR_LG1_CASE(4, 2, 1, 4); NR_LG1_CASE(4, 2, 2, 4); NR_LG1_CASE(2, 4, 2, 2);
