@@ -552,6 +552,43 @@ def test_split_group_modes(rows, cols, ld):
     assert torch.equal(a_lo, _bf(wa - wa.to(torch.bfloat16).float())) and torch.equal(b_lo, _bf(wb - wb.to(torch.bfloat16).float()))
 
 
+@pytest.mark.parametrize("n_tok,t0", [(4200, 0), (6144, 64)])
+def test_scorer_backward_hidden_kernel_block_shapes_agree(n_tok, t0):
+    """nr_token_mlp_bwd_hidden on a large one-pass token set: the 192 x 256 block that writes only the hi halves of dh^T
+    (what the memory-bank sets of a training step take) against the 128 x 128 block with every output: identical dh^T (hi),
+    zero K padding, the same partial sums to summation order."""
+    g = torch.Generator().manual_seed(n_tok)
+    d, H = 512, 1024
+    x = torch.randn(n_tok // 12, 12, d, generator=g).to(DEV)
+    prep = ops.prepare_tokens(x, torch.ones(n_tok // 12, 12, device=DEV), want_lo=False)
+    n = prep.n_tok
+    w1 = (torch.randn(H, d, generator=g) * 0.03).to(DEV)
+    b1, w2 = (torch.randn(H, generator=g) * 0.1).to(DEV), torch.randn(H, generator=g).to(DEV)
+    w1_hi = w1.to(torch.bfloat16).view(torch.int16).contiguous()
+    dl = (torch.randn(n, generator=g) * 1e-2).to(DEV)
+    ldT = t0 + (n + 63) // 64 * 64 + 64
+    i16 = dict(dtype=torch.int16, device=DEV)
+
+    def run(hi_only):
+        rows = int(hip.lib().nr_token_mlp_bwd_part_rows(n, H, hip.PREC_BF16, int(hi_only)))
+        dhT_hi = torch.full((H, ldT), 7, **i16)
+        dhT_lo = None if hi_only else torch.full((H, ldT), 7, **i16)
+        p2, p1, pl = (torch.full((rows, k), float("nan"), device=DEV) for k in (H, H, 1))
+        hip.call("nr_token_mlp_bwd_hidden", hip.ptr(prep.hi), None, hip.ptr(prep.norm), n, d, hip.ptr(w1_hi), None, hip.ptr(b1),
+                 hip.ptr(w2), H, hip.PREC_BF16, hip.ptr(dl), hip.ptr(dhT_hi), hip.ptr(dhT_lo, allow_none=True), ldT, t0, None, None,
+                 hip.ptr(p2), hip.ptr(p1), hip.ptr(pl), hip.stream_ptr())
+        return dhT_hi, rows, p2.sum(0), p1.sum(0), pl.sum()
+    big, rows_big, a2, a1, al = run(True)
+    small, rows_small, b2_, b1_, bl = run(False)
+    assert rows_big == 2 * ((n + 191) // 192) and rows_small == 2 * ((n + 127) // 128)
+    pad = (n + 63) // 64 * 64
+    assert torch.equal(big[:, t0:t0 + pad], small[:, t0:t0 + pad])
+    assert int(big[:, t0 + n:t0 + pad].abs().max()) == 0 if pad > n else True        # K padding written as zeros
+    assert int((big[:, :t0] != 7).sum()) == 0 and int((big[:, t0 + pad:] != 7).sum()) == 0      # nothing outside the set's columns
+    for x_, y_ in ((a2, b2_), (a1, b1_), (al, bl)):
+        assert maxdiff(x_, y_) < 1e-5 * max(float(y_.abs().max()), 1e-6)
+
+
 def test_pack_and_unpack_of_the_exchange_step():
     """nr_pack_shard / nr_unpack_gathered: two ranks' shards packed, concatenated as the all-gather would, unpacked
     rank-major with the u8 masks turned into fp32 multipliers."""
