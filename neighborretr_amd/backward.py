@@ -265,6 +265,8 @@ def _global_backward(sv, hp, shapes, gs, g1_params):
     Gt, Gv = gt_shape[1], gv_shape[1]
     K, T = int(hp["num_neighbors"]), hp["temperature"]
     g1_w1t, g1_b1t, g1_w2t, g1_w1v, g1_b1v, g1_w2v = g1_params
+    if sv["S"].is_cuda:
+        _record_on_current_stream(sv)
     coef = ops.rowloss_coef(gs, hp, B)
     dS_dir, dG_dir, dC_rows, dwc, dls_rows = ops.row_losses_bwd(sv["S"], sv["G"], sv["tgt_r"], sv["tgt_c"], sv["c0"],
                                                                 sv["c1"], sv["wc_t"], sv["wc_v"], sv["ls"], K, T, coef)
@@ -304,6 +306,26 @@ def _global_backward(sv, hp, shapes, gs, g1_params):
     return dS, d_c0, d_c1, dmean_t, dmean_v, d_gt, d_gv, d_ls, g1
 
 
+def _record_on_current_stream(obj, seen=None):
+    """record_stream(current) on every CUDA tensor reachable from `obj` (dicts, sequences, ops.Prepared-like objects): what a
+    backward reads may have been allocated on another stream of the forward (local / bank streams)."""
+    cur = torch.cuda.current_stream()
+    seen = set() if seen is None else seen
+    stack = [obj]
+    while stack:
+        o = stack.pop()
+        if id(o) in seen:
+            continue
+        seen.add(id(o))
+        if torch.is_tensor(o):
+            if o.is_cuda:
+                o.record_stream(cur)
+        elif isinstance(o, dict):
+            stack.extend(o.values())
+        elif isinstance(o, (list, tuple)):                     # (ops.Prepared is a namedtuple)
+            stack.extend(o)
+
+
 def _local_backward(sv, shapes, masks, exact, plan, model, text_feat, video_feat, mb_feat_t, mb_feat_v, scorer_params,
                     dS, d_c0, d_c1, dmean_t, dmean_v):
     """The token side of the loss head's backward: the three fused products (batch x batch, text x bank-video, bank-text x video)
@@ -312,6 +334,8 @@ def _local_backward(sv, shapes, masks, exact, plan, model, text_feat, video_feat
     (B, Nt, d), (_, Nv, _), (M, _, _), _, _, _ = shapes
     text_mask, video_mask = masks
     w1t, b1t, w2t, w1v, b1v, w2v = scorer_params
+    if dS.is_cuda:
+        _record_on_current_stream(sv)
     pt, pv, pbt, pbv = sv["pt"], sv["pv"], sv["pbt"], sv["pbv"]
     lo = exact
     aux0, aux1, aux2 = sv["aux"]
@@ -387,16 +411,26 @@ class HeadLocalFn(torch.autograd.Function):
     def forward(ctx, model, hp, bridge, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v, gt, gv, logit_scale,
                 g1, text_feat, video_feat, w1t, b1t, w2t, b2t, w1v, b1v, w2v, b2v):
         prec = model._prec()
+        stepwise = bridge.pop("join", None)       # gt = gv = None: the clustering's launches, a generator driven by the head
+        if stepwise is not None:
+            # the clustering is issued launch by launch on THIS stream, interleaved (in capture order) with the local branch and
+            # the early bank chains on the local stream -- the loss-only step's schedule (head.head_forward)
+            extra = dict(join=stepwise, local_stream=model._local_stream(text_feat.device), bank_early=model.bank_early,
+                         capture_order=model.capture_order)
+            gt_in = gv_in = None
+        else:
+            extra = dict(join=model._take_join())
+            gt_in, gv_in = gt.detach(), gv.detach()
         losses, sv = head.head_forward(text_feat.detach(), video_feat.detach(), text_mask, video_mask,
-                                       mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v, gt.detach(), gv.detach(),
+                                       mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v, gt_in, gv_in,
                                        model.scorer_weights("text_weight_fc"), model.scorer_weights("video_weight_fc"),
-                                       hp, logit_scale.detach(), prec, keep=True, join=model._take_join(),
+                                       hp, logit_scale.detach(), prec, keep=True,
                                        bank_streams=model._bank_streams(text_feat.device),
-                                       **model._global_scorers(text_feat, video_feat))
+                                       **extra, **model._global_scorers(text_feat, video_feat))
         ctx.sv, ctx.exact = sv, prec == hip.PREC_BF16X3
         ctx.model, ctx.plan = model, head.precision_plan(prec)
         ctx.masks = (text_mask, video_mask)
-        ctx.shapes = (text_feat.shape, video_feat.shape, mb_feat_t.shape, mb_feat_v.shape, gt.shape, gv.shape)
+        ctx.shapes = (text_feat.shape, video_feat.shape, mb_feat_t.shape, mb_feat_v.shape, sv["gt2"].shape, sv["gv2"].shape)
         sv["gt2"], sv["gv2"] = sv["gt2"].reshape(-1, sv["gt2"].shape[-1]), sv["gv2"].reshape(-1, sv["gv2"].shape[-1])
         ctx.save_for_backward(text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v)
         bridge["losses"], bridge["sv"], bridge["shapes"] = losses, sv, ctx.shapes
@@ -440,14 +474,22 @@ SPLIT_HEAD_NODES = True       # False: the head as ONE autograd node (HeadLossFn
 
 
 def head_loss_nodes(model, hp, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v, text_feat, video_feat, gt, gv,
-                    logit_scale, scorer_params, g1_params):
-    """The differentiable fused head -> (total, centrality, uniform, neighbour, kl)."""
+                    logit_scale, scorer_params, g1_params, cluster=None):
+    """The differentiable fused head -> (total, centrality, uniform, neighbour, kl).
+    cluster: None (gt / gv are the global tokens, autograd-tracked), or (launches, make_nodes) with gt = gv = None: `launches` a
+    generator that issues the token clustering launch by launch and returns (gt, gv) -- HeadLocalFn's forward drives it,
+    interleaved with the head's local branch -- and make_nodes() -> (gt, gv) creating the clustering's autograd nodes afterwards
+    (their forwards only wrap what has been computed; see modeling._compute_losses)."""
     if not SPLIT_HEAD_NODES:
         return HeadLossFn.apply(model, hp, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                                 text_feat, video_feat, gt, gv, logit_scale, *scorer_params, *g1_params)
     bridge = {}
+    if cluster is not None:
+        bridge["join"] = cluster[0]
     S, c0, c1, mean_t, mean_v = HeadLocalFn.apply(model, hp, bridge, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t,
                                                   mb_mask_v, gt, gv, logit_scale, None, text_feat, video_feat, *scorer_params)
+    if cluster is not None:
+        gt, gv = cluster[1]()
     return HeadGlobalFn.apply(hp, bridge, S, c0, c1, mean_t, mean_v, gt, gv, logit_scale, *g1_params)
 
 

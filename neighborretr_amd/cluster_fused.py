@@ -288,7 +288,7 @@ def ctm_stage_group(problems, cache, stepwise=False, want_assign=False, want_sav
                 hip.call("nr_ctm_stage_fwd_range", descs, len(problems), i, i + 1, hip.stream_ptr())
                 yield
             del alive                            # the tensors behind the descriptors stay alive until here
-        return outs, launches()
+        return (outs, launches(), saved) if want_saved else (outs, launches())
     if exchange is not None and any(t["mask"] is not None for t in keep):
         hip.call("nr_ctm_stage_fwd_range", descs, len(problems), 0, 3, hip.stream_ptr())
         exchange(smax)
@@ -355,11 +355,17 @@ class ClusterStagesFn(torch.autograd.Function):
     path -- spend ~37 forward and ~75 backward launches per stage and modality and keep every intermediate alive."""
 
     @staticmethod
-    def forward(ctx, modules, cache, keys, exchange, x_t, mask_t, noise_t, x_v, mask_v, noise_v, *params):
+    def forward(ctx, modules, cache, keys, exchange, pre, x_t, mask_t, noise_t, x_v, mask_v, noise_v, *params):
+        """pre: None, or ((out_t, out_v), saved) of a stage whose kernels have ALREADY been issued (ctm_stage_group(...,
+        stepwise=True, want_saved=True), driven launch by launch from the head's interleaved schedule): this call then only
+        creates the autograd node -- on the stream its backward is to run on."""
         (ctm_t, blk_t), (ctm_v, blk_v) = modules
-        (out_t, out_v), saved = ctm_stage_group([(keys[0], x_t, mask_t, ctm_t, blk_t, noise_t),
-                                                 (keys[1], x_v, mask_v, ctm_v, blk_v, noise_v)], cache, want_saved=True,
-                                                exchange=exchange)
+        if pre is not None:
+            (out_t, out_v), saved = pre
+        else:
+            (out_t, out_v), saved = ctm_stage_group([(keys[0], x_t, mask_t, ctm_t, blk_t, noise_t),
+                                                     (keys[1], x_v, mask_v, ctm_v, blk_v, noise_v)], cache, want_saved=True,
+                                                    exchange=exchange)
         ctx.modules = modules
         ctx.cache, ctx.keys = cache, keys
         ctx.masks = tuple(sv["mask"] for sv in saved)
@@ -370,9 +376,17 @@ class ClusterStagesFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_t, g_v):
         tensors = ctx.saved_tensors
-        if g_t.is_cuda:                      # produced on the head's stream, consumed on this node's (modeling._cluster_stream)
-            g_t.record_stream(torch.cuda.current_stream())
-            g_v.record_stream(torch.cuda.current_stream())
+        if g_t.is_cuda:
+            # The incoming gradients were produced on the head's stream, and -- when the forward's launches were driven from the
+            # head's schedule -- so was everything this node saved: tell the allocator that THIS stream reads them, or the blocks
+            # go back to the producing stream's free list the moment autograd drops them and are handed out again there while
+            # this stream's kernels still read them (the captured step replayed garbage gradients for exactly that reason).
+            cur = torch.cuda.current_stream()
+            g_t.record_stream(cur)
+            g_v.record_stream(cur)
+            for t_ in tensors:
+                if t_ is not None and t_.is_cuda:
+                    t_.record_stream(cur)
         grads_x, grads_p = [], {}
         saved = []
         for i, mask in enumerate(ctx.masks):
@@ -395,11 +409,11 @@ class ClusterStagesFn(torch.autograd.Function):
             for p_ in stage_params(ctm, blk):
                 ordered.append(grads_p.get(id(p_)) if p_.requires_grad else None)
         assert len(ordered) == ctx.n_params
-        return (None, None, None, None, grads_x[0], None, None, grads_x[1], None, None) + tuple(ordered)
+        return (None, None, None, None, None, grads_x[0], None, None, grads_x[1], None, None) + tuple(ordered)
 
 
-def cluster_stages_train(modules, cache, keys, x_t, mask_t, noise_t, x_v, mask_v, noise_v, exchange=None):
+def cluster_stages_train(modules, cache, keys, x_t, mask_t, noise_t, x_v, mask_v, noise_v, exchange=None, pre=None):
     """Differentiable grouped stage (ClusterStagesFn); the stage's parameters ride along as explicit inputs so that
-    autograd routes their gradients.  exchange: see ctm_stage_group (sample-sharded clustering)."""
+    autograd routes their gradients.  exchange: see ctm_stage_group (sample-sharded clustering); pre: see ClusterStagesFn."""
     params = [p for ctm, blk in modules for p in stage_params(ctm, blk)]
-    return ClusterStagesFn.apply(modules, cache, keys, exchange, x_t, mask_t, noise_t, x_v, mask_v, noise_v, *params)
+    return ClusterStagesFn.apply(modules, cache, keys, exchange, pre, x_t, mask_t, noise_t, x_v, mask_v, noise_v, *params)

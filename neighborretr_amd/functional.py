@@ -24,17 +24,17 @@ def _mlp_params(model, name):
 
 
 def head_losses(model, text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
-                gt, gv, hp, logit_scale):
+                gt, gv, hp, logit_scale, cluster=None):
     """Returns a [5] tensor (total, centrality, uniform, neighbour, kl)."""
     pt_params = _mlp_params(model, "text_weight_fc")
     pv_params = _mlp_params(model, "video_weight_fc")
     if not torch.is_tensor(logit_scale):
         logit_scale = torch.tensor(float(logit_scale), device=text_feat.device)
-    if gt is not None and _needs_grad(text_feat, video_feat, gt, gv, logit_scale, *pt_params, *pv_params):
+    if cluster is not None or (gt is not None and _needs_grad(text_feat, video_feat, gt, gv, logit_scale, *pt_params, *pv_params)):
         from .backward import head_loss_nodes
         return head_loss_nodes(model, hp, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                                text_feat, video_feat, gt, gv, logit_scale, (*pt_params, *pv_params),
-                               (*_mlp_params(model, "text_weight_fc1"), *_mlp_params(model, "video_weight_fc1")))
+                               (*_mlp_params(model, "text_weight_fc1"), *_mlp_params(model, "video_weight_fc1")), cluster=cluster)
     losses, _ = head.head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t,
                                   mb_mask_v, gt, gv, model.scorer_weights("text_weight_fc"),
                                   model.scorer_weights("video_weight_fc"), hp, logit_scale, model._prec(),

@@ -385,21 +385,25 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         pt.norm.record_stream(cur)
         pv.norm.record_stream(cur)
     else:
-        if local_stream is not None:
-            wait_stream(cur, local_stream)
-            for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi):
-                t_.record_stream(cur)
-        # The critical path after the join is global logits -> Sinkhorn -> row losses: captured FIRST.  What is left
-        # of the bank chains and the centrality weights feed only the row-loss kernel; with `bank_streams` they are
-        # forked from the join point (an event recorded before the Sinkhorn launch) and run beside the solve.
+        # The critical path after the join is global logits -> Sinkhorn -> row losses: captured FIRST.  The logits and the solve
+        # need the global tokens only, so this stream joins the local branch (whose tail, with the bank chains run early, is
+        # the last bank product) BEHIND the solve, not in front of it.  What is left of the bank chains and the centrality
+        # weights feed only the row-loss kernel; with `bank_streams` they are forked from the join point (an event recorded
+        # before the Sinkhorn launch) and run beside the solve.
         fork = None
         if bank_streams is not None:
             fork = record_event(cur)
         G, g_saved = global_logits(gt, gv, sw_t1, sw_v1, keep=True) if keep else (global_logits(gt, gv, sw_t1, sw_v1), None)
         tgt_r, tgt_c = ops.sinkhorn_targets(G, hp["beta"], 50)
+        if local_stream is not None:
+            wait_stream(cur, local_stream)
+            for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi):
+                t_.record_stream(cur)
         if bank_streams is not None:
             for st_ in bank_streams:
                 wait_event(st_, fork)
+                if local_stream is not None:
+                    wait_stream(st_, local_stream)       # (their launches read the local branch's tokens / weights / means)
             with torch.cuda.stream(bank_streams[1]):
                 pbt, w_bt, lg_bt, aux2, c0 = early[1] or bank_text()
             with torch.cuda.stream(bank_streams[0]):

@@ -106,6 +106,7 @@ class NeighborRetr(nn.Module):
         self._join_global = None
         self._cstream = None
         self.cluster_side_stream = True      # training step: clustering (forward + backward) on its own stream, see _compute_losses
+        self.interleave_training_forward = True   # ... its forward launches interleaved with the head's local branch
         # side streams inside the step (and inside its capture).  With ONE hardware queue (GPU_MAX_HW_QUEUES=1) any capture
         # that forks a stream segfaults in the ROCm 7.2 runtime (tools/capture_one_queue.py: plain torch ops): one stream then
         self.use_side_streams = os.environ.get("GPU_MAX_HW_QUEUES", "") != "1"
@@ -440,6 +441,40 @@ class NeighborRetr(nn.Module):
                 return cluster_stages_train(((self.text_ctm1, self.text_block1), (self.video_ctm1, self.video_block1)),
                                             self._ctm_cache, ("text1", "video1"), t, None, nz.get("t1"), v, None, nz.get("v1"))
             side = self._cluster_stream(text_feat.device)
+            from . import backward as _bw
+            if (side is not None and self.interleave_training_forward and _bw.SPLIT_HEAD_NODES
+                    and self._local_stream(text_feat.device) is not None):
+                # The training forward on the loss-only step's schedule: the clustering's launches are set up here (nothing is
+                # issued yet) and driven one by one by the head, interleaved in capture order with its local branch and the
+                # bank chains (459 -> ~340 us for the forward of the captured step: a branch captured behind all of the
+                # clustering started ~200 us late).  The clustering's autograd nodes are created afterwards, on the stream
+                # their backward is to run on; their forwards only wrap the stages' outputs and saved intermediates.
+                from .cluster_fused import ctm_stage_group
+                build_stage_weights(self._ctm_cache, [("text0", self.text_ctm0, self.text_block0), ("video0", self.video_ctm0, self.video_block0),
+                                                      ("text1", self.text_ctm1, self.text_block1), ("video1", self.video_ctm1, self.video_block1)])
+                mods0 = ((self.text_ctm0, self.text_block0), (self.video_ctm0, self.video_block0))
+                mods1 = ((self.text_ctm1, self.text_block1), (self.video_ctm1, self.video_block1))
+                o0, g0, sv0 = ctm_stage_group([("text0", text_feat, text_mask, *mods0[0], nz.get("t0")),
+                                               ("video0", video_feat, video_mask, *mods0[1], nz.get("v0"))], self._ctm_cache,
+                                              stepwise=True, want_saved=True)
+                o1, g1, sv1 = ctm_stage_group([("text1", o0[0], None, *mods1[0], nz.get("t1")),
+                                               ("video1", o0[1], None, *mods1[1], nz.get("v1"))], self._ctm_cache,
+                                              stepwise=True, want_saved=True)
+
+                def launches():
+                    yield from g0
+                    yield from g1
+                    return o1[0], o1[1]
+
+                def make_nodes():
+                    with torch.cuda.stream(side):
+                        t, v = cluster_stages_train(mods0, self._ctm_cache, ("text0", "video0"), text_feat, text_mask, nz.get("t0"),
+                                                    video_feat, video_mask, nz.get("v0"), pre=((o0[0], o0[1]), sv0))
+                        return cluster_stages_train(mods1, self._ctm_cache, ("text1", "video1"), t, None, nz.get("t1"), v, None,
+                                                    nz.get("v1"), pre=((o1[0], o1[1]), sv1))
+                losses = head_losses(self, text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
+                                     None, None, hp, logit_scale, cluster=(launches(), make_nodes))
+                return losses[0], losses[1], losses[2], losses[3], losses[4]
             if side is None:
                 gt, gv = stages()
             else:
