@@ -416,7 +416,7 @@ class HeadLocalFn(torch.autograd.Function):
             # the clustering is issued launch by launch on THIS stream, interleaved (in capture order) with the local branch and
             # the early bank chains on the local stream -- the loss-only step's schedule (head.head_forward)
             extra = dict(join=stepwise, local_stream=model._local_stream(text_feat.device), bank_early=model.bank_early,
-                         capture_order=model.capture_order)
+                         capture_order=getattr(model, "train_capture_order", None) or model.capture_order)
             gt_in = gv_in = None
         else:
             extra = dict(join=model._take_join())
