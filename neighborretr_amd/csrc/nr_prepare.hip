@@ -5,7 +5,10 @@
 #include "nr_common.h"
 #include "../../include/nr_hip.h"
 
-#define NR_PREP_MAX_PARTS 64     // column-sum partials (kept few: their consumer reduces them serially)
+#ifndef NR_PREP_MAX_PARTS
+#define NR_PREP_MAX_PARTS 256    // column-sum partials = workgroups of a launch that wants them: 16 tokens each up to this many (64 left a
+                                 // 3072-token set with 12 dependent row round trips per wave: 14 us; 256: 4)
+#endif
 #define NR_PREP_MAX_GRID 2048
 #define NR_PREP_MAX_CHUNKS 4   // d <= 1024
 

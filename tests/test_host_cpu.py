@@ -55,7 +55,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert declared == set(hip.exported_symbols()), declared ^ set(hip.exported_symbols())
     assert lib.nr_version() == 1
-    assert lib.nr_prepare_parts(10) == 1 and lib.nr_prepare_parts(10 ** 6) == 64
+    assert lib.nr_prepare_parts(10) == 1 and lib.nr_prepare_parts(3072) == 192 and lib.nr_prepare_parts(10 ** 6) == 256
 
 
 def test_descriptor_structs_have_the_layout_the_library_was_built_with():
