@@ -100,6 +100,47 @@ def test_similarity_backward_planning_no_gpu_needed():
     assert int(lib.nr_local_level_bwd_group_workspace_bytes(4, items)) == 0
 
 
+def test_round3_entry_points_refuse_bad_arguments_before_any_launch():
+    """Argument checks of the grouped backward entry points return NR_EINVAL / NR_EUNSUPPORTED on the host (no GPU needed)."""
+    lib = hip.lib()
+    EINVAL, EUNSUP = -1, -2
+    buf = ctypes.create_string_buffer(4096)
+    ptr = ctypes.addressof(buf)
+    assert lib.nr_local_level_bwd_group(0, None, None, 0, None) == EINVAL
+    assert lib.nr_local_level_bwd_group(5, (hip.SimBwdItem * 5)(), ptr, 4096, None) == EINVAL        # > 4 products
+    assert lib.nr_pool_weight_bwd_group(0, None, None) == EINVAL
+    job = (hip.PoolWJob * 1)()
+    job[0].d_w, job[0].n_src, job[0].N = ptr, 3, 12                                                   # > 2 sources
+    assert lib.nr_pool_weight_bwd_group(1, job, None) == EINVAL
+    ss = (hip.SlabSum * 1)()
+    ss[0].out, ss[0].n, ss[0].n_src = ptr, 6, 1                                                       # n % 4 != 0
+    ss[0].part[0], ss[0].n_slabs[0] = ptr, 1
+    assert lib.nr_slab_sum_group(1, ss, None) == EINVAL
+    op = (hip.SimBwdOperand * 1)()
+    op[0].hi, op[0].out_hi, op[0].n_tok, op[0].d = ptr, ptr, 96, 96                                   # d % 64 != 0
+    assert lib.nr_sim_bwd_operand_group(1, op, None) == EINVAL
+    it = (hip.SplitItem * 1)()
+    it[0].src, it[0].hi, it[0].rows, it[0].cols, it[0].ld = ptr, ptr, 8, 8, 8
+    it[0].mode = 7
+    assert lib.nr_split_group(1, it, None) == EINVAL                                                  # unknown mode
+    it[0].mode, it[0].group = 3, 0
+    assert lib.nr_split_group(1, it, None) == EINVAL                                                  # mode 3 without a sample size
+    lp = (hip.LinearProblem * 2)()
+    for k in range(2):
+        lp[k].x_hi, lp[k].w_hi, lp[k].out, lp[k].M, lp[k].N, lp[k].K = ptr, ptr, ptr, 64, 64, 64
+    lp[0].x_lo, lp[0].w_lo = ptr, ptr                                                                 # one problem split-bf16, one one-pass
+    assert lib.nr_linear_group(2, lp, None) == EINVAL
+    lp[1].x_lo, lp[1].w_lo = ptr, ptr
+    lp[1].ld = 32                                                                                     # row pitch below K
+    assert lib.nr_linear_group(2, lp, None) == EINVAL
+    assert lib.nr_rowloss_coef(ptr, None, None, None, None, 1.0, 1.0, 1.0, 0, ptr, None) == EINVAL    # B = 0
+    assert lib.nr_token_mlp_bwd_hidden(ptr, ptr, ptr, 128, 512, ptr, ptr, ptr, ptr, 1024, hip.PREC_BF16X3, ptr, ptr, ptr, 256, 4, None,
+                                       None, ptr, ptr, ptr, None) == EUNSUP                          # t0 not a multiple of 8
+    assert lib.nr_token_mlp_bwd_part_rows(12288, 1024, hip.PREC_BF16, 1) == 2 * 64                    # 192-row blocks
+    assert lib.nr_token_mlp_bwd_part_rows(12288, 1024, hip.PREC_BF16, 0) == 2 * 96                    # 128-row blocks
+    assert lib.nr_token_mlp_bwd_part_rows(3072, 1024, hip.PREC_BF16X3, 0) == 2 * 24
+
+
 def test_k_slicing_of_a_weight_gradient():
     from neighborretr_amd.backward import _apportion
     assert _apportion([3072, 1536], 8) == [5, 3]
