@@ -57,6 +57,13 @@ def parse():
                     help="N>1: the reference's form instead (modeling.py:274-298): after the all-gather every rank evaluates the whole "
                          "loss; the exchange step stays eager, the loss is replayed from a HIP graph")
     ap.add_argument("--backward", action="store_true", help="also time forward+backward (reported as extra fields)")
+    ap.add_argument("--emulate_world", type=int, nargs="*", default=None, metavar="W",
+                    help="N=1 only, extra field `rank_local` (never the headline): what ONE rank of the sharded step does at these world "
+                         "sizes (default 2 4 8), emulated on this GPU -- its own messages through a 1-rank RCCL communicator, the peers' "
+                         "parts pre-filled (tools/rank_local_times.py; no wire time)")
+    ap.add_argument("--fail_whole_capture", action="store_true",
+                    help="rehearsal switch: rank 0 pretends its whole-step capture failed, so that every rank takes the segmented-graph "
+                         "form together (tests the collective fallback decision)")
     ap.add_argument("--e2e", action="store_true",
                     help="also time BASELINE configs[4] on this GPU: ViT-B/32 towers + temporal transformer (stock PyTorch-ROCm, "
                          "random init, bf16 autocast) feeding the HIP head from synthetic pixels, forward and forward+backward "
@@ -340,14 +347,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- HIP-graph capture.  N = 1: the whole step.  N > 1, sharded loss (default): the whole step INCLUDING its collectives
-    # (packed all-gather, the clustering's max exchange, the gathers of global tokens / centralities, the row-term all-reduce) as
-    # ONE graph -- RCCL collectives capture and replay on this runtime (tools/rccl_capture_probe.py); the replay is checked
-    # against the eager step before it is trusted, anything else falls back to eager launches.  N > 1, --replicated_loss: the
-    # exchange step eager into static buffers, the loss replayed from a graph (round 2's form).
+    # ---- HIP-graph capture.  N = 1: the whole step.  N > 1, sharded loss (default): in order of preference
+    #   "whole"      the whole step INCLUDING its collectives (packed all-gather, the clustering's max exchange, the gathers of
+    #                global tokens / centralities, the row-term all-reduce) as ONE graph -- RCCL collectives capture and replay on
+    #                this runtime (tools/rccl_capture_probe.py); trusted only after a replay has reproduced the eager step;
+    #   "segmented"  the rank-local segments between the collectives as graphs, the collectives eager between their replays
+    #                (comm.SegmentedStep): 6 replays + 5 collectives instead of ~60 eager launches;
+    #   "eager".
+    # Every decision is COLLECTIVE: a rank records its own verdict and never leaves the common sequence of collectives on its
+    # own -- the ranks agree (MIN over a gloo side group with a short timeout) after each capture and after each validation,
+    # and all keep a form or all drop to the next one.  N > 1, --replicated_loss: the exchange step eager into static buffers,
+    # the loss replayed from a graph (round 2's form).
     graph = None
     static = None
-    whole_step_graph = world == 1 or (sharded and args.backend == "nccl")
+    step_form, n_segments = "eager", 0
+    whole_step_graph = world == 1
     if world > 1 and not sharded:
         from neighborretr_amd.dist import packed_allgather
 
@@ -378,37 +392,97 @@ def main():
         abi_calls = hip.N_CALLS - before
     elif world > 1:
         step()
-    # with collectives inside the capture other threads of the process (the process group's watchdog) may touch the runtime
-    # while this thread captures: thread-local capture mode keeps their calls out of the capture's error checking
-    cap_kw = {"capture_error_mode": "thread_local"} if world > 1 else {}
-    if not args.no_graph and (whole_step_graph or not sharded):
-        try:
-            if world > 1 and whole_step_graph:
-                # trust the captured collectives only after a replay has reproduced the eager step (frozen bank: same inputs)
-                model.bank_frozen = True
+    run = step
+    if world > 1 and sharded and not args.no_graph:
+        import datetime
+        from neighborretr_amd import comm
+        hs = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
+
+        def agree(ok):
+            """True iff EVERY rank says ok (a host-side collective on its own gloo group: it does not depend on the state of
+            the RCCL stream, and a rank that died is noticed after two minutes, not ten)."""
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=hs)
+            return bool(int(t.item()))
+
+        def attempt(make, what):
+            """make() -> (replay, keep-alive) captures a replayable form of `step`.  Captured with the bank frozen first and
+            replayed once against the eager step; then captured again for the timed run.  -> replay or None, on every rank alike."""
+            model.bank_frozen = True
+            try:
                 step()
-                eager = result["losses"].clone()
-                gv_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gv_, **cap_kw):
-                    step()
-                gv_.replay()
                 torch.cuda.synchronize()
-                ok = torch.tensor([float(torch.allclose(result["losses"], eager, rtol=1e-5, atol=1e-6))], device=dev)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                eager = result["losses"].clone()
+                form, err = None, None
+                try:
+                    form = make()
+                except Exception as e:      # noqa: BLE001 -- a failed capture is a verdict, not an error
+                    err = f"{type(e).__name__}: {e}"
+                    torch.cuda.synchronize()
+                if not agree(form is not None):
+                    if err:
+                        print(f"[bench] rank {rank}: {what} capture unavailable ({err})", file=sys.stderr)
+                    return None
+                form[0]()                    # every rank replays: the collectives inside / between the graphs match up
+                torch.cuda.synchronize()
+                same = bool(torch.allclose(result["losses"], eager, rtol=1e-5, atol=1e-6))
+                if not agree(same):
+                    if not same:
+                        print(f"[bench] rank {rank}: replayed {what} step differs from the eager one: {result['losses'].tolist()} vs "
+                              f"{eager.tolist()}", file=sys.stderr)
+                    return None
+            finally:
                 model.bank_frozen = False
-                if float(ok.item()) != 1.0:
-                    raise RuntimeError(f"replayed sharded step differs from the eager one: {result['losses'].tolist()} vs {eager.tolist()}")
-                del gv_
+            form = None
+            try:
+                form = make()
+            except Exception as e:          # noqa: BLE001
+                print(f"[bench] rank {rank}: {what} capture (timed form) failed ({type(e).__name__}: {e})", file=sys.stderr)
+                torch.cuda.synchronize()
+            return form if agree(form is not None) else None
+
+        def make_whole():
+            if args.fail_whole_capture:          # rehearsal: rank 0 "fails", the others "succeed" -- all must end up segmented
+                if rank == 0:
+                    raise RuntimeError("--fail_whole_capture")
+                return (lambda: None), None
+            # with collectives inside the capture other threads of the process (the process group's watchdog) may touch the
+            # runtime while this thread captures: thread-local capture mode keeps their calls out of its error checking
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, **cap_kw):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                step()
+            return g.replay, g
+
+        def make_segmented():
+            seg = comm.SegmentedStep(step).capture()
+            return seg.replay, seg
+        form = attempt(make_whole, "whole-step") if (args.backend == "nccl" or args.fail_whole_capture) else None
+        if form is not None:
+            step_form, graph = "whole", form[1]
+        else:
+            model.use_side_streams = False          # a side stream cannot stay forked across a cut between two segments
+            for _ in range(2):
+                step()
+            form = attempt(make_segmented, "segmented")
+            if form is not None:
+                step_form, graph, n_segments = "segmented", form[1], form[1].n_segments
+            else:
+                model.use_side_streams = True
+        if form is not None:
+            run = form[0]
+    elif not args.no_graph:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
                 (step if whole_step_graph else after_gather)()
             graph = g
+            step_form = "whole" if whole_step_graph else "exchange eager + loss graph"
+            if whole_step_graph:
+                run = g.replay
         except Exception as e:          # graphs are an optimisation, never a requirement
             print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
-            model.bank_frozen = False
             torch.cuda.synchronize()
-    run = graph.replay if (graph is not None and whole_step_graph) else step
 
     # Clock ramp: the first ~0.1 s of back-to-back steps after an idle period run 10 % slower than the steady state (measured:
     # 0.361 ms/step for the first 200 steps after a 20-step warm-up, 0.324 for every later 200) -- the chip has to leave its
@@ -498,6 +572,21 @@ def main():
 
     if args.e2e and world == 1:
         extra["e2e"] = e2e_bench(dev)
+
+    if args.emulate_world is not None and world == 1:
+        # what one rank of the sharded step would do at W ranks, on this GPU (extra field; tools/rank_local_times.py)
+        from tools import rank_local_times as RL
+        RL.init_one_rank_group()
+        keep = (model.config.world_size, model.config.local_rank, model.shard_loss)
+        lines_ = []
+        full_dev = {k: torch.from_numpy(v).to(dev) for k, v in full.items()}
+        try:
+            extra["rank_local"] = {"what": "rank 0 of the sharded loss-only step at W ranks, emulated on one GPU: its own messages through a "
+                                           "1-rank RCCL communicator, the peers' parts pre-filled; no wire time (tools/rank_local_times.py)",
+                                   "per_world": [RL.measure(model, full_dev, W, 0, dev, lines_) for W in (args.emulate_world or [2, 4, 8])]}
+        finally:
+            model.config.world_size, model.config.local_rank, model.shard_loss = keep
+        dist.destroy_process_group()
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------------
     roofline = None
@@ -594,7 +683,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: B=128 d=512 Nt=24 Nv=12 M=512 K=20 (MSR-VTT shape), "
                                    "loss-only forward incl. token clustering and bank push",
                        "global_batch": c["B"], "per_rank_batch": b, "precision_plan": args.precision,
-                       "hip_graph": graph is not None, "parallelism": f"dp{world} (packed all-gather + " + (("loss, bank and clustering work sharded over the ranks; " + ("every collective inside the one HIP graph" if graph is not None else "launched eagerly") + ")") if sharded else "replicated loss; exchange step eager, loss from a HIP graph)"),
+                       "hip_graph": graph is not None, "step_form": step_form, "graph_segments": n_segments,
+                       "parallelism": f"dp{world} (packed all-gather + " + (("loss, bank and clustering work sharded over the ranks; " + {"whole": "every collective inside the one HIP graph", "segmented": f"{n_segments} rank-local segments as HIP graphs, the collectives eager between them", "eager": "launched eagerly"}[step_form] + ")") if sharded else "replicated loss; exchange step eager, loss from a HIP graph)"),
                        "memory_bank": "ring (device head) + persistent prepared bf16 shadow, extended by the batch rows at every push"},
             "losses": [round(float(x), 5) for x in losses],
             "ms_per_step_min": round(min(rep_ms), 4), "ms_per_step_median": round(float(np.median(rep_ms)), 4),

@@ -19,6 +19,8 @@ reduction.
 import torch
 import torch.distributed as dist
 
+from . import comm
+
 
 def _world(args):
     return int(getattr(args, "world_size", 1))
@@ -31,8 +33,8 @@ class PackedAllGather(torch.autograd.Function):
         b = text_feat.shape[0]
         ctx.rank, ctx.b, ctx.W = int(getattr(args, "local_rank", 0)), b, W
         ctx.sharded = bool(getattr(args, "shard_loss", False))
-        if dist.is_initialized():
-            ctx.rank = dist.get_rank()
+        if dist.is_initialized() or comm.backend() == "emulated":
+            ctx.rank = comm.get_rank()
         if W == 1:
             return text_feat.view_as(text_feat), video_feat.view_as(video_feat), idx, text_mask, video_mask
         dev = text_feat.device
@@ -52,7 +54,7 @@ class PackedAllGather(torch.autograd.Function):
             # supplied static destinations (a captured graph reads them), the masks already as fp32 multipliers
             from . import ops
             ops.pack_shard(pieces, send, offs)
-            dist.all_gather_into_tensor(recv, send)
+            comm.all_gather_into_tensor(recv, send)
             out = getattr(args, "_gather_out", None)
             if out is None:
                 out = (torch.empty((W * b,) + tuple(tf.shape[1:]), dtype=torch.float32, device=dev),
@@ -67,7 +69,7 @@ class PackedAllGather(torch.autograd.Function):
         parts = [p.view(-1).view(torch.uint8) for p in pieces]
         for p, n, o in zip(parts, sizes, offs):
             send[o:o + n] = p
-        dist.all_gather_into_tensor(recv, send)
+        comm.all_gather_into_tensor(recv, send)
         recv = recv.view(W, total)
 
         def take(k, dtype, shape):
@@ -93,13 +95,13 @@ class PackedAllGather(torch.autograd.Function):
         outs = []
         for g in (g_tf, g_vf):
             g = g.contiguous()
-            if dist.get_backend() == "gloo":
+            if comm.backend() == "gloo":
                 g = g.clone()
-                dist.all_reduce(g)
+                comm.all_reduce(g)
                 outs.append(g[sl] / ctx.W)
             else:
                 o = torch.empty((ctx.b,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-                dist.reduce_scatter_tensor(o, g)
+                comm.reduce_scatter_tensor(o, g)
                 outs.append(o / ctx.W)
         return outs[0], outs[1], None, None, None, None
 

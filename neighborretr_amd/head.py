@@ -452,7 +452,7 @@ def head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t
     every rank enqueues the same sequence whatever its streams do.  No host synchronisation anywhere: with the "nccl"
     backend (RCCL) the whole sharded step captures into ONE HIP graph (tools/rccl_capture_probe.py,
     profiles/r03_rccl_capture.txt)."""
-    import torch.distributed as dist
+    from . import comm
     B, Nt, d = text_feat.shape
     Nv = video_feat.shape[1]
     M = mb_feat_v.shape[0]
@@ -518,11 +518,11 @@ def head_forward_sharded(text_feat, video_feat, text_mask, video_mask, mb_feat_t
             t_.record_stream(cur)
     mine = L["mine"]
     everyone = torch.empty((world, 2, b), dtype=torch.float32, device=mine.device)
-    dist.all_gather_into_tensor(everyone.view(-1), mine.view(-1))
+    comm.all_gather_into_tensor(everyone.view(-1), mine.view(-1))
     c0 = everyone[:, 0, :].reshape(B).contiguous()
     c1 = everyone[:, 1, :].reshape(B).contiguous()
     wc_t, wc_v, _ = ops.centrality_weights_pair(gt2, gv2, L["mean_t"], L["mean_v"], hp["centrality_scale"], False)
     ls = logit_scale.detach().float().reshape(1).contiguous()
     rowloss = ops.row_losses_slab(L["S_rows"], L["S_cols"], r0, G, tgt_r, tgt_c, c0, c1, wc_t, wc_v, ls, K, hp["temperature"])
-    dist.all_reduce(rowloss)                       # every row was written by exactly one rank, zeros elsewhere
+    comm.all_reduce(rowloss)                       # every row was written by exactly one rank, zeros elsewhere
     return ops.loss_finalize(rowloss, hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])

@@ -319,6 +319,8 @@ class NeighborRetr(nn.Module):
             return None
         world = int(getattr(self.config, "world_size", 1))
         if world > 1:
+            from . import comm
+            comm.begin_step()
             # the reference's 5 all_gathers + barrier (modeling.py:274-280) as one packed collective.  Its backward depends
             # on how the loss is evaluated (replicated: slice; sharded: reduce-scatter), decided before the gather
             self.config.shard_loss = self._shard_now(world, text_feat, gathered_rows=text_feat.shape[0] * world,
@@ -387,20 +389,20 @@ class NeighborRetr(nn.Module):
         shard_now = self._shard_now(world, text_feat, video_tokens=video_feat.shape[1])
         if shard_now and torch.is_grad_enabled():
             # training step with the loss sharded over the ranks (neighborretr_amd.sharded)
-            import torch.distributed as dist
+            from . import comm
             from .sharded import sharded_training_losses
             losses = sharded_training_losses(self, text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v,
-                                             mb_mask_t, mb_mask_v, hp, logit_scale, dist.get_rank(), world, noise)
+                                             mb_mask_t, mb_mask_v, hp, logit_scale, comm.get_rank(), world, noise)
             return losses[0], losses[1], losses[2], losses[3], losses[4]
         if (shard_now and not torch.is_grad_enabled()
                 and self._can_fuse_clustering(text_feat, mods) and self._can_fuse_clustering(video_feat, mods)):
-            import torch.distributed as dist
+            from . import comm
             # The clustering is sharded by samples too: every rank clusters ITS b samples and the [b, c, d] global tokens are
             # all-gathered.  Its masked stage fills distances with the maximum over the WHOLE gathered batch
             # (cluster.py:473-475, `dist_matrix.max()`), so the ranks exchange that maximum (one all-reduce of two floats)
             # between the stage's front and back kernels -- without it the densities of samples with fewer than k valid
             # tokens would differ from the replicated result.
-            rank_ = dist.get_rank()
+            rank_ = comm.get_rank()
             if self.shard_clustering:
                 def join():
                     return self._gather_global(*self._merge_sharded(text_feat, video_feat, text_mask, video_mask, nz, rank_, world), world)
@@ -593,7 +595,7 @@ class NeighborRetr(nn.Module):
         """Both clustering stages on THIS rank's samples of the gathered batch (rows [rank b, (rank+1) b)) -> the rank's
         global tokens (gt [b,c,d], gv [b,c,d]); differentiable when gradients are enabled (ClusterStagesFn).  The noise rows
         are the rank's rows of the batch-wide draw, so the result equals the rank's rows of the replicated clustering."""
-        import torch.distributed as dist
+        from . import comm
         from .cluster_fused import cluster_stages_train, ctm_stage_group
         b = text_feat.shape[0] // world
         rows = slice(rank * b, (rank + 1) * b)
@@ -603,7 +605,7 @@ class NeighborRetr(nn.Module):
 
         def exchange(smax):
             g = torch.stack([s_.max() for s_ in smax])
-            dist.all_reduce(g, op=dist.ReduceOp.MAX)
+            comm.all_reduce(g, op="max")
             for s_, v in zip(smax, g):
                 s_[:1] = v
         mods0 = ((self.text_ctm0, self.text_block0), (self.video_ctm0, self.video_block0))
@@ -622,17 +624,17 @@ class NeighborRetr(nn.Module):
     @staticmethod
     def _gather_global(gt, gv, world):
         """The ranks' global tokens (equal shapes for text and video: [b,c,d]) in ONE all-gather -> ([B,c,d], [B,c,d])."""
-        import torch.distributed as dist
+        from . import comm
         if gt.shape != gv.shape:
             out = []
             for g in (gt, gv):
                 full = torch.empty((world,) + tuple(g.shape), dtype=g.dtype, device=g.device)
-                dist.all_gather_into_tensor(full.view(-1), g.contiguous().view(-1))
+                comm.all_gather_into_tensor(full.view(-1), g.contiguous().view(-1))
                 out.append(full.flatten(0, 1))
             return tuple(out)
         pair = torch.stack((gt, gv)).contiguous()                                  # [2,b,c,d]
         full = torch.empty((world,) + tuple(pair.shape), dtype=pair.dtype, device=pair.device)
-        dist.all_gather_into_tensor(full.view(-1), pair.view(-1))
+        comm.all_gather_into_tensor(full.view(-1), pair.view(-1))
         return full[:, 0].flatten(0, 1), full[:, 1].flatten(0, 1)
 
     def _merge_one(self, which, feat, mask, noise0=None, noise1=None):

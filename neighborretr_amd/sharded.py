@@ -25,9 +25,8 @@ the reference's effective gradient; the exchange step's backward then AVERAGES t
 Returned values are the FULL losses on every rank (one all-reduce of five numbers), with the partial gradient attached.
 """
 import torch
-import torch.distributed as dist
 
-from . import ops
+from . import comm, ops
 from .functional import local_level_sim
 
 NEG_BIG = -9e15
@@ -41,18 +40,18 @@ class _GatherCat(torch.autograd.Function):
         ctx.rank, ctx.world, ctx.n = rank, world, x.shape[0]
         x = x.contiguous()
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x)
+        comm.all_gather_into_tensor(out, x)
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        if dist.get_backend() == "gloo":                      # no reduce_scatter in gloo
+        if comm.backend() == "gloo":                          # no reduce_scatter in gloo
             g = g.clone()
-            dist.all_reduce(g)
+            comm.all_reduce(g)
             return g[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n], None, None
         out = torch.empty((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-        dist.reduce_scatter_tensor(out, g)
+        comm.reduce_scatter_tensor(out, g)
         return out, None, None
 
 
@@ -62,13 +61,13 @@ class _AllReduceSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         y = x.clone()
-        dist.all_reduce(y)
+        comm.all_reduce(y)
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = g.clone()
-        dist.all_reduce(g)
+        comm.all_reduce(g)
         return g
 
 
@@ -208,6 +207,6 @@ def sharded_training_losses(model, text_feat, video_feat, text_mask, video_mask,
     wv_full = torch.zeros((B,), dtype=torch.float32, device=text_feat.device).index_add(0, torch.arange(r0, r0 + b, device=text_feat.device), w_video)
     part = SlabRowLossFn.apply(S_rows, S_cols, G, tgt_r, tgt_c, c0, c1, wt_full, wv_full, logit_scale.reshape(1).float(), hp, r0)
     full = part.detach().clone()
-    dist.all_reduce(full)                                                              # the reference's (full) values
+    comm.all_reduce(full)                                                              # the reference's (full) values
     # value: full;  gradient: W x this rank's share (DDP's mean over ranks then yields the full-loss gradient)
     return full + (_ScaleGrad.apply(part, float(world)) - part.detach())

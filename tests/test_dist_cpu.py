@@ -140,3 +140,89 @@ def test_eval_gather_with_a_test_set_not_divisible_by_the_rank_count():
         for p in procs:
             p.join(timeout=60)
         assert all(r[1] == "ok" for r in res), res
+
+
+def _toy_step(x, rank, world):
+    """A step with the collective pattern of the sharded loss: gather -> max exchange -> compute -> sum of row terms -> the
+    differentiable gather's reduce-scatter form."""
+    from neighborretr_amd import comm
+    comm.begin_step()
+    n = x.shape[0]
+    full = torch.empty((world * n,) + tuple(x.shape[1:]))
+    comm.all_gather_into_tensor(full, x)
+    m = full[rank * n:(rank + 1) * n].abs().max().reshape(1)
+    comm.all_reduce(m, op="max")
+    rows = torch.zeros(world * n)
+    rows[rank * n:(rank + 1) * n] = (full[rank * n:(rank + 1) * n] @ full.sum(0)) / m
+    comm.all_reduce(rows)
+    part = full * (rank + 1.0)
+    mine = torch.empty_like(x)
+    if comm.backend() == "gloo":
+        part = part.clone()
+        comm.all_reduce(part)
+        mine = part[rank * n:(rank + 1) * n].clone()
+    else:
+        comm.reduce_scatter_tensor(mine, part)
+    return rows, mine
+
+
+def _toy_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = torch.randn(3, 4, generator=torch.Generator().manual_seed(7 + rank))
+        rows, mine = _toy_step(x, rank, world)
+        q.put((rank, rows.numpy(), mine.numpy()))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_emulated_world_matches_a_real_two_rank_job():
+    """comm.EmulatedWorld (how the per-rank step at W = 2 / 4 / 8 is measured on one GPU): the ranks of a job run one at a time,
+    the peers' parts of every collective come from settled buffers -- same results as the same step on two real gloo ranks;
+    a step whose ranks disagree about the kind of a collective is refused."""
+    import numpy as np
+    import pytest
+    from neighborretr_amd import comm
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_toy_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    real = {r: (a, b) for r, a, b in (q.get(timeout=180) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+    assert all(not isinstance(v[0], str) for v in real.values()), real
+    ew = comm.EmulatedWorld(world, real_collectives=False)
+    got = {}
+
+    def run(r):
+        x = torch.randn(3, 4, generator=torch.Generator().manual_seed(7 + r))
+        with comm.use(ew.comm(r)):
+            assert comm.get_rank() == r and comm.get_world_size() == world and comm.backend() == "emulated"
+            got[r] = _toy_step(x, r, world)
+    sweeps = ew.settle(run)
+    assert 2 <= sweeps <= 5 and not ew.recording
+    run(0), run(1)                              # frozen form: the peers' parts are read, nothing is recorded
+    for r in range(world):
+        np.testing.assert_allclose(got[r][0].numpy(), real[r][0], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(got[r][1].numpy(), real[r][1], rtol=1e-5, atol=1e-6)
+    assert comm.get_world_size() == 1 and comm.backend() == "none"        # outside the block: torch.distributed (not initialised here)
+
+    bad = comm.EmulatedWorld(2, real_collectives=False)
+
+    def diverging(r):
+        with comm.use(bad.comm(r)):
+            comm.begin_step()
+            t = torch.ones(2)
+            if r == 0:
+                comm.all_reduce(t)
+            else:
+                comm.all_gather_into_tensor(torch.empty(4), t)
+    with pytest.raises(RuntimeError, match="collective sequences differ"):
+        bad.settle(diverging)

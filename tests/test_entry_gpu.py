@@ -130,7 +130,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     GPU call and relays rank 0's JSON line.  gloo backend: the two ranks share this box's one GPU (RCCL needs a GPU each)."""
     import json
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "2",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--fail_whole_capture"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -139,3 +139,9 @@ def test_bench_launches_its_own_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["config"]["per_rank_batch"] == 64
     assert d["parity"]["pass"] and d["roofline"]["frac"] > 0.1
+    # N > 1 never runs the ~60 eager launches of round 3 (4.2 ms / step on two gloo ranks): rank 0's whole-step capture "fails"
+    # (--fail_whole_capture), the ranks agree, and ALL of them take the segmented form -- the rank-local segments between the
+    # five collectives replayed as HIP graphs (validated against the eager step inside bench.py before it is timed)
+    assert d["config"]["step_form"] == "segmented" and d["config"]["graph_segments"] == 6, d["config"]
+    assert "whole-step capture unavailable (RuntimeError: --fail_whole_capture)" in r.stderr
+    assert d["ms_per_step"] < 2.0, d["ms_per_step"]

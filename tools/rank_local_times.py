@@ -1,0 +1,280 @@
+#!/usr/bin/env python
+"""What ONE rank of the sharded loss-only step does at W = 2 / 4 / 8, measured on the one GPU of a box.
+
+    python tools/rank_local_times.py [--worlds 2 4 8] [--rank 0] [--B 128 --M 512 --K 20] [--out profiles/r04_rank_local.txt]
+
+The W-rank job is emulated (neighborretr_amd.comm.EmulatedWorld): rank r runs exactly the code of `bench.py --gpus W` --
+`NeighborRetr.forward` with config.world_size = W: packed exchange step, the rank's share of the clustering with the batch-wide
+maximum exchanged inside, gather of the global tokens, logits, Sinkhorn, the rank's 2/W of the batch x batch product and 1/W of
+both bank products, centrality gather, slab row losses, row-term all-reduce, bank push -- on b = B/W samples; every collective
+moves THIS rank's real message through a 1-rank RCCL communicator and finds the peers' parts in pre-filled buffers (one device
+copy per gather stands in for their writes).  So launch count, kernel sizes and message sizes are the W-rank job's; the
+peers' wire time (xGMI) is NOT in these numbers.  Before anything is timed, every emulated rank's losses are checked against
+the replicated single-rank step on the same gathered batch.
+
+Timed per W (HIP-graph replays, un-profiled): the whole step as ONE graph (collectives inside), the same step on ONE stream
+(= the sum of its kernels' time), the step as SEGMENTED graphs (comm.SegmentedStep: the fallback when a whole-step capture is
+refused), the eager step, and the pieces of the critical chain.  (modeling.py:274-298, until_module.py:367-412.)
+"""
+import argparse
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neighborretr_amd import comm, hip, modeling, synth  # noqa: E402
+
+CFG = dict(B=128, Nt=24, Nv=12, M=512, K=20)
+
+
+def init_one_rank_group(backend="nccl"):
+    if dist.is_initialized():
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.init_process_group(backend, rank=0, world_size=1)
+
+
+def replay_time(replay, reps=200, repeats=3):
+    """us per replay: `reps` back-to-back replays between two events, best and median of `repeats`."""
+    for _ in range(10):
+        replay()
+    ts = []
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / reps)
+    return float(np.median(ts))
+
+
+def capture(fn, warm=3):
+    """-> (graph, what fn returned inside the capture)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        res = fn()
+    return g, res
+
+
+class RankLocal:
+    """The emulated W-rank job around one model: settle(), check(), and timed forms of rank r's step."""
+
+    def __init__(self, model, full, world, device, real_collectives=True):
+        self.m, self.full, self.W, self.dev = model, full, int(world), device
+        self.B = full["text_feat"].shape[0]
+        if self.B % self.W:
+            raise ValueError("the global batch must divide over the emulated ranks")
+        self.b = self.B // self.W
+        self.world = comm.EmulatedWorld(self.W, real_collectives=real_collectives)
+        self.rng0 = model._rng_state_on(device).clone()
+        self.shards = [{k: full[k][r * self.b:(r + 1) * self.b].contiguous() for k in ("text_feat", "video_feat", "text_mask", "video_mask", "idx")}
+                       for r in range(self.W)]
+        self.losses = [None] * self.W
+
+    def configure(self, rank):
+        c = self.m.config
+        c.world_size, c.local_rank = self.W, rank
+        self.m.shard_loss = True
+        self.m._rng_state.copy_(self.rng0)          # every rank of a real job draws the same batch-wide DPC-KNN noise (same seed)
+
+    def step(self, rank, communicator):
+        s = self.shards[rank]
+        with comm.use(communicator), torch.no_grad():
+            out = self.m(s["text_feat"], s["text_mask"], s["video_feat"], s["video_mask"], s["idx"], 0)
+        base = out[0]._base
+        return base if base is not None and base.numel() == 5 else torch.stack(out)
+
+    def settle(self):
+        self.m.bank_frozen = True
+
+        def run(r):
+            self.configure(r)
+            self.losses[r] = self.step(r, self.world.comm(r)).clone()
+        try:
+            return self.world.settle(run)
+        finally:
+            self.m.bank_frozen = False
+
+    def replicated_losses(self):
+        """The single-rank step on the same gathered batch, same noise, bank untouched."""
+        c = self.m.config
+        c.world_size, c.local_rank = 1, 0
+        self.m.shard_loss = None
+        self.m._rng_state.copy_(self.rng0)
+        self.m.bank_frozen = True
+        try:
+            f = self.full
+            with torch.no_grad():
+                out = self.m(f["text_feat"], f["text_mask"], f["video_feat"], f["video_mask"], f["idx"], 0)
+            return torch.stack(list(out)).clone()
+        finally:
+            self.m.bank_frozen = False
+
+    def check(self, tol=2e-5):
+        ref = self.replicated_losses()
+        worst = max(float((l - ref).abs().max()) for l in self.losses)
+        if not worst <= tol:
+            raise AssertionError(f"emulated W={self.W}: rank losses differ from the replicated step by {worst:.3e} (> {tol})")
+        return worst, ref
+
+
+def measure(model, full, W, rank, dev, lines):
+    rl = RankLocal(model, full, W, dev)
+    sweeps = rl.settle()
+    worst, ref = rl.check()
+    c = rl.world.comm(rank)
+    rl.configure(rank)
+    out = {"W": W, "b": rl.b, "sweeps": sweeps, "max_dL_vs_replicated": worst}
+
+    def step():
+        return rl.step(rank, c)
+
+    def validated(make):
+        """Builds a replayable form of the step with the bank frozen and the noise stream rewound, replays it once and returns
+        max |dL| against the settled eager losses of this rank (then the caller rebuilds it unfrozen for timing)."""
+        model.bank_frozen = True
+        try:
+            model._rng_state.copy_(rl.rng0)
+            replay, result = make()
+            model._rng_state.copy_(rl.rng0)
+            replay()
+            torch.cuda.synchronize()
+            return float((result - rl.losses[rank]).abs().max())
+        finally:
+            model.bank_frozen = False
+
+    def whole():
+        g, res = capture(step)
+        return g.replay, res
+
+    def segmented():
+        for _ in range(2):
+            step()
+        seg = comm.SegmentedStep(step, c).capture()
+        out["segments"] = seg.n_segments
+        return seg.replay, seg.result
+
+    step()
+    torch.cuda.synchronize()
+    n0 = hip.N_CALLS
+    step()
+    out["abi_calls"], out["collectives"] = hip.N_CALLS - n0, c.n_collectives
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        step()
+    torch.cuda.synchronize()
+    out["eager_us"] = (time.perf_counter() - t0) / 50 * 1e6
+    # one graph, the shipped two-stream schedule
+    out["graph_dL"] = validated(whole)
+    out["graph_us"] = replay_time(whole()[0])
+    # segmented graphs and the one-stream graph (a side stream cannot stay open across a cut)
+    model.use_side_streams = False
+    try:
+        out["segmented_dL"] = validated(segmented)
+        out["segmented_us"] = replay_time(segmented()[0])
+        out["one_stream_graph_us"] = replay_time(whole()[0])
+    finally:
+        model.use_side_streams = True
+    # pieces of the critical chain (each its own graph)
+    s = rl.shards[rank]
+    cfgm = model.config
+    tm_all, vm_all = full["text_mask"].float(), full["video_mask"].float()
+    with torch.no_grad():
+        nz = model._draw_noise(rl.B, CFG["Nt"], CFG["Nv"], dev)
+
+        def exchange():
+            from neighborretr_amd.dist import packed_allgather
+            with comm.use(c):
+                c.begin_step()
+                cfgm.shard_loss = True
+                packed_allgather(s["text_feat"], s["video_feat"], s["idx"], s["text_mask"], s["video_mask"], cfgm)
+
+        def cluster_and_gather():
+            with comm.use(c):
+                c.seq = 1                       # behind the exchange step: the maximum exchange, then the token gather
+                model._gather_global(*model._merge_sharded(full["text_feat"], full["video_feat"], tm_all, vm_all, nz, rank, W), W)
+        out["exchange_us"] = replay_time(capture(exchange)[0].replay)
+        out["cluster_gather_us"] = replay_time(capture(cluster_and_gather)[0].replay)
+    lines.append(f"W={W} b={rl.b:3d}  settled in {sweeps} sweeps, every rank's losses == replicated step to {worst:.1e}")
+    lines.append(f"    rank {rank}: {out['abi_calls']} C-ABI calls + {out['collectives']} collectives per step")
+    lines.append(f"    whole step, ONE graph (collectives inside, two streams) : {out['graph_us']:7.1f} us   (replay vs eager |dL| {out['graph_dL']:.1e})")
+    lines.append(f"    whole step, one graph, ONE stream (sum of kernel time)  : {out['one_stream_graph_us']:7.1f} us")
+    lines.append(f"    SEGMENTED graphs ({out['segments']} segments + {out['collectives']} eager collectives)      : {out['segmented_us']:7.1f} us   (replay vs eager |dL| {out['segmented_dL']:.1e})")
+    lines.append(f"    eager launches                                          : {out['eager_us']:7.1f} us")
+    lines.append(f"    pieces: exchange step (pack, all-gather, unpack) {out['exchange_us']:6.1f} us;  rank's clustering incl. max exchange + token gather {out['cluster_gather_us']:6.1f} us")
+    return out
+
+
+def build(dev, precision="bf16"):
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=CFG["K"]), precision=precision)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}, strict=False)
+    m = m.to(dev).train()
+    with torch.no_grad():
+        m.clip.logit_scale.fill_(float(np.log(100.0)))
+    c = CFG
+    full_np = synth.make_problem(1002, c["B"], c["Nt"], c["Nv"], c["M"])
+    full = {k: torch.from_numpy(v).to(dev) for k, v in full_np.items()}
+    m.mb_feat_t, m.mb_feat_v = full["mb_feat_t"], full["mb_feat_v"]
+    m.mb_mask_t, m.mb_mask_v = full["mb_mask_t"], full["mb_mask_v"]
+    m.mb_ind = torch.arange(10 ** 6, 10 ** 6 + c["M"], device=dev)
+    return m, full
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--worlds", type=int, nargs="*", default=[2, 4, 8])
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--B", type=int, default=CFG["B"], help="global batch (default: configs[1])")
+    ap.add_argument("--M", type=int, default=CFG["M"])
+    ap.add_argument("--K", type=int, default=CFG["K"])
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    CFG.update(B=args.B, M=args.M, K=args.K)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    init_one_rank_group()
+    model, full = build(dev)
+    lines = [f"rank-local times of the sharded loss-only step, configs[1] (B={CFG['B']}, Nt={CFG['Nt']}, Nv={CFG['Nv']}, M={CFG['M']}), emulated "
+             f"on one MI355X: this rank's messages through a 1-rank RCCL communicator, peers' parts pre-filled (no wire time)"]
+    # the single-rank step for scale
+    model.config.world_size = 1
+
+    def one():
+        with torch.no_grad():
+            model(full["text_feat"], full["text_mask"], full["video_feat"], full["video_mask"], full["idx"], 0)
+    lines.append(f"W=1 b={CFG['B']}  the replicated step as one graph: {replay_time(capture(one)[0].replay):7.1f} us")
+    res = []
+    for W in args.worlds:
+        res.append(measure(model, full, W, min(args.rank, W - 1), dev, lines))
+    text = "\n".join(lines)
+    print(text)
+    if args.out:
+        with open(os.path.join(ROOT, args.out), "w") as f:
+            f.write(text + "\n")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
