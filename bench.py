@@ -32,6 +32,13 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 CFG = dict(B=128, Nt=24, Nv=12, M=512, K=20, d=512)
+# BASELINE.json configs[k]: [1] is the headline workload (the default, what `value` is quoted on); [2] and [3] are the two
+# MFMA-bound shapes, run on ONE GPU as extra lines (`--config 2|3`; profiles/r04_bench_c2.json, _c3.json)
+CFGS = {1: dict(B=128, Nt=24, Nv=12, M=512, K=20, d=512, name="BASELINE configs[1]: B=128 d=512 Nt=24 Nv=12 M=512 K=20 (MSR-VTT shape)"),
+        2: dict(B=1024, Nt=24, Nv=12, M=512, K=20, d=512, name="BASELINE configs[2] on ONE GPU: global B=1024 d=512 Nt=24 Nv=12 M=512 K=20"),
+        3: dict(B=128, Nt=64, Nv=64, M=1024, K=20, d=512,
+                name="BASELINE configs[3] on ONE GPU: ActivityNet shape B=128 d=512 Nt=64 Nv=64 M=1024 K=20, 3 / 6 global tokens per "
+                     "sample (centrality_multi_token='mean': the reference raises at this shape, until_module.py:321)")}
 
 
 def algorithmic_flops(B, Nt, Nv, M, d=512, H=1024):
@@ -46,13 +53,18 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "bf16_all"])
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3],
+                    help="BASELINE.json configs[k]: 1 = the headline workload (default); 2 (global B=1024) and 3 (ActivityNet token counts, "
+                         "M=1024) run the same step on ONE GPU as extra lines -- no CPU baseline, no reference fixture at those sizes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL; gloo only to rehearse ranks that share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--shard_loss", action="store_true",
-                    help="N>1: similarity / bank / clustering work sharded over the ranks (head.head_forward_sharded) -- the DEFAULT "
-                         "for N>1 since round 3 (kept as a flag for older command lines)")
+    ap.add_argument("--sync_step", "--shard_loss", dest="sync_step", action="store_true",
+                    help="N>1: the SYNCHRONOUS sharded step instead of the step-interleaved default -- every rank takes part in every "
+                         "step's loss: similarity / bank / clustering work sharded over the ranks (head.head_forward_sharded), five "
+                         "collectives per step.  This is what a training step needs; at B=128 it is a latency chain that sharding does "
+                         "not shorten (profiles/r04_rank_local.txt)")
     ap.add_argument("--replicated_loss", action="store_true",
                     help="N>1: the reference's form instead (modeling.py:274-298): after the all-gather every rank evaluates the whole "
                          "loss; the exchange step stays eager, the loss is replayed from a HIP graph")
@@ -68,12 +80,15 @@ def parse():
                     help="also time BASELINE configs[4] on this GPU: ViT-B/32 towers + temporal transformer (stock PyTorch-ROCm, "
                          "random init, bf16 autocast) feeding the HIP head from synthetic pixels, forward and forward+backward "
                          "(extra field `e2e`; never the headline value)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    CFG.update(CFGS[args.config])
+    return args
 
 
 def build_model(precision, device):
     from neighborretr_amd import modeling, synth
-    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=CFG["K"]), precision=precision)
+    over = dict(centrality_multi_token="mean") if CFG["Nt"] > 24 else {}
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=CFG["K"], **over), precision=precision)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}, strict=False)
     m = m.to(device).train()
     with torch.no_grad():
@@ -192,6 +207,8 @@ def parity_gates(model, dev):
         return None
     g = np.load(path)
     c = CFG
+    if (int(g["B"]), int(g["Nt"]), int(g["Nv"]), int(g["M"]), int(g["K"])) != (c["B"], c["Nt"], c["Nv"], c["M"], c["K"]):
+        return None                          # --config 2 / 3: the reference fixture is of configs[1]
     assert (int(g["B"]), int(g["Nt"]), int(g["Nv"]), int(g["M"]), int(g["K"])) == (c["B"], c["Nt"], c["Nv"], c["M"], c["K"])
     prob = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_problem(int(g["seed"]), c["B"], c["Nt"], c["Nv"], c["M"]).items()}
     nz = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_noise(int(g["seed"]), c["B"], c["Nt"], c["Nv"]).items()}
@@ -316,13 +333,21 @@ def main():
     from neighborretr_amd import hip, ops, synth
     c = CFG
     if c["B"] % world:
-        raise SystemExit("global batch 128 must divide over the ranks")
+        raise SystemExit(f"global batch {c['B']} must divide over the ranks")
     b = c["B"] // world
     model = build_model(args.precision, dev)
     model.config.world_size, model.config.local_rank = world, rank
-    sharded = world > 1 and not args.replicated_loss
+    # N > 1, three forms of the job.  DEFAULT: step-interleaved (model.interleave_steps): every rank gathers every step's batch
+    # and pushes it into its bank replica, the loss of step k is evaluated on rank k mod W with the full single-rank kernels --
+    # loss-only steps depend on each other through the bank alone.  --sync_step: the sharded synchronous step.
+    # --replicated_loss: the reference's form (every rank evaluates every loss).
+    interleaved = world > 1 and not args.sync_step and not args.replicated_loss
+    sharded = world > 1 and args.sync_step and not args.replicated_loss
     if world > 1:
         model.shard_loss = sharded
+        model.interleave_steps = interleaved
+    n_round = world if interleaved else 1          # steps after which every rank has evaluated a loss
+    ctr = [0]                                      # the job's step counter (host side; identical on every rank)
     full = synth.make_problem(1002, c["B"], c["Nt"], c["Nv"], c["M"])
     sl = slice(rank * b, (rank + 1) * b)
     shard = {k: torch.from_numpy(full[k][sl]).to(dev) for k in ("text_feat", "video_feat", "text_mask", "video_mask", "idx")}
@@ -337,10 +362,15 @@ def main():
         return base if base is not None and base.numel() == 5 else torch.stack(losses)
 
     def step():
-        """The WHOLE step through the model's forward: [N>1: packed all-gather ->] losses -> bank push."""
+        """The WHOLE step through the model's forward: [N>1: packed all-gather ->] losses -> bank push.  (Interleaved: the
+        losses on the step's owner, exchange + bank push on the other ranks.)"""
+        if interleaved:
+            model._step_index = ctr[0]
+        ctr[0] += 1
         with torch.no_grad():
             losses = model(shard["text_feat"], shard["text_mask"], shard["video_feat"], shard["video_mask"], shard["idx"], 0)
-            result["losses"] = _as_vector(losses)
+            if losses is not None:
+                result["losses"] = _as_vector(losses)
 
     def sync():
         if world > 1:
@@ -362,7 +392,7 @@ def main():
     static = None
     step_form, n_segments = "eager", 0
     whole_step_graph = world == 1
-    if world > 1 and not sharded:
+    if world > 1 and args.replicated_loss:
         from neighborretr_amd.dist import packed_allgather
 
         def gather():
@@ -381,19 +411,18 @@ def main():
             with torch.no_grad():
                 gather()
             (graph.replay if graph is not None else after_gather)()
-    for _ in range(3):
+    for _ in range(3 * n_round):
         step()
     torch.cuda.synchronize()
-    abi_calls = None
-    if rank == 0:                         # launches of one eager step: C-ABI entry-point calls (a grouped stage call = up to 7 kernels)
-        before = hip.N_CALLS
+    # launches of one eager step: C-ABI entry-point calls (a grouped stage call = up to 7 kernels); interleaved: of one round
+    # of W steps on this rank (one loss evaluation + W - 1 exchange-and-push steps), divided by W
+    before = hip.N_CALLS
+    for _ in range(n_round):
         step()
-        torch.cuda.synchronize()
-        abi_calls = hip.N_CALLS - before
-    elif world > 1:
-        step()
+    torch.cuda.synchronize()
+    abi_calls = round((hip.N_CALLS - before) / n_round, 1) if rank == 0 else None
     run = step
-    if world > 1 and sharded and not args.no_graph:
+    if world > 1 and not args.replicated_loss and not args.no_graph:
         import datetime
         from neighborretr_amd import comm
         hs = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
@@ -410,7 +439,9 @@ def main():
             replayed once against the eager step; then captured again for the timed run.  -> replay or None, on every rank alike."""
             model.bank_frozen = True
             try:
-                step()
+                ctr[0] = 0
+                for _ in range(n_round):
+                    step()
                 torch.cuda.synchronize()
                 eager = result["losses"].clone()
                 form, err = None, None
@@ -423,7 +454,9 @@ def main():
                     if err:
                         print(f"[bench] rank {rank}: {what} capture unavailable ({err})", file=sys.stderr)
                     return None
-                form[0]()                    # every rank replays: the collectives inside / between the graphs match up
+                ctr[0] = 0
+                for _ in range(n_round):     # every rank replays: the collectives inside / between the graphs match up
+                    form[0]()
                 torch.cuda.synchronize()
                 same = bool(torch.allclose(result["losses"], eager, rtol=1e-5, atol=1e-6))
                 if not agree(same):
@@ -441,35 +474,58 @@ def main():
                 torch.cuda.synchronize()
             return form if agree(form is not None) else None
 
+        def per_phase(capture_one):
+            """The replayable form of `step`: one capture, or -- interleaved -- two: the step this rank owns and the step it
+            does not; replay() picks by the job's step counter, as the eager step does."""
+            if not interleaved:
+                g = capture_one()
+                return g.replay, g
+            forms = {}
+            for own in (True, False):
+                ctr[0] = rank if own else rank + 1
+                forms[own] = capture_one()
+
+            def replay():
+                own = ctr[0] % world == rank
+                ctr[0] += 1
+                forms[own].replay()
+            return replay, forms
+
         def make_whole():
             if args.fail_whole_capture:          # rehearsal: rank 0 "fails", the others "succeed" -- all must end up segmented
                 if rank == 0:
                     raise RuntimeError("--fail_whole_capture")
                 return (lambda: None), None
-            # with collectives inside the capture other threads of the process (the process group's watchdog) may touch the
-            # runtime while this thread captures: thread-local capture mode keeps their calls out of its error checking
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                step()
-            return g.replay, g
+
+            def one():
+                # with collectives inside the capture other threads of the process (the process group's watchdog) may touch
+                # the runtime while this thread captures: thread-local capture mode keeps their calls out of its error checking
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    step()
+                return g
+            return per_phase(one)
 
         def make_segmented():
-            seg = comm.SegmentedStep(step).capture()
-            return seg.replay, seg
+            return per_phase(lambda: comm.SegmentedStep(step).capture())
+
+        def segments_of(keep):
+            return keep[True].n_segments if interleaved else keep.n_segments
         form = attempt(make_whole, "whole-step") if (args.backend == "nccl" or args.fail_whole_capture) else None
         if form is not None:
             step_form, graph = "whole", form[1]
         else:
             model.use_side_streams = False          # a side stream cannot stay forked across a cut between two segments
-            for _ in range(2):
+            for _ in range(2 * n_round):
                 step()
             form = attempt(make_segmented, "segmented")
             if form is not None:
-                step_form, graph, n_segments = "segmented", form[1], form[1].n_segments
+                step_form, graph, n_segments = "segmented", form[1], segments_of(form[1])
             else:
                 model.use_side_streams = True
         if form is not None:
             run = form[0]
+        ctr[0] = 0
     elif not args.no_graph:
         try:
             g = torch.cuda.CUDAGraph()
@@ -489,8 +545,13 @@ def main():
     # idle power state.  Part of the untimed set-up, like the capture warm-ups above: >= 0.4 s of steps before the contract's
     # W warm-up steps, so that the timed K steps measure the steady state whatever W is.
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.4:
-        for _ in range(50):
+    if world == 1:
+        while time.perf_counter() - t_ramp < 0.4:
+            for _ in range(50):
+                run()
+            torch.cuda.synchronize()
+    else:                                   # the SAME number of steps on every rank: a clock-bounded loop would let the ranks disagree
+        for _ in range(1200):
             run()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -649,7 +710,7 @@ def main():
         if not os.path.exists(pmc):
             pmc = os.path.join(ROOT, "profiles", "r02_pmc_sim.json")
         pmc_name = "profiles/" + os.path.basename(pmc)
-        if os.path.exists(pmc):     # PMC counters need rocprofv3 (separate passes): the committed passes are quoted here
+        if os.path.exists(pmc) and args.config == 1:     # PMC counters need rocprofv3 (separate passes): the committed passes are quoted here
             pj = json.load(open(pmc))
             traffic, mfma_busy = pj.get("bytes_per_launch_avg_over_step"), pj.get("mfma_busy_frac_flops_weighted")
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -659,7 +720,8 @@ def main():
                     "mfma_busy_frac": mfma_busy,
                     "mfma_busy_source": pmc_name + ": SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / (SQ_BUSY_CYCLES / shader engines), "
                                         "weighted by the MFMA flops each launch issues",
-                    "kernel": ("nr_sim_pair_kernel (fused local_level: the 2 bank products as chained 192x384 tile pairs through one "
+                    "kernel": "nr_sim_reg_kernel (fused local_level; block shape chosen per launch for this shape), 3 launches/step" if args.config != 1 else
+                              ("nr_sim_pair_kernel (fused local_level: the 2 bank products as chained 192x384 tile pairs through one "
                                "ping-pong K loop) + nr_sim_reg_kernel (the split-bf16 batch product on 96x192 blocks), both on 2x4 "
                                "waves = 2 launches/step") if paired else
                               ("nr_sim_reg_kernel (fused local_level: 2 bank products on 192x384 blocks, ping-pong K loop + the "
@@ -675,16 +737,23 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "sim+loss steps/sec at global B=128, d=512",
+            "metric": f"sim+loss steps/sec at global B={c['B']}, d=512",
             "value": round(args.steps / dt, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "abi_calls_per_rank_step": abi_calls,
-            "config": {"workload": "BASELINE configs[1]: B=128 d=512 Nt=24 Nv=12 M=512 K=20 (MSR-VTT shape), "
-                                   "loss-only forward incl. token clustering and bank push",
+            "config": {"workload": c["name"] + ", loss-only forward incl. token clustering and bank push",
                        "global_batch": c["B"], "per_rank_batch": b, "precision_plan": args.precision,
                        "hip_graph": graph is not None, "step_form": step_form, "graph_segments": n_segments,
-                       "parallelism": f"dp{world} (packed all-gather + " + (("loss, bank and clustering work sharded over the ranks; " + {"whole": "every collective inside the one HIP graph", "segmented": f"{n_segments} rank-local segments as HIP graphs, the collectives eager between them", "eager": "launched eagerly"}[step_form] + ")") if sharded else "replicated loss; exchange step eager, loss from a HIP graph)"),
+                       "parallelism": f"dp{world}: " + (
+                           ("packed all-gather every step on every rank, bank replicated by pushing every gathered batch; the loss of step k "
+                            "evaluated on rank k mod W with the single-rank kernels (step-interleaved: loss-only steps depend on each other "
+                            "through the bank alone)" if interleaved else
+                            "packed all-gather + loss, bank and clustering work sharded over the ranks, five collectives per step (synchronous)"
+                            if sharded else "packed all-gather + replicated loss; exchange step eager, loss from a HIP graph")
+                           + "; " + {"whole": "collectives inside the HIP graph(s)", "segmented": f"{n_segments} rank-local segments per step as HIP "
+                                     "graphs, the collectives eager between them", "eager": "launched eagerly",
+                                     "exchange eager + loss graph": "exchange eager + loss graph"}[step_form]) if world > 1 else "dp1",
                        "memory_bank": "ring (device head) + persistent prepared bf16 shadow, extended by the batch rows at every push"},
             "losses": [round(float(x), 5) for x in losses],
             "ms_per_step_min": round(min(rep_ms), 4), "ms_per_step_median": round(float(np.median(rep_ms)), 4),
@@ -698,7 +767,7 @@ def main():
             line["parity"] = parity_gates(model, dev)
         finally:
             model.config.world_size, model.shard_loss = ws_, sl_
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if watchdog is not None:

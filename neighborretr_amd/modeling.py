@@ -128,6 +128,15 @@ class NeighborRetr(nn.Module):
         # streams, kept as the cross-check of the gradient tests.  (None is accepted as "default" for older callers.)
         self.fused_training_clustering = True
         self.shard_clustering = True               # with the sharded loss: every rank clusters its own samples only
+        # Loss-only steps on W > 1 ranks, STEP-INTERLEAVED: every step, every rank takes part in the packed
+        # all-gather and pushes the gathered batch into its replica of the memory bank (same ring, same prepared shadow, same noise
+        # stream as a single-rank run); the step's LOSS is evaluated by ONE rank, the step's owner (step index mod W), with the
+        # full replicated kernels.  Consecutive loss-only steps depend on each other through the bank alone, and the bank depends
+        # on the inputs alone, so the ranks work on W consecutive steps at once: per W steps a rank pays one loss evaluation and
+        # W exchange-and-push steps instead of W latency chains.  forward() returns None on the ranks that do not own the step.
+        # Only without gradients (a training step needs every rank's gradient before the next step: the sharded loss is its form).
+        self.interleave_steps = False
+        self._step_index = 0
         self._ctm_cache = {}
 
     # ------------------------------------------------------------------ construction helpers
@@ -328,7 +337,35 @@ class NeighborRetr(nn.Module):
             from .dist import packed_allgather
             text_feat, video_feat, idx, text_mask, video_mask = packed_allgather(
                 text_feat, video_feat, idx, text_mask, video_mask, self.config)
+            if self._interleaving():
+                k, self._step_index = self._step_index, self._step_index + 1
+                if k % world != comm.get_rank():
+                    self.bank_only_step(text_feat, video_feat, text_mask, video_mask, idx)
+                    return None
         return self.loss_step(text_feat, video_feat, text_mask, video_mask, idx)
+
+    def _interleaving(self):
+        return bool(self.interleave_steps) and not torch.is_grad_enabled() and int(getattr(self.config, "world_size", 1)) > 1
+
+    def bank_only_step(self, text_feat, video_feat, text_mask, video_mask, idx):
+        """A step this rank does not own (interleave_steps): everything of loss_step that outlives the step -- the ring head and
+        the noise stream move exactly as in loss_step (same prologue launch), the batch's prepared rows extend the bank's
+        shadow, the batch takes the oldest rows' place (modeling.py:309-310) -- and none of the loss.  Three launches."""
+        raw_scale = self.clip.logit_scale
+        sizes = self._noise_sizes(text_feat.shape[1], video_feat.shape[1])
+        B = text_feat.shape[0]
+        with torch.no_grad():
+            shadow = self._bank_shadow()                                  # built before the first push, like the owner's step does
+            ring = None if self.bank_frozen else self._ring_ready(B)
+            text_mask, video_mask, _, _ = ops.step_prologue(text_mask, video_mask, raw_scale, self._rng_state_on(text_feat.device),
+                                                            B * sum(sizes.values()), ring=ring)
+            self._ring_advanced = ring is not None
+            if self.bank_frozen:
+                return
+            if shadow is not None:
+                pt, pv = ops.prepare_tokens_pair(text_feat, text_mask, video_feat, video_mask, want_lo=True, want_colsum=True)
+                self._last_prepared = {"pt": pt, "pv": pv}
+            self.update_memory_bank(idx, text_feat, video_feat, text_mask, video_mask)
 
     def loss_step(self, text_feat, video_feat, text_mask, video_mask, idx):
         """Everything after the exchange step: the five losses on the (gathered) global batch and the
@@ -541,7 +578,7 @@ class NeighborRetr(nn.Module):
         (_compute_losses: called on the gathered batch): the two must agree, the exchange step's backward depends on it.
         The AUTOMATIC choice also needs one global token per sample in training: sharded_training_losses covers that case
         only, the replicated head trains at ActivityNet token counts too (centrality_multi_token = "mean")."""
-        if world < 2 or not text_feat.is_cuda:
+        if world < 2 or not text_feat.is_cuda or self._interleaving():
             return False
         rows = text_feat.shape[0] if gathered_rows is None else gathered_rows
         if self.shard_loss is not None:

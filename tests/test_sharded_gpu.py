@@ -206,3 +206,73 @@ def test_slab_row_losses_on_hip_match_the_torch_restatement():
         scale = float(y.grad.abs().max())
         err = float((x.grad - y.grad).abs().max())
         assert err < 2e-4 * scale + 1e-9, (name, err, scale)
+
+
+def _interleaved_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from neighborretr_amd import modeling, synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B, Nt, Nv, M, K, steps = 32, 24, 12, 64, 8, 6
+    b = B // world
+    torch.manual_seed(11)                           # the noise stream's seed: the same on every rank, as in the entry point
+
+    def build():
+        m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}, strict=False)
+        m = m.to(dev).train()
+        p = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_problem(77, B, Nt, Nv, M).items()}
+        m.mb_feat_t, m.mb_feat_v, m.mb_mask_t, m.mb_mask_v = p["mb_feat_t"], p["mb_feat_v"], p["mb_mask_t"], p["mb_mask_v"]
+        m.mb_ind = torch.arange(M, device=dev)
+        return m
+    batches = [{k: torch.from_numpy(v).to(dev) for k, v in synth.make_problem(500 + s, B, Nt, Nv, M).items()} for s in range(steps)]
+    for s, p in enumerate(batches):
+        p["idx"] = torch.arange(1000 * s, 1000 * s + B, device=dev)
+    # the single-rank run: every step's losses, the bank at the end
+    m1 = build()
+    ref = []
+    with torch.no_grad():
+        for p in batches:
+            ref.append(torch.stack(m1(p["text_feat"], p["text_mask"], p["video_feat"], p["video_mask"], p["idx"], 0)).cpu())
+    # the step-interleaved job on the same stream of batches
+    m = build()
+    m.config.world_size, m.config.local_rank = world, rank
+    m.interleave_steps = True
+    sl = slice(rank * b, (rank + 1) * b)
+    mine = {}
+    with torch.no_grad():
+        for s, p in enumerate(batches):
+            out = m(p["text_feat"][sl].contiguous(), p["text_mask"][sl].contiguous(), p["video_feat"][sl].contiguous(),
+                    p["video_mask"][sl].contiguous(), p["idx"][sl].contiguous(), 0)
+            assert (out is not None) == (s % world == rank)
+            if out is not None:
+                mine[s] = torch.stack(out).cpu()
+    bank_same = all(torch.equal(getattr(m, k), getattr(m1, k)) for k in ("mb_ind", "mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v"))
+    sh, sh1 = m._bank_shadow(), m1._bank_shadow()
+    m._bank_fifo(), m1._bank_fifo()
+    torch.save({"ref": ref, "mine": mine, "bank_same": bank_same, "had_shadow": sh is not None and sh1 is not None}, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_step_interleaved_job_equals_the_single_rank_run_bit_for_bit(tmp_path):
+    """model.interleave_steps on two ranks (gloo, one card): every step is gathered and pushed on both ranks, its loss evaluated
+    on rank (step mod 2).  The losses of every step and the memory bank after the last one are those of the single-rank run on
+    the same stream of batches -- identical bits: same kernels, same ring, same noise stream (the reference's semantics:
+    modeling.py:274-312, every step sees the bank left by the steps before it)."""
+    import torch.multiprocessing as mp
+    world, port = 2, 29641
+    out = str(tmp_path / "res")
+    mp.spawn(_interleaved_worker, args=(world, port, out), nprocs=world, join=True)
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    steps = len(res[0]["ref"])
+    for s in range(steps):
+        owner = res[s % world]
+        assert s in owner["mine"] and s not in res[(s + 1) % world]["mine"]
+        assert torch.isfinite(owner["ref"][s]).all()
+        assert torch.equal(owner["mine"][s], owner["ref"][s]), (s, owner["mine"][s], owner["ref"][s])
+    assert all(r["bank_same"] and r["had_shadow"] for r in res)
+    assert not torch.equal(res[0]["ref"][0], res[0]["ref"][2])          # the steps differ (new batch, moved bank)

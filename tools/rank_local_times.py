@@ -17,6 +17,7 @@ Timed per W (HIP-graph replays, un-profiled): the whole step as ONE graph (colle
 refused), the eager step, and the pieces of the critical chain.  (modeling.py:274-298, until_module.py:367-412.)
 """
 import argparse
+import contextlib
 import os
 import socket
 import sys
@@ -96,9 +97,10 @@ class RankLocal:
         self.m.shard_loss = True
         self.m._rng_state.copy_(self.rng0)          # every rank of a real job draws the same batch-wide DPC-KNN noise (same seed)
 
-    def step(self, rank, communicator):
+    def step(self, rank, communicator=None):
+        """communicator None: whatever is current (comm.SegmentedStep installs its own around the step)."""
         s = self.shards[rank]
-        with comm.use(communicator), torch.no_grad():
+        with (comm.use(communicator) if communicator is not None else contextlib.nullcontext()), torch.no_grad():
             out = self.m(s["text_feat"], s["text_mask"], s["video_feat"], s["video_mask"], s["idx"], 0)
         base = out[0]._base
         return base if base is not None and base.numel() == 5 else torch.stack(out)
@@ -130,7 +132,12 @@ class RankLocal:
             self.m.bank_frozen = False
 
     def check(self, tol=2e-5):
-        ref = self.replicated_losses()
+        keep = (self.m.interleave_steps,)
+        self.m.interleave_steps = False
+        try:
+            ref = self.replicated_losses()
+        finally:
+            self.m.interleave_steps, = keep
         worst = max(float((l - ref).abs().max()) for l in self.losses)
         if not worst <= tol:
             raise AssertionError(f"emulated W={self.W}: rank losses differ from the replicated step by {worst:.3e} (> {tol})")
@@ -169,7 +176,7 @@ def measure(model, full, W, rank, dev, lines):
     def segmented():
         for _ in range(2):
             step()
-        seg = comm.SegmentedStep(step, c).capture()
+        seg = comm.SegmentedStep(lambda: rl.step(rank), c).capture()
         out["segments"] = seg.n_segments
         return seg.replay, seg.result
 
@@ -227,6 +234,81 @@ def measure(model, full, W, rank, dev, lines):
     return out
 
 
+def measure_interleaved(model, full, W, rank, dev, lines):
+    """The step-interleaved job (model.interleave_steps): per step one packed all-gather on every rank; the owner of the step
+    (step index mod W) evaluates the loss with the single-rank kernels, the others push the gathered batch into their bank
+    replica.  Times rank `rank`'s two kinds of step and what W consecutive steps cost it."""
+    rl = RankLocal(model, full, W, dev)
+    model.interleave_steps = True
+    out = {"W": W, "b": rl.b}
+    try:
+        c = rl.world.comm(rank)
+
+        def configure(r):
+            cfg = model.config
+            cfg.world_size, cfg.local_rank = W, r
+            model.shard_loss = False
+
+        def settle_run(r):
+            configure(r)
+            model._rng_state.copy_(rl.rng0)
+            model._step_index = r                       # rank r as the owner of "its" step
+            rl.losses[r] = rl.step(r, rl.world.comm(r)).clone()
+        model.bank_frozen = True
+        try:
+            out["sweeps"] = rl.world.settle(settle_run)
+        finally:
+            model.bank_frozen = False
+        worst, _ = rl.check(tol=0.0)                    # the owner runs the single-rank kernels on the gathered batch: bit for bit
+        out["max_dL_vs_replicated"] = worst
+        configure(rank)
+
+        def step_as(own):
+            def f():
+                model._step_index = rank if own else rank + 1
+                s = rl.shards[rank]
+                with torch.no_grad():
+                    return model(s["text_feat"], s["text_mask"], s["video_feat"], s["video_mask"], s["idx"], 0)
+            return f
+        times = {}
+        for own in (True, False):
+            f = step_as(own)
+            with comm.use(c):
+                f()
+                torch.cuda.synchronize()
+                n0 = hip.N_CALLS
+                f()
+                calls = hip.N_CALLS - n0
+                g, _ = capture(f)
+                t_graph = replay_time(g.replay)
+                model.use_side_streams = False
+                try:
+                    for _ in range(2):
+                        f()
+                    seg = comm.SegmentedStep(f, c).capture()
+                    t_seg, n_seg = replay_time(seg.replay), seg.n_segments
+                finally:
+                    model.use_side_streams = True
+            times[own] = (t_graph, t_seg, n_seg, calls)
+        for key, k in (("graph", 0), ("segmented", 1)):
+            per_round = times[True][k] + (W - 1) * times[False][k]
+            out[key + "_us_per_round"] = per_round
+            out[key + "_steps_per_s"] = W / per_round * 1e6
+        out["owner_step_us"], out["other_step_us"] = times[True][0], times[False][0]
+        out["owner_step_segmented_us"], out["other_step_segmented_us"] = times[True][1], times[False][1]
+        out["abi_calls"] = {"owner": times[True][3], "other": times[False][3]}
+    finally:
+        model.interleave_steps = False
+    lines.append(f"W={W} b={rl.b:3d}  step-interleaved: the owner's losses == the single-rank step bit for bit (max |dL| {out['max_dL_vs_replicated']:.1e})")
+    lines.append(f"    rank {rank}, a step it OWNS  (exchange + full loss + push): {times[True][3]:3d} C-ABI calls, one graph {times[True][0]:7.1f} us, "
+                 f"{times[True][2]} segments + 1 eager collective {times[True][1]:7.1f} us")
+    lines.append(f"    rank {rank}, any OTHER step  (exchange + push)            : {times[False][3]:3d} C-ABI calls, one graph {times[False][0]:7.1f} us, "
+                 f"{times[False][2]} segments + 1 eager collective {times[False][1]:7.1f} us")
+    lines.append(f"    W={W} consecutive steps cost a rank {out['graph_us_per_round']:7.1f} us  ->  {out['graph_steps_per_s']:8.0f} steps/s for the job "
+                 f"(segmented form: {out['segmented_us_per_round']:7.1f} us -> {out['segmented_steps_per_s']:8.0f} steps/s); no wire time in these")
+    return out
+
+
 def build(dev, precision="bf16"):
     m = modeling.NeighborRetr(modeling.default_config(num_neighbors=CFG["K"]), precision=precision)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}, strict=False)
@@ -265,9 +347,12 @@ def main():
         with torch.no_grad():
             model(full["text_feat"], full["text_mask"], full["video_feat"], full["video_mask"], full["idx"], 0)
     lines.append(f"W=1 b={CFG['B']}  the replicated step as one graph: {replay_time(capture(one)[0].replay):7.1f} us")
-    res = []
+    lines.append("---- SYNCHRONOUS sharded step (every rank takes part in every step's loss; five collectives per step) ----")
     for W in args.worlds:
-        res.append(measure(model, full, W, min(args.rank, W - 1), dev, lines))
+        measure(model, full, W, min(args.rank, W - 1), dev, lines)
+    lines.append("---- STEP-INTERLEAVED (one collective per step; the loss of step k on rank k mod W) ----")
+    for W in args.worlds:
+        measure_interleaved(model, full, W, min(args.rank, W - 1), dev, lines)
     text = "\n".join(lines)
     print(text)
     if args.out:
