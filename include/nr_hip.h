@@ -24,7 +24,9 @@
 extern "C" {
 #endif
 
-#define NR_ABI_VERSION 1
+/* bumped whenever a signature or the layout of a descriptor struct changes (2: NrCtmStageDesc gained x_hi/x_lo/out_hi/out_lo in
+ * round 3, nr_stream_create / nr_stream_destroy in round 4); a binding compares nr_version() with the value it was written for */
+#define NR_ABI_VERSION 2
 
 /* precision of the MFMA contractions */
 #define NR_PREC_BF16 0   /* one bf16 pass (training path)                                   */
@@ -44,6 +46,12 @@ size_t nr_struct_size(const char* name);
  * eagerly, trainer.py:84-110); used by neighborretr_amd/capture_guard.py to validate the step's fork / join topology per
  * capture before handing it to the runtime.  Host-only, no launch, no sync. */
 int nr_stream_capture_id(void* stream, unsigned long long* id);
+
+/* A new non-blocking HIP stream (hipStreamCreateWithFlags) / its destruction.  No counterpart in the reference.  The host code
+ * forks the step's branches onto streams created for ONE graph capture each (neighborretr_amd/streams.py): a stream object
+ * that has taken part in an earlier capture is never handed to a later one.  Host-only. */
+int nr_stream_create(void** stream);
+int nr_stream_destroy(void* stream);
 
 /* F.normalize (eps 1e-12) + mask multiply + bf16 hi/lo split of a token matrix.
  * Replaces modeling.py:495-496 and the two mask einsums :500-501 (a masked token becomes a zero

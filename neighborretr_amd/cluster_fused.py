@@ -309,13 +309,12 @@ HIP_BACKWARD = True
 # None: two streams inside a capture (6.3 -> 5.3 ms for the captured training step with the fused clustering), one when the
 # step is launched eagerly (the stream switches cost the host more than the overlap returns: 8.4 vs 9.2 ms)
 BACKWARD_ON_TWO_STREAMS = None
-_BWD_STREAMS = {}
+_BWD_OWNER = object()
 
 
 def _backward_stream(device):
-    if device not in _BWD_STREAMS:
-        _BWD_STREAMS[device] = torch.cuda.Stream(device=device)
-    return _BWD_STREAMS[device]
+    from . import streams
+    return streams.side(_BWD_OWNER, "cluster_bwd", device)          # cached for eager launches, new for every capture
 
 
 def _torch_backward(ctx, saved, g_t, g_v):

@@ -298,7 +298,7 @@ class SegmentedStep:
         self._begin()
 
     def capture(self):
-        inner = self.comm if self.comm is not None else current()
+        inner = self._inner = self.comm if self.comm is not None else current()
         torch.cuda.synchronize()
         self.stream.wait_stream(torch.cuda.current_stream())
         ok = False
@@ -328,6 +328,7 @@ class SegmentedStep:
     def replay(self):
         """On the CURRENT stream (a captured graph replays on any stream; hopping to the capture stream and back costs two
         cross-stream event waits per step, ~100 us measured)."""
+        self._inner.begin_step()                 # (communicators that number their collectives: the step starts over)
         for i, g in enumerate(self.graphs):
             g.replay()
             if i < len(self.collectives):

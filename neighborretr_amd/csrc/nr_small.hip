@@ -31,6 +31,21 @@ extern "C" int nr_stream_capture_id(void* stream, unsigned long long* id) {
     return NR_OK;
 }
 
+extern "C" int nr_stream_create(void** stream) {
+    if (!stream) return NR_EINVAL;
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) return (int)e;
+    *stream = (void*)s;
+    return NR_OK;
+}
+
+extern "C" int nr_stream_destroy(void* stream) {
+    if (!stream) return NR_EINVAL;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    return e == hipSuccess ? NR_OK : (int)e;
+}
+
 // ---- out[i] = scale * sum_p part[p,i]  (until_module.py:181) -----------------------------------
 // 64 outputs per workgroup; wave w sums the parts p = w, w+4, ... (independent loads in flight),
 // the four partial sums meet in LDS -- fixed order, deterministic.

@@ -17,6 +17,7 @@ PREC_BF16 = 0
 PREC_BF16X3 = 1
 OUT_FULL, OUT_ROWSUM, OUT_COLSUM = 0, 1, 2
 NR_EINVAL, NR_EUNSUPPORTED = -1, -2          # status codes of include/nr_hip.h
+ABI_VERSION = 2                              # NR_ABI_VERSION this binding was written for (checked at load)
 
 _lib = None
 
@@ -111,6 +112,8 @@ _SIGNATURES = {
     "nr_version": ([], _I),
     "nr_struct_size": ([ctypes.c_char_p], _Z),
     "nr_stream_capture_id": ([_P, ctypes.POINTER(ctypes.c_ulonglong)], _I),
+    "nr_stream_create": ([ctypes.POINTER(_P)], _I),
+    "nr_stream_destroy": ([_P], _I),
     "nr_prepare_parts": ([_I], _I),
     "nr_prepare_tokens": ([_P, _P, _I, _I, _I, _P, _P, _P, _P, _P], _I),
     "nr_prepare_tokens_pair": ([_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P], _I),
@@ -221,6 +224,9 @@ def lib():
                 if want != ctypes.sizeof(cls):
                     raise NrHipError(f"{LIB_PATH}: sizeof({cname}) is {want}, the Python mirror has {ctypes.sizeof(cls)} "
                                      "-- rebuild the extension (python -m neighborretr_amd.build --force)")
+        if int(handle.nr_version()) != ABI_VERSION:
+            raise NrHipError(f"{LIB_PATH}: C ABI version {int(handle.nr_version())}, this binding was written for {ABI_VERSION} -- rebuild "
+                             "the extension (python -m neighborretr_amd.build --force)")
         _lib = handle
     return _lib
 

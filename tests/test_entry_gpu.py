@@ -92,6 +92,19 @@ def test_graphed_training_step_keeps_the_reference_fifo():
         assert torch.equal(graphed.mb_ind, want)
 
 
+def test_graphed_step_survives_five_recaptures():
+    """VERDICT r3 #5 / ADVICE r3: one process, seven captures of different stream topologies -- the loss-only step, then
+    GraphedStep through five bank-generation changes with the clustering form alternating (tools/capture_sequence.py); every
+    replay is compared with the eager step.  Round 3 hid a segfault at the fourth capture of such a sequence behind one child
+    process per setting; side streams are now created per capture (neighborretr_amd/streams.py).  In a child process, so that a
+    dying runtime is a test failure with the Python stack in it, not the end of the test run."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "capture_sequence.py")], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "ok 7 captures in one process" in r.stdout, r.stdout[-2000:]
+    print(r.stdout)
+
+
 @pytest.mark.parametrize("shard", [0])
 def test_main_retrieval_two_ranks_on_one_gpu(tmp_path, shard):
     """The W>1 branch of the entry point (process-group init, DDP wrap, packed exchange step in forward and in the bank

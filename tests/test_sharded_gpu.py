@@ -250,10 +250,14 @@ def _interleaved_worker(rank, world, port, out_path):
             assert (out is not None) == (s % world == rank)
             if out is not None:
                 mine[s] = torch.stack(out).cpu()
+    # the prepared shadow of the bank (normalised bf16 pairs + norms) is kept in step with the ring on BOTH kinds of step
+    sh, sh1 = m._mb_shadow, m1._mb_shadow
+    had_shadow = sh is not None and sh1 is not None
+    shadow_same = had_shadow and all(torch.equal(getattr(a, f), getattr(b_, f)) for a, b_ in zip(sh, sh1) for f in ("hi", "lo", "norm"))
+    heads = (int(m._mb_head_dev.item()), int(m1._mb_head_dev.item()))
     bank_same = all(torch.equal(getattr(m, k), getattr(m1, k)) for k in ("mb_ind", "mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v"))
-    sh, sh1 = m._bank_shadow(), m1._bank_shadow()
-    m._bank_fifo(), m1._bank_fifo()
-    torch.save({"ref": ref, "mine": mine, "bank_same": bank_same, "had_shadow": sh is not None and sh1 is not None}, f"{out_path}.{rank}")
+    torch.save({"ref": ref, "mine": mine, "bank_same": bank_same, "had_shadow": had_shadow, "shadow_same": shadow_same, "heads": heads},
+               f"{out_path}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -274,5 +278,5 @@ def test_step_interleaved_job_equals_the_single_rank_run_bit_for_bit(tmp_path):
         assert s in owner["mine"] and s not in res[(s + 1) % world]["mine"]
         assert torch.isfinite(owner["ref"][s]).all()
         assert torch.equal(owner["mine"][s], owner["ref"][s]), (s, owner["mine"][s], owner["ref"][s])
-    assert all(r["bank_same"] and r["had_shadow"] for r in res)
+    assert all(r["bank_same"] and r["had_shadow"] and r["shadow_same"] and r["heads"][0] == r["heads"][1] for r in res), res
     assert not torch.equal(res[0]["ref"][0], res[0]["ref"][2])          # the steps differ (new batch, moved bank)
