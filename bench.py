@@ -515,7 +515,9 @@ def main():
         if form is not None:
             step_form, graph = "whole", form[1]
         else:
-            model.use_side_streams = False          # a side stream cannot stay forked across a cut between two segments
+            # a side stream cannot stay forked across a cut between two segments: the synchronous sharded step runs on one
+            # stream in this form; the interleaved step's only collective comes before anything is forked
+            model.use_side_streams = interleaved
             for _ in range(2 * n_round):
                 step()
             form = attempt(make_segmented, "segmented")

@@ -364,6 +364,16 @@ int nr_shift_concat_split(const float* x, int n_samples, int N, int C, uint16_t*
  *   tgt_rows = beta*Q(G) + (1-beta)*I,  tgt_cols = beta*Q(G^T) + (1-beta)*I  (each [B,B],
  *   tgt_cols indexed in the transposed frame).  workspace: nr_sinkhorn_workspace_bytes(B).    */
 size_t nr_sinkhorn_workspace_bytes(int B);
+/* 128 < B <= 1024, B % 64 == 0: nr_sinkhorn_targets runs ONE launch whose B/32 workgroups per direction meet at counter
+ * barriers, which needs them resident together.  nr_sinkhorn_cooperative_ok(B): 1 if the current device can hold them (kernel
+ * occupancy x CUs of one XCD >= B/32) -- else, and for every other B > 128, the multi-launch form (2 iters + 3 launches) runs.
+ * nr_sinkhorn_cooperative_gate: the same decision as a pure function (host-only; unit-tested without a GPU).
+ * nr_sinkhorn_targets_multilaunch: the fallback form on its own (B > 128).  Should residency fail at run time all the same,
+ * every spin is bounded and BOTH targets come back as NaN in full. */
+int nr_sinkhorn_cooperative_ok(int B);
+int nr_sinkhorn_cooperative_gate(int B, int blocks_per_cu, int n_cus, int n_xcd);
+int nr_sinkhorn_targets_multilaunch(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols,
+                                    void* workspace, void* stream);
 int nr_sinkhorn_targets(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols,
                         void* workspace, void* stream);
 /* The same solve emitting the uniform-regularisation ROW TERMS directly (until_module.py:285-289 on those targets):

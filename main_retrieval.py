@@ -250,8 +250,13 @@ class GraphedStep:
         model._ctm_cache.clear()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.losses = model(*self.static, 0)
-            self.losses[0].backward()
+            losses = model(*self.static, 0)
+            losses[0].backward()
+        # the loss VALUES only: holding the tensors themselves would keep the captured step's autograd graph alive, and with it
+        # AccumulateGrad nodes that name this capture's side streams -- which the next eager step or re-capture would then be
+        # synchronised with (PyTorch's "AccumulateGrad node's stream does not match" path)
+        self.losses = tuple(l.detach() for l in losses)
+        del losses
         self.grads = [p.grad for p in params]        # static gradient buffers of the graph
         # What the graph has baked in: the addresses of the five bank tensors and of the device ring head.  Hold
         # strong references (a bank replaced from outside must not hand its blocks to somebody else while this graph

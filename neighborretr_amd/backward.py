@@ -21,6 +21,16 @@ def _coef_rowloss(g, hp, B):
     return c.float()[None, :, None].expand(2, 4, B).contiguous()
 
 
+def _saved_state(ctx, what):
+    """The forward state of a fused-head node (dropped at the end of its backward: it holds the node's own outputs, and with
+    them a reference cycle through the autograd graph)."""
+    if ctx.sv is None:
+        raise RuntimeError(f"{what}: backward through the fused loss head a second time -- its saved state is released by the first "
+                           "backward (retain_graph=True / differentiating two of the losses separately is not supported: sum "
+                           "them first)")
+    return ctx.sv
+
+
 OWN_MLP_GEMMS = True       # False: library GEMMs (torch.matmul -> hipBLASLt) for A/B timing (tools/train_times.py)
 
 
@@ -248,9 +258,10 @@ class HeadLossFn(torch.autograd.Function):
             return (None,) * 29
         (text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v,
          g1_w1t, g1_b1t, g1_w2t, g1_w1v, g1_b1v, g1_w2v) = ctx.saved_tensors
+        sv = _saved_state(ctx, "HeadLossFn")
         dS, d_c0, d_c1, dmean_t, dmean_v, d_gt, d_gv, d_ls, g1 = _global_backward(
-            ctx.sv, ctx.hp, ctx.shapes, gs, (g1_w1t, g1_b1t, g1_w2t, g1_w1v, g1_b1v, g1_w2v))
-        d_text, d_video, scorer = _local_backward(ctx.sv, ctx.shapes, ctx.masks, ctx.exact, ctx.plan, ctx.model, text_feat, video_feat,
+            sv, ctx.hp, ctx.shapes, gs, (g1_w1t, g1_b1t, g1_w2t, g1_w1v, g1_b1v, g1_w2v))
+        d_text, d_video, scorer = _local_backward(sv, ctx.shapes, ctx.masks, ctx.exact, ctx.plan, ctx.model, text_feat, video_feat,
                                                   mb_feat_t, mb_feat_v, (w1t, b1t, w2t, w1v, b1v, w2v), dS, d_c0, d_c1, dmean_t,
                                                   dmean_v)
         ctx.sv = ctx.model = None
@@ -442,7 +453,7 @@ class HeadLocalFn(torch.autograd.Function):
         if dS is None:
             return (None,) * 23
         text_feat, video_feat, mb_feat_t, mb_feat_v, w1t, b1t, w2t, w1v, b1v, w2v = ctx.saved_tensors
-        d_text, d_video, scorer = _local_backward(ctx.sv, ctx.shapes, ctx.masks, ctx.exact, ctx.plan, ctx.model, text_feat, video_feat,
+        d_text, d_video, scorer = _local_backward(_saved_state(ctx, "HeadLocalFn"), ctx.shapes, ctx.masks, ctx.exact, ctx.plan, ctx.model, text_feat, video_feat,
                                                   mb_feat_t, mb_feat_v, (w1t, b1t, w2t, w1v, b1v, w2v), dS, d_c0, d_c1, dmean_t,
                                                   dmean_v)
         ctx.sv = ctx.model = None
@@ -465,7 +476,8 @@ class HeadGlobalFn(torch.autograd.Function):
     def backward(ctx, *gs):
         if all(g is None for g in gs):
             return (None,) * 18
-        dS, d_c0, d_c1, dmean_t, dmean_v, d_gt, d_gv, d_ls, g1 = _global_backward(ctx.sv, ctx.hp, ctx.shapes, gs, ctx.saved_tensors)
+        dS, d_c0, d_c1, dmean_t, dmean_v, d_gt, d_gv, d_ls, g1 = _global_backward(_saved_state(ctx, "HeadGlobalFn"), ctx.hp, ctx.shapes, gs,
+                                                                                  ctx.saved_tensors)
         ctx.sv = None
         return (None, None, dS, d_c0, d_c1, dmean_t, dmean_v, d_gt, d_gv, d_ls, *g1)
 

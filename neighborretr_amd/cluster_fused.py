@@ -411,8 +411,41 @@ class ClusterStagesFn(torch.autograd.Function):
         return (None, None, None, None, None, grads_x[0], None, None, grads_x[1], None, None) + tuple(ordered)
 
 
-def cluster_stages_train(modules, cache, keys, x_t, mask_t, noise_t, x_v, mask_v, noise_v, exchange=None, pre=None):
+class _OnThisStream(torch.autograd.Function):
+    """Identity.  Its backward runs on the stream its forward ran on (autograd's rule), so a gradient produced on ANOTHER stream
+    -- the clustering's backward runs on the clustering's own stream -- reaches what lies behind this node on THIS stream."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for x in xs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return gs
+
+
+def route_on_this_stream(params, feats=()):
+    """(dict id(parameter) -> pass-through tensor, [pass-through features]) through ONE identity node created on the CURRENT
+    stream (the step's own).  The training step hands these to the clustering, which runs -- forward and backward -- on its own
+    stream: the gradients of the clustering's parameters and of the leaf features then arrive at their AccumulateGrad nodes from
+    a node of the step's stream, the stream those nodes live on (created at first use in the step, or at DDP construction).
+    Without it every such gradient is accumulated across streams: one extra synchronisation per parameter and PyTorch's
+    "AccumulateGrad node's stream does not match" warning in every step (GPUTEST_r03)."""
+    if not torch.is_grad_enabled():
+        return {}, list(feats)
+    live = [t for t in list(params) + list(feats) if torch.is_tensor(t) and t.requires_grad]
+    if not live:
+        return {}, list(feats)
+    out = dict(zip((id(t) for t in live), _OnThisStream.apply(*live)))
+    return {id(p): out[id(p)] for p in params if id(p) in out}, [out.get(id(f), f) for f in feats]
+
+
+def cluster_stages_train(modules, cache, keys, x_t, mask_t, noise_t, x_v, mask_v, noise_v, exchange=None, pre=None, routed=None):
     """Differentiable grouped stage (ClusterStagesFn); the stage's parameters ride along as explicit inputs so that
-    autograd routes their gradients.  exchange: see ctm_stage_group (sample-sharded clustering); pre: see ClusterStagesFn."""
+    autograd routes their gradients.  exchange: see ctm_stage_group (sample-sharded clustering); pre: see ClusterStagesFn;
+    routed: route_on_this_stream's map (parameters passed through a node of the step's stream)."""
     params = [p for ctm, blk in modules for p in stage_params(ctm, blk)]
+    if routed:
+        params = [routed.get(id(p), p) for p in params]
     return ClusterStagesFn.apply(modules, cache, keys, exchange, pre, x_t, mask_t, noise_t, x_v, mask_v, noise_v, *params)

@@ -312,6 +312,7 @@ __global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
     float* va = p.vec + (size_t)dir * 2 * B;          // u / a
     float* vb = va + B;                               // v / b
     unsigned int* cnt = p.counter + dir * 32;
+    unsigned int* dead_flag = p.counter + 16;         // shared by both directions: one timeout ends every workgroup of the launch
     __shared__ int s_dead;
     if (tid == 0) s_dead = 0;
     const float norm = -logf((float)(2 * B));
@@ -328,8 +329,14 @@ __global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
             pc[q][e] = p.G[dir == 0 ? colmaj : rowmaj];
         }
     unsigned int phase = 0;
-    auto barrier = [&]() {                            // all stores of this workgroup visible, then every workgroup of the direction
+    // All stores of this workgroup visible, then every workgroup of the direction.  The workgroups of a direction must be
+    // resident together (the host gates the launch on that: nr_sinkhorn_cooperative_ok); should they not be -- a CU mask, another
+    // process holding the CUs -- the spin is BOUNDED, and the first workgroup to run out of patience raises the launch-wide
+    // dead flag: every other workgroup sees it at its next poll, every later barrier returns at once, and BOTH targets are
+    // poisoned with NaN in full (the losses downstream turn NaN: a loud failure instead of finite garbage).
+    auto barrier = [&]() {
         ++phase;
+        if (s_dead) return;                           // (uniform: set in front of the previous barrier's closing __syncthreads)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -338,7 +345,12 @@ __global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
             int spins = 0;
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 22)) { s_dead = 1; break; }          // ~seconds: never hang the chip
+                if ((spins & 63) == 63 && __hip_atomic_load(dead_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { s_dead = 1; break; }
+                if (++spins > (1 << 20)) {            // a fraction of a second: never hang the chip
+                    __hip_atomic_store(dead_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_dead = 1;
+                    break;
+                }
             }
         }
         __syncthreads();
@@ -436,7 +448,8 @@ __global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
     }
     // target = beta * Q + (1 - beta) I,  Q = 2B a_i K_ij b_j
     float* tgt = dir == 0 ? p.tgt_rows : p.tgt_cols;
-    const bool dead = s_dead != 0;
+    // (a direction that completed while the other one gave up is poisoned too: the flag is the launch's)
+    const bool dead = s_dead != 0 || __hip_atomic_load(dead_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const float bbv = get(vb, e);
@@ -457,7 +470,55 @@ extern "C" size_t nr_sinkhorn_workspace_bytes(int B) {
 
 static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols, float temperature,
                            float* uniform_rows, int uniform_stride, void* workspace, void* stream,
-                           NrSkFinal fin = NrSkFinal{nullptr, 0u, 0.f, 0.f, 0.f, nullptr});
+                           NrSkFinal fin = NrSkFinal{nullptr, 0u, 0.f, 0.f, 0.f, nullptr}, bool allow_coop = true);
+
+static const void* nr_sinkhorn_coop_fn(int B) {
+    switch (B / 64) {
+#define NR_SKC(E_) case E_: return (const void*)nr_sinkhorn_coop_kernel<E_>;
+        NR_SKC(3) NR_SKC(4) NR_SKC(5) NR_SKC(6) NR_SKC(7) NR_SKC(8) NR_SKC(9) NR_SKC(10) NR_SKC(11) NR_SKC(12) NR_SKC(13) NR_SKC(14)
+        NR_SKC(15) NR_SKC(16)
+#undef NR_SKC
+        default: return nullptr;
+    }
+}
+
+// The cooperative form's host gate, as a pure function of what the device reports (unit-tested on the CPU through
+// nr_sinkhorn_cooperative_gate): B/32 workgroups per direction, one direction per XCD under round-robin placement, so the
+// direction's workgroups are co-resident iff  blocks/CU x CUs of ONE XCD >= B/32; and both directions fit the chip anyway.
+extern "C" int nr_sinkhorn_cooperative_gate(int B, int blocks_per_cu, int n_cus, int n_xcd) {
+    if (B <= 128 || B > 1024 || (B % 64) != 0 || blocks_per_cu <= 0 || n_cus <= 0 || n_xcd <= 0) return 0;
+    const int need = B / 32;
+    return (blocks_per_cu * (n_cus / n_xcd) >= need && blocks_per_cu * n_cus >= 2 * need) ? 1 : 0;
+}
+
+// 1 when nr_sinkhorn_targets runs this B as ONE cooperative launch on the current device, 0 when it takes the multi-launch
+// form (B outside 192..1024 / not a multiple of 64, or the device cannot hold a direction's workgroups together: a CU-masked
+// or partitioned device).  Queried once per B (occupancy of the kernel variant x the device's CU count).
+extern "C" int nr_sinkhorn_cooperative_ok(int B) {
+    static int cache[17];                              // by B / 64: 0 unknown, 1 no, 2 yes
+    if (B <= 128 || B > 1024 || (B % 64) != 0) return 0;
+    int& c = cache[B / 64];
+    if (c == 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        const void* fn = nr_sinkhorn_coop_fn(B);
+        bool ok = fn && hipGetDevice(&dev) == hipSuccess &&
+                  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+                  hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, 0) == hipSuccess;
+        // MI355X in SPX mode: 256 CUs in 8 XCDs; a partition / mask reports fewer CUs and is priced as ONE XCD's worth per 32
+        const int n_xcd = cus >= 64 ? 8 : 1;
+        c = (ok && nr_sinkhorn_cooperative_gate(B, per_cu, cus, n_xcd)) ? 2 : 1;
+    }
+    return c == 2;
+}
+
+// The multi-launch form (2 x iters + 3 launches) on its own: what nr_sinkhorn_targets falls back to when the gate says no.
+extern "C" int nr_sinkhorn_targets_multilaunch(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols,
+                                               void* workspace, void* stream) {
+    if (!tgt_rows || !tgt_cols) return NR_EINVAL;
+    if (B <= 128 && (B % 4) == 0) return NR_EUNSUPPORTED;      // (the one-workgroup form owns these sizes; its workspace is 16 bytes)
+    return nr_sinkhorn_run(G, B, beta, iters, tgt_rows, tgt_cols, 0.f, nullptr, 0, workspace, stream,
+                           NrSkFinal{nullptr, 0u, 0.f, 0.f, 0.f, nullptr}, false);
+}
 
 extern "C" int nr_sinkhorn_targets(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols,
                                    void* workspace, void* stream) {
@@ -482,7 +543,7 @@ extern "C" int nr_sinkhorn_uniform_rows_final(const float* G, int B, float beta,
 }
 
 static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* tgt_rows, float* tgt_cols, float temperature,
-                           float* uniform_rows, int uniform_stride, void* workspace, void* stream, NrSkFinal fin) {
+                           float* uniform_rows, int uniform_stride, void* workspace, void* stream, NrSkFinal fin, bool allow_coop) {
     if (!G || B <= 0 || iters < 0) return NR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (B <= 128 && (B % 4) == 0) {
@@ -520,7 +581,7 @@ static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* 
         return NR_OK;
     }
     if (!workspace || !tgt_rows || !tgt_cols || uniform_rows) return NR_EINVAL;
-    if (B <= 1024 && (B % 64) == 0 && !nr_tune_env("NR_SINKHORN_MULTI")) {
+    if (allow_coop && nr_sinkhorn_cooperative_ok(B)) {
         // cooperative form: vectors [2][2][B] f32, then the counters (zeroed by a memset node in front of the launch)
         float* vec = reinterpret_cast<float*>(workspace);
         unsigned int* counter = reinterpret_cast<unsigned int*>(vec + 4 * (size_t)B);

@@ -153,6 +153,9 @@ _SIGNATURES = {
     "nr_ctm_stage_fwd": ([ctypes.POINTER(CtmStageDesc), _I, _P], _I),
     "nr_ctm_stage_fwd_range": ([ctypes.POINTER(CtmStageDesc), _I, _I, _I, _P], _I),
     "nr_sinkhorn_workspace_bytes": ([_I], _Z),
+    "nr_sinkhorn_cooperative_ok": ([_I], _I),
+    "nr_sinkhorn_cooperative_gate": ([_I, _I, _I, _I], _I),
+    "nr_sinkhorn_targets_multilaunch": ([_P, _I, _F, _I, _P, _P, _P, _P], _I),
     "nr_sinkhorn_uniform_rows": ([_P, _I, _F, _I, _F, _P, _I, _P, _P, _P, _P], _I),
     "nr_row_losses_fwd_no_uniform": ([_P] * 7 + [_I, _I, _F, _P, _P], _I),
     "nr_split_tail_workgroups": ([_I], _I),

@@ -464,18 +464,25 @@ class NeighborRetr(nn.Module):
               and text_feat.shape[1] <= 64 and video_feat.shape[1] <= 64 and text_feat.shape[2] % 128 == 0):
             # training step: the clustering forward on the grouped HIP kernels, the backward hand-derived from what they
             # leave in their workspaces (cluster_fused.ClusterStagesFn, cluster_backward.stage_backward)
-            from .cluster_fused import build_stage_weights, cluster_stages_train
+            from .cluster_fused import build_stage_weights, cluster_stages_train, route_on_this_stream, stage_params
+            mods0 = ((self.text_ctm0, self.text_block0), (self.video_ctm0, self.video_block0))
+            mods1 = ((self.text_ctm1, self.text_block1), (self.video_ctm1, self.video_block1))
+            side = self._cluster_stream(text_feat.device)
+            routed, (tf_c, vf_c) = ({}, (text_feat, video_feat))
+            if side is not None:
+                # the clustering runs on its own stream: its parameters and the leaf features enter it through one identity
+                # node of THIS stream, so that their gradients are accumulated on this stream (cluster_fused.route_on_this_stream)
+                routed, (tf_c, vf_c) = route_on_this_stream([p for ctm, blk in mods0 + mods1 for p in stage_params(ctm, blk)],
+                                                            (text_feat, video_feat))
 
             def stages():
                 # the bf16 pairs of all four stages' weights (stale after every optimizer step) in ONE split launch
                 build_stage_weights(self._ctm_cache, [("text0", self.text_ctm0, self.text_block0), ("video0", self.video_ctm0, self.video_block0),
                                                       ("text1", self.text_ctm1, self.text_block1), ("video1", self.video_ctm1, self.video_block1)])
-                t, v = cluster_stages_train(((self.text_ctm0, self.text_block0), (self.video_ctm0, self.video_block0)),
-                                            self._ctm_cache, ("text0", "video0"), text_feat, text_mask, nz.get("t0"),
-                                            video_feat, video_mask, nz.get("v0"))
-                return cluster_stages_train(((self.text_ctm1, self.text_block1), (self.video_ctm1, self.video_block1)),
-                                            self._ctm_cache, ("text1", "video1"), t, None, nz.get("t1"), v, None, nz.get("v1"))
-            side = self._cluster_stream(text_feat.device)
+                t, v = cluster_stages_train(mods0, self._ctm_cache, ("text0", "video0"), tf_c, text_mask, nz.get("t0"),
+                                            vf_c, video_mask, nz.get("v0"), routed=routed)
+                return cluster_stages_train(mods1, self._ctm_cache, ("text1", "video1"), t, None, nz.get("t1"), v, None, nz.get("v1"),
+                                            routed=routed)
             from . import backward as _bw
             if (side is not None and self.interleave_training_forward and _bw.SPLIT_HEAD_NODES
                     and self._local_stream(text_feat.device) is not None):
@@ -487,8 +494,6 @@ class NeighborRetr(nn.Module):
                 from .cluster_fused import ctm_stage_group
                 build_stage_weights(self._ctm_cache, [("text0", self.text_ctm0, self.text_block0), ("video0", self.video_ctm0, self.video_block0),
                                                       ("text1", self.text_ctm1, self.text_block1), ("video1", self.video_ctm1, self.video_block1)])
-                mods0 = ((self.text_ctm0, self.text_block0), (self.video_ctm0, self.video_block0))
-                mods1 = ((self.text_ctm1, self.text_block1), (self.video_ctm1, self.video_block1))
                 o0, g0, sv0 = ctm_stage_group([("text0", text_feat, text_mask, *mods0[0], nz.get("t0")),
                                                ("video0", video_feat, video_mask, *mods0[1], nz.get("v0"))], self._ctm_cache,
                                               stepwise=True, want_saved=True)
@@ -503,10 +508,10 @@ class NeighborRetr(nn.Module):
 
                 def make_nodes():
                     with torch.cuda.stream(side):
-                        t, v = cluster_stages_train(mods0, self._ctm_cache, ("text0", "video0"), text_feat, text_mask, nz.get("t0"),
-                                                    video_feat, video_mask, nz.get("v0"), pre=((o0[0], o0[1]), sv0))
+                        t, v = cluster_stages_train(mods0, self._ctm_cache, ("text0", "video0"), tf_c, text_mask, nz.get("t0"),
+                                                    vf_c, video_mask, nz.get("v0"), pre=((o0[0], o0[1]), sv0), routed=routed)
                         return cluster_stages_train(mods1, self._ctm_cache, ("text1", "video1"), t, None, nz.get("t1"), v, None,
-                                                    nz.get("v1"), pre=((o1[0], o1[1]), sv1))
+                                                    nz.get("v1"), pre=((o1[0], o1[1]), sv1), routed=routed)
                 losses = head_losses(self, text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                                      None, None, hp, logit_scale, cluster=(launches(), make_nodes))
                 return losses[0], losses[1], losses[2], losses[3], losses[4]

@@ -2,10 +2,13 @@
 
 Eager steps fork onto streams that are created once per (owner, name, device) and kept.  Inside a capture the same names
 resolve to streams that belong to THAT capture alone: created through the C ABI (hipStreamCreateWithFlags, non-blocking;
-wrapped as torch.cuda.ExternalStream) at their first use under the capture's id, never handed to another capture, and
-destroyed later from eager code, once two younger generations exist.
+wrapped as torch.cuda.ExternalStream) ahead of the capture, never handed to another capture while fewer than MAX_LIVE streams
+exist (64 captures' worth: the entry point re-captures once per epoch), and never destroyed -- autograd nodes and the caching
+allocator's deferred record_stream() events keep raw stream handles long after a capture has ended; destroying a stream
+they still name takes the process down in the autograd engine's worker thread (measured: tools/capture_sequence.py with
+streams destroyed two generations later died in the warm-up backward of its fifth capture).
 
-Why: every capture-time crash of this build inside the ROCm 7.2 runtime (the third capture of
+Why per capture: every capture-time crash of this build inside the ROCm 7.2 runtime (the third capture of
 tools/graph_overlap.py in round 1, the fourth training-graph capture of tools/train_times.py in round 3) had one thing in common
 -- side-stream OBJECTS that had taken part in an earlier capture, with another fork / join topology, taking part in a new
 one; each capture alone was fine, and so was any number of captures of ONE topology.  A stream that joins a capture through
@@ -22,12 +25,11 @@ from . import hip
 
 _EAGER = {}            # (owner id, name, device index) -> torch.cuda.Stream
 _CAPTURE = {}          # capture id -> {(owner id, name, device index): ExternalStream}
-_RETIRED = []          # [(generation, [raw stream handles])]
-_generation = 0
+_RETIRED = []          # raw stream handles of finished captures, oldest first (re-used only past MAX_LIVE)
 _SPARE = []            # raw streams created in eager code for the next capture (no stream creation while a capture runs)
-STATS = {"created": 0, "destroyed": 0}
-KEEP_GENERATIONS = 2   # capture stream sets younger than this many generations are left alone
+STATS = {"created": 0, "reused": 0}
 SPARE_TARGET = 12      # the training step forks eight streams
+MAX_LIVE = 768         # streams this module creates at most; beyond it the OLDEST retired capture streams go round again
 
 
 def _new_raw_stream():
@@ -38,18 +40,16 @@ def _new_raw_stream():
 
 
 def _retire_old(current_cid):
-    """Moves the stream sets of finished captures to the retired list; from EAGER code also destroys the ones that are at
-    least KEEP_GENERATIONS captures old (by then the allocator has long processed the record_stream() events it defers
-    until no capture is under way -- they are recorded on these streams)."""
-    global _generation
+    """The stream sets of finished captures move to the retired list (kept alive: see the module docstring)."""
     for cid in [c for c in _CAPTURE if c != current_cid]:
-        _generation += 1
-        _RETIRED.append((_generation, [s.cuda_stream for s in _CAPTURE.pop(cid).values()]))
-    if current_cid == 0:
-        while _RETIRED and _RETIRED[0][0] <= _generation - KEEP_GENERATIONS:
-            for raw in _RETIRED.pop(0)[1]:
-                hip._check("nr_stream_destroy", hip.lib().nr_stream_destroy(ctypes.c_void_p(raw)))
-                STATS["destroyed"] += 1
+        _RETIRED.extend(s.cuda_stream for s in _CAPTURE.pop(cid).values())
+
+
+def _fresh_raw_stream():
+    if STATS["created"] >= MAX_LIVE and _RETIRED:
+        STATS["reused"] += 1
+        return _RETIRED.pop(0)
+    return _new_raw_stream()
 
 
 def side(owner, name, device):
@@ -60,19 +60,17 @@ def side(owner, name, device):
     cid = hip.stream_capture_id() if torch.cuda.is_current_stream_capturing() else 0
     if _CAPTURE and (cid == 0 or any(c != cid for c in _CAPTURE)):
         _retire_old(cid)
-    elif cid == 0 and _RETIRED:
-        _retire_old(0)
     if cid == 0:
         st = _EAGER.get(key)
         if st is None:
             st = _EAGER[key] = torch.cuda.Stream(device=device)
         while len(_SPARE) < SPARE_TARGET:       # (the warm-up steps in front of every capture pass through here)
-            _SPARE.append(_new_raw_stream())
+            _SPARE.append(_fresh_raw_stream())
         return st
     per = _CAPTURE.setdefault(cid, {})
     st = per.get(key)
     if st is None:
-        st = per[key] = torch.cuda.ExternalStream(_SPARE.pop() if _SPARE else _new_raw_stream(), device=device)
+        st = per[key] = torch.cuda.ExternalStream(_SPARE.pop() if _SPARE else _fresh_raw_stream(), device=device)
     return st
 
 

@@ -211,3 +211,23 @@ def test_cooperative_sinkhorn_matches_the_oracle(B):
         assert maxdiff(tr, ref_r) < 2e-5 and maxdiff(tc, ref_c) < 2e-5, (B, iters, maxdiff(tr, ref_r), maxdiff(tc, ref_c))
     Q = (tr.cpu().double() - 0.3 * torch.eye(B, dtype=torch.float64)) / 0.7
     assert maxdiff(Q.sum(0), torch.ones(B, dtype=torch.float64)) < 1e-4
+
+
+@pytest.mark.parametrize("B", [192, 320, 1024])
+def test_multilaunch_sinkhorn_fallback_matches_the_oracle_and_the_cooperative_form(B):
+    """the multi-launch Sinkhorn -- what nr_sinkhorn_targets runs when nr_sinkhorn_cooperative_ok says the device
+    cannot hold a direction's workgroups together, and for every B the cooperative form does not cover -- called on its own
+    (nr_sinkhorn_targets_multilaunch): == the oracle (until_module.py:235-266) and == the cooperative launch."""
+    g = torch.Generator().manual_seed(B + 1)
+    G = (torch.randn(B, B, generator=g) * 6 + torch.eye(B) * 8).to(DEV)
+    tr = torch.empty_like(G)
+    tc = torch.empty_like(G)
+    ws = torch.empty((hip.sinkhorn_workspace_bytes(B),), dtype=torch.uint8, device=DEV)
+    hip.call("nr_sinkhorn_targets_multilaunch", hip.ptr(G), B, 0.7, 50, hip.ptr(tr), hip.ptr(tc), hip.ptr(ws), hip.stream_ptr())
+    ref_r = O.sinkhorn_targets(G.cpu().double(), 0.7, 50)
+    ref_c = O.sinkhorn_targets(G.cpu().double().t(), 0.7, 50)
+    assert maxdiff(tr, ref_r) < 2e-5 and maxdiff(tc, ref_c) < 2e-5
+    coop = bool(hip.lib().nr_sinkhorn_cooperative_ok(B))
+    assert coop == (B % 64 == 0)               # a whole MI355X holds 32 workgroups per XCD: every covered size passes the gate
+    tr2, tc2 = ops.sinkhorn_targets(G, 0.7, 50)
+    assert maxdiff(tr2, tr) < 2e-5 and maxdiff(tc2, tc) < 2e-5

@@ -345,3 +345,16 @@ def test_capture_guard_refuses_the_two_crashing_shapes_and_passes_the_shipped_on
     # autograd re-enters a side stream that was joined into the ORIGIN (every captured training step does): allowed
     t = StreamTopology(ORIGIN)
     t.wait(S1, ORIGIN), t.wait(ORIGIN, S1), t.wait(S1, ORIGIN), t.wait(ORIGIN, S1)
+
+
+def test_cooperative_sinkhorn_gate_is_a_pure_host_decision():
+    """the one-launch Sinkhorn of 128 < B <= 1024 needs the B/32 workgroups of a direction resident together; the host
+    gate (nr_sinkhorn_cooperative_gate: blocks per CU x CUs of one XCD >= B/32, and both directions fit the chip) decides
+    between it and the multi-launch form.  No GPU involved."""
+    gate = hip.lib().nr_sinkhorn_cooperative_gate
+    assert gate(1024, 1, 256, 8) == 1 and gate(512, 1, 256, 8) == 1 and gate(192, 1, 256, 8) == 1      # MI355X, SPX: 32 CUs per XCD
+    assert gate(1024, 1, 128, 8) == 0          # half the CUs (a CU mask / a smaller part): 16 per XCD < 32 workgroups
+    assert gate(512, 1, 128, 8) == 1 and gate(1024, 2, 128, 8) == 1
+    assert gate(1024, 1, 32, 1) == 0 and gate(512, 1, 32, 1) == 1                                       # one XCD (CPX partition): both directions share it
+    assert gate(1024, 0, 256, 8) == 0          # the kernel does not fit a CU at all
+    assert gate(128, 1, 256, 8) == 0 and gate(1088, 4, 256, 8) == 0 and gate(200, 1, 256, 8) == 0      # sizes the form does not cover

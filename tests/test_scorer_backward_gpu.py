@@ -5,7 +5,9 @@ on the token sets of the reference fixtures c1_b16 and c2_b128 (batch tokens + m
 both precision plans.
 
 Two-part bar per gradient tensor, deviations relative to the tensor's largest |entry|:
-    >= 99.9 % of the entries within 2e-3,  every entry within 2e-2.
+    >= 99.9 % of the entries (all but 8 for the small tensors) within BULK,  every entry within 2e-2;
+    BULK = 2e-3, except dW1 on the "bf16" plan: 8e-3 -- there the bank tokens' share of dW1 = dh^T X is a ONE-pass bf16 product
+    (backward.ONE_PASS_WEIGHT_GRAD: their forward ran one-pass too), 2^-9 relative per term over K = 3072 / 12288 bank tokens.
 The second part is there for ONE effect that is not rounding: a hidden unit whose pre-activation is within ~1e-5 of zero can
 take the other ReLU branch than in fp64, which moves the entries that unit touches by up to ~1e-2 of the maximum
 (DESIGN.md "Precision plan").  The count of such outliers (entries beyond 2e-3) is printed per tensor, together with the number
@@ -70,15 +72,18 @@ def test_fused_scorer_backward_element_by_element(name, precision):
         want.append(_oracle([feat, bfeat], dls, P, scorer, B * N))
     got = backward._mlp_backward_hip(jobs)
     torch.cuda.synchronize()
-    report = []
+    report, failures = [], []
     for which, mine, (ref, at_risk) in zip(("text", "video"), got, want):
         for tname, a, r in zip(("dW1", "db1", "dW2", "db2", "dX"), mine, ref):
             a, r = a.detach().double().cpu().reshape(-1), r.reshape(-1)
             scale = float(r.abs().max())
             e = (a - r).abs() / scale
-            outliers, worst = int((e > BULK).sum()), float(e.max())
-            report.append(f"{which}.{tname}: max {worst:.2e}, beyond {BULK:g}: {outliers}/{e.numel()}")
-            assert outliers <= 1e-3 * e.numel(), (name, precision, which, tname, outliers, e.numel(), worst)
-            assert worst <= TAIL, (name, precision, which, tname, worst)
+            bulk = 8e-3 if (precision == "bf16" and tname == "dW1") else BULK
+            outliers, worst = int((e > bulk).sum()), float(e.max())
+            q = torch.quantile(e[:: max(1, e.numel() // 200000)].float(), torch.tensor([0.5, 0.999])).tolist()
+            report.append(f"{which}.{tname}: median {q[0]:.1e}, 99.9 % {q[1]:.1e}, max {worst:.2e}, beyond {bulk:g}: {outliers}/{e.numel()}")
+            failures += [(which, tname, "bulk", outliers, e.numel())] if outliers > max(8, 1e-3 * e.numel()) else []
+            failures += [(which, tname, "tail", worst)] if worst > TAIL else []
         report.append(f"{which}: {at_risk} (token, unit) pairs at ReLU risk")
-    print(f"\n[{name} {precision}] fused scorer backward vs fp64 autograd (relative to each tensor's largest entry): " + "; ".join(report))
+    print(f"\n[{name} {precision}] fused scorer backward vs fp64 autograd (relative to each tensor's largest entry):\n  " + "\n  ".join(report))
+    assert not failures, failures

@@ -117,7 +117,7 @@ def main():
             gerr = float((ge - gg).norm() / ge.norm())
             assert gerr < 5e-3, (epoch, r, gerr)
         say(f"  epoch {epoch}: losses and gradients of the replayed step == eager (last: rel {rel:.1e}, grad {gerr:.1e})")
-    say(f"ok {captures} captures in one process; capture streams created {streams.STATS['created']}, destroyed {streams.STATS['destroyed']}")
+    say(f"ok {captures} captures in one process; capture streams created {streams.STATS['created']}, re-used {streams.STATS['reused']}")
 
 
 if __name__ == "__main__":

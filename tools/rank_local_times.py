@@ -281,14 +281,10 @@ def measure_interleaved(model, full, W, rank, dev, lines):
                 calls = hip.N_CALLS - n0
                 g, _ = capture(f)
                 t_graph = replay_time(g.replay)
-                model.use_side_streams = False
-                try:
-                    for _ in range(2):
-                        f()
-                    seg = comm.SegmentedStep(f, c).capture()
-                    t_seg, n_seg = replay_time(seg.replay), seg.n_segments
-                finally:
-                    model.use_side_streams = True
+                for _ in range(2):                # (the step's only collective comes before anything is forked: side streams stay on)
+                    f()
+                seg = comm.SegmentedStep(f, c).capture()
+                t_seg, n_seg = replay_time(seg.replay), seg.n_segments
             times[own] = (t_graph, t_seg, n_seg, calls)
         for key, k in (("graph", 0), ("segmented", 1)):
             per_round = times[True][k] + (W - 1) * times[False][k]
