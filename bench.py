@@ -438,8 +438,10 @@ def main():
             """make() -> (replay, keep-alive) captures a replayable form of `step`.  Captured with the bank frozen first and
             replayed once against the eager step; then captured again for the timed run.  -> replay or None, on every rank alike."""
             model.bank_frozen = True
+            rng = model._rng_state_on(dev)
             try:
                 ctr[0] = 0
+                rng[1] = 4242                # the DPC-KNN tie-break noise is a function of this counter: the same draws for both passes
                 for _ in range(n_round):
                     step()
                 torch.cuda.synchronize()
@@ -455,6 +457,7 @@ def main():
                         print(f"[bench] rank {rank}: {what} capture unavailable ({err})", file=sys.stderr)
                     return None
                 ctr[0] = 0
+                rng[1] = 4242
                 for _ in range(n_round):     # every rank replays: the collectives inside / between the graphs match up
                     form[0]()
                 torch.cuda.synchronize()

@@ -258,14 +258,19 @@ class _SegmentingComm:
     def begin_step(self):
         self.inner.begin_step()
 
+    # (the noted calls name the inner communicator only: a closure over `self` would tie the SegmentedStep into a reference
+    # cycle, and its graphs would then be destroyed whenever the garbage collector runs -- possibly inside a later capture)
     def all_gather_into_tensor(self, out, inp):
-        self.owner._cut(lambda: self.inner.all_gather_into_tensor(out, inp))
+        inner = self.inner
+        self.owner._cut(lambda: inner.all_gather_into_tensor(out, inp))
 
     def all_reduce(self, t, op="sum"):
-        self.owner._cut(lambda: self.inner.all_reduce(t, op))
+        inner = self.inner
+        self.owner._cut(lambda: inner.all_reduce(t, op))
 
     def reduce_scatter_tensor(self, out, inp):
-        self.owner._cut(lambda: self.inner.reduce_scatter_tensor(out, inp))
+        inner = self.inner
+        self.owner._cut(lambda: inner.reduce_scatter_tensor(out, inp))
 
 
 class SegmentedStep:
@@ -298,9 +303,26 @@ class SegmentedStep:
         self._begin()
 
     def capture(self):
+        import gc
         inner = self._inner = self.comm if self.comm is not None else current()
+        # No garbage collection while a capture is open: a collected CUDAGraph of an earlier form would be destroyed in the
+        # middle of this capture (hipGraphExecDestroy: "operation not permitted when stream is capturing", process aborted --
+        # measured with tools/rank_local_times.py).  Collect first, like torch.cuda.graph() does, then hold the collector off.
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         torch.cuda.synchronize()
         self.stream.wait_stream(torch.cuda.current_stream())
+        ok = False
+        try:
+            self._capture_segments(inner)
+        finally:
+            if gc_was_on:
+                gc.enable()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return self
+
+    def _capture_segments(self, inner):
         ok = False
         with torch.cuda.stream(self.stream):
             self._begin()
@@ -318,8 +340,6 @@ class SegmentedStep:
                     if ok:
                         self.graphs.append(self._open)
                     self._open = None
-        torch.cuda.current_stream().wait_stream(self.stream)
-        return self
 
     @property
     def n_segments(self):

@@ -1,27 +1,40 @@
 """GPU: the FUSED token-scorer backward (backward._mlp_backward_hip -- what every training step runs: nr_token_mlp_bwd_hidden
 recomputes the hidden layer from the normalised bf16 pairs like the forward kernel, grouped GEMMs for dX / dW1, grouped column
-sums) pinned ELEMENT BY ELEMENT against autograd through Linear(512,1024)-ReLU-Linear(1024,1) (modeling.py:485-492) in fp64
-on the token sets of the reference fixtures c1_b16 and c2_b128 (batch tokens + memory-bank tokens of either modality), in
-both precision plans.
+sums) pinned ELEMENT BY ELEMENT (until now only through norms and 64-element slices).
 
-Two-part bar per gradient tensor, deviations relative to the tensor's largest |entry|:
-    >= 99.9 % of the entries (all but 8 for the small tensors) within BULK,  every entry within 2e-2;
-    BULK = 2e-3, except dW1 on the "bf16" plan: 8e-3 -- there the bank tokens' share of dW1 = dh^T X is a ONE-pass bf16 product
-    (backward.ONE_PASS_WEIGHT_GRAD: their forward ran one-pass too), 2^-9 relative per term over K = 3072 / 12288 bank tokens.
-The second part is there for ONE effect that is not rounding: a hidden unit whose pre-activation is within ~1e-5 of zero can
-take the other ReLU branch than in fp64, which moves the entries that unit touches by up to ~1e-2 of the maximum
-(DESIGN.md "Precision plan").  The count of such outliers (entries beyond 2e-3) is printed per tensor, together with the number
-of (token, unit) pairs that are at risk (|pre-activation| < 2e-5 of the row's largest, non-zero upstream gradient)."""
+(1) The kernel chain alone against fp64 autograd through Linear(512,1024)-ReLU-Linear(1024,1) (modeling.py:485-492) on the token
+    sets of the reference fixtures c1_b16 / c2_b128, the BATCH tokens' and the BANK tokens' contributions separately (the gradient
+    is linear in the sets), in both precision plans.
+(2) The scorer parameters' gradients of the WHOLE training step, element by element, against the oracle's autograd (the CPU
+    restatement pinned to the reference: tests/golden/CAPTURE_LOG.txt) -- the fixtures hold only norms of these tensors.
+
+Bars, deviations relative to the tensor's largest |entry| (db2 = sum of the upstream gradient, which is 0 analytically -- softmax
+backward sums to zero over every sample -- is measured against sum |dl| instead):
+    split-bf16 sets (everything on "bf16x3"; the batch tokens on "bf16"):  >= 99.9 % of the entries within 2e-3, all within 2e-2.
+        The tail is ONE effect that is not rounding: a hidden unit whose pre-activation is within ~1e-5 of zero takes the other
+        ReLU branch than in fp64 and moves the entries it touches by ~1e-2 of the maximum (DESIGN.md "Precision plan"); the count
+        of entries beyond 2e-3 and of (token, unit) pairs at risk is printed.
+    one-pass sets (the bank tokens on "bf16": their FORWARD ran one bf16 pass, so this is the gradient of the function that was
+        evaluated): the hidden layer carries 2^-9 relative error, i.e. ~100x as many units decide their ReLU differently from
+        fp64, and dh is rounded to bf16 before the K = 3072 / 12288-token products: >= 99.9 % within 5e-2, all within 0.15.
+    whole step: the bank tokens' share of the scorer gradients is what the loss lets through (d bank-mean / M): bars as for the
+        split sets on "bf16x3"; on "bf16" >= 99.9 % within 1e-2, all within 5e-2 (measured values printed)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
-from neighborretr_amd import backward, head, hip, modeling, ops
-from util import golden, params, problem
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import nr_oracle as O  # noqa: E402
+from neighborretr_amd import backward, head, hip, modeling, ops, synth  # noqa: E402
+from util import golden, noise, params, problem  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-BULK, TAIL = 2e-3, 2e-2
+SPLIT = dict(bulk=2e-3, tail=2e-2)
+ONE_PASS = dict(bulk=5e-2, tail=0.15)
 
 
 def _upstream(w, seed):
@@ -32,17 +45,39 @@ def _upstream(w, seed):
     return ops.token_softmax_bwd(w, d_w.contiguous())
 
 
-def _oracle(feats, dls, P, name, n_dx):
-    """fp64 autograd through the scorer on the concatenated token sets (oracle arithmetic: nr_oracle.token_weights' MLP)."""
-    X = torch.cat([f.reshape(-1, f.shape[-1]) for f in feats]).double().cpu().requires_grad_(True)
-    dl = torch.cat([d.reshape(-1) for d in dls]).double().cpu()
+def _oracle(feat, dl, P, name):
+    """fp64 autograd through the scorer on one token set."""
+    X = feat.reshape(-1, feat.shape[-1]).double().cpu().requires_grad_(True)
+    dl = dl.reshape(-1).double().cpu()
     W1, b1 = P[name + ".0.weight"].double().requires_grad_(True), P[name + ".0.bias"].double().requires_grad_(True)
     W2, b2 = P[name + ".2.weight"].double().requires_grad_(True), P[name + ".2.bias"].double().requires_grad_(True)
     pre = X @ W1.t() + b1
-    logits = torch.relu(pre) @ W2.t() + b2
-    (logits.reshape(-1) * dl).sum().backward()
+    ((torch.relu(pre) @ W2.t() + b2).reshape(-1) * dl).sum().backward()
     at_risk = int(((pre.detach().abs() < 2e-5 * pre.detach().abs().amax(1, keepdim=True)) & (dl != 0)[:, None]).sum())
-    return (W1.grad, b1.grad, W2.grad, b2.grad, X.grad[:n_dx]), at_risk
+    return dict(dW1=W1.grad, db1=b1.grad, dW2=W2.grad, db2=b2.grad, dX=X.grad), at_risk, float(dl.abs().sum())
+
+
+def _compare(tag, mine, ref, bars, dl_abs_sum, report, failures):
+    for tname, a in mine.items():
+        a, r = a.detach().double().cpu().reshape(-1), ref[tname].reshape(-1)
+        scale = dl_abs_sum if tname == "db2" else float(r.abs().max())
+        e = (a - r).abs() / max(scale, 1e-30)
+        outliers, worst = int((e > bars["bulk"]).sum()), float(e.max())
+        q = torch.quantile(e[:: max(1, e.numel() // 200000)].float(), torch.tensor([0.5, 0.999])).tolist() if e.numel() > 1 else [worst, worst]
+        report.append(f"{tag}.{tname}: median {q[0]:.1e}, 99.9 % {q[1]:.1e}, max {worst:.2e}, beyond {bars['bulk']:g}: {outliers}/{e.numel()}")
+        if outliers > max(8, 1e-3 * e.numel()):
+            failures.append((tag, tname, "bulk", outliers, e.numel()))
+        if worst > bars["tail"]:
+            failures.append((tag, tname, "tail", worst))
+
+
+def _model(precision, K):
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K), precision=precision)
+    m.load_state_dict(params(), strict=False)
+    m = m.to(DEV).train()
+    with torch.no_grad():
+        m.clip.logit_scale.fill_(float(np.log(100.0)))
+    return m
 
 
 @pytest.mark.parametrize("name", ["c1_b16", "c2_b128"])
@@ -52,38 +87,54 @@ def test_fused_scorer_backward_element_by_element(name, precision):
     B, Nt, Nv, M, K = (int(g[k]) for k in ("B", "Nt", "Nv", "M", "K"))
     x = problem(int(g["seed"]), B, Nt, Nv, M, device=DEV)
     P = params()
-    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K), precision=precision)
-    m.load_state_dict(P, strict=False)
-    m = m.to(DEV).train()
+    m = _model(precision, K)
     _, p_mlp, p_bank = head.precision_plan(m._prec())
-    jobs, want = [], []
+    report, failures = [], []
     for which, scorer, N, seed in (("text", "text_weight_fc", Nt, 1), ("video", "video_weight_fc", Nv, 2)):
-        feat, mask = x[which + "_feat"], x[which + "_mask"].float()
-        bfeat, bmask = x["mb_feat_" + which[0]], x["mb_mask_" + which[0]].float()
         sw = m.scorer_weights(scorer)
-        sets, dls = [], []
-        for f, mk, n, prec, sd in ((feat, mask, B, p_mlp, seed), (bfeat, bmask, M, p_bank, seed + 10)):
+        sets = (("batch", x[which + "_feat"], x[which + "_mask"].float(), B, p_mlp, seed),
+                ("bank", x["mb_feat_" + which[0]], x["mb_mask_" + which[0]].float(), M, p_bank, seed + 10))
+        for sname, f, mk, n, prec, sd in sets:
             prep = ops.prepare_tokens(f, mk, want_lo=True)
             w, _ = head.token_weights(prep, mk, sw, n, N, prec)
             dl = _upstream(w, sd)
-            sets.append((prep, f.reshape(-1, f.shape[-1]), dl, prec))
-            dls.append(dl)
-        jobs.append(dict(sw=sw, sets=sets, add_to=None))
-        want.append(_oracle([feat, bfeat], dls, P, scorer, B * N))
-    got = backward._mlp_backward_hip(jobs)
-    torch.cuda.synchronize()
-    report, failures = [], []
-    for which, mine, (ref, at_risk) in zip(("text", "video"), got, want):
-        for tname, a, r in zip(("dW1", "db1", "dW2", "db2", "dX"), mine, ref):
-            a, r = a.detach().double().cpu().reshape(-1), r.reshape(-1)
-            scale = float(r.abs().max())
-            e = (a - r).abs() / scale
-            bulk = 8e-3 if (precision == "bf16" and tname == "dW1") else BULK
-            outliers, worst = int((e > bulk).sum()), float(e.max())
-            q = torch.quantile(e[:: max(1, e.numel() // 200000)].float(), torch.tensor([0.5, 0.999])).tolist()
-            report.append(f"{which}.{tname}: median {q[0]:.1e}, 99.9 % {q[1]:.1e}, max {worst:.2e}, beyond {bulk:g}: {outliers}/{e.numel()}")
-            failures += [(which, tname, "bulk", outliers, e.numel())] if outliers > max(8, 1e-3 * e.numel()) else []
-            failures += [(which, tname, "tail", worst)] if worst > TAIL else []
-        report.append(f"{which}: {at_risk} (token, unit) pairs at ReLU risk")
+            # one set per call: its contribution to every gradient on its own (as the FIRST set of a job it also yields dX)
+            (dW1, db1, dW2, db2, dX), = backward._mlp_backward_hip([dict(sw=sw, sets=[(prep, f.reshape(-1, f.shape[-1]), dl, prec)], add_to=None)])
+            torch.cuda.synchronize()
+            ref, at_risk, dl_abs = _oracle(f, dl, P, scorer)
+            bars = SPLIT if int(prec) == hip.PREC_BF16X3 else ONE_PASS
+            _compare(f"{which}/{sname}", dict(dW1=dW1, db1=db1, dW2=dW2, db2=db2, dX=dX), ref, bars, dl_abs, report, failures)
+            report.append(f"{which}/{sname}: {at_risk} (token, unit) pairs within 2e-5 of a ReLU switch; precision {'split-bf16' if int(prec) == hip.PREC_BF16X3 else 'one bf16 pass'}")
     print(f"\n[{name} {precision}] fused scorer backward vs fp64 autograd (relative to each tensor's largest entry):\n  " + "\n  ".join(report))
+    assert not failures, failures
+
+
+@pytest.mark.parametrize("name", ["c1_b16", "c2_b128"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_step_scorer_gradients_element_by_element_vs_the_oracle(name, precision):
+    """The training step's *_weight_fc gradients, every entry, against the oracle's autograd on the fixture's inputs."""
+    g = golden(name)
+    B, Nt, Nv, M, K = (int(g[k]) for k in ("B", "Nt", "Nv", "M", "K"))
+    seed = int(g["seed"])
+    x, nz = problem(seed, B, Nt, Nv, M, device=DEV), noise(seed, B, Nt, Nv, device=DEV)
+    m = _model(precision, K)
+    c = m.config
+    losses = m._compute_losses(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"], x["mb_feat_t"], x["mb_feat_v"],
+                               x["mb_mask_t"], x["mb_mask_v"], c.centrality_scale, c.beta, K, c.temperature, m.clip.logit_scale.exp(), noise=nz)
+    losses[0].backward()
+    torch.cuda.synchronize()
+    xc, nzc = problem(seed, B, Nt, Nv, M), noise(seed, B, Nt, Nv)
+    Pc = {k: v.clone().requires_grad_(k.startswith(("text_weight_fc.", "video_weight_fc."))) for k, v in params().items()}
+    hp = dict(synth.DEFAULT_HP, num_neighbors=K)
+    ref = O.compute_losses(xc["text_feat"], xc["video_feat"], xc["text_mask"], xc["video_mask"], xc["mb_feat_t"], xc["mb_feat_v"],
+                           xc["mb_mask_t"], xc["mb_mask_v"], Pc, hp, torch.tensor(100.0), nzc)
+    ref[0].backward()
+    named = dict(m.named_parameters())
+    bars = SPLIT if precision == "bf16x3" else dict(bulk=1e-2, tail=5e-2)
+    report, failures = [], []
+    for scorer in ("text_weight_fc", "video_weight_fc"):
+        mine = {t: named[f"{scorer}.{k}"].grad for t, k in (("dW1", "0.weight"), ("db1", "0.bias"), ("dW2", "2.weight"))}
+        want = {t: Pc[f"{scorer}.{k}"].grad.double() for t, k in (("dW1", "0.weight"), ("db1", "0.bias"), ("dW2", "2.weight"))}
+        _compare(scorer, mine, want, bars, 1.0, report, failures)
+    print(f"\n[{name} {precision}] scorer gradients of the whole training step vs the oracle's autograd:\n  " + "\n  ".join(report))
     assert not failures, failures
