@@ -588,6 +588,19 @@ def main():
         rep_ms.append(float(tr.item()) / args.steps * 1e3)
 
     extra = {}
+    if world > 1:
+        # the exchange step alone (pack, packed all-gather, unpack; eager), so that a rehearsal on gloo ranks -- whose collectives
+        # go through the host -- shows how much of a step is the collective's own data path
+        from neighborretr_amd.dist import packed_allgather as _pg
+        with torch.no_grad():
+            for _ in range(3):
+                _pg(shard["text_feat"], shard["video_feat"], shard["idx"], shard["text_mask"], shard["video_mask"], model.config)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                _pg(shard["text_feat"], shard["video_feat"], shard["idx"], shard["text_mask"], shard["video_mask"], model.config)
+            sync()
+        extra["exchange_step_ms"] = round((time.perf_counter() - t1) / 10 * 1e3, 4)
     if args.backward and world == 1:
         tf = shard["text_feat"].clone().requires_grad_(True)
         vf = shard["video_feat"].clone().requires_grad_(True)

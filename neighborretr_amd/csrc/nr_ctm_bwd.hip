@@ -292,8 +292,12 @@ __device__ __forceinline__ float nr_rl(float v, int lane) {
 #define NR_ATT_LD 129
 // NCH token chunks of 32 (N <= 32 * NCH).  NCH == 1: the head's k | v rows are staged in the wave's own LDS slice first
 // ([n][128] floats: every later read is a ds_read at an immediate offset); read straight from global memory they cost a
-// 64-bit address pair per row and the kernel spilled.  NCH == 2 (ActivityNet token counts) keeps the global reads: its slices
-// do not fit the LDS (N x 4 KiB), it runs with spills -- correct, not fast.
+// 64-bit address pair per row and the kernel spilled.  NCH == 2 (ActivityNet token counts: N up to 64) keeps the global reads of
+// k | v -- its slices do not fit the LDS (N x 4 KiB per head) -- and splits the work in two phases so that the 4 x 32 d_k / d_v
+// accumulators of a lane are never live together with the logit pass (154 spilled registers in round 3): phase 1 runs the
+// queries (logits, softmax backward, d_q) and parks every query's d_logit / p row in the wave's LDS slice ([c][128] floats);
+// phase 2 accumulates d_k / d_v over the queries one 32-token chunk at a time from those rows (LDS broadcast reads).  Same
+// arithmetic in the same order as the one-phase form.
 template <int NCH>
 __device__ __forceinline__ void nr_attn_bwd_body(const NrAttnBwdArgs& a, const int b, float* s_ds /* [heads][64] */, float* s_kv) {
     const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
@@ -313,11 +317,13 @@ __device__ __forceinline__ void nr_attn_bwd_body(const NrAttnBwdArgs& a, const i
     }
     auto K_ = [&](int n) -> float { if constexpr (NCH == 1) return sk[n * NR_ATT_LD]; else return a.kv[kvb + (size_t)n * 2 * C]; };
     auto V_ = [&](int n) -> float { if constexpr (NCH == 1) return sk[n * NR_ATT_LD + 64]; else return a.kv[kvb + (size_t)n * 2 * C + C]; };
-    float dk[NCH][32], dv[NCH][32];
+    constexpr int NACC = NCH == 1 ? 1 : 0;            // one-phase form: accumulators live through the query loop
+    float dk[NACC ? NCH : 1][32], dv[NACC ? NCH : 1][32];
+    if constexpr (NCH == 1) {
 #pragma unroll
-    for (int u = 0; u < NCH; ++u)
-#pragma unroll
-        for (int n = 0; n < 32; ++n) dk[u][n] = dv[u][n] = 0.f;
+        for (int n = 0; n < 32; ++n) dk[0][n] = dv[0][n] = 0.f;
+    }
+    float* s_rows = s_kv + (size_t)h * c * 128;       // NCH > 1: [c][d_logit 64 | p 64] of this wave
     const float sc_n = lane < N ? a.score[(size_t)b * N + lane] : -INFINITY;
     float dsc = 0.f;                       // lane n: sum over queries of d_logit[n] (this head)
     for (int ci = 0; ci < c; ++ci) {
@@ -343,16 +349,12 @@ __device__ __forceinline__ void nr_attn_bwd_body(const NrAttnBwdArgs& a, const i
             d_ += __shfl_xor(d_, 32);
             if (lane < N) { lg = l_ * a.scale; dp = d_; }
         } else {
-#pragma unroll
-            for (int u = 0; u < NCH; ++u) {
-#pragma unroll
-                for (int n = 0; n < 32; ++n) {
-                    if (u * 32 + n < N) {
-                        const float l_ = nr_wave_sum(qv * K_(u * 32 + n)) * a.scale;
-                        const float d_ = nr_wave_sum(da * V_(u * 32 + n));
-                        if (lane == u * 32 + n) { lg = l_; dp = d_; }
-                    }
-                }
+            // (a rolled loop: fully unrolled, the 2 x 64 row loads of a query are hoisted together and the kernel spills)
+#pragma unroll 4
+            for (int n = 0; n < N; ++n) {
+                const float l_ = nr_wave_sum(qv * K_(n)) * a.scale;
+                const float d_ = nr_wave_sum(da * V_(n));
+                if (lane == n) { lg = l_; dp = d_; }
             }
         }
         lg += sc_n;                         // masked tokens: -inf -> p = 0
@@ -362,17 +364,21 @@ __device__ __forceinline__ void nr_attn_bwd_body(const NrAttnBwdArgs& a, const i
         const float dl = p * (dp - nr_wave_sum(p * dp));       // softmax backward
         dsc += dl;
         float dq = 0.f;
-#pragma unroll
-        for (int u = 0; u < NCH; ++u) {
+        if constexpr (NCH == 1) {
 #pragma unroll
             for (int n = 0; n < 32; ++n) {
-                if (u * 32 + n < N) {
-                    const float dln = nr_rl(dl, u * 32 + n), pn = nr_rl(p, u * 32 + n);
-                    dq += dln * K_(u * 32 + n);
-                    dk[u][n] += dln * qv;
-                    dv[u][n] += pn * da;
+                if (n < N) {
+                    const float dln = nr_rl(dl, n);
+                    dq += dln * K_(n);
+                    dk[0][n] += dln * qv;
+                    dv[0][n] += nr_rl(p, n) * da;
                 }
             }
+        } else {
+#pragma unroll 4
+            for (int n = 0; n < N; ++n) dq += nr_rl(dl, n) * K_(n);
+            s_rows[ci * 128 + lane] = dl;
+            s_rows[ci * 128 + 64 + lane] = p;
         }
         dq *= a.scale;
         a.d_q[qo] = dq;
@@ -380,13 +386,12 @@ __device__ __forceinline__ void nr_attn_bwd_body(const NrAttnBwdArgs& a, const i
         a.dq_hi[qo] = hb;
         a.dq_lo[qo] = nr_f2bf(dq - nr_bf2f(hb));
     }
-#pragma unroll
-    for (int u = 0; u < NCH; ++u)
+    auto store_chunk = [&](const float (&dkc)[32], const float (&dvc)[32], int u) {
 #pragma unroll
         for (int n = 0; n < 32; ++n)
             if (u * 32 + n < N) {
                 const size_t o = kvb + (size_t)(u * 32 + n) * 2 * C;
-                const float k_ = dk[u][n] * a.scale, v_ = dv[u][n];
+                const float k_ = dkc[n] * a.scale, v_ = dvc[n];
                 a.d_kv[o] = k_;
                 a.d_kv[o + C] = v_;
                 uint16_t hb = nr_f2bf(k_);
@@ -396,6 +401,29 @@ __device__ __forceinline__ void nr_attn_bwd_body(const NrAttnBwdArgs& a, const i
                 a.dkv_hi[o + C] = hb;
                 a.dkv_lo[o + C] = nr_f2bf(v_ - nr_bf2f(hb));
             }
+    };
+    if constexpr (NCH == 1) {
+        store_chunk(dk[0], dv[0], 0);
+    } else {
+        __syncthreads();                    // (every wave reads only its own rows; the barrier orders its LDS stores before them)
+        for (int u = 0; u < NCH; ++u) {
+            if (u * 32 >= N) break;
+            float dkc[32], dvc[32];
+#pragma unroll
+            for (int n = 0; n < 32; ++n) dkc[n] = dvc[n] = 0.f;
+            for (int ci = 0; ci < c; ++ci) {
+                const size_t qo = ((size_t)b * c + ci) * C + (size_t)h * 64 + lane;
+                const float qv = a.q[qo], da = a.d_att[qo];
+                const float* row = s_rows + ci * 128 + u * 32;
+#pragma unroll
+                for (int n = 0; n < 32; ++n) {
+                    dkc[n] += row[n] * qv;          // (tokens >= N hold d_logit = p = 0)
+                    dvc[n] += row[64 + n] * da;
+                }
+            }
+            store_chunk(dkc, dvc, u);
+        }
+    }
     // d_score[n] = sum over heads and queries of d_logit (the score biases every head and query): heads meet in LDS
     s_ds[h * 64 + lane] = dsc;
     __syncthreads();
@@ -442,7 +470,15 @@ extern "C" int nr_ctm_attn_bwd(int n, const NrCtmAttnBwdDesc* d, void* stream) {
         }
         hipLaunchKernelGGL(nr_attn_bwd_group_kernel<1>, dim3(total), dim3(64 * heads), lds, (hipStream_t)stream, g);
     } else {
-        hipLaunchKernelGGL(nr_attn_bwd_group_kernel<2>, dim3(total), dim3(64 * heads), 0, (hipStream_t)stream, g);
+        int cmax = 0;
+        for (int i = 0; i < n; ++i) cmax = d[i].cnum > cmax ? d[i].cnum : cmax;
+        const size_t lds = (size_t)heads * cmax * 128 * sizeof(float);                 // every query's d_logit | p row, per head
+        if (lds > 150 * 1024) return NR_EUNSUPPORTED;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)nr_attn_bwd_group_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(nr_attn_bwd_group_kernel<2>, dim3(total), dim3(64 * heads), lds, (hipStream_t)stream, g);
     }
     NR_LAUNCH_CHECK();
     return NR_OK;
@@ -495,9 +531,11 @@ __device__ __forceinline__ void nr_ln_bwd_row(const float (&x)[CPL], float (&dyv
 
 #define MB_THREADS 512      // 8 waves: the row state (three rows + five gradient accumulators + three parameter vectors, CPL
                             // registers each) needs the 256-register budget of two waves per SIMD
-template <int CPL>
+// THREADS: MB_THREADS for C <= 512 (CPL = 8); C > 512 (CPL = 16: eleven CPL-sized register vectors) runs 256 threads -- one wave per
+// SIMD, the whole 512-register file of a lane (at two waves per SIMD the kernel spilled 903 registers, round 3).
+template <int CPL, int THREADS = MB_THREADS>
 __device__ __forceinline__ void nr_mid_bwd_body(const NrMidBwdArgs& a, const int b, float* sm /* dynamic LDS */) {
-    constexpr int NW = MB_THREADS / 64;
+    constexpr int NW = THREADS / 64;
     const int N = a.N, C = a.C, c = a.cnum;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cpl = C / 64;
@@ -612,7 +650,7 @@ __device__ __forceinline__ void nr_mid_bwd_body(const NrMidBwdArgs& a, const int
         for (int q = 0; q < CPL; ++q)
             if (q < cpl) s_red[wave * C + q * 64 + lane] = v[q];
         __syncthreads();
-        for (int ch = tid; ch < C; ch += MB_THREADS) {
+        for (int ch = tid; ch < C; ch += THREADS) {
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) s += s_red[w * C + ch];
@@ -626,7 +664,7 @@ __device__ __forceinline__ void nr_mid_bwd_body(const NrMidBwdArgs& a, const int
     reduce(dws, 4);
     if (lane == 0) s_bs[wave] = dbs;
     __syncthreads();
-    for (int ch = tid; ch < C; ch += MB_THREADS) {
+    for (int ch = tid; ch < C; ch += THREADS) {
         float s = 0.f;
         if (ch == 0)
             for (int w = 0; w < NW; ++w) s += s_bs[w];
@@ -634,11 +672,11 @@ __device__ __forceinline__ void nr_mid_bwd_body(const NrMidBwdArgs& a, const int
     }
 }
 
-template <int CPL>
-__global__ __launch_bounds__(MB_THREADS) void nr_mid_bwd_group_kernel(NrBwdGroupOf<NrMidBwdArgs> g) {
+template <int CPL, int THREADS = MB_THREADS>
+__global__ __launch_bounds__(THREADS) void nr_mid_bwd_group_kernel(NrBwdGroupOf<NrMidBwdArgs> g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int gi = g.find(blockIdx.x);
-    nr_mid_bwd_body<CPL>(g.p[gi], blockIdx.x - g.start[gi], sm);
+    nr_mid_bwd_body<CPL, THREADS>(g.p[gi], blockIdx.x - g.start[gi], sm);
 }
 
 extern "C" int nr_ctm_mid_bwd(int n, const NrCtmMidBwdDesc* d, void* stream) {
@@ -665,13 +703,13 @@ extern "C" int nr_ctm_mid_bwd(int n, const NrCtmMidBwdDesc* d, void* stream) {
         total += s.n_samples;
     }
     for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
-    const void* k = small ? (const void*)nr_mid_bwd_group_kernel<8> : (const void*)nr_mid_bwd_group_kernel<CF_MAX_CPL>;
+    const void* k = small ? (const void*)nr_mid_bwd_group_kernel<8> : (const void*)nr_mid_bwd_group_kernel<CF_MAX_CPL, 256>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     if (small) hipLaunchKernelGGL(nr_mid_bwd_group_kernel<8>, dim3(total), dim3(MB_THREADS), lds, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(nr_mid_bwd_group_kernel<CF_MAX_CPL>, dim3(total), dim3(MB_THREADS), lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((nr_mid_bwd_group_kernel<CF_MAX_CPL, 256>), dim3(total), dim3(256), lds, (hipStream_t)stream, g);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

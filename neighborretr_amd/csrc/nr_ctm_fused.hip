@@ -12,10 +12,11 @@
 #include "nr_ctm_bodies.h"
 #include "../../include/nr_hip.h"
 
-template <int CPL>
-__global__ __launch_bounds__(CF_THREADS) void nr_ctm_front_kernel(NrCtmFrontArgs p) {
+// (C > 512: sixteen channels per lane need more than the 128 registers of a 1024-thread workgroup: 512 threads there)
+template <int CPL, int THREADS = CF_THREADS>
+__global__ __launch_bounds__(THREADS) void nr_ctm_front_kernel(NrCtmFrontArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sx[];      // [N][C] normalised tokens
-    nr_ctm_front_body<CPL>(p, blockIdx.x, sx);
+    nr_ctm_front_body<CPL, THREADS>(p, blockIdx.x, sx);
 }
 
 extern "C" int nr_ctm_front(const float* y, const float* mask, int n_samples, int N, int C, const float* ln_w,
@@ -29,14 +30,14 @@ extern "C" int nr_ctm_front(const float* y, const float* mask, int n_samples, in
     if (lds > 150 * 1024) return NR_EUNSUPPORTED;
     const bool small = C <= 512;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(small ? (const void*)nr_ctm_front_kernel<8> : (const void*)nr_ctm_front_kernel<CF_MAX_CPL>,
+        hipError_t e = hipFuncSetAttribute(small ? (const void*)nr_ctm_front_kernel<8> : (const void*)nr_ctm_front_kernel<CF_MAX_CPL, 512>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     NrCtmFrontArgs p{y, mask, ln_w, ln_b, sc_w, sc_b, n1_w, n1_b, eps, 1.0f / sqrtf((float)C), N, C, xn, kvn, score, tokw, dist, smax,
                      kvn_hi, kvn_lo};
     if (small) hipLaunchKernelGGL(nr_ctm_front_kernel<8>, dim3(n_samples), dim3(CF_THREADS), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(nr_ctm_front_kernel<CF_MAX_CPL>, dim3(n_samples), dim3(CF_THREADS), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((nr_ctm_front_kernel<CF_MAX_CPL, 512>), dim3(n_samples), dim3(512), lds, (hipStream_t)stream, p);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }

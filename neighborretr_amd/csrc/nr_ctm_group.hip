@@ -234,28 +234,28 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
             for (int i = 0; i < n; ++i) few = few && d[i].N <= 8 && d[i].cnum * (d[i].C / 128) <= 4 * BK_MAXJ;
             if (fusable && few) {
                 hipLaunchKernelGGL((nr_group_front_back_kernel<8, 256>), dim3(total), dim3(256), front_lds, st, gf, gb);
-            } else if (fusable) {
-                const void* k = small ? (const void*)nr_group_front_back_kernel<8> : (const void*)nr_group_front_back_kernel<CF_MAX_CPL>;
+            } else if (fusable && small) {
+                const void* k = (const void*)nr_group_front_back_kernel<8>;
                 if (front_lds > 64 * 1024) {
                     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds);
                     if (e != hipSuccess) return (int)e;
                 }
-                if (small) hipLaunchKernelGGL(nr_group_front_back_kernel<8>, dim3(total), dim3(CF_THREADS), front_lds, st, gf, gb);
-                else hipLaunchKernelGGL(nr_group_front_back_kernel<CF_MAX_CPL>, dim3(total), dim3(CF_THREADS), front_lds, st, gf, gb);
+                hipLaunchKernelGGL(nr_group_front_back_kernel<8>, dim3(total), dim3(CF_THREADS), front_lds, st, gf, gb);
             } else {
+                // C > 512: sixteen channels per lane of seven per-channel vectors do not fit the 128 registers a 1024-thread
+                // workgroup leaves a lane (48 spilled registers, round 3) -- 512-thread workgroups, and never the fused
+                // front + back form (the back launch below runs on its own)
                 if (front_lds > 64 * 1024) {
-                    hipError_t e = hipFuncSetAttribute(small ? (const void*)nr_group_front_kernel<8> : (const void*)nr_group_front_kernel<CF_MAX_CPL>,
+                    hipError_t e = hipFuncSetAttribute(small ? (const void*)nr_group_front_kernel<8> : (const void*)nr_group_front_kernel<CF_MAX_CPL, 512>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds);
                     if (e != hipSuccess) return (int)e;
                 }
-                const char* te = nr_tune_env("NR_CTM_THREADS");          // tuning hook: 512-thread workgroups for front / back / attention
-                if (small && te && atoi(te) == 512) hipLaunchKernelGGL((nr_group_front_kernel<8, 512>), dim3(total), dim3(512), front_lds, st, gf);
-                else if (small) hipLaunchKernelGGL(nr_group_front_kernel<8>, dim3(total), dim3(CF_THREADS), front_lds, st, gf);
-                else hipLaunchKernelGGL(nr_group_front_kernel<CF_MAX_CPL>, dim3(total), dim3(CF_THREADS), front_lds, st, gf);
+                if (small) hipLaunchKernelGGL(nr_group_front_kernel<8>, dim3(total), dim3(CF_THREADS), front_lds, st, gf);
+                else hipLaunchKernelGGL((nr_group_front_kernel<CF_MAX_CPL, 512>), dim3(total), dim3(512), front_lds, st, gf);
             }
             NR_LAUNCH_CHECK();
         }
-        if (first <= 3 && 3 < last && !fusable) {
+        if (first <= 3 && 3 < last && !(fusable && small)) {
             size_t lds = 0;                      // token rows of the largest problem, if every problem's rows fit
             bool fits = true;
             for (int i = 0; i < n; ++i) {

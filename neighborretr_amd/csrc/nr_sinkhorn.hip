@@ -302,8 +302,13 @@ struct NrSkCoopArgs {
     unsigned int* counter;       // [2 dir][32] (one 128-byte line each), zero on entry
 };
 
-template <int EPL>               // entries per lane = B / 64
+// EPL = entries per lane = B / 64.  PC_LDS: the column-major copy of the kernel matrix lives in dynamic LDS (4 EPL floats per
+// thread, [4 EPL][512]: conflict-free) instead of registers -- from EPL = 13 (B >= 832) two register copies of 4 EPL entries plus
+// the scaling-vector slice no longer fit the 256 registers a lane has at two waves per SIMD (69 spilled registers at EPL = 16
+// in round 3); the b-update reads it once per iteration, next to a ~2 us barrier.
+template <int EPL, bool PC_LDS = (EPL >= 13)>
 __global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sk_pc_lds[];
     NR_CRITICAL_PATH();
     const int dir = blockIdx.x & 7;
     if (dir > 1) return;
@@ -317,16 +322,20 @@ __global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
     if (tid == 0) s_dead = 0;
     const float norm = -logf((float)(2 * B));
     const float mass = 1.0f / (float)(2 * B);
-    // X[i][j] = G[i][j] (dir 0) or G[j][i] (dir 1);  pr[q][e] = X[line q][64 e + lane],  pc[q][e] = X[64 e + lane][line q]
+    // X[i][j] = G[i][j] (dir 0) or G[j][i] (dir 1);  pr(q, e) = X[line q][64 e + lane],  pc(q, e) = X[64 e + lane][line q]
     const int l0 = 32 * wg + 4 * wave;
-    float pr[4][EPL], pc[4][EPL];
+    float pr[4][EPL], pc_reg[PC_LDS ? 1 : 4][PC_LDS ? 1 : EPL];
+    auto pc = [&](int q, int e) -> float& {
+        if constexpr (PC_LDS) return sk_pc_lds[(q * EPL + e) * 512 + tid];
+        else return pc_reg[q][e];
+    };
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const size_t rowmaj = (size_t)(l0 + q) * B + e * 64 + lane, colmaj = (size_t)(e * 64 + lane) * B + l0 + q;
             pr[q][e] = p.G[dir == 0 ? rowmaj : colmaj];
-            pc[q][e] = p.G[dir == 0 ? colmaj : rowmaj];
+            pc(q, e) = p.G[dir == 0 ? colmaj : rowmaj];
         }
     unsigned int phase = 0;
     // All stores of this workgroup visible, then every workgroup of the direction.  The workgroups of a direction must be
@@ -380,14 +389,14 @@ __global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
             for (int e = 0; e < EPL; ++e) {
                 const float uu = get(va, e);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { pc[q][e] += uu; mx[q] = fmaxf(mx[q], pc[q][e]); }      // pc <- X + u
+                for (int q = 0; q < 4; ++q) { const float x = pc(q, e) + uu; pc(q, e) = x; mx[q] = fmaxf(mx[q], x); }      // pc <- X + u
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float m = nr_wave_max(mx[q]);
                 float t = 0.f;
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) t += __expf(pc[q][e] - m);
+                for (int e = 0; e < EPL; ++e) t += __expf(pc(q, e) - m);
                 v_own[q] = norm - (m + __logf(nr_wave_sum(t)));
                 put(vb, q, v_own[q]);
             }
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 pr[q][e] = __expf(pr[q][e] + u_own[q] + vv);
-                pc[q][e] = __expf(pc[q][e] + v_own[q]);
+                pc(q, e) = __expf(pc(q, e) + v_own[q]);
             }
         }
         // a = b = 1: publish b = 1 through vb's slots only after everybody has read v from them
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) { pr[q][e] = __expf(pr[q][e]); pc[q][e] = __expf(pc[q][e]); }
+            for (int e = 0; e < EPL; ++e) { pr[q][e] = __expf(pr[q][e]); pc(q, e) = __expf(pc(q, e)); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) put(vb, q, 1.0f);
         barrier();
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
             for (int q = 0; q < 4; ++q) {
                 float c = 0.f;
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) c += pc[q][e] * aa[e];
+                for (int e = 0; e < EPL; ++e) c += pc(q, e) * aa[e];
                 put(vb, q, mass * __builtin_amdgcn_rcpf(nr_wave_sum(c)));
             }
         }
@@ -472,6 +481,9 @@ static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* 
                            float* uniform_rows, int uniform_stride, void* workspace, void* stream,
                            NrSkFinal fin = NrSkFinal{nullptr, 0u, 0.f, 0.f, 0.f, nullptr}, bool allow_coop = true);
 
+// dynamic LDS of the cooperative kernel: the column-major matrix copy of the wide variants (EPL >= 13), 4 EPL floats per thread
+static size_t nr_sinkhorn_coop_lds(int B) { return B / 64 >= 13 ? (size_t)4 * (B / 64) * 512 * sizeof(float) : 0; }
+
 static const void* nr_sinkhorn_coop_fn(int B) {
     switch (B / 64) {
 #define NR_SKC(E_) case E_: return (const void*)nr_sinkhorn_coop_kernel<E_>;
@@ -501,9 +513,11 @@ extern "C" int nr_sinkhorn_cooperative_ok(int B) {
     if (c == 0) {
         int dev = 0, cus = 0, per_cu = 0;
         const void* fn = nr_sinkhorn_coop_fn(B);
+        const size_t lds = nr_sinkhorn_coop_lds(B);
         bool ok = fn && hipGetDevice(&dev) == hipSuccess &&
                   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-                  hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, 0) == hipSuccess;
+                  (lds <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
+                  hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, lds) == hipSuccess;
         // MI355X in SPX mode: 256 CUs in 8 XCDs; a partition / mask reports fewer CUs and is priced as ONE XCD's worth per 32
         const int n_xcd = cus >= 64 ? 8 : 1;
         c = (ok && nr_sinkhorn_cooperative_gate(B, per_cu, cus, n_xcd)) ? 2 : 1;
@@ -590,7 +604,7 @@ static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* 
         NrSkCoopArgs a{G, B, iters, beta, tgt_rows, tgt_cols, vec, counter};
         const dim3 grid(8 * (B / 32));
         switch (B / 64) {
-#define NR_SKC(E_) case E_: hipLaunchKernelGGL(nr_sinkhorn_coop_kernel<E_>, grid, dim3(512), 0, st, a); break;
+#define NR_SKC(E_) case E_: hipLaunchKernelGGL(nr_sinkhorn_coop_kernel<E_>, grid, dim3(512), nr_sinkhorn_coop_lds(B), st, a); break;
             NR_SKC(3) NR_SKC(4) NR_SKC(5) NR_SKC(6) NR_SKC(7) NR_SKC(8) NR_SKC(9) NR_SKC(10) NR_SKC(11) NR_SKC(12) NR_SKC(13) NR_SKC(14)
             NR_SKC(15) NR_SKC(16)
 #undef NR_SKC
