@@ -61,19 +61,19 @@ class RetrievalMetrics:
 
     @staticmethod
     def tensor_text_to_video_metrics(sim_tensor, top_k=(1, 5, 10, 50)):
-        """Multi-sentence text->video metrics (utils/metrics.py:82-126).  `sim_tensor[i, s, j]` is the score of
-        sentence s of video i against video j, padded with -inf / NaN where video i has fewer sentences (the
-        layout the double argsort and the two diagonals of the reference imply); every valid (i, s) contributes
-        the rank of video i in its row."""
-        if not torch.is_tensor(sim_tensor):
-            sim_tensor = torch.tensor(sim_tensor)
-        stacked = sim_tensor.permute(1, 0, 2)
-        first = torch.argsort(stacked, dim=-1, descending=True)
-        second = torch.argsort(first, dim=-1, descending=False)
-        ranks = torch.flatten(torch.diagonal(second, dim1=1, dim2=2))
-        diag = torch.flatten(torch.diagonal(sim_tensor, dim1=0, dim2=2))
-        valid = ranks[~torch.logical_or(torch.isinf(diag), torch.isnan(diag))].cpu()
-        return RetrievalMetrics.multi_sentence_metrics_from_ranks(valid, top_k)
+        """Multi-sentence text->video metrics with the reference's interface (utils/metrics.py:82-126): `sim_tensor[i, s, j]` =
+        score of sentence s of video i against video j, -inf / NaN where video i has fewer sentences.  The rank of every valid
+        sentence's own video is COUNTED -- scores above its own (NaN scores sort first) plus equal scores at lower video
+        indices, i.e. a stable descending order, the rule of nr_group_slab_ranks -- instead of sorted out of the padded tensor;
+        the product's evaluator never builds that tensor (neighborretr_amd.evaluator: row slabs + nr_group_slab_ranks)."""
+        sim = torch.as_tensor(sim_tensor)
+        n_video = sim.shape[0]
+        video = torch.arange(n_video, device=sim.device)
+        own = sim[video, :, video]                                        # [video, sentence]: the sentence against its own video
+        ahead = (sim > own[:, :, None]) | torch.isnan(sim)
+        ahead |= (sim == own[:, :, None]) & (video[None, None, :] < video[:, None, None])
+        ranks = ahead.sum(-1)[torch.isfinite(own)]
+        return RetrievalMetrics.multi_sentence_metrics_from_ranks(ranks.cpu(), top_k)
 
     @staticmethod
     def multi_sentence_metrics_from_ranks(ranks, top_k=(1, 5, 10, 50)):
@@ -88,14 +88,11 @@ class RetrievalMetrics:
 
     @staticmethod
     def tensor_video_to_text_sim(sim_tensor):
-        """[n_video, max_sentences, n_video] -> [n_video, n_video] video->text matrix holding, for every
-        (video j, caption group i), the best of group i's sentences (utils/metrics.py:128-148).  Unlike the
-        reference this does not overwrite the NaNs of the caller's tensor."""
-        if not torch.is_tensor(sim_tensor):
-            sim_tensor = torch.tensor(sim_tensor)
-        sim_tensor = torch.where(sim_tensor != sim_tensor, torch.full_like(sim_tensor, float("-inf")), sim_tensor)
-        values, _ = torch.max(sim_tensor, dim=1, keepdim=True)
-        return torch.squeeze(values).T
+        """[n_video, max_sentences, n_video] -> the [n_video, n_video] video->text matrix: entry (j, i) = the best score any
+        sentence of caption group i reaches against video j (utils/metrics.py:128-148); NaN padding never wins, and the
+        caller's tensor is left as it was."""
+        sim = torch.as_tensor(sim_tensor)
+        return torch.nan_to_num(sim, nan=float("-inf"), posinf=float("inf"), neginf=float("-inf")).amax(dim=1).T
 
     def print_metrics(self, metrics, prefix=""):
         msg = (f"{prefix}R@1: {metrics['R1']:.1f} - R@5: {metrics['R5']:.1f} - R@10: {metrics['R10']:.1f} - "
