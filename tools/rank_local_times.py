@@ -305,6 +305,93 @@ def measure_interleaved(model, full, W, rank, dev, lines):
     return out
 
 
+def measure_training(model, full, W, rank, dev, lines, graph=True):
+    """The sharded TRAINING step (neighborretr_amd.sharded: forward + backward, loss / bank / clustering work sharded over the
+    ranks) of rank `rank` at W emulated ranks: five collectives forward (packed gather, clustering maximum, global tokens,
+    centrality slices, loss values), four backward (reduce-scatter of the centrality / token gathers' gradients and of the two
+    gathered feature tensors).  Checked before timing: every rank's losses == the replicated training step, and the MEAN over
+    the ranks of their parameter gradients (what DDP's all-reduce leaves in .grad) == the replicated step's gradients."""
+    rl = RankLocal(model, full, W, dev)
+    out = {"W": W, "b": rl.b}
+    params = [p for p in model.parameters() if p.requires_grad]
+    leaves = [(s["text_feat"].clone().requires_grad_(True), s["video_feat"].clone().requires_grad_(True)) for s in rl.shards]
+
+    def train_step(r, communicator=None):
+        s, (tf, vf) = rl.shards[r], leaves[r]
+        for p_ in params:
+            p_.grad = None
+        tf.grad = vf.grad = None
+        with (comm.use(communicator) if communicator is not None else contextlib.nullcontext()):
+            ls = model(tf, s["text_mask"], vf, s["video_mask"], s["idx"], 0)
+            ls[0].backward()
+        return torch.stack([l.detach() for l in ls])
+    grads = [None] * W
+
+    def settle_run(r):
+        rl.configure(r)
+        rl.losses[r] = train_step(r, rl.world.comm(r)).clone()
+        grads[r] = [None if p_.grad is None else p_.grad.clone() for p_ in params]
+    model.bank_frozen = True
+    try:
+        out["sweeps"] = rl.world.settle(settle_run, max_sweeps=24)
+        # the replicated training step on the gathered batch
+        cfg = model.config
+        cfg.world_size, cfg.local_rank = 1, 0
+        model.shard_loss = None
+        model._rng_state.copy_(rl.rng0)
+        for p_ in params:
+            p_.grad = None
+        tf = full["text_feat"].clone().requires_grad_(True)
+        ref = model(tf, full["text_mask"], full["video_feat"], full["video_mask"], full["idx"], 0)
+        ref[0].backward()
+        ref_l = torch.stack([l.detach() for l in ref])
+        out["max_dL_vs_replicated"] = max(float((l - ref_l).abs().max()) for l in rl.losses)
+        worst = 0.0
+        for k, p_ in enumerate(params):
+            if p_.grad is None:
+                continue
+            mean = sum(g[k] for g in grads if g[k] is not None) / W
+            worst = max(worst, float((mean - p_.grad).abs().max() / p_.grad.abs().max().clamp_min(1e-20)))
+        out["max_param_grad_dev"] = worst
+        own = leaves[rank][0].grad
+        want = tf.grad[rank * rl.b:(rank + 1) * rl.b]
+        out["feature_grad_dev"] = float((own - want).abs().max() / want.abs().max())
+        if not (out["max_dL_vs_replicated"] <= 1e-3 and worst <= 2e-2 and out["feature_grad_dev"] <= 2e-2):
+            raise AssertionError(f"emulated sharded training step at W={W} deviates from the replicated one: {out}")
+    finally:
+        model.bank_frozen = False
+    c = rl.world.comm(rank)
+    rl.configure(rank)
+
+    def step():
+        return train_step(rank, c)
+    step()
+    torch.cuda.synchronize()
+    n0 = hip.N_CALLS
+    step()
+    out["abi_calls"], out["collectives"] = hip.N_CALLS - n0, c.n_collectives
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    out["eager_us"] = (time.perf_counter() - t0) / 20 * 1e6
+    out["graph_us"] = None
+    if graph:
+        with model.graph_capture_mode():
+            g, _ = capture(step)
+        out["graph_us"] = replay_time(g.replay, reps=50)
+        del g
+    lines.append(f"W={W} b={rl.b:3d}  sharded TRAINING step (forward + backward): losses == replicated to {out['max_dL_vs_replicated']:.1e}, mean over ranks of "
+                 f"the parameter gradients == replicated to {out['max_param_grad_dev']:.1e} of each tensor's largest entry, this rank's feature "
+                 f"gradient to {out['feature_grad_dev']:.1e}  (settled in {out['sweeps']} sweeps)")
+    lines.append(f"    rank {rank}: {out['abi_calls']} C-ABI calls + {out['collectives']} collectives per step;  eager {out['eager_us']:7.1f} us"
+                 + (f";  ONE graph (forward + backward + the 1-rank RCCL collectives) {out['graph_us']:7.1f} us" if out["graph_us"] else ""))
+    return out
+
+
 def build(dev, precision="bf16"):
     m = modeling.NeighborRetr(modeling.default_config(num_neighbors=CFG["K"]), precision=precision)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}, strict=False)
@@ -328,6 +415,8 @@ def main():
     ap.add_argument("--M", type=int, default=CFG["M"])
     ap.add_argument("--K", type=int, default=CFG["K"])
     ap.add_argument("--out", default=None)
+    ap.add_argument("--train", action="store_true", help="also the sharded TRAINING step (forward + backward) per world size")
+    ap.add_argument("--only_train", action="store_true")
     args = ap.parse_args()
     CFG.update(B=args.B, M=args.M, K=args.K)
     torch.cuda.set_device(0)
@@ -343,12 +432,17 @@ def main():
         with torch.no_grad():
             model(full["text_feat"], full["text_mask"], full["video_feat"], full["video_mask"], full["idx"], 0)
     lines.append(f"W=1 b={CFG['B']}  the replicated step as one graph: {replay_time(capture(one)[0].replay):7.1f} us")
-    lines.append("---- SYNCHRONOUS sharded step (every rank takes part in every step's loss; five collectives per step) ----")
-    for W in args.worlds:
-        measure(model, full, W, min(args.rank, W - 1), dev, lines)
-    lines.append("---- STEP-INTERLEAVED (one collective per step; the loss of step k on rank k mod W) ----")
-    for W in args.worlds:
-        measure_interleaved(model, full, W, min(args.rank, W - 1), dev, lines)
+    if not args.only_train:
+        lines.append("---- SYNCHRONOUS sharded step (every rank takes part in every step's loss; five collectives per step) ----")
+        for W in args.worlds:
+            measure(model, full, W, min(args.rank, W - 1), dev, lines)
+        lines.append("---- STEP-INTERLEAVED (one collective per step; the loss of step k on rank k mod W) ----")
+        for W in args.worlds:
+            measure_interleaved(model, full, W, min(args.rank, W - 1), dev, lines)
+    if args.train or args.only_train:
+        lines.append("---- sharded TRAINING step (neighborretr_amd.sharded), forward + backward ----")
+        for W in args.worlds:
+            measure_training(model, full, W, min(args.rank, W - 1), dev, lines)
     text = "\n".join(lines)
     print(text)
     if args.out:
