@@ -423,59 +423,32 @@ def main():
     abi_calls = round((hip.N_CALLS - before) / n_round, 1) if rank == 0 else None
     run = step
     if world > 1 and not args.replicated_loss and not args.no_graph:
-        import datetime
         from neighborretr_amd import comm
-        hs = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
+        cc = comm.CollectiveCapture(world, rank, log=lambda msg: print(f"[bench] {msg}", file=sys.stderr))
+        rng = model._rng_state_on(dev)
 
-        def agree(ok):
-            """True iff EVERY rank says ok (a host-side collective on its own gloo group: it does not depend on the state of
-            the RCCL stream, and a rank that died is noticed after two minutes, not ten)."""
-            t = torch.tensor([1 if ok else 0], dtype=torch.int32)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=hs)
-            return bool(int(t.item()))
+        def eager_pass():
+            ctr[0] = 0
+            rng[1] = 4242                    # the DPC-KNN tie-break noise is a function of this counter: the same draws for both passes
+            for _ in range(n_round):
+                step()
 
         def attempt(make, what):
-            """make() -> (replay, keep-alive) captures a replayable form of `step`.  Captured with the bank frozen first and
-            replayed once against the eager step; then captured again for the timed run.  -> replay or None, on every rank alike."""
-            model.bank_frozen = True
-            rng = model._rng_state_on(dev)
-            try:
-                ctr[0] = 0
-                rng[1] = 4242                # the DPC-KNN tie-break noise is a function of this counter: the same draws for both passes
-                for _ in range(n_round):
-                    step()
-                torch.cuda.synchronize()
-                eager = result["losses"].clone()
-                form, err = None, None
-                try:
-                    form = make()
-                except Exception as e:      # noqa: BLE001 -- a failed capture is a verdict, not an error
-                    err = f"{type(e).__name__}: {e}"
-                    torch.cuda.synchronize()
-                if not agree(form is not None):
-                    if err:
-                        print(f"[bench] rank {rank}: {what} capture unavailable ({err})", file=sys.stderr)
-                    return None
-                ctr[0] = 0
-                rng[1] = 4242
-                for _ in range(n_round):     # every rank replays: the collectives inside / between the graphs match up
-                    form[0]()
-                torch.cuda.synchronize()
-                same = bool(torch.allclose(result["losses"], eager, rtol=1e-5, atol=1e-6))
-                if not agree(same):
-                    if not same:
-                        print(f"[bench] rank {rank}: replayed {what} step differs from the eager one: {result['losses'].tolist()} vs "
-                              f"{eager.tolist()}", file=sys.stderr)
-                    return None
-            finally:
-                model.bank_frozen = False
-            form = None
-            try:
-                form = make()
-            except Exception as e:          # noqa: BLE001
-                print(f"[bench] rank {rank}: {what} capture (timed form) failed ({type(e).__name__}: {e})", file=sys.stderr)
-                torch.cuda.synchronize()
-            return form if agree(form is not None) else None
+            """make() -> (replay, keep-alive): a replayable form of `step`, validated against the eager step on every rank
+            (comm.CollectiveCapture.attempt) -> the form or None, on every rank alike."""
+            def make_pass():
+                replay, keep = make()
+
+                def replay_pass():
+                    ctr[0] = 0
+                    rng[1] = 4242
+                    for _ in range(n_round):
+                        replay()
+                return replay_pass, (replay, keep)
+            form = cc.attempt(what, eager_pass, make_pass, lambda: result["losses"],
+                              lambda a, b_: torch.allclose(a, b_, rtol=1e-5, atol=1e-6),
+                              freeze=lambda on: setattr(model, "bank_frozen", on))
+            return None if form is None else form[1]
 
         def per_phase(capture_one):
             """The replayable form of `step`: one capture, or -- interleaved -- two: the step this rank owns and the step it

@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 /* bumped whenever a signature or the layout of a descriptor struct changes (2: NrCtmStageDesc gained x_hi/x_lo/out_hi/out_lo in
- * round 3, nr_stream_create / nr_stream_destroy in round 4); a binding compares nr_version() with the value it was written for */
+ * round 3, nr_stream_create / nr_stream_destroy, NrBankAbsorbDesc in round 4); a binding compares nr_version() with the value it was written for */
 #define NR_ABI_VERSION 2
 
 /* precision of the MFMA contractions */
@@ -643,6 +643,31 @@ int nr_bank_push(void* bank, const void* batch, int capacity, int n_new, size_t 
  * a captured HIP graph pushes to a new place at every replay.                                      */
 int nr_bank_ring_push(int n_tensors, void* const* banks, const void* const* batches, const size_t* row_bytes,
                       int capacity, int head_new, const int32_t* head_dev, int n_new, void* stream);
+
+/* A gathered batch straight into the memory bank, ONE launch (step-interleaved multi-rank job: a step whose loss another rank
+ * evaluates leaves nothing behind on this rank but the FIFO push of modeling.py:309-310 and the bank's prepared shadow).
+ * Reads the RECEIVE buffer of the packed exchange step -- world records of record_bytes bytes, each holding per_rank samples'
+ * text tokens f32 [per_rank, Nt, d] at off_text, video tokens at off_video, ids i64 at off_index, masks u8 [per_rank, N] at
+ * off_text_mask / off_video_mask (nr_pack_shard's layout) -- and
+ *   moves the ring head back by world * per_rank (as nr_step_prologue does) and writes the samples at the new head on:
+ *   bank_text [capacity, Nt, d] / bank_video f32, bank_index i64 [capacity], bank_*_mask f32 [capacity, N];
+ *   the same rows PREPARED (normalised x mask as bf16 hi / lo + norms: nr_prepare_tokens' arithmetic, bit for bit) into
+ *   shadow_* (hi / lo [capacity * N, d], norm [capacity * N]; all six NULL: no shadow kept);
+ *   rng_state (optional): the noise stream's step counter advances by one, as a step's nr_step_prologue advances it.
+ * counter: a zeroed device word, zero again when the launch ends.  world * per_rank < capacity; d % 256 == 0, d <= 1024. */
+typedef struct NrBankAbsorbDesc {
+    const void* gathered;
+    uint64_t record_bytes, off_text, off_video, off_index, off_text_mask, off_video_mask;
+    int32_t world, per_rank, Nt, Nv, d, capacity;
+    float *bank_text, *bank_video, *bank_text_mask, *bank_video_mask;
+    int64_t* bank_index;
+    uint16_t *shadow_text_hi, *shadow_text_lo, *shadow_video_hi, *shadow_video_lo;
+    float *shadow_text_norm, *shadow_video_norm;
+    int32_t* ring_head;
+    uint64_t* rng_state;
+    uint32_t* counter;
+} NrBankAbsorbDesc;
+int nr_bank_absorb_gathered(const NrBankAbsorbDesc* desc, void* stream);
 
 /* Rank of the diagonal in every row under the reference's tie rule (metrics.py:58-66):
  *   greater[i] = #{j : S[i,j] > S[i,i]},  equal[i] = #{j : S[i,j] == S[i,i]} (includes j=i). */

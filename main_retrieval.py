@@ -90,8 +90,10 @@ def get_args():
                         "PyTorch-ROCm modules, random init unless --init_model) in front of the HIP head; --synthetic then "
                         "feeds random pixels [b, frames, 3, 224, 224] and token ids instead of token features")
     p.add_argument("--hip_graph", type=int, default=0,
-                   help="1: forward + backward of the training step replayed from ONE captured HIP graph "
-                        "(single rank; the eager step is bound by the host issuing ~560 launches)")
+                   help="1: the training step replayed from captured HIP graphs instead of ~90 eager launches.  One rank: forward + "
+                        "backward as ONE graph.  Several ranks: the whole data-parallel step -- exchange, loss, backward, gradient "
+                        "average -- as one graph with the RCCL collectives inside, or (when that is refused / fails its validation, "
+                        "and on gloo) the rank-local segments between the collectives as graphs; the ranks decide together")
     args = p.parse_args()
     if args.batch_size % max(1, int(os.environ.get("WORLD_SIZE", "1"))):
         raise ValueError("--batch_size must divide over the ranks (args_parser.py:149-165)")
@@ -208,37 +210,59 @@ def clear_memory_bank(model):
 
 
 class GraphedStep:
-    """Forward + backward of one training step as a captured HIP graph with static input buffers: replay()
-    leaves the losses in .losses and the gradients in the parameters' .grad (the optimizer step stays eager)."""
+    """Forward + backward of one training step as a captured HIP graph with static input buffers: run() leaves the losses in
+    .losses and the gradients in the parameters' .grad (the optimizer step stays eager).
 
-    def __init__(self, model, example, params):
+    world_size > 1: the step that is replayed is the WHOLE data-parallel step -- exchange step, loss, backward with the
+    reductions of its differentiable collectives, and the gradient average over the ranks (one all-reduce of a flat buffer that
+    the parameters' .grad are views of; what DistributedDataParallel's bucketed all-reduce computes, optimizer.py:79-84) --
+    in the best form every rank can take (neighborretr_amd.comm.CollectiveCapture): ONE graph with the RCCL collectives
+    inside; else the rank-local segments between the collectives as graphs (comm.SegmentedStep); else eager launches.  Each
+    form is validated against the eager step on every rank before it is used."""
+
+    def __init__(self, model, example, params, args=None):
         self.static = [t.clone() for t in example]
         self.params = params
         self.model = model
+        self.world = int(getattr(args, "world_size", 1)) if args is not None else 1
+        self.rank = int(getattr(args, "rank", 0)) if args is not None else 0
+        self.backend = getattr(args, "dist_backend", "nccl") if args is not None else "nccl"
+        self.form = "eager"
+        self.cc = None
         self.capture()
 
     def capture(self):
         with self.model.graph_capture_mode():
-            self._capture()
+            if self.world > 1:
+                self._capture_parallel()
+            else:
+                self._capture()
 
-    def _capture(self):
-        model, params = self.model, self.params
-        B = self.static[0].shape[0]
-        # Warm-up on a side stream, as graph capture requires -- with the bank FROZEN: a warm-up step that pushed its
-        # batch would leave the static batch in the bank three times (and three more times after every re-capture),
-        # which is not the reference's FIFO (modeling.py:222-249).
+    def _warm_up(self, step):
+        """Warm-up on a side stream, as graph capture requires -- with the bank FROZEN: a warm-up step that pushed its batch
+        would leave the static batch in the bank three times (and three more times after every re-capture), which is not the
+        reference's FIFO (modeling.py:222-249)."""
+        model = self.model
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         model.bank_frozen = True
         try:
             with torch.cuda.stream(side):
                 for _ in range(3):
-                    for p in params:
-                        p.grad = None
-                    model(*self.static, 0)[0].backward()
+                    step()
         finally:
             model.bank_frozen = False
         torch.cuda.current_stream().wait_stream(side)
+
+    def _capture(self):
+        model, params = self.model, self.params
+        B = self.static[0].shape[0]
+
+        def fwd_bwd():
+            for p in params:
+                p.grad = None
+            model(*self.static, 0)[0].backward()
+        self._warm_up(fwd_bwd)
         # the device-resident ring head must exist before the capture (creating it is a host-to-device copy)
         model._ring_ready(B)
         torch.cuda.synchronize()
@@ -258,18 +282,109 @@ class GraphedStep:
         self.losses = tuple(l.detach() for l in losses)
         del losses
         self.grads = [p.grad for p in params]        # static gradient buffers of the graph
+        self.replay, self.form = self.graph.replay, "whole"
+        self._remember_bank()
+
+    def _remember_bank(self):
         # What the graph has baked in: the addresses of the five bank tensors and of the device ring head.  Hold
         # strong references (a bank replaced from outside must not hand its blocks to somebody else while this graph
         # can still replay) and remember the bank's storage generation; run() re-captures when it has moved on.
+        model = self.model
         self.bank_refs = (dict(model._mb), model._mb_head_dev)
         self.generation = model._mb_gen
+
+    def _capture_parallel(self):
+        from neighborretr_amd import comm
+        model, params, W = self.model, self.params, self.world
+        B = self.static[0].shape[0] * W
+        if self.cc is None:
+            self.cc = comm.CollectiveCapture(W, self.rank, log=lambda msg: print(f"[GraphedStep] {msg}", flush=True))
+
+        def fwd_bwd():
+            for p in params:
+                p.grad = None
+            model(*self.static, 0)[0].backward()
+        self._warm_up(fwd_bwd)
+        model._ring_ready(B)
+        torch.cuda.synchronize()
+        # the parameters that receive a gradient (the same set in every step: DDP's find_unused_parameters bookkeeping,
+        # optimizer.py:79-84, done once) get views of ONE flat buffer as their .grad; autograd accumulates into them in place
+        used = [p for p in params if p.grad is not None]
+        flat = torch.zeros(sum(p.numel() for p in used), dtype=torch.float32, device=used[0].device)
+        views, off = [], 0
+        for p in used:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        out = {}
+        rng = model._rng_state_on(flat.device)
+
+        def step():
+            flat.zero_()
+            for p, v in zip(used, views):
+                p.grad = v
+            losses = model(*self.static, 0)
+            losses[0].backward()
+            comm.all_reduce(flat)                     # the gradient average over the ranks: one collective, one flat buffer
+            flat.mul_(1.0 / W)
+            out["losses"] = torch.stack([l.detach() for l in losses])
+
+        def eager_pass():
+            rng[1] = 4242                             # the same DPC-KNN tie-break draws for the eager and the replayed pass
+            step()
+
+        def result():
+            return [out["losses"], flat]
+
+        def same(a, b_):
+            return bool(torch.allclose(a[0], b_[0], rtol=1e-4, atol=1e-6)
+                        and (a[1] - b_[1]).norm() <= 1e-3 * b_[1].norm() + 1e-12)
+
+        def whole():
+            model._scorer_cache.clear()
+            model._ctm_cache.clear()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                step()
+
+            def replay_pass():
+                rng[1] = 4242
+                g.replay()
+            return replay_pass, g
+
+        def segmented():
+            model._scorer_cache.clear()
+            model._ctm_cache.clear()
+            seg = comm.SegmentedStep(step, capture_error_mode="relaxed").capture()
+
+            def replay_pass():
+                rng[1] = 4242
+                seg.replay()
+            return replay_pass, seg
+        freeze = lambda on: setattr(model, "bank_frozen", on)      # noqa: E731
+        form = self.cc.attempt("whole-step", eager_pass, whole, result, same, freeze) if self.backend == "nccl" else None
+        self.form = "whole"
+        if form is None:
+            form = self.cc.attempt("segmented", eager_pass, segmented, result, same, freeze)
+            self.form = "segmented"
+        if form is None:
+            self.form, self.replay, self.keep = "eager", step, None
+        else:
+            self.keep = form[1]
+            self.replay = form[1].replay
+        self.grads = None
+        self._used, self._views, self._out = used, views, out
+        self._remember_bank()
 
     def run(self, batch):
         if self.model._mb_gen != self.generation:    # the bank's tensors / ring head were replaced: the graph is stale
             self.capture()
         for dst, src in zip(self.static, batch):
             dst.copy_(src)
-        self.graph.replay()
+        self.replay()
+        if self.world > 1:
+            for p, g in zip(self._used, self._views):    # optimizer.zero_grad(set_to_none=True) drops them: put them back
+                p.grad = g
+            return tuple(self._out["losses"].unbind(0))
         for p, g in zip(self.params, self.grads):    # optimizer.zero_grad(set_to_none=True) drops them: put them back
             p.grad = g
         return self.losses
@@ -283,10 +398,11 @@ def train_epoch(args, model, ddp, data, optimizer, epoch, global_step):
     for i in range(len(data)):
         global_step += 1
         text, text_mask, video, video_mask, idx = data.batch(i, args.device)
-        if args.hip_graph and args.world_size == 1:
+        if args.hip_graph:
             if graphed is None:
                 graphed = args._graphed_step = GraphedStep(model, (text, text_mask, video, video_mask, idx),
-                                                           [p for p in model.parameters() if p.requires_grad])
+                                                           [p for p in model.parameters() if p.requires_grad], args)
+                log(args, f"training step replayed as: {graphed.form}")
             losses = graphed.run((text, text_mask, video, video_mask, idx))
             loss = None
         else:
@@ -344,7 +460,9 @@ def main():
         log(args, f"init_model: {len(missing)} missing / {len(unexpected)} unexpected keys")
     model = model.to(args.device)
     ddp = model
-    if args.world_size > 1:
+    # (--hip_graph 1 replays the whole data-parallel step, gradient average included, from graphs: GraphedStep; a DDP wrapper
+    # would keep AccumulateGrad nodes of the default stream alive, which a capture must not be synchronised with)
+    if args.world_size > 1 and not args.hip_graph:
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[args.device_index],
                                                         find_unused_parameters=True)   # optimizer.py:79-84
     Data = SyntheticClips if args.encoders else SyntheticFeatures

@@ -282,9 +282,13 @@ class SegmentedStep:
     runs the sharded step on one stream for this form, `model.use_side_streams = False`).  Nothing here synchronises the host:
     with RCCL the eager collectives are ordered with the replays by the stream; gloo collectives block the host themselves."""
 
-    def __init__(self, fn, comm=None):
+    def __init__(self, fn, comm=None, capture_error_mode="thread_local"):
+        """capture_error_mode "relaxed": for a step whose collectives are also issued from ANOTHER thread -- the backward of a
+        training step runs in the autograd engine's worker thread, and a capture begun in thread-local mode may only be ended by
+        the thread that began it."""
         self.fn = fn
         self.comm = comm
+        self.mode = capture_error_mode
         self.graphs, self.collectives = [], []
         self.stream = torch.cuda.Stream()
         self.pool = torch.cuda.graph_pool_handle()
@@ -292,7 +296,7 @@ class SegmentedStep:
 
     def _begin(self):
         g = torch.cuda.CUDAGraph()
-        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        g.capture_begin(pool=self.pool, capture_error_mode=self.mode)
         self._open = g
 
     def _cut(self, thunk):
@@ -353,3 +357,73 @@ class SegmentedStep:
             g.replay()
             if i < len(self.collectives):
                 self.collectives[i]()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+class CollectiveCapture:
+    """Choosing the replayed form of a step that contains collectives, TOGETHER with every other rank.
+
+    A rank that drops out of the common sequence of collectives on its own -- because its capture failed, or its validation
+    did -- leaves the others waiting in a collective it will never join.  So every decision here is collective: each rank
+    records its own verdict, never raises past a collective, and the ranks agree (MIN over a gloo side group with a short
+    timeout: host-side, independent of the state of the RCCL stream) after each capture and after each validation; all keep a
+    form or all drop to the next one (bench.py: whole-step graph -> segmented graphs -> eager; main_retrieval.GraphedStep)."""
+
+    def __init__(self, world, rank, timeout_s=120, log=None):
+        import datetime
+        self.world, self.rank = int(world), int(rank)
+        self.log = log or (lambda msg: None)
+        self.side = None
+        if self.world > 1:
+            self.side = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=timeout_s))
+
+    def agree(self, ok):
+        """True iff EVERY rank says ok."""
+        if self.side is None:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.side)
+        return bool(int(t.item()))
+
+    def attempt(self, what, eager_pass, make, result, same, freeze=None):
+        """One form, tried by every rank at once.
+            eager_pass()      the eager step(s) whose result the form must reproduce (called with the bank frozen)
+            make()            -> (replay_pass, keep_alive): captures the form; replay_pass() replays what eager_pass ran
+            result()          -> the tensor(s) to compare, after either pass
+            same(a, b)        -> bool
+            freeze(on)        freezes / releases what a step changes for good (the memory bank) around the validation
+        Captured frozen and validated first, then captured again for use.  -> (replay_pass, keep_alive) or None, on all ranks alike."""
+        if freeze:
+            freeze(True)
+        try:
+            eager_pass()
+            torch.cuda.synchronize()
+            want = result()
+            want = [t.clone() for t in want] if isinstance(want, (list, tuple)) else want.clone()
+            form, err = None, None
+            try:
+                form = make()
+            except Exception as e:          # noqa: BLE001 -- a failed capture is a verdict, not an error
+                err = f"{type(e).__name__}: {e}"
+                torch.cuda.synchronize()
+            if not self.agree(form is not None):
+                if err:
+                    self.log(f"rank {self.rank}: {what} capture unavailable ({err})")
+                return None
+            form[0]()                        # every rank replays: the collectives inside / between the graphs match up
+            torch.cuda.synchronize()
+            ok = bool(same(result(), want))
+            if not self.agree(ok):
+                if not ok:
+                    self.log(f"rank {self.rank}: the replayed {what} step differs from the eager one")
+                return None
+        finally:
+            if freeze:
+                freeze(False)
+        form = None
+        try:
+            form = make()
+        except Exception as e:              # noqa: BLE001
+            self.log(f"rank {self.rank}: {what} capture (form to be used) failed ({type(e).__name__}: {e})")
+            torch.cuda.synchronize()
+        return form if self.agree(form is not None) else None

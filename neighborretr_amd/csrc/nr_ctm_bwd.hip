@@ -350,7 +350,6 @@ __device__ __forceinline__ void nr_attn_bwd_body(const NrAttnBwdArgs& a, const i
             if (lane < N) { lg = l_ * a.scale; dp = d_; }
         } else {
             // (a rolled loop: fully unrolled, the 2 x 64 row loads of a query are hoisted together and the kernel spills)
-#pragma unroll 4
             for (int n = 0; n < N; ++n) {
                 const float l_ = nr_wave_sum(qv * K_(n)) * a.scale;
                 const float d_ = nr_wave_sum(da * V_(n));
@@ -375,7 +374,6 @@ __device__ __forceinline__ void nr_attn_bwd_body(const NrAttnBwdArgs& a, const i
                 }
             }
         } else {
-#pragma unroll 4
             for (int n = 0; n < N; ++n) dq += nr_rl(dl, n) * K_(n);
             s_rows[ci * 128 + lane] = dl;
             s_rows[ci * 128 + 64 + lane] = p;

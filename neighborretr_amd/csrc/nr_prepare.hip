@@ -164,3 +164,105 @@ extern "C" int nr_split_bf16(const float* x, size_t n, uint16_t* hi, uint16_t* l
     NR_LAUNCH_CHECK();
     return NR_OK;
 }
+
+// ---- a gathered batch straight into the memory bank (step-interleaved job: a step this rank does not own) ----------------------
+// What such a step leaves behind is the FIFO push of modeling.py:309-310 (ring form) and the bank's prepared shadow; nothing else of
+// the gathered batch is needed.  One launch does it from the RECEIVE buffer of the packed all-gather: the ring head moves back
+// by the batch (as nr_step_prologue moves it), every token row is copied into its ring slot as fp32 AND prepared (normalise, mask,
+// bf16 hi / lo, norm: the arithmetic of nr_prepare_body, bit for bit) into the shadow's slot, masks (u8 -> f32) and sample ids
+// follow, and the noise stream's counter advances by one step -- nr_unpack_gathered + nr_step_prologue + nr_prepare_tokens_pair
+// + nr_bank_ring_push of the eager path.  The new head is published by the LAST workgroup (every workgroup has read the old
+// one by then); `counter` is a zeroed word the launch leaves zeroed.
+template <int CH>
+__global__ __launch_bounds__(256) void nr_bank_absorb_kernel(NrBankAbsorbDesc a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int B = a.world * a.per_rank, d = a.d;
+    const int rows_t = B * a.Nt, total = rows_t + B * a.Nv;
+    int nh = (__hip_atomic_load(a.ring_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - B) % a.capacity;
+    if (nh < 0) nh += a.capacity;
+    const char* recv = reinterpret_cast<const char*>(a.gathered);
+    for (int row = blockIdx.x * 4 + wave; row < total; row += gridDim.x * 4) {
+        const bool text = row < rows_t;
+        const int r = text ? row : row - rows_t, N = text ? a.Nt : a.Nv;
+        const int i = r / N, tok = r - i * N, w = i / a.per_rank, s = i - w * a.per_rank;
+        const char* rec = recv + (size_t)w * a.record_bytes;
+        const float* xr = reinterpret_cast<const float*>(rec + (text ? a.off_text : a.off_video)) + ((size_t)s * N + tok) * d;
+        const unsigned char* mrow = reinterpret_cast<const unsigned char*>(rec + (text ? a.off_text_mask : a.off_video_mask)) + (size_t)s * N;
+        int rr = nh + i;
+        if (rr >= a.capacity) rr -= a.capacity;
+        const size_t drow = (size_t)rr * N + tok;
+        float* bank = (text ? a.bank_text : a.bank_video) + drow * d;
+        uint16_t* hi = text ? a.shadow_text_hi : a.shadow_video_hi;
+        uint16_t* lo = text ? a.shadow_text_lo : a.shadow_video_lo;
+        float* nrm_out = text ? a.shadow_text_norm : a.shadow_video_norm;
+        f32x4_t v[CH];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            v[c] = *reinterpret_cast<const f32x4_t*>(xr + (c * 64 + lane) * 4);
+            *reinterpret_cast<f32x4_t*>(bank + (c * 64 + lane) * 4) = v[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss += v[c][e] * v[c][e];
+        }
+        if (tok == 0) {                                    // the sample's mask row and id travel with its first token
+            float* bm = (text ? a.bank_text_mask : a.bank_video_mask) + (size_t)rr * N;
+            if (lane < N) bm[lane] = (float)mrow[lane];
+            if (text && lane == 0)
+                a.bank_index[rr] = reinterpret_cast<const long long*>(rec + a.off_index)[s];
+        }
+        if (hi) {
+            ss = nr_wave_sum(ss);
+            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+            const float inv = 1.0f / nrm, mk = (float)mrow[tok];
+            if (lane == 0) nrm_out[drow] = nrm;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                uint16_t h[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = (v[c][e] * inv) * mk;
+                    h[e] = nr_f2bf(y);
+                    l[e] = nr_f2bf(y - nr_bf2f(h[e]));
+                }
+                const size_t o = drow * d + (c * 64 + lane) * 4;
+                *reinterpret_cast<uint2*>(hi + o) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                *reinterpret_cast<uint2*>(lo + o) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == gridDim.x - 1) {
+            __hip_atomic_store(a.ring_head, nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.rng_state) a.rng_state[1] += 1ull;
+            __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+extern "C" int nr_bank_absorb_gathered(const NrBankAbsorbDesc* desc, void* stream) {
+    if (!desc) return NR_EINVAL;
+    const NrBankAbsorbDesc& a = *desc;
+    if (!a.gathered || !a.bank_text || !a.bank_video || !a.bank_index || !a.bank_text_mask || !a.bank_video_mask || !a.ring_head || !a.counter)
+        return NR_EINVAL;
+    if (a.world <= 0 || a.per_rank <= 0 || a.Nt <= 0 || a.Nv <= 0 || a.d <= 0 || a.capacity <= 0) return NR_EINVAL;
+    const long long B = (long long)a.world * a.per_rank;
+    if (B >= a.capacity) return NR_EUNSUPPORTED;            // (the batch would wrap onto itself: the caller's cat-and-cut path)
+    if ((a.d % 256) != 0 || a.d / 256 > NR_PREP_MAX_CHUNKS || a.Nt > 64 || a.Nv > 64) return NR_EUNSUPPORTED;
+    const bool shadow = a.shadow_text_hi != nullptr;
+    if (shadow != (a.shadow_text_lo && a.shadow_text_norm && a.shadow_video_hi && a.shadow_video_lo && a.shadow_video_norm)) return NR_EINVAL;
+    if ((a.off_text % 16) != 0 || (a.off_video % 16) != 0 || (a.off_index % 8) != 0 || (a.record_bytes % 16) != 0) return NR_EINVAL;
+    const long long rows = B * ((long long)a.Nt + a.Nv);
+    int grid = (int)((rows + 3) / 4);
+    if (grid > NR_PREP_MAX_GRID) grid = NR_PREP_MAX_GRID;
+    hipStream_t st = (hipStream_t)stream;
+    switch (a.d / 256) {
+        case 1: hipLaunchKernelGGL(nr_bank_absorb_kernel<1>, dim3(grid), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(nr_bank_absorb_kernel<2>, dim3(grid), dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL(nr_bank_absorb_kernel<3>, dim3(grid), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(nr_bank_absorb_kernel<4>, dim3(grid), dim3(256), 0, st, a); break;
+    }
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}

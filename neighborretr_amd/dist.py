@@ -106,6 +106,34 @@ class PackedAllGather(torch.autograd.Function):
         return outs[0], outs[1], None, None, None, None
 
 
+def packed_gather_raw(text_feat, video_feat, idx, text_mask, video_mask, args):
+    """The exchange step up to the collective, without autograd: pack, one all-gather -> (receive buffer uint8 [W * record],
+    layout dict: W, b, record, sizes, offs, shapes).  GPU tensors only.  What nr_bank_absorb_gathered and unpack_raw read."""
+    from . import ops
+    W = _world(args)
+    dev = text_feat.device
+    pieces = [text_feat.detach().float().contiguous(), video_feat.detach().float().contiguous(), idx.to(torch.int64).contiguous(),
+              text_mask.to(torch.uint8).contiguous(), video_mask.to(torch.uint8).contiguous()]
+    sizes = [p.numel() * p.element_size() for p in pieces]
+    offs = [sum(sizes[:k]) for k in range(5)]
+    total = (sum(sizes) + 15) // 16 * 16
+    send = torch.empty(total, dtype=torch.uint8, device=dev)
+    recv = torch.empty(W * total, dtype=torch.uint8, device=dev)
+    ops.pack_shard(pieces, send, offs)
+    comm.all_gather_into_tensor(recv, send)
+    return recv, dict(W=W, b=text_feat.shape[0], record=total, sizes=sizes, offs=offs, shapes=[tuple(p.shape[1:]) for p in pieces])
+
+
+def unpack_raw(recv, lay):
+    """The five gathered tensors (features f32, ids i64, masks f32) of a receive buffer of packed_gather_raw."""
+    from . import ops
+    W, b, dev = lay["W"], lay["b"], recv.device
+    dt = (torch.float32, torch.float32, torch.int64, torch.float32, torch.float32)
+    out = [torch.empty((W * b,) + shp, dtype=t, device=dev) for shp, t in zip(lay["shapes"], dt)]
+    ops.unpack_gathered(recv, W, lay["record"], lay["sizes"], lay["offs"], out, [False, False, False, True, True])
+    return tuple(out)
+
+
 def packed_allgather(text_feat, video_feat, idx, text_mask, video_mask, args):
     """-> (text_feat, video_feat, idx, text_mask, video_mask) with the batch dim multiplied by W."""
     return PackedAllGather.apply(text_feat, video_feat, idx, text_mask, video_mask, args)

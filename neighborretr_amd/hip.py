@@ -98,7 +98,17 @@ class PoolWJob(ctypes.Structure):
     _fields_ = [("src", PoolWSrc * 2), ("d_w", _P)] + [(n, ctypes.c_int32) for n in ("n_src", "side", "N", "accumulate")]
 
 
-STRUCTS = {"NrCtmStageDesc": CtmStageDesc, "NrLocalLevelProblem": LocalLevelProblem, "NrSplitItem": SplitItem,
+class BankAbsorbDesc(ctypes.Structure):
+    """NrBankAbsorbDesc of include/nr_hip.h."""
+    _fields_ = ([("gathered", _P)] + [(n, ctypes.c_uint64) for n in ("record_bytes", "off_text", "off_video", "off_index", "off_text_mask",
+                                                                      "off_video_mask")]
+                + [(n, ctypes.c_int32) for n in ("world", "per_rank", "Nt", "Nv", "d", "capacity")]
+                + [(n, _P) for n in ("bank_text", "bank_video", "bank_text_mask", "bank_video_mask", "bank_index", "shadow_text_hi",
+                                     "shadow_text_lo", "shadow_video_hi", "shadow_video_lo", "shadow_text_norm", "shadow_video_norm",
+                                     "ring_head", "rng_state", "counter")])
+
+
+STRUCTS = {"NrBankAbsorbDesc": BankAbsorbDesc, "NrCtmStageDesc": CtmStageDesc, "NrLocalLevelProblem": LocalLevelProblem, "NrSplitItem": SplitItem,
            "NrColsumItem": ColsumItem, "NrLinearProblem": LinearProblem, "NrCtmAttnBwdDesc": CtmAttnBwdDesc,
            "NrCtmMidBwdDesc": CtmMidBwdDesc, "NrSimBwdItem": SimBwdItem, "NrSimBwdOperand": SimBwdOperand, "NrSlabSum": SlabSum,
            "NrPoolWSrc": PoolWSrc, "NrPoolWJob": PoolWJob}
@@ -193,6 +203,7 @@ _SIGNATURES = {
     "nr_step_prologue": ([_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P], _I),
     "nr_bank_push": ([_P, _P, _I, _I, _Z, _P, _P], _I),
     "nr_bank_ring_push": ([_I, _P, _P, _P, _I, _I, _P, _I, _P], _I),
+    "nr_bank_absorb_gathered": ([ctypes.POINTER(BankAbsorbDesc), _P], _I),
     "nr_diag_ranks": ([_P, _I, _P, _P, _P], _I),
     "nr_slab_ranks": ([_P, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),
     "nr_group_slab_ranks": ([_P, _I, _I, _I, _P, _I, _P, _P, _P, _P], _I),

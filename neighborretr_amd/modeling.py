@@ -330,18 +330,52 @@ class NeighborRetr(nn.Module):
             # on how the loss is evaluated (replicated: slice; sharded: reduce-scatter), decided before the gather
             self.config.shard_loss = self._shard_now(world, text_feat, gathered_rows=text_feat.shape[0] * world,
                                                      video_tokens=video_feat.shape[1])
-            from .dist import packed_allgather
-            text_feat, video_feat, idx, text_mask, video_mask = packed_allgather(
-                text_feat, video_feat, idx, text_mask, video_mask, self.config)
+            from .dist import packed_allgather, packed_gather_raw, unpack_raw
             if self._interleaving():
                 k, self._step_index = self._step_index, self._step_index + 1
-                if k % world != comm.get_rank():
+                owner = k % world == comm.get_rank()
+                if text_feat.is_cuda:
+                    with torch.no_grad():
+                        recv, lay = packed_gather_raw(text_feat, video_feat, idx, text_mask, video_mask, self.config)
+                        if not owner and self._absorb_gathered(recv, lay):
+                            return None                        # the whole step in three launches: pack, all-gather, absorb
+                        text_feat, video_feat, idx, text_mask, video_mask = unpack_raw(recv, lay)
+                else:
+                    text_feat, video_feat, idx, text_mask, video_mask = packed_allgather(
+                        text_feat, video_feat, idx, text_mask, video_mask, self.config)
+                if not owner:
                     self.bank_only_step(text_feat, video_feat, text_mask, video_mask, idx)
                     return None
+                return self.loss_step(text_feat, video_feat, text_mask, video_mask, idx)
+            text_feat, video_feat, idx, text_mask, video_mask = packed_allgather(
+                text_feat, video_feat, idx, text_mask, video_mask, self.config)
         return self.loss_step(text_feat, video_feat, text_mask, video_mask, idx)
 
     def _interleaving(self):
         return bool(self.interleave_steps) and not torch.is_grad_enabled() and int(getattr(self.config, "world_size", 1)) > 1
+
+    def _absorb_gathered(self, recv, lay):
+        """A step this rank does not own, from the exchange step's receive buffer in ONE launch (nr_bank_absorb_gathered): ring
+        head, noise counter, fp32 bank rows and the prepared shadow rows.  False when the bank is not a device ring that holds
+        more than a batch, or frozen (the caller then unpacks and takes bank_only_step)."""
+        (Nt, d), (Nv, _) = lay["shapes"][0], lay["shapes"][1]
+        B = lay["W"] * lay["b"]
+        if self.bank_frozen or d % 256 or d > 1024 or Nt > 64 or Nv > 64:
+            return False
+        mb = self._mb
+        if tuple(mb["mb_feat_t"].shape[1:]) != (Nt, d) or tuple(mb["mb_feat_v"].shape[1:]) != (Nv, d) or mb["mb_ind"].dtype != torch.int64:
+            return False
+        if any(mb[k].dtype != torch.float32 for k in ("mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v")):
+            return False
+        ring = self._ring_ready(B)
+        if ring is None:
+            return False
+        shadow = self._bank_shadow()                       # (built before the first push, like the owner's step does)
+        if shadow is not None and (shadow[0].lo is None or shadow[1].lo is None):
+            return False
+        ops.bank_absorb_gathered(recv, lay, mb, shadow, ring[0], ring[2], self._rng_state_on(recv.device))
+        self._last_prepared = {}
+        return True
 
     def bank_only_step(self, text_feat, video_feat, text_mask, video_mask, idx):
         """A step this rank does not own (interleave_steps): everything of loss_step that outlives the step -- the ring head and

@@ -653,6 +653,34 @@ def unpack_gathered(gathered, world, record_bytes, nbytes, offsets, outs, u8_to_
              (ctypes.c_int * n)(*[1 if c else 0 for c in u8_to_f32]), hip.stream_ptr())
 
 
+def bank_absorb_gathered(recv, lay, bank, shadow, ring_head, capacity, rng_state):
+    """nr_bank_absorb_gathered: the gathered batch in `recv` (dist.packed_gather_raw) goes straight into the memory bank's ring --
+    fp32 rows, masks, ids -- and, prepared, into its bf16 shadow; the ring head moves back by the batch and the noise stream's
+    counter advances.  bank: dict of the five mb_* tensors; shadow: (text Prepared, video Prepared) or None."""
+    dev = recv.device
+    key = ("absorb", dev)
+    counter = _COUNTERS.get(key)
+    if counter is None:
+        counter = _COUNTERS[key] = torch.zeros((1,), dtype=torch.int32, device=dev)
+    a = hip.BankAbsorbDesc()
+    a.gathered = hip.ptr(recv, torch.uint8)
+    a.record_bytes = lay["record"]
+    a.off_text, a.off_video, a.off_index, a.off_text_mask, a.off_video_mask = lay["offs"]
+    (Nt, d), (Nv, _) = lay["shapes"][0], lay["shapes"][1]
+    a.world, a.per_rank, a.Nt, a.Nv, a.d, a.capacity = lay["W"], lay["b"], Nt, Nv, d, int(capacity)
+    a.bank_text, a.bank_video = hip.ptr(bank["mb_feat_t"], torch.float32), hip.ptr(bank["mb_feat_v"], torch.float32)
+    a.bank_text_mask, a.bank_video_mask = hip.ptr(bank["mb_mask_t"], torch.float32), hip.ptr(bank["mb_mask_v"], torch.float32)
+    a.bank_index = hip.ptr(bank["mb_ind"], torch.int64)
+    if shadow is not None:
+        st, sv = shadow
+        a.shadow_text_hi, a.shadow_text_lo, a.shadow_text_norm = hip.ptr(st.hi), hip.ptr(st.lo), hip.ptr(st.norm, torch.float32)
+        a.shadow_video_hi, a.shadow_video_lo, a.shadow_video_norm = hip.ptr(sv.hi), hip.ptr(sv.lo), hip.ptr(sv.norm, torch.float32)
+    a.ring_head = hip.ptr(ring_head, torch.int32)
+    a.rng_state = hip.ptr(rng_state, torch.int64)
+    a.counter = hip.ptr(counter, torch.int32)
+    hip.call("nr_bank_absorb_gathered", a, hip.stream_ptr())
+
+
 def step_prologue(mask0, mask1, logit_scale, rng_state, n_noise, ring=None):
     """nr_step_prologue: (mask0 fp32, mask1 fp32, exp(logit_scale) [1] or None, noise [n_noise] or None).
     int64 masks are converted by the kernel; fp32 masks pass through untouched.

@@ -105,19 +105,23 @@ def test_graphed_step_survives_five_recaptures():
     print(r.stdout)
 
 
-@pytest.mark.parametrize("shard", [0])
-def test_main_retrieval_two_ranks_on_one_gpu(tmp_path, shard):
+@pytest.mark.parametrize("hip_graph", [0, 1])
+def test_main_retrieval_two_ranks_on_one_gpu(tmp_path, hip_graph):
     """The W>1 branch of the entry point (process-group init, DDP wrap, packed exchange step in forward and in the bank
     load, reduce_losses) with two gloo ranks sharing the card.  RCCL needs one GPU per rank; the code around the
-    collective calls is what executes here."""
-    port = 29631
+    collective calls is what executes here.  hip_graph = 1: the whole data-parallel step (exchange, loss, backward, gradient
+    average) replayed from graphs -- on gloo the segmented form (the ranks agree on it; main_retrieval.GraphedStep)."""
+    port = 29631 + hip_graph
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "main_retrieval.py"), "--do_train", "1", "--synthetic",
            "--batch_size", "32", "--num_neighbors", "8", "--mb_batch", "2", "--epochs", "1", "--synthetic_train", "128",
-           "--synthetic_test", "100", "--n_display", "2", "--output_dir", str(tmp_path), "--dist_backend", "gloo"]
+           "--synthetic_test", "100", "--n_display", "2", "--output_dir", str(tmp_path), "--dist_backend", "gloo",
+           "--hip_graph", str(hip_graph)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "memory bank: 64 samples" in r.stdout                       # 2 batches x 16 per rank x 2 ranks, gathered
+    if hip_graph:
+        assert "training step replayed as: segmented" in r.stdout, r.stdout[-2000:]
     losses = [float(l.split(" loss ")[1].split()[0]) for l in r.stdout.splitlines() if " loss " in l]
     assert losses and all(x == x and x < 1e4 for x in losses), r.stdout[-2000:]
     assert "text->video R@1" in r.stdout
