@@ -259,9 +259,7 @@ class GraphedStep:
         B = self.static[0].shape[0]
 
         def fwd_bwd():
-            for p in params:
-                p.grad = None
-            model(*self.static, 0)[0].backward()
+            return torch.autograd.grad(model(*self.static, 0)[0], params, allow_unused=True)
         self._warm_up(fwd_bwd)
         # the device-resident ring head must exist before the capture (creating it is a host-to-device copy)
         model._ring_ready(B)
@@ -272,16 +270,18 @@ class GraphedStep:
         # captured too and every replay re-derives them from the fp32 parameters the optimizer has just updated
         model._scorer_cache.clear()
         model._ctm_cache.clear()
+        # torch.autograd.grad, not .backward(): the gradients come back as the graph's own static tensors and NO AccumulateGrad
+        # node takes part.  Those nodes outlive a step whenever anything still holds its losses (a training loop's `losses`
+        # variable, DDP), on the stream they were created on; a capture that has to synchronise with such a stream -- the
+        # default stream in particular -- dies inside the runtime (PyTorch warns "AccumulateGrad node's stream does not match
+        # ... break CUDA graph capture"; measured: tools/rank_local_times.py, round 4).
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             losses = model(*self.static, 0)
-            losses[0].backward()
-        # the loss VALUES only: holding the tensors themselves would keep the captured step's autograd graph alive, and with it
-        # AccumulateGrad nodes that name this capture's side streams -- which the next eager step or re-capture would then be
-        # synchronised with (PyTorch's "AccumulateGrad node's stream does not match" path)
-        self.losses = tuple(l.detach() for l in losses)
+            grads = torch.autograd.grad(losses[0], params, allow_unused=True)
+        self.losses = tuple(l.detach() for l in losses)          # the loss VALUES only (no autograd graph kept alive)
         del losses
-        self.grads = [p.grad for p in params]        # static gradient buffers of the graph
+        self.grads = list(grads)                     # static gradient buffers of the graph (None: the step does not reach it)
         self.replay, self.form = self.graph.replay, "whole"
         self._remember_bank()
 
@@ -300,16 +300,16 @@ class GraphedStep:
         if self.cc is None:
             self.cc = comm.CollectiveCapture(W, self.rank, log=lambda msg: print(f"[GraphedStep] {msg}", flush=True))
 
+        seen = {}
+
         def fwd_bwd():
-            for p in params:
-                p.grad = None
-            model(*self.static, 0)[0].backward()
+            seen["g"] = torch.autograd.grad(model(*self.static, 0)[0], params, allow_unused=True)
         self._warm_up(fwd_bwd)
         model._ring_ready(B)
         torch.cuda.synchronize()
         # the parameters that receive a gradient (the same set in every step: DDP's find_unused_parameters bookkeeping,
-        # optimizer.py:79-84, done once) get views of ONE flat buffer as their .grad; autograd accumulates into them in place
-        used = [p for p in params if p.grad is not None]
+        # optimizer.py:79-84, done once) get views of ONE flat buffer as their .grad
+        used = [p for p, g in zip(params, seen.pop("g")) if g is not None]
         flat = torch.zeros(sum(p.numel() for p in used), dtype=torch.float32, device=used[0].device)
         views, off = [], 0
         for p in used:
@@ -319,11 +319,9 @@ class GraphedStep:
         rng = model._rng_state_on(flat.device)
 
         def step():
-            flat.zero_()
-            for p, v in zip(used, views):
-                p.grad = v
             losses = model(*self.static, 0)
-            losses[0].backward()
+            grads = torch.autograd.grad(losses[0], used)          # (no AccumulateGrad nodes in a captured step: see _capture)
+            torch._foreach_copy_(views, list(grads))
             comm.all_reduce(flat)                     # the gradient average over the ranks: one collective, one flat buffer
             flat.mul_(1.0 / W)
             out["losses"] = torch.stack([l.detach() for l in losses])

@@ -267,12 +267,17 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
             if (!use_lds) lds = 0;
             if (lds > 40 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void*)nr_group_back_kernel<BK_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#ifdef NR_TUNE
                 if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nr_group_back_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
                 if (e != hipSuccess) return (int)e;
             }
+#ifdef NR_TUNE
             const char* te = nr_tune_env("NR_CTM_THREADS");
             if (te && atoi(te) == 512) hipLaunchKernelGGL(nr_group_back_kernel<512>, dim3(total), dim3(512), lds, st, gb, use_lds);
-            else hipLaunchKernelGGL(nr_group_back_kernel<BK_THREADS>, dim3(total), dim3(BK_THREADS), lds, st, gb, use_lds);
+            else
+#endif
+            hipLaunchKernelGGL(nr_group_back_kernel<BK_THREADS>, dim3(total), dim3(BK_THREADS), lds, st, gb, use_lds);
             NR_LAUNCH_CHECK();
         }
     }

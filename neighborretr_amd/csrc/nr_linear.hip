@@ -170,31 +170,41 @@ int nr_linear_group_launch(const NrLinearArgs* probs, int n, hipStream_t st, boo
         }
 #define NR_LG1_CASE(MI_, NI_, ST_, WC_) if (mi == MI_ && ni == NI_ && stg == ST_ && wcols == WC_) return nr_linear_group_launch_s<MI_, NI_, ST_, WC_, false, false>(probs, n, st)
         NR_LG1_CASE(2, 2, 1, 4); NR_LG1_CASE(2, 2, 2, 4); NR_LG1_CASE(2, 2, 1, 2); NR_LG1_CASE(2, 2, 2, 2);
+#ifdef NR_TUNE      // shapes only the NR_LINEAR_TILE1 hook of a tuning build asks for
         NR_LG1_CASE(4, 2, 1, 4); NR_LG1_CASE(4, 2, 2, 4); NR_LG1_CASE(2, 4, 2, 2);
+#endif
 #undef NR_LG1_CASE
         return NR_EUNSUPPORTED;
     }
     if (conv) {                      // token convolutions: the two shapes the clustering stages use (and their neighbours)
         if (wcols == 4 || mi > 2) { mi = 2; ni = 2; stg = 1; }
 #define NR_LGC_CASE(MI_, NI_, ST_) if (mi == MI_ && ni == NI_ && stg == ST_) return nr_linear_group_launch_s<MI_, NI_, ST_, 2, true>(probs, n, st)
-        NR_LGC_CASE(2, 2, 1); NR_LGC_CASE(2, 2, 2); NR_LGC_CASE(1, 2, 2); NR_LGC_CASE(1, 2, 4);
+        NR_LGC_CASE(2, 2, 1); NR_LGC_CASE(1, 2, 2); NR_LGC_CASE(1, 2, 4);
+#ifdef NR_TUNE
+        NR_LGC_CASE(2, 2, 2);
+#endif
 #undef NR_LGC_CASE
         return NR_EUNSUPPORTED;
     }
     if (wcols == 4) {
 #define NR_LG8_CASE(MI_, NI_, ST_) if (mi == MI_ && ni == NI_ && stg == ST_) return nr_linear_group_launch_s<MI_, NI_, ST_, 4>(probs, n, st)
-        NR_LG8_CASE(4, 2, 1); NR_LG8_CASE(4, 2, 2);       // 128 x 128 on 8 waves
-        NR_LG8_CASE(2, 2, 1); NR_LG8_CASE(2, 2, 2);       // 64 x 128
+        NR_LG8_CASE(2, 2, 1);                             // 64 x 128 on 8 waves (the shape the table above picks)
+#ifdef NR_TUNE      // the other 8-wave shapes: NR_LINEAR_TILE of a tuning build only
+        NR_LG8_CASE(4, 2, 1); NR_LG8_CASE(4, 2, 2);       // 128 x 128
+        NR_LG8_CASE(2, 2, 2);
         NR_LG8_CASE(4, 4, 1);                             // 128 x 256
         NR_LG8_CASE(2, 4, 1); NR_LG8_CASE(2, 4, 2);       // 64 x 256
+#endif
 #undef NR_LG8_CASE
         return NR_EUNSUPPORTED;
     }
 #define NR_LG_CASE(MI_, NI_, ST_) if (mi == MI_ && ni == NI_ && stg == ST_) return nr_linear_group_launch_s<MI_, NI_, ST_>(probs, n, st)
     NR_LG_CASE(4, 4, 1);
-    NR_LG_CASE(2, 4, 1); NR_LG_CASE(2, 4, 2);
-    NR_LG_CASE(2, 2, 1); NR_LG_CASE(2, 2, 2);
+    NR_LG_CASE(2, 2, 1);
     NR_LG_CASE(1, 2, 2); NR_LG_CASE(1, 2, 4);
+#ifdef NR_TUNE
+    NR_LG_CASE(2, 4, 1); NR_LG_CASE(2, 4, 2); NR_LG_CASE(2, 2, 2);
+#endif
 #undef NR_LG_CASE
     return NR_EUNSUPPORTED;
 }

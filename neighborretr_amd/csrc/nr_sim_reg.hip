@@ -530,14 +530,18 @@ static int nr_sim_reg_launch(NrSimRegArgs& a, hipStream_t st) {
     // 96 x 192 split-bf16 on 2 x 4 waves (48 x 48 per wave): the two-stage ring fits (144 KB) -> ping-pong K loop
     if constexpr (big && X3 && MI * NI == 9) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 2, WC, true>(a, st);
     else {
-    const bool one_stage = big ? X3 : (mid ? false : nr_pick_stages((long)a.ntx * a.nty) == 1);
-    if (one_stage) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 1, WC>(a, st);
+    if constexpr (!(big && !X3)) {          // (8-wave one-pass blocks always prefetch for themselves: no one-stage form of them)
+        const bool one_stage = big ? X3 : (mid ? false : nr_pick_stages((long)a.ntx * a.nty) == 1);
+        if (one_stage) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 1, WC>(a, st);
+    }
     if constexpr (big && X3) return NR_EUNSUPPORTED;
     else {
+#ifdef NR_TUNE
         if constexpr (big && NI == 3) {          // 192 x 192: three stages fit (144 KB)
             const char* e = nr_tune_env("NR_SIM_STAGES");
             if (e && atoi(e) == 3) return nr_sim_reg_launch_s<MI, NI, TPS, FPS, X3, ARGS, 3, WC>(a, st);
         }
+#endif
         if constexpr (big) {
             // 8-wave blocks on the two-stage ring: ping-pong K loop (NrGemmTile::run_pp); NR_SIM_PP=0 = the plain loop (A/B)
             const char* e = nr_tune_env("NR_SIM_PP");

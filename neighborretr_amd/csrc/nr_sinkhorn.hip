@@ -578,19 +578,27 @@ static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* 
         if (need + 4096 > (size_t)lds_cap) return NR_EUNSUPPORTED;
         // entries per thread: 16 (1024 threads) / 32 (512) / 64 (256); NR_SINKHORN_EPT overrides (tuning hook)
         int ept = 32;
-        if (const char* e = nr_tune_env("NR_SINKHORN_EPT")) ept = atoi(e);
         static size_t attr_set[3] = {0, 0, 0};             // per kernel variant: the dynamic-LDS limit already granted
+#ifdef NR_TUNE
+        if (const char* e = nr_tune_env("NR_SINKHORN_EPT")) ept = atoi(e);
+#endif
         size_t& granted = attr_set[ept == 16 ? 0 : ept == 64 ? 2 : 1];
         if (lds > 64 * 1024 && lds > granted) {
-            const void* k = ept == 16 ? (const void*)nr_sinkhorn_small_kernel<16> : ept == 64 ? (const void*)nr_sinkhorn_small_kernel<64>
-                                                                                             : (const void*)nr_sinkhorn_small_kernel<32>;
+            const void* k = (const void*)nr_sinkhorn_small_kernel<32>;
+#ifdef NR_TUNE
+            if (ept == 16) k = (const void*)nr_sinkhorn_small_kernel<16>;
+            if (ept == 64) k = (const void*)nr_sinkhorn_small_kernel<64>;
+#endif
             hipError_t er = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (er != hipSuccess) return (int)er;
             granted = lds;
         }
+#ifdef NR_TUNE
         if (ept == 16) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<16>, dim3(2), dim3(1024), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride, fin);
         else if (ept == 64) hipLaunchKernelGGL(nr_sinkhorn_small_kernel<64>, dim3(2), dim3(256), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride, fin);
-        else hipLaunchKernelGGL(nr_sinkhorn_small_kernel<32>, dim3(2), dim3(512), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride, fin);
+        else
+#endif
+        hipLaunchKernelGGL(nr_sinkhorn_small_kernel<32>, dim3(2), dim3(512), lds, st, G, B, beta, iters, tgt_rows, tgt_cols, temperature, uniform_rows, uniform_stride, fin);
         NR_LAUNCH_CHECK();
         return NR_OK;
     }

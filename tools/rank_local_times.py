@@ -316,15 +316,21 @@ def measure_training(model, full, W, rank, dev, lines, graph=True):
     params = [p for p in model.parameters() if p.requires_grad]
     leaves = [(s["text_feat"].clone().requires_grad_(True), s["video_feat"].clone().requires_grad_(True)) for s in rl.shards]
 
-    def train_step(r, communicator=None):
-        s, (tf, vf) = rl.shards[r], leaves[r]
+    def train_step(r, communicator=None, functional=False):
+        """functional: torch.autograd.grad instead of .backward() -- the form a CAPTURED step takes (main_retrieval.GraphedStep):
+        no AccumulateGrad node, whose stream may be one the capture must not touch, takes part."""
+        s, (tf_, vf_) = rl.shards[r], leaves[r]
         for p_ in params:
             p_.grad = None
-        tf.grad = vf.grad = None
+        tf_.grad = vf_.grad = None
         with (comm.use(communicator) if communicator is not None else contextlib.nullcontext()):
-            ls = model(tf, s["text_mask"], vf, s["video_mask"], s["idx"], 0)
-            ls[0].backward()
+            ls = model(tf_, s["text_mask"], vf_, s["video_mask"], s["idx"], 0)
+            if functional:
+                keep["grads"] = torch.autograd.grad(ls[0], params + [tf_, vf_], allow_unused=True)
+            else:
+                ls[0].backward()
         return torch.stack([l.detach() for l in ls])
+    keep = {}
     grads = [None] * W
 
     def settle_run(r):
@@ -359,6 +365,9 @@ def measure_training(model, full, W, rank, dev, lines, graph=True):
         own = leaves[rank][0].grad
         want = tf.grad[rank * rl.b:(rank + 1) * rl.b]
         out["feature_grad_dev"] = float((own - want).abs().max() / want.abs().max())
+        # drop the replicated step's autograd graph NOW: while its losses live, the parameters' AccumulateGrad nodes live too, on
+        # the (default) stream this step ran on -- and a later capture that has to synchronise with them dies in the runtime
+        del ref, ref_l, tf, own, want
         if not (out["max_dL_vs_replicated"] <= 1e-3 and worst <= 2e-2 and out["feature_grad_dev"] <= 2e-2):
             raise AssertionError(f"emulated sharded training step at W={W} deviates from the replicated one: {out}")
     finally:
@@ -384,7 +393,7 @@ def measure_training(model, full, W, rank, dev, lines, graph=True):
     out["graph_us"] = None
     if graph:
         with model.graph_capture_mode():
-            g, _ = capture(step)
+            g, _ = capture(lambda: train_step(rank, c, functional=True))
         out["graph_us"] = replay_time(g.replay, reps=50)
         del g
     lines.append(f"W={W} b={rl.b:3d}  sharded TRAINING step (forward + backward): losses == replicated to {out['max_dL_vs_replicated']:.1e}, mean over ranks of "
