@@ -360,6 +360,11 @@ class SegmentedStep:
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
+def _sync():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 class CollectiveCapture:
     """Choosing the replayed form of a step that contains collectives, TOGETHER with every other rank.
 
@@ -397,7 +402,7 @@ class CollectiveCapture:
             freeze(True)
         try:
             eager_pass()
-            torch.cuda.synchronize()
+            _sync()
             want = result()
             want = [t.clone() for t in want] if isinstance(want, (list, tuple)) else want.clone()
             form, err = None, None
@@ -405,13 +410,13 @@ class CollectiveCapture:
                 form = make()
             except Exception as e:          # noqa: BLE001 -- a failed capture is a verdict, not an error
                 err = f"{type(e).__name__}: {e}"
-                torch.cuda.synchronize()
+                _sync()
             if not self.agree(form is not None):
                 if err:
                     self.log(f"rank {self.rank}: {what} capture unavailable ({err})")
                 return None
             form[0]()                        # every rank replays: the collectives inside / between the graphs match up
-            torch.cuda.synchronize()
+            _sync()
             ok = bool(same(result(), want))
             if not self.agree(ok):
                 if not ok:
@@ -425,5 +430,5 @@ class CollectiveCapture:
             form = make()
         except Exception as e:              # noqa: BLE001
             self.log(f"rank {self.rank}: {what} capture (form to be used) failed ({type(e).__name__}: {e})")
-            torch.cuda.synchronize()
+            _sync()
         return form if self.agree(form is not None) else None

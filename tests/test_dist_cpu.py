@@ -226,3 +226,63 @@ def test_emulated_world_matches_a_real_two_rank_job():
                 comm.all_gather_into_tensor(torch.empty(4), t)
     with pytest.raises(RuntimeError, match="collective sequences differ"):
         bad.settle(diverging)
+
+
+def _capture_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from neighborretr_amd import comm
+        log = []
+        cc = comm.CollectiveCapture(world, rank, timeout_s=60, log=log.append)
+        state = {"v": torch.zeros(3), "frozen": []}
+
+        def eager():
+            t = torch.full((3,), float(rank + 1))
+            comm.all_reduce(t)                               # a collective inside the step: every rank must keep taking part
+            state["v"] = t
+
+        def form(fail_on=None, wrong_on=None):
+            def make():
+                if fail_on == rank:
+                    raise RuntimeError("capture refused here")
+
+                def replay():
+                    t = torch.full((3,), float(rank + 1))
+                    comm.all_reduce(t)
+                    state["v"] = t + (1.0 if wrong_on == rank else 0.0)
+                return replay, "keep"
+            return make
+        same = lambda a, b: bool(torch.equal(a, b))          # noqa: E731
+        freeze = lambda on: state["frozen"].append(on)        # noqa: E731
+        got = [cc.attempt("whole-step", eager, form(fail_on=0), lambda: state["v"], same, freeze),      # rank 0 cannot capture
+               cc.attempt("whole-step", eager, form(wrong_on=1), lambda: state["v"], same, freeze),     # rank 1 replays wrongly
+               cc.attempt("segmented", eager, form(), lambda: state["v"], same, freeze)]               # fine everywhere
+        ok = (got[0] is None and got[1] is None and got[2] is not None and got[2][1] == "keep"
+              and state["frozen"] == [True, False] * 3 and cc.agree(True) and not cc.agree(rank == 0))
+        q.put((rank, "ok" if ok else f"unexpected: {[g is not None for g in got]} {state['frozen']}", log))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), []))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_capture_decisions_are_collective():
+    """ADVICE r3 (bench.py:397): a rank whose graph capture fails, or whose replay fails its validation, must not leave the
+    common sequence of collectives on its own.  comm.CollectiveCapture: rank 0 "cannot capture" the first form, rank 1 "replays
+    wrongly" the second, the third works -- both ranks end up with (None, None, form), having matched every collective on the
+    way (a mismatch would hang this test until the side group's timeout)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_capture_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (msg, log) for r, msg, log in (q.get(timeout=180) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+    assert all(v[0] == "ok" for v in res.values()), res
+    assert any("whole-step capture unavailable (RuntimeError: capture refused here)" in l for l in res[0][1])
+    assert any("replayed whole-step step differs" in l for l in res[1][1]) and not res[0][1][1:]
