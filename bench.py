@@ -8,15 +8,25 @@ One STEP = one pass of the hot path over one synthetic batch already resident in
     tokens)  ->  prepare / scorer / fused local_level x3 / Sinkhorn / row losses  ->  memory-bank
     FIFO push,   i.e. `NeighborRetr.forward` in training mode minus the encoders, loss-only
     forward (BASELINE.json configs[0] "loss-only forward").
-Workload = BASELINE.json configs[1]: global B=128, d=512, Nt=24, Nv=12, M=512, K=20 (MSR-VTT shape).
-For N>1 the GLOBAL batch stays 128 (the metric is quoted at global B=128): each rank holds b=128/N
-samples, gathers (one packed RCCL all-gather, eager), and -- like the reference (modeling.py:274-298)
--- evaluates the full loss (replayed from a HIP graph), so `scaling` is "strong".  The JSON line also carries:
+Workload = BASELINE.json configs[1]: global B=128, d=512, Nt=24, Nv=12, M=512, K=20 (MSR-VTT shape); `--config 2|3` run
+configs[2] / [3] on ONE GPU as extra lines.  The step is replayed from HIP graphs.
+For N>1 the GLOBAL batch stays 128 (the metric is quoted at global B=128; `scaling` "strong"): each rank holds b=128/N samples of
+every step.  Three forms of the job:
+  default        step-interleaved: every step is gathered (one packed RCCL all-gather) and pushed into the bank replica on EVERY
+                 rank; its LOSS is evaluated on rank (step mod N) with the single-rank kernels -- loss-only steps depend on each
+                 other through the bank alone.  Losses and bank are bit-identical to the single-rank run.
+  --sync_step    the synchronous sharded step: every rank takes part in every loss (five collectives per step).
+  --replicated_loss   the reference's semantics (modeling.py:274-298): every rank evaluates every loss.
+A step that contains collectives is replayed as ONE graph with the RCCL collectives inside, or as the graphs of its rank-local
+segments with the collectives eager between them, or eagerly -- the ranks decide together (comm.CollectiveCapture); the line says
+which (`config.step_form`).  The JSON line also carries:
   roofline     the fused local_level kernel (the dominant kernel): algorithmic flops per launch
                (F_sim / 3 launches) / its average duration, timed live
                with HIP events on the launch stream, against the dense bf16 MFMA peak;
   cpu_baseline the CPU oracle (a port of the reference algorithm, oracle/nr_oracle.py) timed on this
-               host's cores on the same workload (N=1, rank 0 only; bounded sample).
+               host's cores on the same workload (N=1, rank 0 only; bounded sample);
+  parity       one un-timed step against the reference fixture of this workload;
+  rank_local   (--emulate_world) what one rank of a W-rank job does, emulated on this GPU.
 """
 import argparse
 import json

@@ -572,6 +572,9 @@ static int nr_sim_reg_big(int A, int Nt, int Bv, int Nv, int prec) {
     if (env >= 0 && env <= 2) cap = std::min(cap, env);
     const long wg3 = (long)((A + 3) / 4) * ((Bv + 15) / 16);
     if (x3 && env == 3 && wg3 >= 256) return 3;
+    // (96 x 192 on the two-stage ping-pong loop only while the 192 x 192 blocks would not fill the chip: at B = 1024 the latter win
+    // although they can only run a ONE-stage ring -- batch x batch product of configs[2] 1372 us against ~1510, step 2.638 vs
+    // 2.661 ms, two A/B pairs in one session, profiles/r04_c2_ab.txt)
     if (x3 && env < 0 && wg3 >= 256 && (long)((A + 7) / 8) * ((Bv + 15) / 16) < 256) return 3;
     if (cap >= 2 && (long)((A + 7) / 8) * ((Bv + 31) / 32) >= 256) return 2;
     if (cap >= 1 && (long)((A + 7) / 8) * ((Bv + 15) / 16) >= 256) return 1;
