@@ -14,6 +14,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import comm
+
 from . import ops
 from .metrics import RetrievalMetrics
 
@@ -86,7 +88,7 @@ def sharded_retrieval_ranks(model, text_feat, video_feat, text_mask, video_mask,
     for text i the number of videos scoring above / equal to its own video (metrics.py:58-66 on S), and for video j the
     number of texts scoring above / equal to its own text (the same on S.T)."""
     W = _world(args)
-    rank = dist.get_rank() if (W > 1 and dist.is_initialized()) else 0
+    rank = comm.get_rank() if W > 1 else 0
     N = text_feat.shape[0]
     if video_feat.shape[0] != N:
         raise ValueError("single-sentence retrieval: one text per video expected")
@@ -101,7 +103,7 @@ def sharded_retrieval_ranks(model, text_feat, video_feat, text_mask, video_mask,
         mine[:n] = S_slab[torch.arange(n, device=dev), torch.arange(r0, r1, device=dev)]
     if W > 1:
         allv = torch.empty((W * width,), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(allv, mine)
+        comm.all_gather_into_tensor(allv, mine)
         diag = torch.cat([allv[r * width: r * width + (slab_bounds(N, W, r)[1] - slab_bounds(N, W, r)[0])] for r in range(W)])
     else:
         diag = mine[:n]
@@ -115,9 +117,9 @@ def sharded_retrieval_ranks(model, text_feat, video_feat, text_mask, video_mask,
     rows_pad = torch.zeros((2, width), dtype=torch.int32, device=dev)
     rows_pad[0, :n], rows_pad[1, :n] = g_rows, e_rows
     if W > 1:
-        dist.all_reduce(cols)                              # partial column counts -> complete
+        comm.all_reduce(cols)                              # partial column counts -> complete
         allr = torch.empty((W, 2, width), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(allr.view(-1), rows_pad.view(-1))
+        comm.all_gather_into_tensor(allr.view(-1), rows_pad.view(-1))
     else:
         allr = rows_pad[None]
     allr = allr.cpu().numpy()
@@ -145,7 +147,7 @@ def sharded_multi_sentence_metrics(model, text_feat, video_feat, text_mask, vide
     launch (nr_group_slab_ranks) gives every row's rank and the slab's per-video best scores, and a MAX all-reduce of
     the V x V best-score matrix + an all-gather of the Ns ranks complete them; no padded tensor exists."""
     W = _world(args)
-    rank = dist.get_rank() if (W > 1 and dist.is_initialized()) else 0
+    rank = comm.get_rank() if W > 1 else 0
     Ns, V = text_feat.shape[0], video_feat.shape[0]
     ends = np.asarray(cut_off_points, dtype=np.int64) + 1
     if len(ends) != V or (np.diff(ends) <= 0).any() or ends[0] <= 0 or ends[-1] != Ns:
@@ -163,9 +165,9 @@ def sharded_multi_sentence_metrics(model, text_feat, video_feat, text_mask, vide
     else:
         gmax = torch.full((V, V), float("-inf"), dtype=torch.float32, device=dev)
     if W > 1:
-        dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+        comm.all_reduce(gmax, op="max")
         allr = torch.empty((W, width), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(allr.view(-1), mine)
+        comm.all_gather_into_tensor(allr.view(-1), mine)
         ranks = torch.cat([allr[r, :slab_bounds(Ns, W, r)[1] - slab_bounds(Ns, W, r)[0]] for r in range(W)])
     else:
         ranks = mine[:n]

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_emulated_ranks_match_the_replicated_step_and_replay_as_graphs():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rank_local_times.py"), "--worlds", "2", "4", "--B", "32", "--M", "64",
-                        "--K", "8", "--rank", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--K", "8", "--rank", "1", "--eval", "--train"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     print(r.stdout)
     for W, b in ((2, 16), (4, 8)):
@@ -28,3 +28,10 @@ def test_emulated_ranks_match_the_replicated_step_and_replay_as_graphs():
     assert len(re.findall(r"SEGMENTED graphs \(6 segments", r.stdout)) == 2, r.stdout
     for dl in re.findall(r"replay vs eager \|dL\| ([0-9.e+-]+)", r.stdout):
         assert float(dl) <= 2e-5, r.stdout
+    # the step-interleaved job: the owner's losses are the single-rank step's, bit for bit; a non-owned step is three launches
+    assert len(re.findall(r"step-interleaved: the owner's losses == the single-rank step bit for bit \(max \|dL\| 0.0e\+00\)", r.stdout)) == 2
+    assert len(re.findall(r"any OTHER step  \(exchange \+ push\) +: +2 C-ABI calls", r.stdout)) == 2, r.stdout
+    # RCCL-only branches on the 1-rank communicator: the evaluator's fp32 / int32 collectives, and the sharded TRAINING step's
+    # reduce-scatters (tools/rank_local_times.py raises if any emulated rank's ranks / losses / gradients are off)
+    assert "sharded evaluation, W=4 emulated ranks" in r.stdout and "== the single-rank ones" in r.stdout
+    assert len(re.findall(r"sharded TRAINING step \(forward \+ backward\): losses == replicated", r.stdout)) == 2, r.stdout

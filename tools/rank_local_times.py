@@ -404,6 +404,44 @@ def measure_training(model, full, W, rank, dev, lines, graph=True):
     return out
 
 
+def check_eval(model, dev, lines, W=4, N=203):
+    """The sharded evaluation (neighborretr_amd.evaluator: a row slab of S and its rank counts per rank, fp32 / int32 collectives)
+    with W emulated ranks, every collective on the 1-rank RCCL communicator: the ranks every emulated rank ends up with ==
+    the single-rank ranks (the reference's `cols`, metrics.py:58-66), single- and multi-sentence."""
+    from types import SimpleNamespace
+    from neighborretr_amd import evaluator
+    t, v, tm, vm = synth.make_samples(4242, "eval", N, CFG["Nt"], CFG["Nv"])
+    t, v, tm, vm = (torch.from_numpy(a).to(dev) for a in (t, v, tm, vm))
+    tm, vm = tm.float(), vm.float()
+    one = SimpleNamespace(world_size=1, local_rank=0)
+    with torch.no_grad():
+        ref = evaluator.sharded_retrieval_ranks(model, t, v, tm, vm, one)
+        ends = np.cumsum(np.random.RandomState(3).randint(1, 4, size=N))
+        ends = ends[ends <= N]
+        if ends[-1] != N:
+            ends = np.append(ends, N)
+        V = len(ends)
+        ref_ms = evaluator.sharded_multi_sentence_metrics(model, t, v[:V].contiguous(), tm, vm[:V].contiguous(), ends - 1, one)
+        world = comm.EmulatedWorld(W)
+        got, got_ms = {}, {}
+
+        def run(r):
+            c = world.comm(r)
+            args = SimpleNamespace(world_size=W, local_rank=r)
+            with comm.use(c):
+                c.begin_step()
+                got[r] = evaluator.sharded_retrieval_ranks(model, t, v, tm, vm, args)
+                got_ms[r] = evaluator.sharded_multi_sentence_metrics(model, t, v[:V].contiguous(), tm, vm[:V].contiguous(), ends - 1, args)
+        sweeps = world.settle(run)
+        run(0)                                        # once more from the frozen buffers
+    for r in range(W):
+        assert all(np.array_equal(a, b) for a, b in zip(got[r], ref)), f"emulated rank {r}: retrieval ranks differ from the single-rank ones"
+        assert got_ms[r][0] == ref_ms[0] and got_ms[r][1]["cols"] == ref_ms[1]["cols"], f"emulated rank {r}: multi-sentence metrics differ"
+    lines.append(f"sharded evaluation, W={W} emulated ranks, N={N}: every rank's text->video / video->text rank counts and the multi-sentence "
+                 f"metrics ({V} videos) == the single-rank ones (settled in {sweeps} sweeps; fp32 gather, int32 all-reduce / all-gather, MAX "
+                 f"all-reduce on the 1-rank RCCL communicator)")
+
+
 def build(dev, precision="bf16"):
     m = modeling.NeighborRetr(modeling.default_config(num_neighbors=CFG["K"]), precision=precision)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(7).items()}, strict=False)
@@ -429,6 +467,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--train", action="store_true", help="also the sharded TRAINING step (forward + backward) per world size")
     ap.add_argument("--only_train", action="store_true")
+    ap.add_argument("--eval", action="store_true", help="also check the sharded evaluation's collectives under the emulated world")
     args = ap.parse_args()
     CFG.update(B=args.B, M=args.M, K=args.K)
     torch.cuda.set_device(0)
@@ -451,6 +490,10 @@ def main():
         lines.append("---- STEP-INTERLEAVED (one collective per step; the loss of step k on rank k mod W) ----")
         for W in args.worlds:
             measure_interleaved(model, full, W, min(args.rank, W - 1), dev, lines)
+    if args.eval:
+        lines.append("---- sharded EVALUATION (neighborretr_amd.evaluator) ----")
+        model.config.world_size, model.config.local_rank = 1, 0
+        check_eval(model, dev, lines)
     if args.train or args.only_train:
         lines.append("---- sharded TRAINING step (neighborretr_amd.sharded), forward + backward ----")
         for W in args.worlds:
