@@ -67,6 +67,11 @@ def parse():
                     help="BASELINE.json configs[k]: 1 = the headline workload (default); 2 (global B=1024) and 3 (ActivityNet token counts, "
                          "M=1024) run the same step on ONE GPU as extra lines -- no CPU baseline, no reference fixture at those sizes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--unroll", type=int, default=4,
+                    help="consecutive steps captured per HIP graph, every dependency between them kept (the bank push of step k before "
+                         "the bank products of step k+1): one replay then issues U steps and the ~10 us between two replays is paid "
+                         "once per U steps (round 3: 312 / 306 / 304 us per step at U = 1 / 2 / 4).  A remainder of K mod U steps is "
+                         "replayed step by step.  Step-interleaved job (N > 1): U = N, one round per graph.  1 = one step per graph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL; gloo only to rehearse ranks that share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -358,6 +363,7 @@ def main():
         model.interleave_steps = interleaved
     n_round = world if interleaved else 1          # steps after which every rank has evaluated a loss
     ctr = [0]                                      # the job's step counter (host side; identical on every rank)
+    budget = [0]                                   # steps the caller still wants: a replay may cover several (see --unroll)
     full = synth.make_problem(1002, c["B"], c["Nt"], c["Nv"], c["M"])
     sl = slice(rank * b, (rank + 1) * b)
     shard = {k: torch.from_numpy(full[k][sl]).to(dev) for k in ("text_feat", "video_feat", "text_mask", "video_mask", "idx")}
@@ -437,11 +443,15 @@ def main():
         cc = comm.CollectiveCapture(world, rank, log=lambda msg: print(f"[bench] {msg}", file=sys.stderr))
         rng = model._rng_state_on(dev)
 
+        seen = {"ok": True}
+
         def eager_pass():
             ctr[0] = 0
             rng[1] = 4242                    # the DPC-KNN tie-break noise is a function of this counter: the same draws for both passes
             for _ in range(n_round):
                 step()
+            torch.cuda.synchronize()
+            seen["eager"], seen["ok"] = result["losses"].clone(), True
 
         def attempt(make, what):
             """make() -> (replay, keep-alive): a replayable form of `step`, validated against the eager step on every rank
@@ -450,13 +460,20 @@ def main():
                 replay, keep = make()
 
                 def replay_pass():
-                    ctr[0] = 0
-                    rng[1] = 4242
-                    for _ in range(n_round):
-                        replay()
+                    # two rounds: the first step by step (the owner / other graphs), the second as ONE replay (the round graph);
+                    # with the bank frozen and the noise counter rewound both must reproduce the eager round
+                    for allowed in ((0, n_round) if (interleaved and args.unroll != 1) else (0,)):
+                        ctr[0] = 0
+                        rng[1] = 4242
+                        budget[0] = allowed
+                        done = 0
+                        while done < n_round:
+                            done += replay() or 1
+                        torch.cuda.synchronize()       # (each pass is held against the eager round; the verdict is agreed on by all ranks)
+                        seen["ok"] = seen["ok"] and bool(torch.allclose(result["losses"], seen["eager"], rtol=1e-5, atol=1e-6))
                 return replay_pass, (replay, keep)
             form = cc.attempt(what, eager_pass, make_pass, lambda: result["losses"],
-                              lambda a, b_: torch.allclose(a, b_, rtol=1e-5, atol=1e-6),
+                              lambda a, b_: seen["ok"] and torch.allclose(a, b_, rtol=1e-5, atol=1e-6),
                               freeze=lambda on: setattr(model, "bank_frozen", on))
             return None if form is None else form[1]
 
@@ -464,17 +481,36 @@ def main():
             """The replayable form of `step`: one capture, or -- interleaved -- two: the step this rank owns and the step it
             does not; replay() picks by the job's step counter, as the eager step does."""
             if not interleaved:
-                g = capture_one()
+                g = capture_one(step)
                 return g.replay, g
-            forms = {}
+            forms, outs = {}, {}
             for own in (True, False):
                 ctr[0] = rank if own else rank + 1
-                forms[own] = capture_one()
+                forms[own] = capture_one(step)
+                outs[own] = result.get("losses")
+            if args.unroll != 1:                 # one whole round (W consecutive steps: this rank's own and the W - 1 others)
+                ctr[0] = 0
+
+                def one_round():
+                    for _ in range(world):
+                        step()
+                forms["round"] = capture_one(one_round)
+                outs["round"] = result.get("losses")
 
             def replay():
+                """The next step; a whole round at once when the counter stands at a round's start and the caller allows it."""
+                if "round" in forms and ctr[0] % world == 0 and budget[0] >= world:
+                    ctr[0] += world
+                    budget[0] -= world - 1
+                    forms["round"].replay()
+                    result["losses"] = outs["round"]
+                    return world
                 own = ctr[0] % world == rank
                 ctr[0] += 1
                 forms[own].replay()
+                if own:
+                    result["losses"] = outs[True]      # (each graph writes the losses into its own pool)
+                return 1
             return replay, forms
 
         def make_whole():
@@ -483,17 +519,17 @@ def main():
                     raise RuntimeError("--fail_whole_capture")
                 return (lambda: None), None
 
-            def one():
+            def one(fn):
                 # with collectives inside the capture other threads of the process (the process group's watchdog) may touch
                 # the runtime while this thread captures: thread-local capture mode keeps their calls out of its error checking
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    step()
+                    fn()
                 return g
             return per_phase(one)
 
         def make_segmented():
-            return per_phase(lambda: comm.SegmentedStep(step).capture())
+            return per_phase(lambda fn: comm.SegmentedStep(fn).capture())
 
         def segments_of(keep):
             return keep[True].n_segments if interleaved else keep.n_segments
@@ -523,6 +559,24 @@ def main():
             step_form = "whole" if whole_step_graph else "exchange eager + loss graph"
             if whole_step_graph:
                 run = g.replay
+                if args.unroll > 1:              # U consecutive steps as one graph (their dependencies kept), K mod U singly
+                    out1 = result["losses"]
+                    gU = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gU):
+                        for _ in range(args.unroll):
+                            step()
+                    outU = result["losses"]
+                    graph = (g, gU)
+
+                    def run():                   # noqa: F811
+                        if budget[0] >= args.unroll:
+                            budget[0] -= args.unroll - 1
+                            gU.replay()
+                            result["losses"] = outU      # (each graph writes the losses into its own pool)
+                            return args.unroll
+                        g.replay()
+                        result["losses"] = out1
+                        return 1
         except Exception as e:          # graphs are an optimisation, never a requirement
             print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
@@ -532,22 +586,26 @@ def main():
     # 0.361 ms/step for the first 200 steps after a 20-step warm-up, 0.324 for every later 200) -- the chip has to leave its
     # idle power state.  Part of the untimed set-up, like the capture warm-ups above: >= 0.4 s of steps before the contract's
     # W warm-up steps, so that the timed K steps measure the steady state whatever W is.
+    def run_steps(n):
+        """EXACTLY n steps: replays that cover several steps (--unroll) only while that many are still wanted."""
+        budget[0] = n
+        while budget[0] > 0:
+            run()
+            budget[0] -= 1
     t_ramp = time.perf_counter()
     if world == 1:
         while time.perf_counter() - t_ramp < 0.4:
-            for _ in range(50):
-                run()
+            run_steps(48)
             torch.cuda.synchronize()
     else:                                   # the SAME number of steps on every rank: a clock-bounded loop would let the ranks disagree
-        for _ in range(1200):
-            run()
+        run_steps(1200)
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        run()
+    run_steps(args.warmup)
+    if interleaved:                         # the timed steps start at a round's start on every rank
+        run_steps((-ctr[0]) % world)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
+    run_steps(args.steps)
     sync()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -562,8 +620,7 @@ def main():
     for _ in range(max(5, min(25, int(200 / max(args.steps, 1))))):
         sync()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
+        run_steps(args.steps)
         sync()
         tr = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         if world > 1:
@@ -746,6 +803,8 @@ def main():
             "config": {"workload": c["name"] + ", loss-only forward incl. token clustering and bank push",
                        "global_batch": c["B"], "per_rank_batch": b, "precision_plan": args.precision,
                        "hip_graph": graph is not None, "step_form": step_form, "graph_segments": n_segments,
+                       "steps_per_graph": (1 if (graph is None or args.unroll == 1 or step_form == "exchange eager + loss graph")
+                                           else (world if interleaved else (args.unroll if world == 1 else 1))),
                        "parallelism": f"dp{world}: " + (
                            ("packed all-gather every step on every rank, bank replicated by pushing every gathered batch; the loss of step k "
                             "evaluated on rank k mod W with the single-rank kernels (step-interleaved: loss-only steps depend on each other "

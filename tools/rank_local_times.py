@@ -286,6 +286,18 @@ def measure_interleaved(model, full, W, rank, dev, lines):
                 seg = comm.SegmentedStep(f, c).capture()
                 t_seg, n_seg = replay_time(seg.replay), seg.n_segments
             times[own] = (t_graph, t_seg, n_seg, calls)
+        # one ROUND (this rank's own step and the W - 1 others) as ONE graph: what `bench.py --gpus W` replays (--unroll)
+        def one_round():
+            for k in range(W):
+                model._step_index = k
+                s_ = rl.shards[rank]
+                with torch.no_grad():
+                    model(s_["text_feat"], s_["text_mask"], s_["video_feat"], s_["video_mask"], s_["idx"], 0)
+        with comm.use(c):
+            g_round, _ = capture(one_round)
+            out["round_graph_us"] = replay_time(g_round.replay, reps=60)
+            del g_round
+        out["round_graph_steps_per_s"] = W / out["round_graph_us"] * 1e6
         for key, k in (("graph", 0), ("segmented", 1)):
             per_round = times[True][k] + (W - 1) * times[False][k]
             out[key + "_us_per_round"] = per_round
@@ -302,6 +314,7 @@ def measure_interleaved(model, full, W, rank, dev, lines):
                  f"{times[False][2]} segments + 1 eager collective {times[False][1]:7.1f} us")
     lines.append(f"    W={W} consecutive steps cost a rank {out['graph_us_per_round']:7.1f} us  ->  {out['graph_steps_per_s']:8.0f} steps/s for the job "
                  f"(segmented form: {out['segmented_us_per_round']:7.1f} us -> {out['segmented_steps_per_s']:8.0f} steps/s); no wire time in these")
+    lines.append(f"    the round as ONE graph ({W} steps per replay): {out['round_graph_us']:7.1f} us  ->  {out['round_graph_steps_per_s']:8.0f} steps/s")
     return out
 
 
