@@ -84,6 +84,10 @@ def parse():
                     help="N>1: the reference's form instead (modeling.py:274-298): after the all-gather every rank evaluates the whole "
                          "loss; the exchange step stays eager, the loss is replayed from a HIP graph")
     ap.add_argument("--backward", action="store_true", help="also time forward+backward (reported as extra fields)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N=1: the U steps of an unrolled graph strictly one after the other (A/B switch).  Default: step k+1 starts "
+                         "as soon as step k has moved the ring head and pushed its batch, i.e. beside step k's Sinkhorn solve and row "
+                         "losses (modeling.StepPipeline); the graph is held against U single-step replays before it is used")
     ap.add_argument("--emulate_world", type=int, nargs="*", default=None, metavar="W",
                     help="N=1 only, extra field `rank_local` (never the headline): what ONE rank of the sharded step does at these world "
                          "sizes (default 2 4 8), emulated on this GPU -- its own messages through a 1-rank RCCL communicator, the peers' "
@@ -406,6 +410,7 @@ def main():
     # the loss replayed from a graph (round 2's form).
     graph = None
     static = None
+    unroll_check = None
     step_form, n_segments = "eager", 0
     whole_step_graph = world == 1
     if world > 1 and args.replicated_loss:
@@ -561,15 +566,86 @@ def main():
                 run = g.replay
                 if args.unroll > 1:              # U consecutive steps as one graph (their dependencies kept), K mod U singly
                     out1 = result["losses"]
-                    gU = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gU):
+                    outs_u = []
+
+                    def unrolled(pipelined):
+                        """U steps into the running capture.  pipelined: every step on a stream of its own that waits for the
+                        previous step's prologue (ring head, noise counter) and bank push only -- not for its Sinkhorn solve and
+                        row losses -- and takes its side streams / finalize word from its own slot (modeling.StepPipeline)."""
+                        from neighborretr_amd import streams
+                        from neighborretr_amd.capture_guard import record_event, wait_event, wait_stream
+                        from neighborretr_amd.modeling import StepPipeline
+                        del outs_u[:]
+                        if not pipelined:
+                            for _ in range(args.unroll):
+                                step()
+                                outs_u.append(result["losses"])
+                            return
+                        origin, prev, ends = torch.cuda.current_stream(), None, []
+                        try:
+                            for k in range(args.unroll):
+                                own = streams.side(model, f"step#{k}", dev)
+                                if prev is None:
+                                    wait_stream(own, origin)
+                                else:
+                                    for ev in (prev.push_done, prev.prologue_done):
+                                        if ev is not None:
+                                            wait_event(own, ev)
+                                model._pipeline = StepPipeline(k)
+                                with torch.cuda.stream(own):
+                                    step()
+                                    result["losses"].record_stream(origin)
+                                prev = model._pipeline
+                                outs_u.append(result["losses"])
+                                ends.append(record_event(own))
+                        finally:
+                            model._pipeline = None
+                        for ev in ends:
+                            wait_event(origin, ev)
+
+                    def capture_unrolled(pipelined):
+                        gu = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gu):
+                            unrolled(pipelined)
+                        return gu, list(outs_u)
+
+                    def state():
+                        sh = model._mb_shadow or ()
+                        return ([model._mb[k_] for k_ in model._mb] + [t_ for p_ in sh for t_ in (p_.hi, p_.lo, p_.norm) if t_ is not None]
+                                + [model._mb_head_dev, model._rng_state])
+
+                    def equals_single_steps(gu, outs):
+                        """The unrolled graph against U replays of the single-step graph from the same bank / ring / noise state:
+                        every step's losses and the state left behind, bit for bit."""
+                        saved = [t_.clone() for t_ in state()]
+                        gu.replay()
+                        torch.cuda.synchronize()
+                        got, after = [o.clone() for o in outs], [t_.clone() for t_ in state()]
+                        for t_, s_ in zip(state(), saved):
+                            t_.copy_(s_)
+                        want = []
                         for _ in range(args.unroll):
-                            step()
-                    outU = result["losses"]
+                            g.replay()
+                            torch.cuda.synchronize()
+                            want.append(out1.clone())
+                        same = all(torch.equal(a_, b_) for a_, b_ in zip(got, want)) and all(torch.equal(a_, b_) for a_, b_ in zip(after, state()))
+                        return same, max(float((a_ - b_).abs().max()) for a_, b_ in zip(got, want))
+                    gU, outs = capture_unrolled(not args.no_pipeline)
+                    unroll_form = "sequential" if args.no_pipeline else "pipelined"
+                    ok_, dl_ = equals_single_steps(gU, outs)
+                    if not ok_ and not args.no_pipeline:
+                        print(f"[bench] the pipelined {args.unroll}-step graph differs from single-step replays (max |dL| {dl_:.2e}): taking the "
+                              "sequential form", file=sys.stderr)
+                        gU, outs = capture_unrolled(False)
+                        unroll_form = "sequential (the pipelined form failed its check)"
+                        ok_, dl_ = equals_single_steps(gU, outs)
+                    unroll_check = {"steps_per_graph": args.unroll, "form": unroll_form, "equals_single_step_replays": bool(ok_), "max_dL": dl_}
+                    outU = outs[-1]
                     graph = (g, gU)
+                    use_unrolled = bool(ok_)             # (a graph that does not reproduce the single steps is never timed)
 
                     def run():                   # noqa: F811
-                        if budget[0] >= args.unroll:
+                        if use_unrolled and budget[0] >= args.unroll:
                             budget[0] -= args.unroll - 1
                             gU.replay()
                             result["losses"] = outU      # (each graph writes the losses into its own pool)
@@ -803,6 +879,7 @@ def main():
             "config": {"workload": c["name"] + ", loss-only forward incl. token clustering and bank push",
                        "global_batch": c["B"], "per_rank_batch": b, "precision_plan": args.precision,
                        "hip_graph": graph is not None, "step_form": step_form, "graph_segments": n_segments,
+                       "unrolled_graph": unroll_check,
                        "steps_per_graph": (1 if (graph is None or args.unroll == 1 or step_form == "exchange eager + loss graph")
                                            else (world if interleaved else (args.unroll if world == 1 else 1))),
                        "parallelism": f"dp{world}: " + (

@@ -130,7 +130,7 @@ PAIR_BANK_PRODUCTS = os.environ.get("NR_PAIR_BANK", "0") == "1"
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                  gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None,
                  bank_streams=None, local_stream=None, bank_early=0,
-                 capture_order=((7, 5), (7, 1 << 30)), bank_prepared=None, prepared_out=None, bank_push=None, bb_late=False):
+                 capture_order=((7, 5), (7, 1 << 30)), bank_prepared=None, prepared_out=None, bank_push=None, bb_late=False, slot=0):
     """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None).
 
     `join`: optional callable run right before the first use of gt / gv.  Either the caller produces the
@@ -323,7 +323,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         g_ready = record_event(cur)
         rowloss = torch.empty((2, 4, B), dtype=torch.float32, device=G.device)
         losses = torch.empty((5,), dtype=torch.float32, device=G.device)
-        counter = ops.split_tail_counter(G.device)
+        counter = ops.split_tail_counter(G.device, slot)
         wts = (hp["uniform_weight"], hp["neighbor_weight"], hp["kl_weight"])
         # The two self-finalizing launches share `counter`; only the one that finishes last resets it.  If anything raises
         # between them (the push callable, an NR_E* status), the word would stay non-zero and every later step would finalize
@@ -371,7 +371,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
                 torch.cuda.synchronize(G.device)
                 counter.zero_()
             else:
-                ops.forget_split_tail_counter(G.device)   # an aborted capture: the next step takes a fresh zeroed word
+                ops.forget_split_tail_counter(G.device, slot)   # an aborted capture: the next step takes a fresh zeroed word
             raise
         wait_stream(cur, side)
         if push_stream is not None:

@@ -43,6 +43,21 @@ class FeatureModeCLIP(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
 
 
+class StepPipeline:
+    """Consecutive loss-only steps captured into ONE HIP graph so that they OVERLAP (bench.py --unroll): step k + 1 may start as
+    soon as step k has moved the ring head and pushed its batch -- its clustering -> logits -> Sinkhorn chain then runs while
+    step k's Sinkhorn solve (two workgroups) and row losses are still in flight; nothing else orders two steps (every step has its
+    own buffers; the bank products of step k + 1 follow its own prologue, hence step k's push).  While one is installed as
+    `model._pipeline`, a step (a) takes its side streams from the set of `slot` (a stream forked in one step is never forked
+    again in the same capture: capture_guard), (b) leaves two events behind: `prologue_done` (ring head / noise counter moved)
+    and `push_done` (the batch is in the bank and its prepared shadow), (c) uses the finalize word of its slot."""
+
+    def __init__(self, slot):
+        self.slot = int(slot)
+        self.prologue_done = None
+        self.push_done = None
+
+
 class NeighborRetr(nn.Module):
     def __init__(self, config, clip=None, width=512, precision="bf16", with_encoders=False, encoder_dims=None):
         """clip: any module with encode_text / encode_image / logit_scale (e.g. the reference's own CLIP).
@@ -133,6 +148,7 @@ class NeighborRetr(nn.Module):
         # Only without gradients (a training step needs every rank's gradient before the next step: the sharded loss is its form).
         self.interleave_steps = False
         self._step_index = 0
+        self._pipeline = None               # a StepPipeline while consecutive steps are being captured overlapped (bench.py)
         self._ctm_cache = {}
 
     # ------------------------------------------------------------------ construction helpers
@@ -412,6 +428,9 @@ class NeighborRetr(nn.Module):
                 text_mask, video_mask, raw_scale if scale_in_kernel else None,
                 self._rng_state_on(text_feat.device), B * sum(sizes.values()), ring=ring)
             self._ring_advanced = ring is not None
+            if self._pipeline is not None:
+                from .capture_guard import record_event
+                self._pipeline.prologue_done = record_event(torch.cuda.current_stream())
             logit_scale = ls_exp.reshape(()) if scale_in_kernel else raw_scale.exp()
             noise = self._slice_noise(flat, B, sizes)
         else:
@@ -425,6 +444,9 @@ class NeighborRetr(nn.Module):
         def push():
             self.update_memory_bank(idx, text_feat, video_feat, text_mask, video_mask)
             self._pushed = True
+            if self._pipeline is not None:
+                from .capture_guard import record_event
+                self._pipeline.push_done = record_event(torch.cuda.current_stream())
         self._push_fn = None if self.bank_frozen else push
         losses = self._compute_losses(text_feat, video_feat, text_mask, video_mask,
                                       self._mb["mb_feat_t"], self._mb["mb_feat_v"], self._mb["mb_mask_t"], self._mb["mb_mask_v"],
@@ -764,30 +786,37 @@ class NeighborRetr(nn.Module):
     # Side streams (neighborretr_amd.streams): eager steps use streams cached per model; inside a HIP-graph capture every name
     # resolves to a stream created for THAT capture alone -- a stream object that has been part of an earlier capture is never
     # handed to a later one (the re-captures of main_retrieval.GraphedStep, one per bank generation, walk this path).
+    def _slot(self):
+        return self._pipeline.slot if self._pipeline is not None else 0
+
+    def _sname(self, name):
+        """Stream names of the running step: the steps of a pipelined capture (StepPipeline) each fork their own set."""
+        return name if self._pipeline is None else f"{name}#{self._pipeline.slot}"
+
     def _side_streams(self, device):
         # default priority: high-priority side streams made the captured graph 1.8x SLOWER on ROCm 7.2
         from . import streams
-        return streams.side(self, "text", device), streams.side(self, "video", device)
+        return streams.side(self, self._sname("text"), device), streams.side(self, self._sname("video"), device)
 
     def _cluster_stream(self, device):
         """Stream of the training step's token clustering (forward and, through autograd, backward), or None."""
         if not (self.use_side_streams and self.cluster_side_stream and device.type == "cuda"):
             return None
         from . import streams
-        return streams.side(self, "cluster", device)
+        return streams.side(self, self._sname("cluster"), device)
 
     def _local_stream(self, device):
         if not (self.use_side_streams and device.type == "cuda"):
             return None
         from . import streams
-        return streams.side(self, "local", device)
+        return streams.side(self, self._sname("local"), device)
 
     def _bank_streams(self, device):
         """Side streams of the two memory-bank chains (head.head_forward), or None when streams are off."""
         if not (self.use_side_streams and self.bank_side_streams and device.type == "cuda"):
             return None
         from . import streams
-        return tuple(streams.side(self, n, device) for n in ("bank0", "bank1", "push"))      # two bank chains + the bank push
+        return tuple(streams.side(self, self._sname(n), device) for n in ("bank0", "bank1", "push"))      # two bank chains + the bank push
 
     def _take_join(self):
         j, self._join_global = self._join_global, None

@@ -296,19 +296,20 @@ def sinkhorn_uniform_rows(G, beta, T, rowloss, iters=50):
     return True
 
 
-def split_tail_counter(dev):
+def split_tail_counter(dev, slot=0):
     """The zero-initialised device word shared by the two self-finalizing launches of the split tail (one per
-    device: the launch that finishes last resets it, and steps on one device are ordered)."""
-    key = ("split_tail", dev)
+    device: the launch that finishes last resets it, and steps on one device are ordered; steps whose tails may overlap --
+    consecutive steps of a pipelined graph, modeling.StepPipeline -- take different `slot`s)."""
+    key = ("split_tail", dev, int(slot))
     c = _COUNTERS.get(key)
     if c is None:
         c = _COUNTERS[key] = torch.zeros((1,), dtype=torch.int32, device=dev)
     return c
 
 
-def forget_split_tail_counter(dev):
+def forget_split_tail_counter(dev, slot=0):
     """Drops the device's shared finalize word (the next split_tail_counter call allocates a zeroed one)."""
-    _COUNTERS.pop(("split_tail", dev), None)
+    _COUNTERS.pop(("split_tail", dev, int(slot)), None)
 
 
 def sinkhorn_uniform_rows_final(G, beta, T, rowloss, counter, wu, wn, wkl, losses, iters=50):

@@ -28,7 +28,7 @@ _CAPTURE = {}          # capture id -> {(owner id, name, device index): External
 _RETIRED = []          # raw stream handles of finished captures, oldest first (re-used only past MAX_LIVE)
 _SPARE = []            # raw streams created in eager code for the next capture (no stream creation while a capture runs)
 STATS = {"created": 0, "reused": 0}
-SPARE_TARGET = 12      # the training step forks eight streams
+SPARE_TARGET = 64      # the training step forks eight streams; a pipelined capture of U loss-only steps 6 U + U
 MAX_LIVE = 768         # streams this module creates at most; beyond it the OLDEST retired capture streams go round again
 
 
