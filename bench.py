@@ -569,11 +569,10 @@ def main():
                     outs_u = []
 
                     def unrolled(pipelined):
-                        """U steps into the running capture.  pipelined: every step on a stream of its own that waits for the
-                        previous step's prologue (ring head, noise counter) and bank push only -- not for its Sinkhorn solve and
-                        row losses -- and takes its side streams / finalize word from its own slot (modeling.StepPipeline)."""
-                        from neighborretr_amd import streams
-                        from neighborretr_amd.capture_guard import record_event, wait_event, wait_stream
+                        """U steps into the running capture.  pipelined: a step's tail (Sinkhorn solve, row losses, bank push) stays
+                        forked until the capture ends; the next step starts behind this step's logits and bank push
+                        (modeling.StepPipeline)."""
+                        from neighborretr_amd.capture_guard import wait_event, wait_stream
                         from neighborretr_amd.modeling import StepPipeline
                         del outs_u[:]
                         if not pipelined:
@@ -581,27 +580,19 @@ def main():
                                 step()
                                 outs_u.append(result["losses"])
                             return
-                        origin, prev, ends = torch.cuda.current_stream(), None, []
+                        origin, prev, pending = torch.cuda.current_stream(), None, []
                         try:
                             for k in range(args.unroll):
-                                own = streams.side(model, f"step#{k}", dev)
-                                if prev is None:
-                                    wait_stream(own, origin)
-                                else:
-                                    for ev in (prev.push_done, prev.prologue_done):
-                                        if ev is not None:
-                                            wait_event(own, ev)
-                                model._pipeline = StepPipeline(k)
-                                with torch.cuda.stream(own):
-                                    step()
-                                    result["losses"].record_stream(origin)
-                                prev = model._pipeline
+                                if prev is not None and prev.push_done is not None:
+                                    wait_event(origin, prev.push_done)       # ring head and bank rows: the one dependency between two steps
+                                model._pipeline = prev = StepPipeline(k)
+                                step()                                       # prologue -> clustering -> logits on the origin; the rest forked
                                 outs_u.append(result["losses"])
-                                ends.append(record_event(own))
+                                pending += prev.pending
                         finally:
                             model._pipeline = None
-                        for ev in ends:
-                            wait_event(origin, ev)
+                        for st_ in pending:
+                            wait_stream(origin, st_)
 
                     def capture_unrolled(pipelined):
                         gu = torch.cuda.CUDAGraph()
@@ -654,8 +645,10 @@ def main():
                         result["losses"] = out1
                         return 1
         except Exception as e:          # graphs are an optimisation, never a requirement
+            import traceback
+            traceback.print_exc()       # (with the chain: an exception inside a capture is followed by capture_end's own)
             print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
+            graph, run = None, step
             torch.cuda.synchronize()
 
     # Clock ramp: the first ~0.1 s of back-to-back steps after an idle period run 10 % slower than the steady state (measured:

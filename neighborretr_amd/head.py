@@ -130,7 +130,8 @@ PAIR_BANK_PRODUCTS = os.environ.get("NR_PAIR_BANK", "0") == "1"
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
                  gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None,
                  bank_streams=None, local_stream=None, bank_early=0,
-                 capture_order=((7, 5), (7, 1 << 30)), bank_prepared=None, prepared_out=None, bank_push=None, bb_late=False, slot=0):
+                 capture_order=((7, 5), (7, 1 << 30)), bank_prepared=None, prepared_out=None, bank_push=None, bb_late=False, slot=0,
+                 pipeline=None):
     """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None).
 
     `join`: optional callable run right before the first use of gt / gv.  Either the caller produces the
@@ -144,7 +145,12 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     tokens ("pt", "pv") -- what the bank shadow is extended with at the push.
     `bank_push`: optional callable that pushes the batch into the memory bank (modeling.py:309-310).  The split tail
     calls it on its side stream as soon as both bank products have read the bank -- beside the Sinkhorn solve instead
-    of behind it on the critical path; the other paths leave it to the caller."""
+    of behind it on the critical path; the other paths leave it to the caller.
+    `pipeline` (split tail only; modeling.StepPipeline): consecutive steps captured overlapped.  The Sinkhorn solve then runs
+    on `pipeline.tail_stream` (forked from this stream behind the logits) and NOTHING is joined back here: the streams still
+    at work when this function returns -- solve, row losses, bank push -- are appended to `pipeline.pending`, to be joined
+    into the capture's origin stream by whoever captures the steps (every join of a capture goes into its origin:
+    capture_guard).  This stream is then free for the next step's prologue and clustering while this step's tail runs."""
     B, Nt, d = text_feat.shape
     Nv = video_feat.shape[1]
     M = mb_feat_v.shape[0]
@@ -328,8 +334,16 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         # The two self-finalizing launches share `counter`; only the one that finishes last resets it.  If anything raises
         # between them (the push callable, an NR_E* status), the word would stay non-zero and every later step would finalize
         # on incomplete row terms without an error: zero it before passing the exception on.
+        tail = pipeline.tail_stream if pipeline is not None else None
         try:
-            ops.sinkhorn_uniform_rows_final(G, hp["beta"], hp["temperature"], rowloss, counter, *wts, losses, 50)
+            if tail is not None:
+                wait_stream(tail, cur)
+                with torch.cuda.stream(tail):
+                    ops.sinkhorn_uniform_rows_final(G, hp["beta"], hp["temperature"], rowloss, counter, *wts, losses, 50)
+                for t_ in (G, rowloss, losses):
+                    t_.record_stream(tail)
+            else:
+                ops.sinkhorn_uniform_rows_final(G, hp["beta"], hp["temperature"], rowloss, counter, *wts, losses, 50)
             tgt_r = tgt_c = None
             side, side2 = bank_streams[0], bank_streams[1]
             push_stream = bank_streams[2] if len(bank_streams) > 2 else None
@@ -373,9 +387,18 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
             else:
                 ops.forget_split_tail_counter(G.device, slot)   # an aborted capture: the next step takes a fresh zeroed word
             raise
-        wait_stream(cur, side)
-        if push_stream is not None:
-            wait_stream(cur, push_stream)
+        if pipeline is not None:
+            pipeline.pending += [tail, side] + ([push_stream] if push_stream is not None else [])
+            # Nothing is joined into this stream, which goes straight on to the NEXT step: whatever was allocated on it and is
+            # still read by this step's forked streams must not go back to its free list when this function returns
+            for t_ in (gt2, gv2, gt, gv, ls, logit_scale, text_mask, video_mask, G, rowloss, losses):
+                if torch.is_tensor(t_) and t_.is_cuda:
+                    for st_ in (tail, side, side2, local_stream) + ((push_stream,) if push_stream is not None else ()):
+                        t_.record_stream(st_)
+        else:
+            wait_stream(cur, side)
+            if push_stream is not None:
+                wait_stream(cur, push_stream)
         for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi, c0, c1, wc_t, wc_v, G, rowloss, losses):
             t_.record_stream(cur)
             t_.record_stream(side)

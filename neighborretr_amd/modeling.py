@@ -44,18 +44,22 @@ class FeatureModeCLIP(nn.Module):
 
 
 class StepPipeline:
-    """Consecutive loss-only steps captured into ONE HIP graph so that they OVERLAP (bench.py --unroll): step k + 1 may start as
-    soon as step k has moved the ring head and pushed its batch -- its clustering -> logits -> Sinkhorn chain then runs while
-    step k's Sinkhorn solve (two workgroups) and row losses are still in flight; nothing else orders two steps (every step has its
-    own buffers; the bank products of step k + 1 follow its own prologue, hence step k's push).  While one is installed as
-    `model._pipeline`, a step (a) takes its side streams from the set of `slot` (a stream forked in one step is never forked
-    again in the same capture: capture_guard), (b) leaves two events behind: `prologue_done` (ring head / noise counter moved)
-    and `push_done` (the batch is in the bank and its prepared shadow), (c) uses the finalize word of its slot."""
+    """Consecutive loss-only steps captured into ONE HIP graph so that they OVERLAP (bench.py --unroll).  Inside a capture every
+    join has to go into the capture's ORIGIN stream (capture_guard: a forked stream that joins its own children takes the ROCm
+    7.2 runtime down), so a whole step cannot run on a stream of its own.  Instead the origin carries only what is serial by
+    nature -- prologue -> clustering -> global logits of step k, then of step k + 1, ... -- and everything else of a step is
+    forked and NOT joined back until the capture ends: the local branch and the bank chains as before, and now also the
+    Sinkhorn solve (`tail_stream`; two workgroups, 37 us) and with it the whole tail.  Step k + 1's prologue waits for step k's
+    bank push (the one true dependency between two loss-only steps: ring head and bank rows) and nothing else.  While one of
+    these is installed as `model._pipeline`, a step (a) takes its side streams and its finalize word from `slot` (a stream
+    forked in one step is never forked again in the same capture), (b) leaves `push_done` behind (event: the batch is in the
+    bank and its prepared shadow) and (c) appends the streams it left at work to `pending`."""
 
     def __init__(self, slot):
         self.slot = int(slot)
-        self.prologue_done = None
         self.push_done = None
+        self.tail_stream = None
+        self.pending = []
 
 
 class NeighborRetr(nn.Module):
@@ -428,9 +432,6 @@ class NeighborRetr(nn.Module):
                 text_mask, video_mask, raw_scale if scale_in_kernel else None,
                 self._rng_state_on(text_feat.device), B * sum(sizes.values()), ring=ring)
             self._ring_advanced = ring is not None
-            if self._pipeline is not None:
-                from .capture_guard import record_event
-                self._pipeline.prologue_done = record_event(torch.cuda.current_stream())
             logit_scale = ls_exp.reshape(()) if scale_in_kernel else raw_scale.exp()
             noise = self._slice_noise(flat, B, sizes)
         else:
@@ -788,6 +789,14 @@ class NeighborRetr(nn.Module):
     # handed to a later one (the re-captures of main_retrieval.GraphedStep, one per bank generation, walk this path).
     def _slot(self):
         return self._pipeline.slot if self._pipeline is not None else 0
+
+    def _pipeline_for_head(self, device):
+        """The installed StepPipeline with its tail stream resolved (None: steps are not being captured overlapped)."""
+        pipe = self._pipeline
+        if pipe is not None and pipe.tail_stream is None:
+            from . import streams
+            pipe.tail_stream = streams.side(self, self._sname("tail"), device)
+        return pipe
 
     def _sname(self, name):
         """Stream names of the running step: the steps of a pipelined capture (StepPipeline) each fork their own set."""
