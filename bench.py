@@ -67,11 +67,12 @@ def parse():
                     help="BASELINE.json configs[k]: 1 = the headline workload (default); 2 (global B=1024) and 3 (ActivityNet token counts, "
                          "M=1024) run the same step on ONE GPU as extra lines -- no CPU baseline, no reference fixture at those sizes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
-    ap.add_argument("--unroll", type=int, default=4,
+    ap.add_argument("--unroll", type=int, default=0,
                     help="consecutive steps captured per HIP graph, every dependency between them kept (the bank push of step k before "
                          "the bank products of step k+1): one replay then issues U steps and the ~10 us between two replays is paid "
                          "once per U steps (round 3: 312 / 306 / 304 us per step at U = 1 / 2 / 4).  A remainder of K mod U steps is "
-                         "replayed step by step.  Step-interleaved job (N > 1): U = N, one round per graph.  1 = one step per graph")
+                         "replayed step by step.  0 (default) = the largest U <= 10 that divides --steps (20 -> 10), else 4.  "
+                         "Step-interleaved job (N > 1): U = N, one round per graph.  1 = one step per graph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL; gloo only to rehearse ranks that share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,6 +89,9 @@ def parse():
                     help="N=1: the U steps of an unrolled graph strictly one after the other (A/B switch).  Default: step k+1 starts "
                          "as soon as step k has moved the ring head and pushed its batch, i.e. beside step k's Sinkhorn solve and row "
                          "losses (modeling.StepPipeline); the graph is held against U single-step replays before it is used")
+    ap.add_argument("--decouple_push", action="store_true",
+                    help="pipelined steps, A/B switch: the next step's prologue does not wait for this step's bank push (per-step copy "
+                         "of the ring head; only the bank chains wait).  Bit-identical and slower (0.355 vs 0.293 ms per step)")
     ap.add_argument("--emulate_world", type=int, nargs="*", default=None, metavar="W",
                     help="N=1 only, extra field `rank_local` (never the headline): what ONE rank of the sharded step does at these world "
                          "sizes (default 2 4 8), emulated on this GPU -- its own messages through a 1-rank RCCL communicator, the peers' "
@@ -101,6 +105,8 @@ def parse():
                          "(extra field `e2e`; never the headline value)")
     args = ap.parse_args()
     CFG.update(CFGS[args.config])
+    if args.unroll <= 0:
+        args.unroll = max([u for u in range(2, 11) if args.steps % u == 0] or [4])
     return args
 
 
@@ -583,9 +589,9 @@ def main():
                         origin, prev, pending = torch.cuda.current_stream(), None, []
                         try:
                             for k in range(args.unroll):
-                                if prev is not None and prev.push_done is not None:
+                                if prev is not None and prev.push_done is not None and not args.decouple_push:
                                     wait_event(origin, prev.push_done)       # ring head and bank rows: the one dependency between two steps
-                                model._pipeline = prev = StepPipeline(k)
+                                model._pipeline = prev = StepPipeline(k, prev, decoupled=args.decouple_push)
                                 step()                                       # prologue -> clustering -> logits on the origin; the rest forked
                                 outs_u.append(result["losses"])
                                 pending += prev.pending
@@ -595,6 +601,7 @@ def main():
                             wait_stream(origin, st_)
 
                     def capture_unrolled(pipelined):
+                        model.prepare_pipeline(args.unroll, c["B"])
                         gu = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(gu):
                             unrolled(pipelined)

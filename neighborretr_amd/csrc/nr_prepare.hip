@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256) void nr_bank_absorb_kernel(NrBankAbsorbDesc a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int B = a.world * a.per_rank, d = a.d;
     const int rows_t = B * a.Nt, total = rows_t + B * a.Nv;
-    int nh = (__hip_atomic_load(a.ring_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - B) % a.capacity;
+    const int old_head = __hip_atomic_load(a.ring_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old_head < 0 || old_head >= a.capacity) return;    // (a head outside the ring never becomes a wild write; the counter stays zero)
+    int nh = (old_head - B) % a.capacity;
     if (nh < 0) nh += a.capacity;
     const char* recv = reinterpret_cast<const char*>(a.gathered);
     for (int row = blockIdx.x * 4 + wave; row < total; row += gridDim.x * 4) {

@@ -295,7 +295,9 @@ struct NrRingArgs {
 __global__ __launch_bounds__(256) void nr_bank_ring_kernel(NrRingArgs a) {
     const int t = blockIdx.y, r = blockIdx.x;
     const size_t rb = a.row_bytes[t];
-    int dr = (a.head_dev ? *a.head_dev : a.head_new) + r;
+    int head = a.head_dev ? *a.head_dev : a.head_new;
+    if (head < 0 || head >= a.capacity) return;        // a device-resident head outside the ring never becomes a wild write
+    int dr = head + r;
     if (dr >= a.capacity) dr -= a.capacity;
     const char* src = (const char*)a.batch[t] + (size_t)r * rb;
     char* dst = (char*)a.bank[t] + (size_t)dr * rb;

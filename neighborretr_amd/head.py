@@ -211,8 +211,14 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
                     yield
                     early[0], early[1] = (pbv_, w_bv_, lg_bv_, None, c1_), (pbt_, w_bt_, lg_bt_, None, c0_)
 
+    def after_previous_push():
+        """Pipelined steps: whatever reads the memory bank waits for the PREVIOUS step's push (on the stream it runs on)."""
+        if pipeline is not None and pipeline.prev_push_done is not None:
+            wait_event(torch.cuda.current_stream(), pipeline.prev_push_done)
+
     def bank_video_steps():
         # text x bank-video, row mean  -> centrality of text j  (used by the v2t neighbour loss)
+        after_previous_push()
         if bank_prepared is not None:
             pbv = bank_prepared[1]
         else:
@@ -232,6 +238,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
 
     def bank_text_steps():
         # bank-text x video, column mean -> centrality of video j (used by the t2v neighbour loss)
+        after_previous_push()
         if bank_prepared is not None:
             pbt = bank_prepared[0]
         else:

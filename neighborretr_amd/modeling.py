@@ -49,15 +49,23 @@ class StepPipeline:
     7.2 runtime down), so a whole step cannot run on a stream of its own.  Instead the origin carries only what is serial by
     nature -- prologue -> clustering -> global logits of step k, then of step k + 1, ... -- and everything else of a step is
     forked and NOT joined back until the capture ends: the local branch and the bank chains as before, and now also the
-    Sinkhorn solve (`tail_stream`; two workgroups, 37 us) and with it the whole tail.  Step k + 1's prologue waits for step k's
-    bank push (the one true dependency between two loss-only steps: ring head and bank rows) and nothing else.  While one of
+    Sinkhorn solve (`tail_stream`; two workgroups, 37 us) and with it the whole tail.  The one true dependency between two
+    loss-only steps is the memory bank: step k + 1's prologue (it moves the ring head) and bank chains wait for step k's push
+    (`push_done` / `prev_push_done`).  While one of
     these is installed as `model._pipeline`, a step (a) takes its side streams and its finalize word from `slot` (a stream
     forked in one step is never forked again in the same capture), (b) leaves `push_done` behind (event: the batch is in the
     bank and its prepared shadow) and (c) appends the streams it left at work to `pending`."""
 
-    def __init__(self, slot):
+    def __init__(self, slot, prev=None, decoupled=False):
         self.slot = int(slot)
+        # decoupled: the NEXT step's prologue does not wait for this step's push (own copy of the ring head per step; only the
+        # bank chains wait).  Correct (bit-identical), and SLOWER: 0.355 ms per step against 0.293 with the origin waiting for the
+        # push before the next prologue -- the steps then overlap so far that both chains of two steps share the CUs
+        # (bench.py --decouple_push; A/B in one session, round 4).  Off by default.
+        self.decoupled = bool(decoupled)
         self.push_done = None
+        self.prev_push_done = prev.push_done if prev is not None else None    # the bank reads of THIS step wait for it
+        self.head = None             # this step's own copy of the ring head (its push reads it; the next prologue moves the shared one)
         self.tail_stream = None
         self.pending = []
 
@@ -329,7 +337,8 @@ class NeighborRetr(nn.Module):
             else:
                 self._mb_shadow = None             # pushed without prepared rows (direct call): rebuild on next use
         self._last_prepared = {}
-        ops.bank_ring_push(banks, rows, 0, head_dev=ring[0])
+        pipe = self._pipeline
+        ops.bank_ring_push(banks, rows, 0, head_dev=pipe.head if (pipe is not None and pipe.head is not None) else ring[0])
 
     # ------------------------------------------------------------------ forward (modeling.py:251-312)
     def forward(self, text_ids, text_mask, video, video_mask=None, idx=None, global_step=0, logger=None):
@@ -432,6 +441,12 @@ class NeighborRetr(nn.Module):
                 text_mask, video_mask, raw_scale if scale_in_kernel else None,
                 self._rng_state_on(text_feat.device), B * sum(sizes.values()), ring=ring)
             self._ring_advanced = ring is not None
+            if self._pipeline is not None and self._pipeline.decoupled and ring is not None:
+                # this step's own copy of the ring head, in a PERSISTENT word per slot: the push reads it late, on its own stream --
+                # a per-step allocation of this stream would be handed out again to the next step before the push has run
+                # (measured: "Memory access fault", the push wrote at a recycled word's value)
+                self._pipeline.head = self._head_slot(self._pipeline.slot, ring[0])
+                self._pipeline.head.copy_(ring[0])
             logit_scale = ls_exp.reshape(()) if scale_in_kernel else raw_scale.exp()
             noise = self._slice_noise(flat, B, sizes)
         else:
@@ -789,6 +804,23 @@ class NeighborRetr(nn.Module):
     # handed to a later one (the re-captures of main_retrieval.GraphedStep, one per bank generation, walk this path).
     def _slot(self):
         return self._pipeline.slot if self._pipeline is not None else 0
+
+    def _head_slot(self, slot, like):
+        slots = self.__dict__.setdefault("_head_slots", {})
+        key = (int(slot), like.device)
+        if key not in slots:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("pipelined steps: call model.prepare_pipeline(n_steps, batch) before the capture (the per-step "
+                                   "copies of the ring head must not live in a graph's memory pool)")
+            slots[key] = torch.zeros_like(like)
+        return slots[key]
+
+    def prepare_pipeline(self, n_steps, batch_rows):
+        """Before capturing `n_steps` overlapped steps (StepPipeline): the persistent per-step words they need."""
+        ring = self._ring_ready(batch_rows)
+        if ring is not None:
+            for k in range(int(n_steps)):
+                self._head_slot(k, ring[0])
 
     def _pipeline_for_head(self, device):
         """The installed StepPipeline with its tail stream resolved (None: steps are not being captured overlapped)."""

@@ -11,7 +11,8 @@ for r in csv.DictReader(open(sys.argv[1])):
                  int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0), int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 1)) or 1)))
 rows.sort(key=lambda r: r[1])
 starts = [i for i, r in enumerate(rows) if r[0].startswith("nr_step_prologue")]
-a, b = starts[-3], starts[-2]                  # a steady-state step well inside the timed loop
+n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # consecutive steps to print (pipelined graphs: 2 shows the overlap)
+a, b = starts[-2 - n_steps], starts[-2]          # steady-state step(s) well inside the timed loop
 t0 = rows[a][1]
 crit_q = rows[a][3]
 crit_end = 0
