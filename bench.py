@@ -72,7 +72,7 @@ def parse():
                          "the bank products of step k+1): one replay then issues U steps and the ~10 us between two replays is paid "
                          "once per U steps (round 3: 312 / 306 / 304 us per step at U = 1 / 2 / 4).  A remainder of K mod U steps is "
                          "replayed step by step.  0 (default) = the largest U <= 10 that divides --steps (20 -> 10), else 4.  "
-                         "Step-interleaved job (N > 1): U = N, one round per graph.  1 = one step per graph")
+                         "N > 1: one graph per step (see --round_graph).  1 = one step per graph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL; gloo only to rehearse ranks that share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,6 +89,10 @@ def parse():
                     help="N=1: the U steps of an unrolled graph strictly one after the other (A/B switch).  Default: step k+1 starts "
                          "as soon as step k has moved the ring head and pushed its batch, i.e. beside step k's Sinkhorn solve and row "
                          "losses (modeling.StepPipeline); the graph is held against U single-step replays before it is used")
+    ap.add_argument("--round_graph", action="store_true",
+                    help="step-interleaved job, A/B switch: a whole round (this rank's own step and the N - 1 others) as ONE graph instead "
+                         "of one graph per step.  Emulated, it is SLOWER (660 vs 620 us per round at N = 8, profiles/r04_rank_local.txt): "
+                         "inside a multi-stream graph every node costs more than in the single-stream graph of a non-owned step")
     ap.add_argument("--decouple_push", action="store_true",
                     help="pipelined steps, A/B switch: the next step's prologue does not wait for this step's bank push (per-step copy "
                          "of the ring head; only the bank chains wait).  Bit-identical and slower (0.355 vs 0.293 ms per step)")
@@ -107,6 +111,10 @@ def parse():
     CFG.update(CFGS[args.config])
     if args.unroll <= 0:
         args.unroll = max([u for u in range(2, 11) if args.steps % u == 0] or [4])
+    if CFG["B"] >= CFG["M"]:
+        # a batch as large as the bank replaces it wholesale (modeling.py:244-249: new tensors every step, no ring): consecutive
+        # steps of one graph would not see each other's bank -- one step per graph there (configs[2] on one GPU)
+        args.unroll = 1
     return args
 
 
@@ -473,7 +481,7 @@ def main():
                 def replay_pass():
                     # two rounds: the first step by step (the owner / other graphs), the second as ONE replay (the round graph);
                     # with the bank frozen and the noise counter rewound both must reproduce the eager round
-                    for allowed in ((0, n_round) if (interleaved and args.unroll != 1) else (0,)):
+                    for allowed in ((0, n_round) if (interleaved and args.round_graph) else (0,)):
                         ctr[0] = 0
                         rng[1] = 4242
                         budget[0] = allowed
@@ -499,7 +507,7 @@ def main():
                 ctr[0] = rank if own else rank + 1
                 forms[own] = capture_one(step)
                 outs[own] = result.get("losses")
-            if args.unroll != 1:                 # one whole round (W consecutive steps: this rank's own and the W - 1 others)
+            if args.round_graph:                 # one whole round (W consecutive steps: this rank's own and the W - 1 others)
                 ctr[0] = 0
 
                 def one_round():
@@ -609,8 +617,8 @@ def main():
 
                     def state():
                         sh = model._mb_shadow or ()
-                        return ([model._mb[k_] for k_ in model._mb] + [t_ for p_ in sh for t_ in (p_.hi, p_.lo, p_.norm) if t_ is not None]
-                                + [model._mb_head_dev, model._rng_state])
+                        return [t_ for t_ in ([model._mb[k_] for k_ in model._mb] + [t_ for p_ in sh for t_ in (p_.hi, p_.lo, p_.norm)]
+                                              + [model._mb_head_dev, model._rng_state]) if t_ is not None]
 
                     def equals_single_steps(gu, outs):
                         """The unrolled graph against U replays of the single-step graph from the same bank / ring / noise state:
@@ -880,7 +888,7 @@ def main():
                        "hip_graph": graph is not None, "step_form": step_form, "graph_segments": n_segments,
                        "unrolled_graph": unroll_check,
                        "steps_per_graph": (1 if (graph is None or args.unroll == 1 or step_form == "exchange eager + loss graph")
-                                           else (world if interleaved else (args.unroll if world == 1 else 1))),
+                                           else ((world if args.round_graph else 1) if interleaved else (args.unroll if world == 1 else 1))),
                        "parallelism": f"dp{world}: " + (
                            ("packed all-gather every step on every rank, bank replicated by pushing every gathered batch; the loss of step k "
                             "evaluated on rank k mod W with the single-rank kernels (step-interleaved: loss-only steps depend on each other "
