@@ -373,7 +373,21 @@ class GraphedStep:
         self._used, self._views, self._out = used, views, out
         self._remember_bank()
 
+    def _eager(self, batch):
+        """A batch whose shapes differ from the captured ones (a loader's last, shorter batch): one eager step with the same
+        outcome -- losses returned, gradients left in .grad -- instead of a graph per shape."""
+        if self.world > 1:
+            raise ValueError("GraphedStep on several ranks needs batches of one shape (the exchange step gathers equal shards: drop "
+                             f"the loader's last batch); got {[tuple(t.shape) for t in batch]} after {[tuple(t.shape) for t in self.static]}")
+        losses = self.model(*batch, 0)
+        grads = torch.autograd.grad(losses[0], self.params, allow_unused=True)
+        for p, g in zip(self.params, grads):
+            p.grad = g
+        return tuple(l.detach() for l in losses)
+
     def run(self, batch):
+        if any(tuple(src.shape) != tuple(dst.shape) for dst, src in zip(self.static, batch)):
+            return self._eager(batch)
         if self.model._mb_gen != self.generation:    # the bank's tensors / ring head were replaced: the graph is stale
             self.capture()
         for dst, src in zip(self.static, batch):

@@ -90,6 +90,20 @@ def test_graphed_training_step_keeps_the_reference_fifo():
         # newest first: the three batches of this epoch, then the head of the epoch's initial bank
         want = torch.cat([batch(3 * epoch + r)[4] for r in (2, 1, 0)] + [torch.arange(5000 + epoch, 5000 + epoch + M, device=dev)])[:M]
         assert torch.equal(graphed.mb_ind, want)
+    # a shorter last batch (another shape than the captured one): an eager step with the same outcome, no re-capture
+    short = tuple(t[:B - 2] for t in batch(7))
+    load_bank(eager, 9), load_bank(graphed, 9)
+    for m_ in (eager, graphed):
+        m_._rng_state_on(torch.device(dev, 0))[1] = 4000
+    eager.zero_grad(set_to_none=True)
+    le = eager(*short, 0)
+    le[0].backward()
+    lg = step.run(short)
+    torch.cuda.synchronize()
+    assert abs(float(lg[0]) - float(le[0].detach())) < 1e-3 * abs(float(le[0].detach()))
+    ge = torch.cat([p.grad.reshape(-1) for p in eager.parameters() if p.grad is not None])
+    gg = torch.cat([p.grad.reshape(-1) for p in graphed.parameters() if p.grad is not None])
+    assert float((ge - gg).norm() / ge.norm()) < 5e-3
 
 
 def test_graphed_step_survives_five_recaptures():
@@ -140,6 +154,22 @@ def test_main_retrieval_with_encoders_end_to_end(tmp_path):
     losses = [float(l.split(" loss ")[1].split()[0]) for l in r.stdout.splitlines() if " loss " in l]
     assert len(losses) == 2 and all(x == x and x < 1e4 for x in losses), r.stdout[-2000:]
     assert "text->video R@1" in r.stdout
+
+
+def test_bench_overlapped_steps_equal_single_step_replays():
+    """`bench.py` (one GPU): U consecutive steps captured into ONE graph and OVERLAPPED (modeling.StepPipeline: the next step's
+    prologue and clustering run beside this step's Sinkhorn solve, row losses and bank push; every join goes into the capture's
+    origin stream) -- bench.py holds the graph against U single-step replays from the same bank / ring / noise state before it
+    times it: every step's losses and the state left behind bit-identical.  Also the strictly sequential form (--no-pipeline)."""
+    import json
+    for extra, form in (([], "pipelined"), (["--no-pipeline"], "sequential")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "2", "--no-cpu-baseline"] + extra,
+                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        u = d["config"]["unrolled_graph"]
+        assert u == {"steps_per_graph": 6, "form": form, "equals_single_step_replays": True, "max_dL": 0.0}, u
+        assert d["config"]["steps_per_graph"] == 6 and d["steps"] == 12 and d["parity"]["pass"]
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
