@@ -100,6 +100,10 @@ def parse():
                     help="N=1 only, extra field `rank_local` (never the headline): what ONE rank of the sharded step does at these world "
                          "sizes (default 2 4 8), emulated on this GPU -- its own messages through a 1-rank RCCL communicator, the peers' "
                          "parts pre-filled (tools/rank_local_times.py; no wire time)")
+    ap.add_argument("--overlap", action="store_true", help="step-interleaved job: the overlapped owned step at any world size (default: from 6 ranks on)")
+    ap.add_argument("--no_overlap", action="store_true",
+                    help="step-interleaved job, A/B switch: the owner evaluates its loss IN FRONT of the following steps (round 4's first "
+                         "form) instead of beside them from a copy of the bank (neighborretr_amd.interleave)")
     ap.add_argument("--fail_whole_capture", action="store_true",
                     help="rehearsal switch: rank 0 pretends its whole-step capture failed, so that every rank takes the segmented-graph "
                          "form together (tests the collective fallback decision)")
@@ -362,6 +366,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        # The job runs on a stream of the pool, not on the legacy default stream: replayed on the default stream, the exchange
+        # graphs of the step-interleaved job and the owner's loss graph on its own stream take turns instead of overlapping
+        # (measured, W = 8 emulated: 723 us per round against 516; tools/rank_local_times.py).  N = 1: no difference (A/B, 3385 vs 3380).
+        job_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(job_stream)
 
     from neighborretr_amd import hip, ops, synth
     c = CFG
@@ -379,6 +388,9 @@ def main():
     if world > 1:
         model.shard_loss = sharded
         model.interleave_steps = interleaved
+        # the owner's loss beside the following steps pays off once W - 1 exchange steps outlast the pair's hand-offs (emulated
+        # rounds, serial / overlapped: W = 2 388 / 446 us, W = 4 470 / 473, W = 8 617 / 516): default from 6 ranks on
+        model.interleave_overlap = interleaved and not args.no_overlap and (args.overlap or world >= 6)
     n_round = world if interleaved else 1          # steps after which every rank has evaluated a loss
     ctr = [0]                                      # the job's step counter (host side; identical on every rank)
     budget = [0]                                   # steps the caller still wants: a replay may cover several (see --unroll)
@@ -505,6 +517,18 @@ def main():
             forms, outs = {}, {}
             for own in (True, False):
                 ctr[0] = rank if own else rank + 1
+                if own and model.interleave_overlap:
+                    # the owned step in two halves (neighborretr_amd.interleave): exchange + bank copy + push on this stream,
+                    # the loss from the copy on the model's loss stream, beside the following steps
+                    from neighborretr_amd.interleave import OverlappedOwnedStep
+
+                    def exchange_half(slot_index):
+                        model._step_index = rank
+                        return model.owned_exchange(shard["text_feat"], shard["text_mask"], shard["video_feat"], shard["video_mask"],
+                                                    shard["idx"], slot_index=slot_index)
+                    forms[own] = OverlappedOwnedStep(model, exchange_half, capture_one)
+                    outs[own] = forms[own].losses
+                    continue
                 forms[own] = capture_one(step)
                 outs[own] = result.get("losses")
             if args.round_graph:                 # one whole round (W consecutive steps: this rank's own and the W - 1 others)
@@ -528,7 +552,8 @@ def main():
                 ctr[0] += 1
                 forms[own].replay()
                 if own:
-                    result["losses"] = outs[True]      # (each graph writes the losses into its own pool)
+                    # (each graph writes the losses into its own pool; the overlapped form has one loss graph per slot)
+                    result["losses"] = getattr(forms[True], "losses", outs[True])
                 return 1
             return replay, forms
 
@@ -552,20 +577,34 @@ def main():
 
         def segments_of(keep):
             return keep[True].n_segments if interleaved else keep.n_segments
-        form = attempt(make_whole, "whole-step") if (args.backend == "nccl" or args.fail_whole_capture) else None
+        # interleaved: each form first with the owner's loss BESIDE the following steps (model.interleave_overlap), then serial
+        overlaps = (True, False) if model.interleave_overlap else (False,)
+        form = None
+        if args.backend == "nccl" or args.fail_whole_capture:
+            for ov in overlaps:
+                model.interleave_overlap = ov
+                form = attempt(make_whole, "whole-step" + (" (loss beside the following steps)" if ov else ""))
+                if form is not None:
+                    break
         if form is not None:
             step_form, graph = "whole", form[1]
         else:
             # a side stream cannot stay forked across a cut between two segments: the synchronous sharded step runs on one
             # stream in this form; the interleaved step's only collective comes before anything is forked
             model.use_side_streams = interleaved
-            for _ in range(2 * n_round):
-                step()
-            form = attempt(make_segmented, "segmented")
+            for ov in overlaps:
+                model.interleave_overlap = ov
+                for _ in range(2 * n_round):
+                    step()
+                torch.cuda.synchronize()
+                form = attempt(make_segmented, "segmented" + (" (loss beside the following steps)" if ov else ""))
+                if form is not None:
+                    break
             if form is not None:
                 step_form, graph, n_segments = "segmented", form[1], segments_of(form[1])
             else:
                 model.use_side_streams = True
+                model.interleave_overlap = False
         if form is not None:
             run = form[0]
         ctr[0] = 0
@@ -898,6 +937,8 @@ def main():
                            + "; " + {"whole": "collectives inside the HIP graph(s)", "segmented": f"{n_segments} rank-local segments per step as HIP "
                                      "graphs, the collectives eager between them", "eager": "launched eagerly",
                                      "exchange eager + loss graph": "exchange eager + loss graph"}[step_form]) if world > 1 else "dp1",
+                       "owner_loss": (("beside the following steps, from a copy of the bank (two graphs per owned step)" if model.interleave_overlap
+                                       else "in front of the following steps") if interleaved else None),
                        "memory_bank": "ring (device head) + persistent prepared bf16 shadow, extended by the batch rows at every push"},
             "losses": [round(float(x), 5) for x in losses],
             "ms_per_step_min": round(min(rep_ms), 4), "ms_per_step_median": round(float(np.median(rep_ms)), 4),

@@ -395,12 +395,12 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
                 ops.forget_split_tail_counter(G.device, slot)   # an aborted capture: the next step takes a fresh zeroed word
             raise
         if pipeline is not None:
-            pipeline.pending += [tail, side] + ([push_stream] if push_stream is not None else [])
+            pipeline.pending += [tail, side] + ([push_stream] if (push_stream is not None and bank_push is not None) else [])
             # Nothing is joined into this stream, which goes straight on to the NEXT step: whatever was allocated on it and is
             # still read by this step's forked streams must not go back to its free list when this function returns
             for t_ in (gt2, gv2, gt, gv, ls, logit_scale, text_mask, video_mask, G, rowloss, losses):
                 if torch.is_tensor(t_) and t_.is_cuda:
-                    for st_ in (tail, side, side2, local_stream) + ((push_stream,) if push_stream is not None else ()):
+                    for st_ in (tail, side, side2, local_stream) + ((push_stream,) if (push_stream is not None and bank_push is not None) else ()):
                         t_.record_stream(st_)
         else:
             wait_stream(cur, side)

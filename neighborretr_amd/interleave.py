@@ -1,0 +1,83 @@
+"""Replayable form of an OVERLAPPED owned step of the step-interleaved job (model.interleave_overlap).
+
+The step-interleaved job evaluates the loss of step k on rank k mod W; every rank gathers and pushes every batch.  Serially a
+rank pays one loss evaluation (~340 us at configs[1]) and W - 1 exchange-and-push steps (~40 us each) per W steps.  The loss
+of step k reads the memory bank as it stood BEFORE batch k was pushed and nothing else that later steps change -- so the owner
+copies that state (`modeling.OwnedSlot`: the prepared bf16 shadow, masks, noise counter), pushes the batch at once like every
+other rank, and evaluates the loss from the copy on a second stream while its first stream already takes part in the following
+steps' exchanges.  Two graphs per owned step:
+
+    A  (exchange half, the step's stream)   pack -> packed all-gather -> unpack into the slot -> bank copy -> absorb
+    B  (loss half, model.owned_loss_stream) loss_step on the slot: prologue, clustering, products, Sinkhorn, row terms
+
+tied together by two events OUTSIDE the graphs: B waits for A; the next A waits for B (one slot).  A contains the step's one
+collective and is captured like any step with collectives (one graph with the RCCL all-gather inside, or comm.SegmentedStep);
+B has none and is a plain graph.  Every step's losses and the bank after any number of steps are bit-identical to the serial
+forms (tools/rank_local_times.py raises otherwise; tests/test_sharded_gpu.py, tests/test_rank_local_gpu.py).
+
+What was measured on the way (W = 8 emulated on one MI355X, profiles/r04_overlap_probe.txt; serial round: 616 us):
+  * the pair as above, one slot: 517-530 us per round (+17-19 % steps/s); a second slot (the next A not waiting for this B) is
+    SLOWER, 577-603 us: two loss graphs queued back to back on the loss stream and the exchange graphs share the CUs for longer;
+  * the whole round as ONE graph with the loss on forked streams: 719 us -- the runtime runs a graph's branches on two hardware
+    queues, both of which the loss already uses; the exchange steps were appended to one of them whatever their capture order
+    (kernel trace: every exchange kernel behind the loss's local chain on the same queue);
+  * stream priorities for either half: 1.0-2.4 ms per round; more hardware queues (GPU_MAX_HW_QUEUES=8): 1.1 ms.
+"""
+import torch
+
+
+class OverlappedOwnedStep:
+    def __init__(self, model, exchange_fn, capture_exchange, warm=2):
+        """exchange_fn(slot_index): runs model.owned_exchange(..., slot_index=slot_index) on the rank's shard (collectives through
+        neighborretr_amd.comm).  capture_exchange(fn) -> an object with .replay() (a CUDAGraph, or a comm.SegmentedStep).
+        One (A, B) pair of graphs per slot of the model (`model.owned_slots`, one by default)."""
+        self.model = model
+        n = max(1, int(model.owned_slots))
+        for k in range(max(warm, 1) * n):          # the slots exist, the shadow is built, every kernel has been launched once
+            model.owned_loss(exchange_fn(k % n))
+        torch.cuda.synchronize()
+        self.side = model.owned_loss_stream(model._owned.rng.device)
+        self.pairs = []
+        for k in range(n):
+            A = capture_exchange(lambda k=k: exchange_fn(k))
+            slot = model._owned_ring[k]
+            B = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(B, stream=self.side):
+                losses = model.owned_loss(slot)
+            base = losses[0]._base                 # the five scalars are views of one [5] tensor
+            self.pairs.append((A, B, base if base is not None and base.numel() == 5 else torch.stack(losses),
+                               torch.cuda.Event(), torch.cuda.Event()))
+        self.turn = 0
+        self.pending = [False] * n
+        self.losses = self.pairs[0][2]             # of the LAST replayed owned step (valid once its loss half has finished)
+
+    @property
+    def A(self):
+        return self.pairs[0][0]
+
+    @property
+    def n_segments(self):
+        return getattr(self.pairs[0][0], "n_segments", 1)
+
+    def replay(self):
+        """On the current stream: A; on the loss stream, behind it: B.  Returns at once (no host synchronisation)."""
+        k = self.turn % len(self.pairs)
+        self.turn += 1
+        A, B, losses, ev_a, ev_b = self.pairs[k]
+        cur = torch.cuda.current_stream()
+        if self.pending[k]:
+            cur.wait_event(ev_b)                   # the slot is free again: its previous loss half has read it
+        A.replay()
+        ev_a.record(cur)
+        self.side.wait_event(ev_a)
+        with torch.cuda.stream(self.side):
+            B.replay()
+            ev_b.record(self.side)
+        self.pending[k] = True
+        self.losses = losses
+
+    def wait(self):
+        """Orders the current stream behind the last loss half."""
+        k = (self.turn - 1) % len(self.pairs)
+        if self.turn and self.pending[k]:
+            torch.cuda.current_stream().wait_event(self.pairs[k][4])

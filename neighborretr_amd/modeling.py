@@ -70,6 +70,48 @@ class StepPipeline:
         self.pending = []
 
 
+class OwnedSlot:
+    """Persistent buffers of an OVERLAPPED owned step of the step-interleaved job (`model.interleave_overlap`): the gathered batch,
+    and the memory bank as the step's loss has to see it -- the prepared bf16 shadow, the masks and the noise counter, copied
+    before the batch is pushed.  With these the loss of step k reads nothing that the exchange-and-push steps k + 1, k + 2, ...
+    write, so it runs on a stream of its own BESIDE them instead of in front of them.  Allocated outside
+    any capture: two graphs (the exchange half and the loss half of the step) name these addresses."""
+
+    def __init__(self, lay, shadow, masks, rng, copy_lo):
+        from .ops import Prepared
+        dev = rng.device
+        B = lay["W"] * lay["b"]
+        dt = (torch.float32, torch.float32, torch.int64, torch.float32, torch.float32)
+        self.batch = [torch.empty((B,) + tuple(shp), dtype=t, device=dev) for shp, t in zip(lay["shapes"], dt)]
+        self.copy_lo = bool(copy_lo)
+        self.shadow = tuple(Prepared(torch.empty_like(p.hi), torch.empty_like(p.lo) if copy_lo else None, torch.empty_like(p.norm),
+                                     None, p.n_tok, p.d) for p in shadow)
+        self.masks = tuple(torch.empty_like(m) for m in masks)
+        self.rng = torch.empty_like(rng)
+        self.scratch = {}                 # the loss half's `_last_prepared` (never the live model's)
+        self.loss_done = None             # event: the loss half of the previous use of this slot has finished reading it
+        self.losses = None
+
+    def _pairs(self, shadow, masks, rng):
+        dst = [self.shadow[0].hi, self.shadow[1].hi, self.shadow[0].norm, self.shadow[1].norm, self.masks[0], self.masks[1], self.rng]
+        src = [shadow[0].hi, shadow[1].hi, shadow[0].norm, shadow[1].norm, masks[0], masks[1], rng]
+        if self.copy_lo:
+            dst += [self.shadow[0].lo, self.shadow[1].lo]
+            src += [shadow[0].lo, shadow[1].lo]
+        return dst, src
+
+    def fits(self, lay, shadow, masks, copy_lo):
+        return (self.copy_lo == bool(copy_lo) and all(tuple(a.shape[1:]) == tuple(s) for a, s in zip(self.batch, lay["shapes"]))
+                and self.batch[0].shape[0] == lay["W"] * lay["b"]
+                and all(a.hi.shape == b.hi.shape for a, b in zip(self.shadow, shadow))
+                and all(a.shape == b.shape and a.dtype == b.dtype for a, b in zip(self.masks, masks)))
+
+    def take(self, shadow, masks, rng):
+        """The bank's prepared shadow, its masks and the noise counter -> this slot (device copies on the current stream)."""
+        dst, src = self._pairs(shadow, masks, rng)
+        torch._foreach_copy_(dst, src)
+
+
 class NeighborRetr(nn.Module):
     def __init__(self, config, clip=None, width=512, precision="bf16", with_encoders=False, encoder_dims=None):
         """clip: any module with encode_text / encode_image / logit_scale (e.g. the reference's own CLIP).
@@ -160,6 +202,15 @@ class NeighborRetr(nn.Module):
         # Only without gradients (a training step needs every rank's gradient before the next step: the sharded loss is its form).
         self.interleave_steps = False
         self._step_index = 0
+        # ... with the owner's loss BESIDE the following steps (OwnedSlot): the owner copies the bank's prepared shadow (19 MB at
+        # configs[1], one bf16 pass on the bank side) before it pushes the batch like every other rank, and evaluates the loss
+        # from that copy on `owned_loss_stream` while this stream goes on with the exchange-and-push steps of the other owners.
+        # Opt-in: the losses an owned step returns are then produced on that stream -- wait_owned_loss() before reading them.
+        self.interleave_overlap = False
+        self.owned_slots = 1                # OwnedSlots in rotation (measured, W = 8 emulated: two slots are SLOWER than one, 598 vs 524 us per round)
+        self._owned_ring = []
+        self._owned_turn = 0
+        self._owned = None                  # the slot of the last overlapped owned step
         self._pipeline = None               # a StepPipeline while consecutive steps are being captured overlapped (bench.py)
         self._ctm_cache = {}
 
@@ -368,6 +419,10 @@ class NeighborRetr(nn.Module):
                         recv, lay = packed_gather_raw(text_feat, video_feat, idx, text_mask, video_mask, self.config)
                         if not owner and self._absorb_gathered(recv, lay):
                             return None                        # the whole step in three launches: pack, all-gather, absorb
+                        if owner and self.interleave_overlap:
+                            slot = self._owned_prepare(recv, lay)
+                            if slot is not None:               # the batch is in the bank already; the loss runs beside what follows
+                                return self._owned_loss_beside(slot)
                         text_feat, video_feat, idx, text_mask, video_mask = unpack_raw(recv, lay)
                 else:
                     text_feat, video_feat, idx, text_mask, video_mask = packed_allgather(
@@ -383,28 +438,136 @@ class NeighborRetr(nn.Module):
     def _interleaving(self):
         return bool(self.interleave_steps) and not torch.is_grad_enabled() and int(getattr(self.config, "world_size", 1)) > 1
 
+    def _absorb_ready(self, lay):
+        """(ring, shadow) when a gathered batch of this layout can go into the bank through nr_bank_absorb_gathered -- the bank is
+        a device ring of fp32 tensors that holds more than a batch, of the batch's token shapes -- else None.  Does not look at
+        `bank_frozen`."""
+        (Nt, d), (Nv, _) = lay["shapes"][0], lay["shapes"][1]
+        B = lay["W"] * lay["b"]
+        if d % 256 or d > 1024 or Nt > 64 or Nv > 64:
+            return None
+        mb = self._mb
+        if tuple(mb["mb_feat_t"].shape[1:]) != (Nt, d) or tuple(mb["mb_feat_v"].shape[1:]) != (Nv, d) or mb["mb_ind"].dtype != torch.int64:
+            return None
+        if any(mb[k].dtype != torch.float32 for k in ("mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v")):
+            return None
+        ring = self._ring_ready(B)
+        if ring is None:
+            return None
+        shadow = self._bank_shadow()                       # (built before the first push, like the owner's step does)
+        if shadow is not None and (shadow[0].lo is None or shadow[1].lo is None):
+            return None
+        return ring, shadow
+
     def _absorb_gathered(self, recv, lay):
         """A step this rank does not own, from the exchange step's receive buffer in ONE launch (nr_bank_absorb_gathered): ring
         head, noise counter, fp32 bank rows and the prepared shadow rows.  False when the bank is not a device ring that holds
         more than a batch, or frozen (the caller then unpacks and takes bank_only_step)."""
-        (Nt, d), (Nv, _) = lay["shapes"][0], lay["shapes"][1]
-        B = lay["W"] * lay["b"]
-        if self.bank_frozen or d % 256 or d > 1024 or Nt > 64 or Nv > 64:
+        pre = None if self.bank_frozen else self._absorb_ready(lay)
+        if pre is None:
             return False
-        mb = self._mb
-        if tuple(mb["mb_feat_t"].shape[1:]) != (Nt, d) or tuple(mb["mb_feat_v"].shape[1:]) != (Nv, d) or mb["mb_ind"].dtype != torch.int64:
-            return False
-        if any(mb[k].dtype != torch.float32 for k in ("mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v")):
-            return False
-        ring = self._ring_ready(B)
-        if ring is None:
-            return False
-        shadow = self._bank_shadow()                       # (built before the first push, like the owner's step does)
-        if shadow is not None and (shadow[0].lo is None or shadow[1].lo is None):
-            return False
-        ops.bank_absorb_gathered(recv, lay, mb, shadow, ring[0], ring[2], self._rng_state_on(recv.device))
+        ring, shadow = pre
+        ops.bank_absorb_gathered(recv, lay, self._mb, shadow, ring[0], ring[2], self._rng_state_on(recv.device))
         self._last_prepared = {}
         return True
+
+    # ------------------------------------------------------------------ overlapped owned step (interleave_overlap)
+    def owned_loss_stream(self, device):
+        """The stream the loss half of an overlapped owned step runs on (one per model; never part of a capture's fork set:
+        the loss half is captured as a graph of its own and REPLAYED on this stream)."""
+        st = self.__dict__.get("_owned_stream")
+        if st is None or st.device != torch.device(device):
+            st = self.__dict__["_owned_stream"] = torch.cuda.Stream(device=device, priority=-1 if os.environ.get("NR_OVL_SIDE_PRIO") == "1" else 0)
+        return st
+
+    def _owned_prepare(self, recv, lay, slot_index=None):
+        """Exchange half of an overlapped owned step, behind the all-gather, on the current stream: the gathered batch unpacked
+        into a slot, the bank as the loss must see it copied into the slot (OwnedSlot.take), then the batch pushed into the
+        live bank exactly as the ranks that do not own the step push it.  The slots take turns (`owned_slots`; slot_index
+        names one: a captured graph is tied to its slot).  -> the slot, or None when the bank cannot absorb (the caller then
+        runs the serial owned step)."""
+        pre = self._absorb_ready(lay)
+        if pre is None or pre[1] is None:
+            return None
+        ring, shadow = pre
+        dev = recv.device
+        rng = self._rng_state_on(dev)
+        masks = (self._mb["mb_mask_t"], self._mb["mb_mask_v"])
+        copy_lo = head.precision_plan(self._prec())[2] == hip.PREC_BF16X3
+        capturing = torch.cuda.is_current_stream_capturing()
+        slots = self._owned_ring
+        if (len(slots) != max(1, int(self.owned_slots)) or slots[0].rng.device != dev
+                or not all(s_.fits(lay, shadow, masks, copy_lo) for s_ in slots)):
+            if capturing:
+                raise RuntimeError("overlapped owned step: run one eager step before the capture (the slots' buffers must not live "
+                                   "in a graph's memory pool)")
+            slots = self._owned_ring = [OwnedSlot(lay, shadow, masks, rng, copy_lo) for _ in range(max(1, int(self.owned_slots)))]
+        if slot_index is None:
+            slot_index, self._owned_turn = self._owned_turn % len(slots), self._owned_turn + 1
+        slot = self._owned = slots[slot_index % len(slots)]
+        if slot.loss_done is not None and not capturing:
+            torch.cuda.current_stream().wait_event(slot.loss_done)     # the previous loss on this slot has read it
+        ops.unpack_gathered(recv, lay["W"], lay["record"], lay["sizes"], lay["offs"], slot.batch, [False, False, False, True, True])
+        slot.take(shadow, masks, rng)
+        if self.bank_frozen:
+            tf, vf, ix, tm, vm = slot.batch
+            self.bank_only_step(tf, vf, tm, vm, ix)        # frozen: only the noise counter moves, as in every other form
+        else:
+            ops.bank_absorb_gathered(recv, lay, self._mb, shadow, ring[0], ring[2], rng)
+            self._last_prepared = {}
+        return slot
+
+    def owned_exchange(self, text_feat, text_mask, video_feat, video_mask, idx, slot_index=None):
+        """The exchange half of an overlapped owned step as a call of its own (what bench.py captures as one graph or as
+        segmented graphs): packed all-gather -> _owned_prepare.  -> the slot; raises when the bank cannot absorb."""
+        from . import comm
+        from .dist import packed_gather_raw
+        comm.begin_step()
+        self._step_index += 1
+        with torch.no_grad():
+            recv, lay = packed_gather_raw(text_feat, video_feat, idx, text_mask.view(-1, text_mask.shape[-1]),
+                                          video_mask.view(-1, video_mask.shape[-1]), self.config)
+            slot = self._owned_prepare(recv, lay, slot_index)
+        if slot is None:
+            raise RuntimeError("overlapped owned step: the memory bank cannot absorb a gathered batch (not a device ring of fp32 "
+                               "tensors larger than the batch, or no prepared shadow)")
+        return slot
+
+    def owned_loss(self, slot=None):
+        """The loss half: loss_step on the slot's batch against the slot's copy of the bank -- bank frozen (the batch has been
+        pushed by the exchange half), the noise drawn from the slot's copy of the counter -- on the current stream."""
+        slot = self._owned if slot is None else slot
+        live = self._mb
+        keep = (self._mb, self._mb_shadow, self._rng_state, self.bank_frozen, self._last_prepared)
+        self._mb = {"mb_ind": live["mb_ind"], "mb_feat_t": live["mb_feat_t"], "mb_feat_v": live["mb_feat_v"],     # (shapes only)
+                    "mb_mask_t": slot.masks[0], "mb_mask_v": slot.masks[1]}
+        self._mb_shadow, self._rng_state, self.bank_frozen, self._last_prepared = slot.shadow, slot.rng, True, slot.scratch
+        try:
+            tf, vf, ix, tm, vm = slot.batch
+            with torch.no_grad():
+                slot.losses = self.loss_step(tf, vf, tm, vm, ix)
+        finally:
+            self._mb, self._mb_shadow, self._rng_state, self.bank_frozen, self._last_prepared = keep
+            slot.scratch.clear()
+        return slot.losses
+
+    def _owned_loss_beside(self, slot):
+        cur = torch.cuda.current_stream()
+        if torch.cuda.is_current_stream_capturing():
+            return self.owned_loss(slot)               # one capture for the whole step: the halves stay in a row
+        side = self.owned_loss_stream(slot.rng.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            losses = self.owned_loss(slot)
+            slot.loss_done = torch.cuda.Event()
+            slot.loss_done.record(side)
+        return losses
+
+    def wait_owned_loss(self):
+        """Orders the current stream behind the loss half of the last overlapped owned step (no host synchronisation)."""
+        slot = self._owned
+        if slot is not None and slot.loss_done is not None:
+            torch.cuda.current_stream().wait_event(slot.loss_done)
 
     def bank_only_step(self, text_feat, video_feat, text_mask, video_mask, idx):
         """A step this rank does not own (interleave_steps): everything of loss_step that outlives the step -- the ring head and

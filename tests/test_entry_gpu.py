@@ -196,6 +196,24 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert d["ms_per_step"] - d["exchange_step_ms"] < 1.5, (d["ms_per_step"], d["exchange_step_ms"])
 
 
+def test_bench_overlapped_owned_step_on_two_ranks():
+    """`--overlap` (the default from 6 ranks on): the owner of a step copies the bank's prepared shadow, pushes the gathered batch
+    at once and evaluates its loss from the copy on a second stream, as a graph of its own, beside the following steps'
+    exchange-and-push graphs (neighborretr_amd.interleave).  bench.py holds the replayed pair against the eager step on every
+    rank before it times it (collective verdict); the parity gate and finite losses here."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline", "--overlap"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["step_form"] == "segmented" and d["config"]["graph_segments"] == 2, d["config"]
+    assert d["config"]["owner_loss"].startswith("beside the following steps"), d["config"]
+    assert "differs from the eager one" not in r.stderr, r.stderr[-2000:]
+    assert d["parity"]["pass"] and all(x == x and abs(x) < 1e4 for x in d["losses"])
+
+
 def test_bench_sync_sharded_step_segmented_on_two_ranks():
     """`--sync_step`: the synchronous sharded step (five collectives per step) on two gloo ranks: the six rank-local segments
     replayed as HIP graphs, validated against the eager step inside bench.py before they are timed."""

@@ -31,6 +31,8 @@ def test_emulated_ranks_match_the_replicated_step_and_replay_as_graphs():
     # the step-interleaved job: the owner's losses are the single-rank step's, bit for bit; a non-owned step is three launches
     assert len(re.findall(r"step-interleaved: the owner's losses == the single-rank step bit for bit \(max \|dL\| 0.0e\+00\)", r.stdout)) == 2
     assert len(re.findall(r"any OTHER step  \(exchange \+ push\) +: +2 C-ABI calls", r.stdout)) == 2, r.stdout
+    # ... and with the owner's loss beside the following steps (modeling.OwnedSlot, interleave.OverlappedOwnedStep): the same bits
+    assert len(re.findall(r"owner's loss BESIDE the following steps .*max \|dL\| 0.0e\+00\)", r.stdout)) == 2, r.stdout
     # RCCL-only branches on the 1-rank communicator: the evaluator's fp32 / int32 collectives, and the sharded TRAINING step's
     # reduce-scatters (tools/rank_local_times.py raises if any emulated rank's ranks / losses / gradients are off)
     assert "sharded evaluation, W=4 emulated ranks" in r.stdout and "== the single-rank ones" in r.stdout

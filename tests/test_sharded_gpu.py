@@ -208,7 +208,7 @@ def test_slab_row_losses_on_hip_match_the_torch_restatement():
         assert err < 2e-4 * scale + 1e-9, (name, err, scale)
 
 
-def _interleaved_worker(rank, world, port, out_path):
+def _interleaved_worker(rank, world, port, out_path, overlap=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from neighborretr_amd import modeling, synth
@@ -241,6 +241,7 @@ def _interleaved_worker(rank, world, port, out_path):
     m = build()
     m.config.world_size, m.config.local_rank = world, rank
     m.interleave_steps = True
+    m.interleave_overlap = overlap          # the owner's loss on a second stream, from a copy of the bank, beside the next steps
     sl = slice(rank * b, (rank + 1) * b)
     mine = {}
     with torch.no_grad():
@@ -249,7 +250,10 @@ def _interleaved_worker(rank, world, port, out_path):
                     p["video_mask"][sl].contiguous(), p["idx"][sl].contiguous(), 0)
             assert (out is not None) == (s % world == rank)
             if out is not None:
-                mine[s] = torch.stack(out).cpu()
+                mine[s] = out                           # (overlapped: still being computed -- read after the loop)
+        m.wait_owned_loss()
+        mine = {s: torch.stack(out).cpu() for s, out in mine.items()}
+    assert (m._owned is not None) == overlap
     # the prepared shadow of the bank (normalised bf16 pairs + norms) is kept in step with the ring on BOTH kinds of step
     sh, sh1 = m._mb_shadow, m1._mb_shadow
     had_shadow = sh is not None and sh1 is not None
@@ -262,15 +266,18 @@ def _interleaved_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_step_interleaved_job_equals_the_single_rank_run_bit_for_bit(tmp_path):
+@pytest.mark.parametrize("overlap", [False, True], ids=["loss-in-front", "loss-beside"])
+def test_step_interleaved_job_equals_the_single_rank_run_bit_for_bit(tmp_path, overlap):
     """model.interleave_steps on two ranks (gloo, one card): every step is gathered and pushed on both ranks, its loss evaluated
     on rank (step mod 2).  The losses of every step and the memory bank after the last one are those of the single-rank run on
     the same stream of batches -- identical bits: same kernels, same ring, same noise stream (the reference's semantics:
-    modeling.py:274-312, every step sees the bank left by the steps before it)."""
+    modeling.py:274-312, every step sees the bank left by the steps before it).  overlap: model.interleave_overlap -- the owner
+    copies the bank's prepared shadow, pushes the batch at once and evaluates its loss from the copy on a second stream while
+    the following steps' exchanges and pushes already run (modeling.OwnedSlot); the same bits again."""
     import torch.multiprocessing as mp
-    world, port = 2, 29641
+    world, port = 2, 29641 + int(overlap)
     out = str(tmp_path / "res")
-    mp.spawn(_interleaved_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_interleaved_worker, args=(world, port, out, overlap), nprocs=world, join=True)
     res = [torch.load(f"{out}.{r}") for r in range(world)]
     steps = len(res[0]["ref"])
     for s in range(steps):

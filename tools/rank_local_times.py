@@ -298,6 +298,76 @@ def measure_interleaved(model, full, W, rank, dev, lines):
             out["round_graph_us"] = replay_time(g_round.replay, reps=60)
             del g_round
         out["round_graph_steps_per_s"] = W / out["round_graph_us"] * 1e6
+        # the owner's loss BESIDE the following steps (model.interleave_overlap, neighborretr_amd.interleave): two graphs per owned
+        # step -- exchange + bank copy + push on this stream, the loss from the copy on the model's loss stream.  Checked first:
+        # frozen bank, rewound noise counter -> the replayed pair's losses == the settled owner's losses, bit for bit; and so
+        # are those of the eager form (forward() with interleave_overlap: the loss launched on the model's loss stream)
+        from neighborretr_amd.interleave import OverlappedOwnedStep
+        model.interleave_overlap = True
+        try:
+            s = rl.shards[rank]
+
+            def exchange_half(slot_index):
+                model._step_index = rank
+                return model.owned_exchange(s["text_feat"], s["text_mask"], s["video_feat"], s["video_mask"], s["idx"], slot_index=slot_index)
+
+            def other_step():
+                model._step_index = rank + 1
+                with torch.no_grad():
+                    model(s["text_feat"], s["text_mask"], s["video_feat"], s["video_mask"], s["idx"], 0)
+            with comm.use(c):
+                model.bank_frozen = True
+                try:
+                    own = OverlappedOwnedStep(model, exchange_half, lambda fn: capture(fn)[0])
+                    out["overlap_dL"] = 0.0
+                    for _ in range(2 * len(own.pairs)):                  # every slot's pair of graphs, twice
+                        model._rng_state.copy_(rl.rng0)
+                        own.replay()
+                        torch.cuda.synchronize()
+                        out["overlap_dL"] = max(out["overlap_dL"], float((own.losses - rl.losses[rank]).abs().max()))
+                    model._rng_state.copy_(rl.rng0)
+                    model._step_index = rank
+                    with torch.no_grad():
+                        ls = model(s["text_feat"], s["text_mask"], s["video_feat"], s["video_mask"], s["idx"], 0)
+                    torch.cuda.synchronize()
+                    out["overlap_eager_dL"] = float((torch.stack(list(ls)) - rl.losses[rank]).abs().max())
+                finally:
+                    model.bank_frozen = False
+                if not (out["overlap_dL"] == 0.0 and out["overlap_eager_dL"] == 0.0):
+                    raise AssertionError(f"overlapped owned step at W={W}: losses differ from the serial owner's ({out})")
+                del own
+                own = OverlappedOwnedStep(model, exchange_half, lambda fn: capture(fn)[0])
+                g_other, _ = capture(other_step)
+
+                # NOT on the default stream: replayed there, the exchange graphs and the loss graph take turns (723 us per round at
+                # W = 8 against 524 on a stream of the pool; the legacy default stream orders itself with the streams a graph
+                # launch uses inside the runtime)
+                xs = torch.cuda.Stream()
+                xs.wait_stream(torch.cuda.current_stream())
+
+                def one_round_overlapped():
+                    with torch.cuda.stream(xs):
+                        own.replay()
+                        for _ in range(W - 1):
+                            g_other.replay()
+                for _ in range(5):
+                    one_round_overlapped()
+                ts = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(60):
+                        one_round_overlapped()
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t0) / 60 * 1e6)
+                out["overlap_us_per_round"] = float(np.median(ts))
+                out["overlap_steps_per_s"] = W / out["overlap_us_per_round"] * 1e6
+                # the two halves alone: exchange (pack, all-gather, unpack into the slot, bank copy, absorb) and loss
+                out["owned_exchange_us"] = replay_time(own.A.replay)
+                out["owned_loss_us"] = replay_time(own.pairs[0][1].replay)
+                del own, g_other
+        finally:
+            model.interleave_overlap = False
         for key, k in (("graph", 0), ("segmented", 1)):
             per_round = times[True][k] + (W - 1) * times[False][k]
             out[key + "_us_per_round"] = per_round
@@ -315,6 +385,10 @@ def measure_interleaved(model, full, W, rank, dev, lines):
     lines.append(f"    W={W} consecutive steps cost a rank {out['graph_us_per_round']:7.1f} us  ->  {out['graph_steps_per_s']:8.0f} steps/s for the job "
                  f"(segmented form: {out['segmented_us_per_round']:7.1f} us -> {out['segmented_steps_per_s']:8.0f} steps/s); no wire time in these")
     lines.append(f"    the round as ONE graph ({W} steps per replay): {out['round_graph_us']:7.1f} us  ->  {out['round_graph_steps_per_s']:8.0f} steps/s")
+    lines.append(f"    owner's loss BESIDE the following steps (two graphs per owned step; replayed pair and eager form == the serial owner's losses, "
+                 f"max |dL| {max(out['overlap_dL'], out['overlap_eager_dL']):.1e}): exchange half {out['owned_exchange_us']:6.1f} us, loss half "
+                 f"{out['owned_loss_us']:6.1f} us alone; "
+                 f"W={W} consecutive steps cost a rank {out['overlap_us_per_round']:7.1f} us  ->  {out['overlap_steps_per_s']:8.0f} steps/s for the job")
     return out
 
 
@@ -480,6 +554,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--train", action="store_true", help="also the sharded TRAINING step (forward + backward) per world size")
     ap.add_argument("--only_train", action="store_true")
+    ap.add_argument("--only_interleaved", action="store_true", help="skip the synchronous sharded step's section")
     ap.add_argument("--eval", action="store_true", help="also check the sharded evaluation's collectives under the emulated world")
     args = ap.parse_args()
     CFG.update(B=args.B, M=args.M, K=args.K)
@@ -497,9 +572,10 @@ def main():
             model(full["text_feat"], full["text_mask"], full["video_feat"], full["video_mask"], full["idx"], 0)
     lines.append(f"W=1 b={CFG['B']}  the replicated step as one graph: {replay_time(capture(one)[0].replay):7.1f} us")
     if not args.only_train:
-        lines.append("---- SYNCHRONOUS sharded step (every rank takes part in every step's loss; five collectives per step) ----")
-        for W in args.worlds:
-            measure(model, full, W, min(args.rank, W - 1), dev, lines)
+        if not args.only_interleaved:
+            lines.append("---- SYNCHRONOUS sharded step (every rank takes part in every step's loss; five collectives per step) ----")
+            for W in args.worlds:
+                measure(model, full, W, min(args.rank, W - 1), dev, lines)
         lines.append("---- STEP-INTERLEAVED (one collective per step; the loss of step k on rank k mod W) ----")
         for W in args.worlds:
             measure_interleaved(model, full, W, min(args.rank, W - 1), dev, lines)
