@@ -25,8 +25,8 @@ extern "C" {
 #endif
 
 /* bumped whenever a signature or the layout of a descriptor struct changes (2: NrCtmStageDesc gained x_hi/x_lo/out_hi/out_lo in
- * round 3, nr_stream_create / nr_stream_destroy, NrBankAbsorbDesc in round 4); a binding compares nr_version() with the value it was written for */
-#define NR_ABI_VERSION 2
+ * round 3, nr_stream_create / nr_stream_destroy, NrBankAbsorbDesc in round 4; 3: nr_pack_shard_convert); a binding compares nr_version() with the value it was written for */
+#define NR_ABI_VERSION 3
 
 /* precision of the MFMA contractions */
 #define NR_PREC_BF16 0   /* one bf16 pass (training path)                                   */
@@ -606,6 +606,12 @@ int nr_centrality_weights_bwd(const float* g, const float* gnorm, const float* m
  * (dst_k[w*bytes_k + i] = rec_w[offset_k + i]); where u8_to_f32[k] != 0 the piece is bytes_k uint8 values per
  * rank written as fp32 (the masks become the multipliers the kernels read).  One launch each.        */
 int nr_pack_shard(int n, const void* const* srcs, const size_t* bytes, const size_t* offsets, void* packed, void* stream);
+/* nr_pack_shard with the masks' dtype conversion folded in (the reference gathers its int64 masks as they are,
+ * modeling.py:277-278; this build's record carries them as u8): kinds[k] = 0 raw bytes, 1 = int64 elements -> u8,
+ * 2 = fp32 elements -> u8 (C truncation, as torch's .to(uint8)); for a converted piece bytes[k] is its ELEMENT count (= the
+ * bytes it takes in the record).  kinds == NULL: all raw.  One launch instead of two element-wise ones and the pack. */
+int nr_pack_shard_convert(int n, const void* const* srcs, const size_t* bytes, const size_t* offsets, const int* kinds,
+                          void* packed, void* stream);
 int nr_unpack_gathered(int n, const void* gathered, int world, size_t record_bytes, const size_t* bytes,
                        const size_t* offsets, void* const* dsts, const int* u8_to_f32, void* stream);
 /* The whole exchange step in one call (SURVEY.md 8b minimum set): nr_pack_shard into `packed` [record_bytes], ONE RCCL

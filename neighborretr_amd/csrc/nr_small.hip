@@ -547,7 +547,7 @@ struct NrPackArgs {
     const char* src[8];
     char* dst[8];
     unsigned long long bytes[8], off[8];     // per piece: size per rank, offset inside a rank's packed record
-    int convert[8];                          // unpack only: 1 = u8 -> f32
+    int convert[8];                          // unpack: 1 = u8 -> f32;  pack: 1 = i64 -> u8, 2 = f32 -> u8 (the masks, as .to(uint8))
     int n, W;
     unsigned long long stride;               // packed record size
 };
@@ -558,6 +558,13 @@ __global__ __launch_bounds__(256) void nr_pack_kernel(NrPackArgs a, char* __rest
     const unsigned long long nb = a.bytes[k];
     const char* s = a.src[k];
     char* d = out + a.off[k];
+    if (a.convert[k]) {                       // a mask of nb elements: int64 / fp32 -> the u8 the record carries
+        const long long* s64 = reinterpret_cast<const long long*>(s);
+        const float* s32 = reinterpret_cast<const float*>(s);
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (unsigned long long)gridDim.x * 256)
+            d[i] = (char)(unsigned char)(a.convert[k] == 1 ? s64[i] : (long long)s32[i]);
+        return;
+    }
     const bool vec = ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d) | nb) & 15) == 0;
     if (vec) {
         for (unsigned long long i = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16; i < nb; i += (unsigned long long)gridDim.x * 4096)
@@ -588,16 +595,19 @@ __global__ __launch_bounds__(256) void nr_unpack_kernel(NrPackArgs a, const char
     }
 }
 
-extern "C" int nr_pack_shard(int n, const void* const* srcs, const size_t* bytes, const size_t* offsets, void* packed, void* stream) {
+extern "C" int nr_pack_shard_convert(int n, const void* const* srcs, const size_t* bytes, const size_t* offsets, const int* kinds,
+                                     void* packed, void* stream) {
     if (n <= 0 || n > 8 || !srcs || !bytes || !offsets || !packed) return NR_EINVAL;
     NrPackArgs a{};
     a.n = n;
     size_t mx = 0;
     for (int k = 0; k < n; ++k) {
         if (!srcs[k]) return NR_EINVAL;
+        if (kinds && (kinds[k] < 0 || kinds[k] > 2)) return NR_EINVAL;
         a.src[k] = static_cast<const char*>(srcs[k]);
         a.bytes[k] = bytes[k];
         a.off[k] = offsets[k];
+        a.convert[k] = kinds ? kinds[k] : 0;
         mx = bytes[k] > mx ? bytes[k] : mx;
     }
     unsigned gx = (unsigned)((mx + 4095) / 4096);
@@ -606,6 +616,10 @@ extern "C" int nr_pack_shard(int n, const void* const* srcs, const size_t* bytes
     hipLaunchKernelGGL(nr_pack_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a, static_cast<char*>(packed));
     NR_LAUNCH_CHECK();
     return NR_OK;
+}
+
+extern "C" int nr_pack_shard(int n, const void* const* srcs, const size_t* bytes, const size_t* offsets, void* packed, void* stream) {
+    return nr_pack_shard_convert(n, srcs, bytes, offsets, nullptr, packed, stream);
 }
 
 extern "C" int nr_unpack_gathered(int n, const void* gathered, int world, size_t record_bytes, const size_t* bytes,

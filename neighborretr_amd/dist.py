@@ -41,10 +41,15 @@ class PackedAllGather(torch.autograd.Function):
         tf = text_feat.detach().float().contiguous()
         vf = video_feat.detach().float().contiguous()
         ix = idx.to(torch.int64).contiguous()
-        tm = text_mask.to(torch.uint8).contiguous()
-        vm = video_mask.to(torch.uint8).contiguous()
+        kinds = [0, 0, 0, 0, 0]
+        if dev.type == "cuda":
+            from . import ops
+            (tm, kinds[3]), (vm, kinds[4]) = ops.mask_piece(text_mask), ops.mask_piece(video_mask)     # converted by the pack kernel
+        else:
+            tm = text_mask.to(torch.uint8).contiguous()
+            vm = video_mask.to(torch.uint8).contiguous()
         pieces = [tf, vf, ix, tm, vm]
-        sizes = [p.numel() * p.element_size() for p in pieces]
+        sizes = [p.numel() * (1 if k else p.element_size()) for p, k in zip(pieces, kinds)]
         offs = [sum(sizes[:k]) for k in range(5)]
         total = (sum(sizes) + 15) // 16 * 16
         send = torch.empty(total, dtype=torch.uint8, device=dev)
@@ -52,8 +57,7 @@ class PackedAllGather(torch.autograd.Function):
         if dev.type == "cuda":
             # one launch packs, one collective moves, one launch unpacks -- straight into `out` when the caller
             # supplied static destinations (a captured graph reads them), the masks already as fp32 multipliers
-            from . import ops
-            ops.pack_shard(pieces, send, offs)
+            ops.pack_shard(pieces, send, offs, kinds)
             comm.all_gather_into_tensor(recv, send)
             out = getattr(args, "_gather_out", None)
             if out is None:
@@ -112,14 +116,15 @@ def packed_gather_raw(text_feat, video_feat, idx, text_mask, video_mask, args):
     from . import ops
     W = _world(args)
     dev = text_feat.device
-    pieces = [text_feat.detach().float().contiguous(), video_feat.detach().float().contiguous(), idx.to(torch.int64).contiguous(),
-              text_mask.to(torch.uint8).contiguous(), video_mask.to(torch.uint8).contiguous()]
-    sizes = [p.numel() * p.element_size() for p in pieces]
+    (tm, k_t), (vm, k_v) = ops.mask_piece(text_mask), ops.mask_piece(video_mask)        # int64 / fp32 masks: converted by the pack kernel
+    kinds = [0, 0, 0, k_t, k_v]
+    pieces = [text_feat.detach().float().contiguous(), video_feat.detach().float().contiguous(), idx.to(torch.int64).contiguous(), tm, vm]
+    sizes = [p.numel() * (1 if k else p.element_size()) for p, k in zip(pieces, kinds)]
     offs = [sum(sizes[:k]) for k in range(5)]
     total = (sum(sizes) + 15) // 16 * 16
     send = torch.empty(total, dtype=torch.uint8, device=dev)
     recv = torch.empty(W * total, dtype=torch.uint8, device=dev)
-    ops.pack_shard(pieces, send, offs)
+    ops.pack_shard(pieces, send, offs, kinds)
     comm.all_gather_into_tensor(recv, send)
     return recv, dict(W=W, b=text_feat.shape[0], record=total, sizes=sizes, offs=offs, shapes=[tuple(p.shape[1:]) for p in pieces])
 

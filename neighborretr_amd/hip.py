@@ -17,7 +17,7 @@ PREC_BF16 = 0
 PREC_BF16X3 = 1
 OUT_FULL, OUT_ROWSUM, OUT_COLSUM = 0, 1, 2
 NR_EINVAL, NR_EUNSUPPORTED = -1, -2          # status codes of include/nr_hip.h
-ABI_VERSION = 2                              # NR_ABI_VERSION this binding was written for (checked at load)
+ABI_VERSION = 3                              # NR_ABI_VERSION this binding was written for (checked at load)
 
 _lib = None
 
@@ -198,6 +198,7 @@ _SIGNATURES = {
     "nr_token_softmax_bwd": ([_P, _P, _I, _I, _P, _P], _I),
     "nr_centrality_weights_bwd": ([_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P], _I),
     "nr_pack_shard": ([_I, _P, _P, _P, _P, _P], _I),
+    "nr_pack_shard_convert": ([_I, _P, _P, _P, _P, _P, _P], _I),
     "nr_unpack_gathered": ([_I, _P, _I, _Z, _P, _P, _P, _P, _P], _I),
     "nr_allgather_packed": ([_P, _I, _I, _P, _P, _P, _Z, _P, _P, _P, _P, _P], _I),
     "nr_step_prologue": ([_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P], _I),

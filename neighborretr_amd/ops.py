@@ -631,16 +631,32 @@ def bank_push(bank, batch, scratch=None):
     return bank
 
 
-def pack_shard(tensors, packed, offsets):
-    """nr_pack_shard: the (contiguous GPU) tensors' bytes at `offsets` inside the uint8 buffer `packed`."""
+def mask_piece(mask):
+    """(tensor, kind) of a mask for pack_shard: int64 / fp32 masks are converted to the record's u8 by the pack kernel itself
+    (kind 1 / 2), u8 ones travel as they are; anything else is converted here."""
+    m = mask.contiguous()
+    if m.dtype == torch.int64:
+        return m, 1
+    if m.dtype == torch.float32:
+        return m, 2
+    return (m if m.dtype == torch.uint8 else m.to(torch.uint8)), 0
+
+
+def pack_shard(tensors, packed, offsets, kinds=None):
+    """nr_pack_shard(_convert): the (contiguous GPU) tensors' bytes at `offsets` inside the uint8 buffer `packed`; a piece of
+    kind 1 / 2 (mask_piece) is converted to u8 on the way and takes one byte per ELEMENT."""
     import ctypes
     n = len(tensors)
     for t in tensors:
         hip.ptr(t)
+    kinds = list(kinds) if kinds is not None else [0] * n
     srcs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
-    nbytes = (ctypes.c_size_t * n)(*[t.numel() * t.element_size() for t in tensors])
+    nbytes = (ctypes.c_size_t * n)(*[t.numel() * (1 if k else t.element_size()) for t, k in zip(tensors, kinds)])
     offs = (ctypes.c_size_t * n)(*offsets)
-    hip.call("nr_pack_shard", n, srcs, nbytes, offs, hip.ptr(packed, torch.uint8), hip.stream_ptr())
+    if any(kinds):
+        hip.call("nr_pack_shard_convert", n, srcs, nbytes, offs, (ctypes.c_int * n)(*kinds), hip.ptr(packed, torch.uint8), hip.stream_ptr())
+    else:
+        hip.call("nr_pack_shard", n, srcs, nbytes, offs, hip.ptr(packed, torch.uint8), hip.stream_ptr())
 
 
 def unpack_gathered(gathered, world, record_bytes, nbytes, offsets, outs, u8_to_f32):

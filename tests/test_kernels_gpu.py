@@ -24,7 +24,7 @@ def _tw(prep, mask, P, prefix, n, N, prec):
 
 
 def test_library_loads_and_version():
-    assert hip.version() == hip.ABI_VERSION == 2
+    assert hip.version() == hip.ABI_VERSION == 3
 
 
 @pytest.mark.parametrize("n,N,d", [(16, 24, 512), (5, 7, 256), (3, 64, 768)])
@@ -612,6 +612,16 @@ def test_pack_and_unpack_of_the_exchange_step():
     for k in range(5):
         ref = torch.cat([shards[r][k] for r in range(W)], 0)
         assert torch.equal(outs[k], ref.float() if k >= 3 else ref)
+    # nr_pack_shard_convert: int64 / fp32 masks (what the loaders / the model hand over) become the record's u8 inside the pack
+    # launch -- the same record, byte for byte, as packing masks converted with .to(uint8) beforehand
+    for mask_dtype in (torch.int64, torch.float32):
+        again = torch.zeros_like(recv)
+        for r in range(W):
+            pieces = shards[r][:3] + [m.to(mask_dtype) for m in shards[r][3:]]
+            kinds = [0, 0, 0] + [ops.mask_piece(m)[1] for m in pieces[3:]]
+            assert kinds[3:] == ([1, 1] if mask_dtype == torch.int64 else [2, 2])
+            ops.pack_shard(pieces, again[r * total:(r + 1) * total], offs, kinds)
+        assert torch.equal(again, recv)
 
 
 @pytest.mark.parametrize("B", [16, 128])
