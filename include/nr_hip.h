@@ -614,6 +614,11 @@ int nr_pack_shard_convert(int n, const void* const* srcs, const size_t* bytes, c
                           void* packed, void* stream);
 int nr_unpack_gathered(int n, const void* gathered, int world, size_t record_bytes, const size_t* bytes,
                        const size_t* offsets, void* const* dsts, const int* u8_to_f32, void* stream);
+/* n <= 12 device-to-device copies (srcs[k] -> dsts[k], bytes[k] each) in one launch.  No counterpart in the reference: the bank
+ * copy in front of an overlapped owned step of the step-interleaved job (the prepared shadow, masks and noise counter as the
+ * step's loss must see them: neighborretr_amd/modeling.py OwnedSlot). */
+int nr_copy_group(int n, const void* const* srcs, void* const* dsts, const size_t* bytes, void* stream);
+
 /* The whole exchange step in one call (SURVEY.md 8b minimum set): nr_pack_shard into `packed` [record_bytes], ONE RCCL
  * all-gather of record_bytes uint8 per rank over xGMI on the caller's communicator (`nccl_comm` = its ncclComm_t),
  * nr_unpack_gathered from `gathered` [world * record_bytes] into the rank-major outputs -- all on `stream`.  RCCL is
@@ -660,7 +665,8 @@ int nr_bank_ring_push(int n_tensors, void* const* banks, const void* const* batc
  *   the same rows PREPARED (normalised x mask as bf16 hi / lo + norms: nr_prepare_tokens' arithmetic, bit for bit) into
  *   shadow_* (hi / lo [capacity * N, d], norm [capacity * N]; all six NULL: no shadow kept);
  *   rng_state (optional): the noise stream's step counter advances by one, as a step's nr_step_prologue advances it.
- * counter: a zeroed device word, zero again when the launch ends.  world * per_rank < capacity; d % 256 == 0, d <= 1024. */
+ * counter: nr_bank_absorb_counter_words() zeroed device words (a two-level ticket: one word per group of workgroups, 64 B
+ *   apart, and the launch's own), all zero again when the launch ends.  world * per_rank < capacity; d % 256 == 0, d <= 1024. */
 typedef struct NrBankAbsorbDesc {
     const void* gathered;
     uint64_t record_bytes, off_text, off_video, off_index, off_text_mask, off_video_mask;
@@ -673,6 +679,7 @@ typedef struct NrBankAbsorbDesc {
     uint64_t* rng_state;
     uint32_t* counter;
 } NrBankAbsorbDesc;
+int nr_bank_absorb_counter_words(void);
 int nr_bank_absorb_gathered(const NrBankAbsorbDesc* desc, void* stream);
 
 /* Rank of the diagonal in every row under the reference's tie rule (metrics.py:58-66):

@@ -173,6 +173,9 @@ extern "C" int nr_split_bf16(const float* x, size_t n, uint16_t* hi, uint16_t* l
 // follow, and the noise stream's counter advances by one step -- nr_unpack_gathered + nr_step_prologue + nr_prepare_tokens_pair
 // + nr_bank_ring_push of the eager path.  The new head is published by the LAST workgroup (every workgroup has read the old
 // one by then); `counter` is a zeroed word the launch leaves zeroed.
+#define NR_ABSORB_GROUP 32
+extern "C" int nr_bank_absorb_counter_words(void) { return 16 * (1 + (NR_PREP_MAX_GRID + NR_ABSORB_GROUP - 1) / NR_ABSORB_GROUP); }
+
 template <int CH>
 __global__ __launch_bounds__(256) void nr_bank_absorb_kernel(NrBankAbsorbDesc a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -233,12 +236,20 @@ __global__ __launch_bounds__(256) void nr_bank_absorb_kernel(NrBankAbsorbDesc a)
         }
     }
     __syncthreads();
+    // Two-level ticket: a thousand device-scope adds to ONE word queue up at the memory side (the launch took 18.5 us, 10 of them
+    // this queue); workgroups add to the word of their group of NR_ABSORB_GROUP (words 64 B apart), the last of a group to the
+    // launch's word.  counter[0]: groups done; counter[16 * (1 + g)]: workgroups of group g done.  All zero again on exit.
     if (threadIdx.x == 0) {
-        const unsigned int ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == gridDim.x - 1) {
-            __hip_atomic_store(a.ring_head, nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.rng_state) a.rng_state[1] += 1ull;
-            __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int g = blockIdx.x / NR_ABSORB_GROUP, n_groups = (gridDim.x + NR_ABSORB_GROUP - 1) / NR_ABSORB_GROUP;
+        const unsigned int in_group = min((unsigned int)NR_ABSORB_GROUP, gridDim.x - g * NR_ABSORB_GROUP);
+        unsigned int* gw = a.counter + 16 * (1 + g);
+        if (__hip_atomic_fetch_add(gw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1) {
+            __hip_atomic_store(gw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1) {
+                __hip_atomic_store(a.ring_head, nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.rng_state) a.rng_state[1] += 1ull;
+                __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }

@@ -646,6 +646,49 @@ extern "C" int nr_unpack_gathered(int n, const void* gathered, int world, size_t
     return NR_OK;
 }
 
+// ---- several device-to-device copies in ONE launch (the bank copy of an overlapped owned step: modeling.OwnedSlot.take) -----------
+struct NrCopyGroupArgs {
+    const char* src[12];
+    char* dst[12];
+    unsigned long long bytes[12];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void nr_copy_group_kernel(NrCopyGroupArgs a) {
+    const int k = blockIdx.y;
+    if (k >= a.n) return;
+    const unsigned long long nb = a.bytes[k];
+    const char* s = a.src[k];
+    char* d = a.dst[k];
+    const bool vec = ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d) | nb) & 15) == 0;
+    if (vec) {
+        for (unsigned long long i = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16; i < nb; i += (unsigned long long)gridDim.x * 4096)
+            *reinterpret_cast<uint4*>(d + i) = *reinterpret_cast<const uint4*>(s + i);
+    } else {
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (unsigned long long)gridDim.x * 256) d[i] = s[i];
+    }
+}
+
+extern "C" int nr_copy_group(int n, const void* const* srcs, void* const* dsts, const size_t* bytes, void* stream) {
+    if (n <= 0 || n > 12 || !srcs || !dsts || !bytes) return NR_EINVAL;
+    NrCopyGroupArgs a{};
+    a.n = n;
+    size_t mx = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!srcs[k] || !dsts[k]) return NR_EINVAL;
+        a.src[k] = static_cast<const char*>(srcs[k]);
+        a.dst[k] = static_cast<char*>(dsts[k]);
+        a.bytes[k] = bytes[k];
+        mx = bytes[k] > mx ? bytes[k] : mx;
+    }
+    unsigned gx = (unsigned)((mx + 16383) / 16384);          // four 16-byte pieces per thread of the largest copy
+    if (gx < 1) gx = 1;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(nr_copy_group_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
 // ---- the whole exchange step behind the C ABI: pack -> ONE RCCL all-gather over xGMI -> unpack --------------------------
 // (reference: 5 x all_gather + barrier per step, modeling.py:274-280 via until_module.py:367-388).  RCCL is resolved at
 // run time -- the copy the caller's framework has already loaded (PyTorch-ROCm ships its own librccl.so.1), else the

@@ -199,12 +199,14 @@ _SIGNATURES = {
     "nr_centrality_weights_bwd": ([_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P], _I),
     "nr_pack_shard": ([_I, _P, _P, _P, _P, _P], _I),
     "nr_pack_shard_convert": ([_I, _P, _P, _P, _P, _P, _P], _I),
+    "nr_copy_group": ([_I, _P, _P, _P, _P], _I),
     "nr_unpack_gathered": ([_I, _P, _I, _Z, _P, _P, _P, _P, _P], _I),
     "nr_allgather_packed": ([_P, _I, _I, _P, _P, _P, _Z, _P, _P, _P, _P, _P], _I),
     "nr_step_prologue": ([_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P], _I),
     "nr_bank_push": ([_P, _P, _I, _I, _Z, _P, _P], _I),
     "nr_bank_ring_push": ([_I, _P, _P, _P, _I, _I, _P, _I, _P], _I),
     "nr_bank_absorb_gathered": ([ctypes.POINTER(BankAbsorbDesc), _P], _I),
+    "nr_bank_absorb_counter_words": ([], _I),
     "nr_diag_ranks": ([_P, _I, _P, _P, _P], _I),
     "nr_slab_ranks": ([_P, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),
     "nr_group_slab_ranks": ([_P, _I, _I, _I, _P, _I, _P, _P, _P, _P], _I),

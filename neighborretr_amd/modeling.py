@@ -109,7 +109,7 @@ class OwnedSlot:
     def take(self, shadow, masks, rng):
         """The bank's prepared shadow, its masks and the noise counter -> this slot (device copies on the current stream)."""
         dst, src = self._pairs(shadow, masks, rng)
-        torch._foreach_copy_(dst, src)
+        ops.copy_group(dst, src)                  # one launch (nr_copy_group); torch._foreach_copy_ issues one copy kernel per tensor here
 
 
 class NeighborRetr(nn.Module):

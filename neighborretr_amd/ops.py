@@ -659,6 +659,19 @@ def pack_shard(tensors, packed, offsets, kinds=None):
         hip.call("nr_pack_shard", n, srcs, nbytes, offs, hip.ptr(packed, torch.uint8), hip.stream_ptr())
 
 
+def copy_group(dsts, srcs):
+    """nr_copy_group: dsts[k] <- srcs[k] (contiguous GPU tensors of equal size and dtype, at most 12) in one launch."""
+    import ctypes
+    n = len(dsts)
+    for d_, s_ in zip(dsts, srcs):
+        hip.ptr(d_)
+        hip.ptr(s_)
+        if d_.dtype != s_.dtype or d_.numel() != s_.numel():
+            raise ValueError("copy_group: source and destination differ in size or dtype")
+    hip.call("nr_copy_group", n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs]), (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts]),
+             (ctypes.c_size_t * n)(*[t.numel() * t.element_size() for t in srcs]), hip.stream_ptr())
+
+
 def unpack_gathered(gathered, world, record_bytes, nbytes, offsets, outs, u8_to_f32):
     """nr_unpack_gathered: [world, record_bytes] uint8 -> the rank-major output tensors `outs`."""
     import ctypes
@@ -677,8 +690,8 @@ def bank_absorb_gathered(recv, lay, bank, shadow, ring_head, capacity, rng_state
     dev = recv.device
     key = ("absorb", dev)
     counter = _COUNTERS.get(key)
-    if counter is None:
-        counter = _COUNTERS[key] = torch.zeros((1,), dtype=torch.int32, device=dev)
+    if counter is None:                 # the launch's two-level ticket: nr_bank_absorb_counter_words() zeroed words, left zeroed
+        counter = _COUNTERS[key] = torch.zeros((hip.lib().nr_bank_absorb_counter_words(),), dtype=torch.int32, device=dev)
     a = hip.BankAbsorbDesc()
     a.gathered = hip.ptr(recv, torch.uint8)
     a.record_bytes = lay["record"]

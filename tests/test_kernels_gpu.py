@@ -624,6 +624,19 @@ def test_pack_and_unpack_of_the_exchange_step():
         assert torch.equal(again, recv)
 
 
+def test_copy_group_copies_every_piece():
+    """nr_copy_group: several tensors of different dtypes and sizes (16-byte multiples and odd byte counts) in one launch."""
+    g = torch.Generator().manual_seed(9)
+    srcs = [torch.randint(-30000, 30000, (512 * 24, 512), generator=g, dtype=torch.int16).to(DEV), torch.randn(6144, generator=g).to(DEV),
+            torch.randn(7, 3, generator=g).to(DEV), torch.tensor([5, 77], dtype=torch.int64, device=DEV),
+            torch.randint(0, 255, (13,), generator=g, dtype=torch.uint8).to(DEV)]
+    dsts = [torch.zeros_like(t) for t in srcs]
+    ops.copy_group(dsts, srcs)
+    assert all(torch.equal(a, b) for a, b in zip(dsts, srcs))
+    with pytest.raises(ValueError):
+        ops.copy_group([torch.zeros(3, device=DEV)], [torch.zeros(4, device=DEV)])
+
+
 @pytest.mark.parametrize("B", [16, 128])
 def test_split_tail_matches_the_single_launch(B):
     """Uniform-CE row terms from the Sinkhorn kernel + the other terms from nr_row_losses_fwd_no_uniform == the
