@@ -477,7 +477,7 @@ class NeighborRetr(nn.Module):
         the loss half is captured as a graph of its own and REPLAYED on this stream)."""
         st = self.__dict__.get("_owned_stream")
         if st is None or st.device != torch.device(device):
-            st = self.__dict__["_owned_stream"] = torch.cuda.Stream(device=device, priority=-1 if os.environ.get("NR_OVL_SIDE_PRIO") == "1" else 0)
+            st = self.__dict__["_owned_stream"] = torch.cuda.Stream(device=device)
         return st
 
     def _owned_prepare(self, recv, lay, slot_index=None):
