@@ -72,11 +72,17 @@ __device__ __forceinline__ float nr_lanes_sum(float v) {
 
 // One block of one product: the whole kernel body, callable from the single-product kernel and from the grouped one
 // (nr_sim_group_kernel, below).  `bid`: the block's index inside ITS product's tile grid.
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false>
+// RT > 1 (TPS = 16 only: the strip is in memory order): a wave strip of 16*MI rows holds RT texts one behind the other, text
+// rt in sub-tiles [rt*MI/RT, (rt+1)*MI/RT) -- twice the rows per wave for the same columns, i.e. the operand bytes per MFMA of
+// the 192 x 384 blocks at 64 x 64 tokens: 256 x 256 blocks = 4 texts x 4 videos on 2 x 4 waves of 128 x 64 (MI, NI = 8, 4).
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false, int RT = 1>
 __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int bid, char* smem) {
     using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES, WC>;
-    constexpr int Nt = MI * TPS, Nv = NI * FPS;
-    constexpr int TAW = 16 / TPS, TBW = 16 / FPS;     // texts / videos per wave
+    static_assert(MI % RT == 0 && (RT == 1 || TPS == 16), "texts stacked in a wave strip: whole sub-tiles each, strip in memory order");
+    constexpr int MIE = MI / RT;                      // sub-tiles per text
+    constexpr int Nt = MIE * TPS, Nv = NI * FPS;
+    constexpr int TXS = 16 / TPS;                     // texts side by side in a 16-row sub-tile
+    constexpr int TAW = RT * TXS, TBW = 16 / FPS;     // texts / videos per wave
     constexpr int TA = 2 * TAW, TB = WC * TBW;        // per workgroup
     constexpr int GX = TPS / 4;                       // lane groups (of 16) that share a text
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,16 +112,22 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
     const int g = lane >> 4, kap = lane & 15;
     const int al = g / GX, tau0 = 4 * (g % GX);       // text within the wave, first token of this lane's regs
     const int bl = kap / FPS, phi = kap % FPS;        // video within the wave, frame offset
-    const int ag = by * TA + wr * TAW + al;
+    int ag[RT], agc[RT];
+    bool ok[RT];
     const int bg = bx * TB + wc * TBW + bl;
-    const bool ok = ag < p.A && bg < p.Bv;
-    const int agc = min(ag, p.A - 1), bgc = min(bg, p.Bv - 1);
+    const int bgc = min(bg, p.Bv - 1);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        ag[rt] = by * TA + wr * TAW + rt * TXS + al;
+        ok[rt] = ag[rt] < p.A && bg < p.Bv;
+        agc[rt] = min(ag[rt], p.A - 1);
+    }
     // this lane's token weights: fetched before the main loop so their latency hides under it -- except in the
     // largest blocks, whose accumulators leave no registers to park them in: there the workgroup's TA*Nt + TB*Nv
     // weights are parked in the LDS behind the ring (LDS-DMA, 64 floats per instruction, issued ahead of the loop's
     // first slice and landed with it) and picked up after the loop -- a global load there would expose its whole
     // latency (~1.5 us of a 16 us launch) in front of the epilogue.
-    constexpr bool LATE_W = MI * NI >= 36;
+    constexpr bool LATE_W = MI * NI >= 32;
     float wt[MI][4], wv[NI];
     float* w_lds = reinterpret_cast<float*>(smem + Tile::RING_BYTES);
     constexpr int WT_N = TA * Nt, WV_N = TB * Nv;
@@ -124,7 +136,7 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
         if constexpr (LATE_W) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                f32x4_t q = *reinterpret_cast<const f32x4_t*>(w_lds + (wr * TAW + al) * Nt + TPS * i + tau0);
+                f32x4_t q = *reinterpret_cast<const f32x4_t*>(w_lds + (wr * TAW + (i / MIE) * TXS + al) * Nt + TPS * (i % MIE) + tau0);
                 wt[i][0] = q[0]; wt[i][1] = q[1]; wt[i][2] = q[2]; wt[i][3] = q[3];
             }
 #pragma unroll
@@ -132,7 +144,7 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
         } else {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                f32x4_t q = *reinterpret_cast<const f32x4_t*>(p.w_t + (size_t)agc * Nt + TPS * i + tau0);
+                f32x4_t q = *reinterpret_cast<const f32x4_t*>(p.w_t + (size_t)agc[i / MIE] * Nt + TPS * (i % MIE) + tau0);
                 wt[i][0] = q[0]; wt[i][1] = q[1]; wt[i][2] = q[2]; wt[i][3] = q[3];
             }
 #pragma unroll
@@ -161,7 +173,9 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
 #ifdef NR_STAMP
     if (blockIdx.x == 0 && threadIdx.x == 0) nr_stamp_buf[5] = __builtin_readcyclecounter() - t_start;
 #endif
-    float t2v = 0.f, v2t = 0.f;
+    float t2v[RT], v2t[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) t2v[rt] = v2t[rt] = 0.f;
     // The pooling epilogue (registers only: max-pools, weighted sums; in the ARGS form also the arg-max stores).  In the
     // ping-pong kernels the waves of group 0 (wave row 0) run it inside the K loop's last phase, beside group 1's final MFMAs.
     // (explicit fma in the weighted sums: S must not depend on how the compiler contracts them in one instantiation or
@@ -181,29 +195,35 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
 #pragma unroll
                 for (int n = 1; n < NI; ++n) m = fmaxf(m, tile.acc[i][n][j]);
                 m = nr_lanes_max<FPS>(m);
-                t2v = __builtin_fmaf(m, wt[i][j], t2v);
+                t2v[i / MIE] = __builtin_fmaf(m, wt[i][j], t2v[i / MIE]);
             }
-        if constexpr (GX >= 2) t2v += __shfl_xor(t2v, 16);
-        if constexpr (GX >= 4) t2v += __shfl_xor(t2v, 32);
 #pragma unroll
-        for (int n = 0; n < NI; ++n) {
-            float m = tile.acc[0][n][0];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) m = fmaxf(m, tile.acc[i][n][j]);
-            if constexpr (GX >= 2) m = fmaxf(m, __shfl_xor(m, 16));
-            if constexpr (GX >= 4) m = fmaxf(m, __shfl_xor(m, 32));
-            v2t = __builtin_fmaf(m, wv[n], v2t);
+        for (int rt = 0; rt < RT; ++rt) {
+            if constexpr (GX >= 2) t2v[rt] += __shfl_xor(t2v[rt], 16);
+            if constexpr (GX >= 4) t2v[rt] += __shfl_xor(t2v[rt], 32);
         }
-        v2t = nr_lanes_sum<FPS>(v2t);
+#pragma unroll
+        for (int n = 0; n < NI; ++n)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float m = tile.acc[rt * MIE][n][0];
+#pragma unroll
+                for (int i = rt * MIE; i < (rt + 1) * MIE; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m = fmaxf(m, tile.acc[i][n][j]);
+                if constexpr (GX >= 2) m = fmaxf(m, __shfl_xor(m, 16));
+                if constexpr (GX >= 4) m = fmaxf(m, __shfl_xor(m, 32));
+                v2t[rt] = __builtin_fmaf(m, wv[n], v2t[rt]);
+            }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) v2t[rt] = nr_lanes_sum<FPS>(v2t[rt]);
     } else {
     // ---- t2v: P[t] = max over the video's frames; sum_t w_t[t] * P[t] -------------------------------
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int t = TPS * i + tau0 + j;
+            const int t = TPS * (i % MIE) + tau0 + j;
             float m = tile.acc[i][0][j];
             int av = phi;
 #pragma unroll
@@ -213,32 +233,37 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
             }
             if constexpr (ARGS) {
                 nr_lanes_argmax<FPS>(m, av);
-                if (ok && phi == 0) {
-                    size_t o = ((size_t)ag * p.Bv + bg) * Nt + t;
+                if (ok[i / MIE] && phi == 0) {
+                    size_t o = ((size_t)ag[i / MIE] * p.Bv + bg) * Nt + t;
                     p.arg_v[o] = (uint8_t)av;
                     p.pmax[o] = m;
                 }
             } else {
                 m = nr_lanes_max<FPS>(m);
             }
-            t2v = __builtin_fmaf(m, wt[i][j], t2v);
+            t2v[i / MIE] = __builtin_fmaf(m, wt[i][j], t2v[i / MIE]);
         }
-    if constexpr (GX >= 2) t2v += __shfl_xor(t2v, 16);
-    if constexpr (GX >= 4) t2v += __shfl_xor(t2v, 32);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        if constexpr (GX >= 2) t2v[rt] += __shfl_xor(t2v[rt], 16);
+        if constexpr (GX >= 4) t2v[rt] += __shfl_xor(t2v[rt], 32);
+    }
 
     // ---- v2t: Q[v] = max over the text's tokens; sum_v w_v[v] * Q[v] --------------------------------
 #pragma unroll
-    for (int n = 0; n < NI; ++n) {
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
         const int v = FPS * n + phi;
-        float m = tile.acc[0][n][0];
+        float m = tile.acc[rt * MIE][n][0];
         int at = tau0;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = rt * MIE; i < (rt + 1) * MIE; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (i == 0 && j == 0) continue;
+                if (i == rt * MIE && j == 0) continue;
                 float x = tile.acc[i][n][j];
-                if (x > m) { m = x; at = TPS * i + tau0 + j; }
+                if (x > m) { m = x; at = TPS * (i - rt * MIE) + tau0 + j; }
             }
         if constexpr (GX >= 2) {
             float om = __shfl_xor(m, 16);
@@ -251,15 +276,16 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
             if (om > m || (om == m && oa < at)) { m = om; at = oa; }
         }
         if constexpr (ARGS) {
-            if (ok && (g % GX) == 0) {
-                size_t o = ((size_t)ag * p.Bv + bg) * Nv + v;
+            if (ok[rt] && (g % GX) == 0) {
+                size_t o = ((size_t)ag[rt] * p.Bv + bg) * Nv + v;
                 p.arg_t[o] = (uint8_t)at;
                 p.qmax[o] = m;
             }
         }
-        v2t = __builtin_fmaf(m, wv[n], v2t);
-    }
-    v2t = nr_lanes_sum<FPS>(v2t);
+        v2t[rt] = __builtin_fmaf(m, wv[n], v2t[rt]);
+      }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) v2t[rt] = nr_lanes_sum<FPS>(v2t[rt]);
 
     }
     };      // pool
@@ -273,18 +299,24 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
     if (blockIdx.x == 0 && threadIdx.x == 0) nr_stamp_buf[6] = __builtin_readcyclecounter() - t_start;
 #endif
 
-    const float S = 0.5f * (t2v + v2t);
+    float S[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) S[rt] = 0.5f * (t2v[rt] + v2t[rt]);
 #ifdef NR_STAMP
     if (blockIdx.x == 0 && threadIdx.x == 0) nr_stamp_buf[4] = __builtin_readcyclecounter() - t_start;
 #endif
     const bool writer = (phi == 0) && ((g % GX) == 0);
     if (p.out_mode == NR_OUT_FULL) {
-        if (writer && ok) p.out[(size_t)ag * p.Bv + bg] = S;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+            if (writer && ok[rt]) p.out[(size_t)ag[rt] * p.Bv + bg] = S[rt];
         return;
     }
     // ---- block-level row / column sums of S (fixed order => deterministic) ---------------------------
     float* sSP = reinterpret_cast<float*>(smem);       // the ring is free: run() ended with a barrier
-    if (writer) sSP[(wr * TAW + al) * TB + wc * TBW + bl] = ok ? S : 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+        if (writer) sSP[(wr * TAW + rt * TXS + al) * TB + wc * TBW + bl] = ok[rt] ? S[rt] : 0.f;
     __syncthreads();
     if (p.out_mode == NR_OUT_ROWSUM) {
         if (tid < TA) {
@@ -303,10 +335,10 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
     }
 }
 
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false>
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false, int RT = 1>
 __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    nr_sim_reg_body<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC, PP>(p, blockIdx.x, smem);
+    nr_sim_reg_body<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC, PP, RT>(p, blockIdx.x, smem);
 }
 
 // ---- two chained tiles per workgroup (the step's two bank products) ---------------------------------------------------
@@ -472,12 +504,12 @@ __global__ __launch_bounds__(512) void nr_sim_group_kernel(NrSimGroup g) {
     else nr_sim_reg_body<3, 3, 8, 4, true, false, 2, 4, true>(g.p[k], b - g.first[k], smem);
 }
 
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false>
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false, int RT = 1>
 static int nr_sim_reg_launch_s(NrSimRegArgs& a, hipStream_t st) {
     using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES, WC>;
-    auto kern = nr_sim_reg_kernel<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC, PP>;
+    auto kern = nr_sim_reg_kernel<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC, PP, RT>;
     size_t lds = Tile::RING_BYTES;
-    if constexpr (MI * NI >= 36)          // the block's token weights, parked behind the ring (LATE_W in the kernel)
+    if constexpr (MI * NI >= 32)          // the block's token weights, parked behind the ring (LATE_W in the kernel)
         lds += sizeof(float) * (2 * (16 / TPS) * MI * TPS + WC * (16 / FPS) * NI * FPS);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -489,9 +521,9 @@ static int nr_sim_reg_launch_s(NrSimRegArgs& a, hipStream_t st) {
 }
 
 // tile grid of a product and its partition over the 8 XCDs
-template <int MI, int NI, int TPS, int FPS, int WC>
+template <int MI, int NI, int TPS, int FPS, int WC, int RT = 1>
 static void nr_sim_reg_plan(NrSimRegArgs& a) {
-    constexpr int TA = 2 * (16 / TPS), TB = WC * (16 / FPS);
+    constexpr int TA = 2 * RT * (16 / TPS), TB = WC * (16 / FPS);
     a.ntx = (a.Bv + TB - 1) / TB;
     a.nty = (a.A + TA - 1) / TA;
     // partition of the tile grid over the 8 XCDs that minimises the operand bytes each L2 has to hold
@@ -502,7 +534,7 @@ static void nr_sim_reg_plan(NrSimRegArgs& a) {
         for (int c = 0; c < 4; ++c) {
             int pr = cand[c][0], pc = cand[c][1];
             if (a.nty % pr || a.ntx % pc) continue;
-            double cost = (double)a.nty * TA * (MI * TPS) / pr + (double)a.ntx * TB * (NI * FPS) / pc;
+            double cost = (double)a.nty * TA * (MI / RT * TPS) / pr + (double)a.ntx * TB * (NI * FPS) / pc;
             if (cost < best) { best = cost; a.PR = pr; a.PC = pc; }
         }
     }
@@ -562,6 +594,9 @@ static int nr_sim_reg_big(int A, int Nt, int Bv, int Nv, int prec) {
         const char* e64 = nr_tune_env("NR_SIM_BIG");
         if (e64 && atoi(e64) == 0) return 0;
         if (prec == NR_PREC_BF16X3) return 0;             // split-bf16 would run a 1-stage ring there: measured slower
+        // 5: 256 x 256 blocks (4 texts x 4 videos, two texts per wave strip) once THEY fill the chip: the operand bytes per
+        // MFMA of the 192 x 384 blocks of the 24 x 12 shape.  NR_SIM_BIG=4 keeps the 128 x 256 blocks (A/B hook)
+        if (!(e64 && atoi(e64) == 4) && (A % 4) == 0 && (long)(A / 4) * ((Bv + 3) / 4) >= 256) return 5;
         return (long)((A + 1) / 2) * ((Bv + 3) / 4) >= 256 ? 4 : 0;
     }
     if (Nt != 24 || Nv != 12) return 0;
@@ -586,7 +621,8 @@ extern "C" int nr_sim_reg_tile(int A, int Nt, int Bv, int Nv, int prec, int* TA,
     int tb = Nv == 12 ? 8 : (Nv == 64 ? 2 : 0);
     if (!ta || !tb) return 0;
     const int big = nr_sim_reg_big(A, Nt, Bv, Nv, prec);
-    if (big == 4) { ta = 2; tb = 4; }
+    if (big == 5) { ta = 4; tb = 4; }
+    else if (big == 4) { ta = 2; tb = 4; }
     else if (big == 3) { ta = 4; tb = 16; }
     else if (big) { ta = 8; tb = big == 2 ? 32 : 16; }
     if (TA) *TA = ta;
@@ -607,6 +643,11 @@ int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16
                             : nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, true, false>(a, st);             \
         return args ? nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, false, true>(a, st)                      \
                     : nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, false, false>(a, st);                    \
+    }
+    if (nr_sim_reg_big(A, Nt, Bv, Nv, prec) == 5) {     // 64 x 64 tokens, 256 x 256 blocks on 2 x 4 waves (one bf16 pass only)
+        nr_sim_reg_plan<8, 4, 16, 16, 4, 2>(a);
+        return args ? nr_sim_reg_launch_s<8, 4, 16, 16, false, true, 2, 4, true, 2>(a, st)
+                    : nr_sim_reg_launch_s<8, 4, 16, 16, false, false, 2, 4, true, 2>(a, st);
     }
     if (nr_sim_reg_big(A, Nt, Bv, Nv, prec) == 4) {     // 64 x 64 tokens, 128 x 256 blocks on 2 x 4 waves
         if (x3) return args ? nr_sim_reg_launch<4, 4, 16, 16, true, true, 4>(a, st) : nr_sim_reg_launch<4, 4, 16, 16, true, false, 4>(a, st);

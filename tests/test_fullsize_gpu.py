@@ -79,6 +79,33 @@ def test_local_level_properties_at_full_size(A, Nt, Bv, Nv, prec):
     assert maxdiff(S[ia][:, ib], ref) < (2e-6 if prec == hip.PREC_BF16X3 else 1e-3)
 
 
+@pytest.mark.parametrize("A,Bv", [(64, 64), (64, 70), (128, 1024)])
+def test_256x256_blocks_of_64_token_products_equal_the_small_blocks(A, Bv):
+    """64 x 64-token products (ActivityNet shape) in one bf16 pass run 256 x 256 blocks -- 4 texts x 4 videos, two texts per wave
+    strip (nr_sim_reg_kernel<8, 4, 16, 16, ..., RT = 2>) -- once those fill the chip.  Per-pair arithmetic does not depend on
+    the block a pair lands in: a few texts taken alone (2 texts -> the 64 x 64-per-wave blocks of nr_sim_reg / nr_sim) give the
+    same rows bit for bit, pooled maxima and arg-max indices of the training form included; ragged column blocks (70 videos)."""
+    N = 64
+    t, tm, wt = _tokens(41, A, N)
+    v, vm, wv = _tokens(42, Bv, N)
+    pt, pv = ops.prepare_tokens(t, tm), ops.prepare_tokens(v, vm)
+    assert hip.local_level_tiles(A, N, Bv, N, hip.PREC_BF16) == (A // 4, (Bv + 3) // 4)             # 4 texts x 4 videos per block
+    S, _ = ops.local_level(pt, pv, wt, wv, A, N, Bv, N, hip.PREC_BF16)
+    Sa, aux = ops.local_level(pt, pv, wt, wv, A, N, Bv, N, hip.PREC_BF16, want_arg=True)
+    assert torch.equal(S, Sa) and torch.isfinite(S).all()
+    for a0 in (0, 1, A // 2 + 1, A - 2):
+        sub = ops.prepare_tokens(t[a0:a0 + 2].contiguous(), tm[a0:a0 + 2].contiguous())
+        assert hip.local_level_tiles(2, N, Bv, N, hip.PREC_BF16)[0] == 1                              # another block shape
+        S2, aux2 = ops.local_level(sub, pv, wt[a0:a0 + 2].contiguous(), wv, 2, N, Bv, N, hip.PREC_BF16, want_arg=True)
+        assert torch.equal(S2, S[a0:a0 + 2]), a0
+        for big, small in zip(aux, aux2):
+            assert torch.equal(small, big[a0:a0 + 2]), a0
+    rs, _ = ops.local_level(pt, pv, wt, wv, A, N, Bv, N, hip.PREC_BF16, hip.OUT_ROWSUM)
+    cs, _ = ops.local_level(pt, pv, wt, wv, A, N, Bv, N, hip.PREC_BF16, hip.OUT_COLSUM)
+    assert maxdiff(ops.reduce_parts(rs, 1.0 / Bv), S.double().mean(1)) < 1e-6
+    assert maxdiff(ops.reduce_parts(cs, 1.0 / A), S.double().mean(0)) < 1e-6
+
+
 def test_sinkhorn_and_row_losses_at_b1024():
     B, K = 1024, 20
     g = torch.Generator().manual_seed(5)
