@@ -42,7 +42,8 @@ class OverlappedOwnedStep:
             A = capture_exchange(lambda k=k: exchange_fn(k))
             slot = model._owned_ring[k]
             B = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(B, stream=self.side):
+            # (thread-local capture mode: the process group's watchdog thread polls its events while this thread captures)
+            with torch.cuda.graph(B, stream=self.side, capture_error_mode="thread_local"):
                 losses = model.owned_loss(slot)
             base = losses[0]._base                 # the five scalars are views of one [5] tensor
             self.pairs.append((A, B, base if base is not None and base.numel() == 5 else torch.stack(losses),
