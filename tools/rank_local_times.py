@@ -304,8 +304,11 @@ def measure_interleaved(model, full, W, rank, dev, lines):
         # are those of the eager form (forward() with interleave_overlap: the loss launched on the model's loss stream)
         from neighborretr_amd.interleave import OverlappedOwnedStep
         model.interleave_overlap = True
+        out["overlap_us_per_round"] = None
         try:
             s = rl.shards[rank]
+            if model._absorb_ready(dict(W=W, b=rl.b, shapes=[tuple(s["text_feat"].shape[1:]), tuple(s["video_feat"].shape[1:])])) is None:
+                raise LookupError("the bank cannot absorb a gathered batch (B >= its capacity): no overlapped form")
 
             def exchange_half(slot_index):
                 model._step_index = rank
@@ -366,6 +369,8 @@ def measure_interleaved(model, full, W, rank, dev, lines):
                 out["owned_exchange_us"] = replay_time(own.A.replay)
                 out["owned_loss_us"] = replay_time(own.pairs[0][1].replay)
                 del own, g_other
+        except LookupError as e:
+            out["overlap_note"] = str(e)
         finally:
             model.interleave_overlap = False
         for key, k in (("graph", 0), ("segmented", 1)):
@@ -385,6 +390,9 @@ def measure_interleaved(model, full, W, rank, dev, lines):
     lines.append(f"    W={W} consecutive steps cost a rank {out['graph_us_per_round']:7.1f} us  ->  {out['graph_steps_per_s']:8.0f} steps/s for the job "
                  f"(segmented form: {out['segmented_us_per_round']:7.1f} us -> {out['segmented_steps_per_s']:8.0f} steps/s); no wire time in these")
     lines.append(f"    the round as ONE graph ({W} steps per replay): {out['round_graph_us']:7.1f} us  ->  {out['round_graph_steps_per_s']:8.0f} steps/s")
+    if out["overlap_us_per_round"] is None:
+        lines.append(f"    owner's loss beside the following steps: {out.get('overlap_note')}")
+        return out
     lines.append(f"    owner's loss BESIDE the following steps (two graphs per owned step; replayed pair and eager form == the serial owner's losses, "
                  f"max |dL| {max(out['overlap_dL'], out['overlap_eager_dL']):.1e}): exchange half {out['owned_exchange_us']:6.1f} us, loss half "
                  f"{out['owned_loss_us']:6.1f} us alone; "
