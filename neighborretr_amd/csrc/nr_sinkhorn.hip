@@ -300,6 +300,7 @@ struct NrSkCoopArgs {
     float *tgt_rows, *tgt_cols;
     float* vec;                  // [2 dir][2][B] scaling vectors
     unsigned int* counter;       // [2 dir][32] (one 128-byte line each), zero on entry
+    int spread;                  // 0: a direction's workgroups on ONE XCD; 1: on two (see the launcher)
 };
 
 // EPL = entries per lane = B / 64.  PC_LDS: the column-major copy of the kernel matrix lives in dynamic LDS (4 EPL floats per
@@ -310,9 +311,10 @@ template <int EPL, bool PC_LDS = (EPL >= 13)>
 __global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sk_pc_lds[];
     NR_CRITICAL_PATH();
-    const int dir = blockIdx.x & 7;
-    if (dir > 1) return;
-    const int wg = blockIdx.x >> 3, B = p.B, nwg = B / 32;
+    const int xcd = blockIdx.x & 7;
+    if (xcd > (p.spread ? 3 : 1)) return;
+    const int dir = xcd & 1;
+    const int wg = p.spread ? 2 * (blockIdx.x >> 3) + (xcd >> 1) : (blockIdx.x >> 3), B = p.B, nwg = B / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* va = p.vec + (size_t)dir * 2 * B;          // u / a
     float* vb = va + B;                               // v / b
@@ -609,8 +611,14 @@ static int nr_sinkhorn_run(const float* G, int B, float beta, int iters, float* 
         unsigned int* counter = reinterpret_cast<unsigned int*>(vec + 4 * (size_t)B);
         hipError_t e = hipMemsetAsync(counter, 0, 256, st);
         if (e != hipSuccess) return (int)e;
-        NrSkCoopArgs a{G, B, iters, beta, tgt_rows, tgt_cols, vec, counter};
-        const dim3 grid(8 * (B / 32));
+        // A direction's B/32 workgroups on ONE XCD keep the barrier's atomics and the scaling vectors inside one L2 -- and hold
+        // that XCD's CUs (131 KB of LDS each from B = 832) for the whole solve: workgroups are dispatched in order, so a kernel
+        // on another queue whose next workgroup is due on a full XCD waits there with everything behind it (configs[2] step:
+        // the bank chains' 285 us of kernels stood still for the solve's 320).  From 16 workgroups per direction on they are
+        // spread over TWO XCDs each (16 CUs of four XCDs at B = 1024): the solve alone is slower, the step is not.
+        const int spread = (B / 32) >= 16 && ((B / 32) % 2) == 0 && !nr_tune_env("NR_SK_NOSPREAD");
+        NrSkCoopArgs a{G, B, iters, beta, tgt_rows, tgt_cols, vec, counter, spread};
+        const dim3 grid(spread ? 8 * (B / 64) : 8 * (B / 32));
         switch (B / 64) {
 #define NR_SKC(E_) case E_: hipLaunchKernelGGL(nr_sinkhorn_coop_kernel<E_>, grid, dim3(512), nr_sinkhorn_coop_lds(B), st, a); break;
             NR_SKC(3) NR_SKC(4) NR_SKC(5) NR_SKC(6) NR_SKC(7) NR_SKC(8) NR_SKC(9) NR_SKC(10) NR_SKC(11) NR_SKC(12) NR_SKC(13) NR_SKC(14)

@@ -366,7 +366,10 @@ class NeighborRetr(nn.Module):
         if b >= cap or not on_gpu:
             # B >= capacity: the bank becomes the first rows of the batch (:244-249); CPU banks: plain cat
             self._bank_fifo()
-            self._mb = {k: torch.cat((new[k].to(v.dtype), v), 0)[:cap].contiguous() for k, v in self._mb.items()}
+            if b >= cap:                           # (cat(batch, bank)[:cap] without the cat: the batch's first `cap` rows)
+                self._mb = {k: new[k][:cap].to(v.dtype, copy=True).contiguous() for k, v in self._mb.items()}
+            else:
+                self._mb = {k: torch.cat((new[k].to(v.dtype), v), 0)[:cap].contiguous() for k, v in self._mb.items()}
             self._mb_shadow = None
             self._mb_gen += 1
             return
