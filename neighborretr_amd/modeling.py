@@ -367,7 +367,13 @@ class NeighborRetr(nn.Module):
             # B >= capacity: the bank becomes the first rows of the batch (:244-249); CPU banks: plain cat
             self._bank_fifo()
             if b >= cap:                           # (cat(batch, bank)[:cap] without the cat: the batch's first `cap` rows)
-                self._mb = {k: new[k][:cap].to(v.dtype, copy=True).contiguous() for k, v in self._mb.items()}
+                rows = {k: new[k][:cap] for k in self._mb}
+                if on_gpu and all(rows[k].is_cuda and rows[k].is_contiguous() and rows[k].dtype == v.dtype and rows[k].shape == v.shape
+                                  for k, v in self._mb.items()):
+                    ops.copy_group(list(self._mb.values()), [rows[k] for k in self._mb])      # in place, one launch: the storage stays
+                    self._mb_shadow = None
+                    return
+                self._mb = {k: rows[k].to(v.dtype, copy=True).contiguous() for k, v in self._mb.items()}
             else:
                 self._mb = {k: torch.cat((new[k].to(v.dtype), v), 0)[:cap].contiguous() for k, v in self._mb.items()}
             self._mb_shadow = None

@@ -343,6 +343,35 @@ def test_forward_updates_memory_bank_fifo_and_eval_returns_none():
         m(x["text_feat"], x["text_mask"], x["video_feat"], x["video_mask"], x["idx"], 0)
 
 
+@pytest.mark.parametrize("M", [8, 16])
+def test_a_batch_as_large_as_the_bank_replaces_it(M):
+    """modeling.py:244-249: with B >= capacity the bank becomes cat(batch, bank)[:capacity] = the batch's first rows.  Here one
+    nr_copy_group launch into the bank's own storage (no cat, no new tensors), from a ring whose head had moved; the next step's
+    losses are those of a model whose bank was SET to those rows."""
+    B, Nt, Nv = 16, 24, 12
+    x = problem(1001, B, Nt, Nv, 40, device=DEV)
+    m, ref = _model("bf16", K=8), _model("bf16", K=8)
+    m.mb_feat_t, m.mb_feat_v = x["mb_feat_t"][:M].clone(), x["mb_feat_v"][:M].clone()
+    m.mb_mask_t, m.mb_mask_v = x["mb_mask_t"][:M].clone(), x["mb_mask_v"][:M].clone()
+    m.mb_ind = torch.arange(1000, 1000 + M, device=DEV)
+    ptrs = {k: v.data_ptr() for k, v in m._mb.items()}
+    with torch.no_grad():
+        m(x["text_feat"], x["text_mask"], x["video_feat"], x["video_mask"], x["idx"], 0)
+    assert {k: v.data_ptr() for k, v in m._mb.items()} == ptrs                     # in place
+    assert torch.equal(m.mb_ind, x["idx"][:M]) and torch.equal(m.mb_feat_v, x["video_feat"][:M])
+    assert torch.equal(m.mb_feat_t, x["text_feat"][:M]) and torch.equal(m.mb_mask_v, x["video_mask"][:M].float())
+    ref.mb_feat_t, ref.mb_feat_v = x["text_feat"][:M].clone(), x["video_feat"][:M].clone()
+    ref.mb_mask_t, ref.mb_mask_v = x["text_mask"][:M].float(), x["video_mask"][:M].float()
+    ref.mb_ind = x["idx"][:M].clone()
+    y = problem(1002, B, Nt, Nv, 40, device=DEV)
+    for mm in (m, ref):
+        mm._rng_state_on(torch.device(DEV, 0))[1] = 77
+    with torch.no_grad():
+        a = torch.stack(m(y["text_feat"], y["text_mask"], y["video_feat"], y["video_mask"], y["idx"], 0))
+        b = torch.stack(ref(y["text_feat"], y["text_mask"], y["video_feat"], y["video_mask"], y["idx"], 0))
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("bank_early", [0, 2])
 def test_step_with_the_bank_products_as_chained_tile_pairs(bank_early):
     """head.PAIR_BANK_PRODUCTS (off by default: it loses inside the step): the loss-only step at the
