@@ -15,9 +15,11 @@ collective and is captured like any step with collectives (one graph with the RC
 B has none and is a plain graph.  Every step's losses and the bank after any number of steps are bit-identical to the serial
 forms (tools/rank_local_times.py raises otherwise; tests/test_sharded_gpu.py, tests/test_rank_local_gpu.py).
 
-What was measured on the way (W = 8 emulated on one MI355X, profiles/r04_overlap_probe.txt; serial round: 616 us):
-  * the pair as above, one slot: 517-530 us per round (+17-19 % steps/s); a second slot (the next A not waiting for this B) is
-    SLOWER, 577-603 us: two loss graphs queued back to back on the loss stream and the exchange graphs share the CUs for longer;
+Measured, W = 8 emulated on one MI355X (profiles/r04_rank_local.txt): serial round 502 us = 15.9 k steps/s; with the pair 420 us =
+19.1 k; a tie at W = 4, a loss at W = 2 (bench.py turns it on from 6 ranks).  What was tried on the way
+(profiles/r04_overlap_probe.txt; serial round at the time: 616 us):
+  * the pair as above, one slot: 517-530 us per round; a second slot (the next A not waiting for this B) is SLOWER, 577-603 us;
+  * the pair replayed from the legacy DEFAULT stream: 723 us, the graphs take turns (bench.py runs N > 1 on a pool stream);
   * the whole round as ONE graph with the loss on forked streams: 719 us -- the runtime runs a graph's branches on two hardware
     queues, both of which the loss already uses; the exchange steps were appended to one of them whatever their capture order
     (kernel trace: every exchange kernel behind the loss's local chain on the same queue);
