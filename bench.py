@@ -100,7 +100,10 @@ def parse():
                     help="N=1 only, extra field `rank_local` (never the headline): what ONE rank of the sharded step does at these world "
                          "sizes (default 2 4 8), emulated on this GPU -- its own messages through a 1-rank RCCL communicator, the peers' "
                          "parts pre-filled (tools/rank_local_times.py; no wire time)")
-    ap.add_argument("--overlap", action="store_true", help="step-interleaved job: the overlapped owned step at any world size (default: from 6 ranks on)")
+    ap.add_argument("--overlap", action="store_true", help="(accepted for older command lines: the overlapped owned step is always tried now)")
+    ap.add_argument("--overlap_tries", type=int, default=3,
+                    help="step-interleaved job: how many times the overlapped owned step is built (on fresh streams) before the fastest "
+                         "validated form -- overlapped or serial -- is kept")
     ap.add_argument("--no_overlap", action="store_true",
                     help="step-interleaved job, A/B switch: the owner evaluates its loss IN FRONT of the following steps (round 4's first "
                          "form) instead of beside them from a copy of the bank (neighborretr_amd.interleave)")
@@ -388,9 +391,8 @@ def main():
     if world > 1:
         model.shard_loss = sharded
         model.interleave_steps = interleaved
-        # the owner's loss beside the following steps pays off once W - 1 exchange steps outlast the pair's hand-offs (emulated
-        # rounds, serial / overlapped: W = 2 388 / 446 us, W = 4 470 / 473, W = 8 617 / 516): default from 6 ranks on
-        model.interleave_overlap = interleaved and not args.no_overlap and (args.overlap or world >= 6)
+        # the owner's loss beside the following steps: built and timed next to the serial form, the faster one is kept (below)
+        model.interleave_overlap = interleaved and not args.no_overlap
     n_round = world if interleaved else 1          # steps after which every rank has evaluated a loss
     ctr = [0]                                      # the job's step counter (host side; identical on every rank)
     budget = [0]                                   # steps the caller still wants: a replay may cover several (see --unroll)
@@ -577,30 +579,70 @@ def main():
 
         def segments_of(keep):
             return keep[True].n_segments if interleaved else keep.n_segments
-        # interleaved: each form first with the owner's loss BESIDE the following steps (model.interleave_overlap), then serial
-        overlaps = (True, False) if model.interleave_overlap else (False,)
+        # Interleaved: every kind of form (whole / segmented) is built with the owner's loss BESIDE the following steps
+        # (model.interleave_overlap) and serial, each validated against the eager steps, and the FASTEST of them is kept -- decided
+        # together: a few rounds of each are timed and the ranks agree on the maximum over ranks (the job runs at its slowest rank's
+        # pace).  How well the loss graphs and the exchange graphs overlap depends on which hardware queues their streams land on
+        # (measured on one GPU, W = 8 emulated: 362-470 us per round against 500 serial, and 2 ms with an unlucky draw under other
+        # queue counts), so the overlapped form is built up to --overlap_tries times on fresh streams.
+        overlap_on = bool(model.interleave_overlap)
+        probes = []
+
+        def probe(form_):
+            """us per step of a validated form over 6 rounds (after 2 warm ones), maximum over the ranks."""
+            replay_ = form_[0]
+            ctr[0] = 0
+            for _ in range(2 * n_round):
+                replay_()
+            sync()
+            t0_ = time.perf_counter()
+            for _ in range(6 * n_round):
+                replay_()
+            sync()
+            t_ = torch.tensor([(time.perf_counter() - t0_) / (6 * n_round) * 1e6], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+
+        def candidates(make, what):
+            """[(us per step, overlap?, form)] of the forms `make` yields: overlapped (several draws of streams) and serial."""
+            out_ = []
+            for ov in ((True, False) if overlap_on else (False,)):
+                model.interleave_overlap = ov
+                for _try in range(max(1, args.overlap_tries) if ov else 1):
+                    if ov:
+                        model._owned_ring, model._owned = [], None         # fresh slots: fresh loss streams
+                        for _ in range(n_round):
+                            step()
+                        torch.cuda.synchronize()
+                    f_ = attempt(make, what + (" (loss beside the following steps)" if ov else ""))
+                    if f_ is None:
+                        break
+                    out_.append([None, ov, f_])
+            if len(out_) > 1:
+                for c_ in out_:
+                    c_[0] = probe(c_[2])
+                    probes.append({"owner_loss_beside": c_[1], "us_per_step": round(c_[0], 1)})
+                out_.sort(key=lambda c_: c_[0])
+            return out_
         form = None
         if args.backend == "nccl" or args.fail_whole_capture:
-            for ov in overlaps:
+            cands = candidates(make_whole, "whole-step")
+            if cands:
+                _, ov, form = cands[0]
                 model.interleave_overlap = ov
-                form = attempt(make_whole, "whole-step" + (" (loss beside the following steps)" if ov else ""))
-                if form is not None:
-                    break
         if form is not None:
             step_form, graph = "whole", form[1]
         else:
             # a side stream cannot stay forked across a cut between two segments: the synchronous sharded step runs on one
             # stream in this form; the interleaved step's only collective comes before anything is forked
             model.use_side_streams = interleaved
-            for ov in overlaps:
+            for _ in range(2 * n_round):
+                step()
+            torch.cuda.synchronize()
+            cands = candidates(make_segmented, "segmented")
+            if cands:
+                _, ov, form = cands[0]
                 model.interleave_overlap = ov
-                for _ in range(2 * n_round):
-                    step()
-                torch.cuda.synchronize()
-                form = attempt(make_segmented, "segmented" + (" (loss beside the following steps)" if ov else ""))
-                if form is not None:
-                    break
-            if form is not None:
                 step_form, graph, n_segments = "segmented", form[1], segments_of(form[1])
             else:
                 model.use_side_streams = True
@@ -939,6 +981,7 @@ def main():
                                      "exchange eager + loss graph": "exchange eager + loss graph"}[step_form]) if world > 1 else "dp1",
                        "owner_loss": (("beside the following steps, from a copy of the bank (two graphs per owned step)" if model.interleave_overlap
                                        else "in front of the following steps") if interleaved else None),
+                       "form_probes": (probes or None) if world > 1 and not args.replicated_loss and not args.no_graph else None,
                        "memory_bank": "ring (device head) + persistent prepared bf16 shadow, extended by the batch rows at every push"},
             "losses": [round(float(x), 5) for x in losses],
             "ms_per_step_min": round(min(rep_ms), 4), "ms_per_step_median": round(float(np.median(rep_ms)), 4),

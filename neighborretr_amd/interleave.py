@@ -8,9 +8,10 @@ other rank, and evaluates the loss from the copy on a second stream while its fi
 steps' exchanges.  Two graphs per owned step:
 
     A  (exchange half, the step's stream)   pack -> packed all-gather -> unpack into the slot -> bank copy -> absorb
-    B  (loss half, model.owned_loss_stream) loss_step on the slot: prologue, clustering, products, Sinkhorn, row terms
+    B  (loss half, the slot's own stream)   loss_step on the slot: prologue, clustering, products, Sinkhorn, row terms
 
-tied together by two events OUTSIDE the graphs: B waits for A; the next A waits for B (one slot).  A contains the step's one
+tied together by two events OUTSIDE the graphs: B waits for A; the next A on the same slot waits for B.  Two slots take turns, each
+with a loss stream of its own.  A contains the step's one
 collective and is captured like any step with collectives (one graph with the RCCL all-gather inside, or comm.SegmentedStep);
 B has none and is a plain graph.  Every step's losses and the bank after any number of steps are bit-identical to the serial
 forms (tools/rank_local_times.py raises otherwise; tests/test_sharded_gpu.py, tests/test_rank_local_gpu.py).
@@ -32,24 +33,24 @@ class OverlappedOwnedStep:
     def __init__(self, model, exchange_fn, capture_exchange, warm=2):
         """exchange_fn(slot_index): runs model.owned_exchange(..., slot_index=slot_index) on the rank's shard (collectives through
         neighborretr_amd.comm).  capture_exchange(fn) -> an object with .replay() (a CUDAGraph, or a comm.SegmentedStep).
-        One (A, B) pair of graphs per slot of the model (`model.owned_slots`, one by default)."""
+        One (A, B) pair of graphs per slot of the model (`model.owned_slots`, two by default)."""
         self.model = model
         n = max(1, int(model.owned_slots))
         for k in range(max(warm, 1) * n):          # the slots exist, the shadow is built, every kernel has been launched once
             model.owned_loss(exchange_fn(k % n))
         torch.cuda.synchronize()
-        self.side = model.owned_loss_stream(model._owned.rng.device)
         self.pairs = []
+        self.slots = list(model._owned_ring)       # (the graphs name these buffers: they live as long as this form does)
         for k in range(n):
             A = capture_exchange(lambda k=k: exchange_fn(k))
             slot = model._owned_ring[k]
             B = torch.cuda.CUDAGraph()
             # (thread-local capture mode: the process group's watchdog thread polls its events while this thread captures)
-            with torch.cuda.graph(B, stream=self.side, capture_error_mode="thread_local"):
+            with torch.cuda.graph(B, stream=slot.stream, capture_error_mode="thread_local"):
                 losses = model.owned_loss(slot)
             base = losses[0]._base                 # the five scalars are views of one [5] tensor
             self.pairs.append((A, B, base if base is not None and base.numel() == 5 else torch.stack(losses),
-                               torch.cuda.Event(), torch.cuda.Event()))
+                               torch.cuda.Event(), torch.cuda.Event(), slot.stream))
         self.turn = 0
         self.pending = [False] * n
         self.losses = self.pairs[0][2]             # of the LAST replayed owned step (valid once its loss half has finished)
@@ -66,16 +67,16 @@ class OverlappedOwnedStep:
         """On the current stream: A; on the loss stream, behind it: B.  Returns at once (no host synchronisation)."""
         k = self.turn % len(self.pairs)
         self.turn += 1
-        A, B, losses, ev_a, ev_b = self.pairs[k]
+        A, B, losses, ev_a, ev_b, side = self.pairs[k]
         cur = torch.cuda.current_stream()
         if self.pending[k]:
             cur.wait_event(ev_b)                   # the slot is free again: its previous loss half has read it
         A.replay()
         ev_a.record(cur)
-        self.side.wait_event(ev_a)
-        with torch.cuda.stream(self.side):
+        side.wait_event(ev_a)
+        with torch.cuda.stream(side):
             B.replay()
-            ev_b.record(self.side)
+            ev_b.record(side)
         self.pending[k] = True
         self.losses = losses
 

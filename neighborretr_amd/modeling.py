@@ -88,6 +88,7 @@ class OwnedSlot:
                                      None, p.n_tok, p.d) for p in shadow)
         self.masks = tuple(torch.empty_like(m) for m in masks)
         self.rng = torch.empty_like(rng)
+        self.stream = torch.cuda.Stream(device=dev)      # the stream this slot's loss half runs on (one per slot: see `owned_slots`)
         self.scratch = {}                 # the loss half's `_last_prepared` (never the live model's)
         self.loss_done = None             # event: the loss half of the previous use of this slot has finished reading it
         self.losses = None
@@ -204,10 +205,13 @@ class NeighborRetr(nn.Module):
         self._step_index = 0
         # ... with the owner's loss BESIDE the following steps (OwnedSlot): the owner copies the bank's prepared shadow (19 MB at
         # configs[1], one bf16 pass on the bank side) before it pushes the batch like every other rank, and evaluates the loss
-        # from that copy on `owned_loss_stream` while this stream goes on with the exchange-and-push steps of the other owners.
+        # from that copy on the slot's own stream while this stream goes on with the exchange-and-push steps of the other owners.
         # Opt-in: the losses an owned step returns are then produced on that stream -- wait_owned_loss() before reading them.
         self.interleave_overlap = False
-        self.owned_slots = 1                # OwnedSlots in rotation (measured, W = 8 emulated: two slots are SLOWER than one, 598 vs 524 us per round)
+        # OwnedSlots in rotation, each with a loss stream of its own.  Measured (W = 8 / 4 emulated, us per round; serial 502 / 407):
+        # one slot 436 / 421 (the next exchange half waits for this loss); two slots with ONE loss stream 491-503 / 423 (two loss
+        # graphs queued on one stream hold the exchange graphs up); two slots, a stream each 362-371 / 349; three 432 / 344
+        self.owned_slots = 2
         self._owned_ring = []
         self._owned_turn = 0
         self._owned = None                  # the slot of the last overlapped owned step
@@ -481,14 +485,6 @@ class NeighborRetr(nn.Module):
         return True
 
     # ------------------------------------------------------------------ overlapped owned step (interleave_overlap)
-    def owned_loss_stream(self, device):
-        """The stream the loss half of an overlapped owned step runs on (one per model; never part of a capture's fork set:
-        the loss half is captured as a graph of its own and REPLAYED on this stream)."""
-        st = self.__dict__.get("_owned_stream")
-        if st is None or st.device != torch.device(device):
-            st = self.__dict__["_owned_stream"] = torch.cuda.Stream(device=device)
-        return st
-
     def _owned_prepare(self, recv, lay, slot_index=None):
         """Exchange half of an overlapped owned step, behind the all-gather, on the current stream: the gathered batch unpacked
         into a slot, the bank as the loss must see it copied into the slot (OwnedSlot.take), then the batch pushed into the
@@ -564,7 +560,7 @@ class NeighborRetr(nn.Module):
         cur = torch.cuda.current_stream()
         if torch.cuda.is_current_stream_capturing():
             return self.owned_loss(slot)               # one capture for the whole step: the halves stay in a row
-        side = self.owned_loss_stream(slot.rng.device)
+        side = slot.stream
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             losses = self.owned_loss(slot)
@@ -573,10 +569,10 @@ class NeighborRetr(nn.Module):
         return losses
 
     def wait_owned_loss(self):
-        """Orders the current stream behind the loss half of the last overlapped owned step (no host synchronisation)."""
-        slot = self._owned
-        if slot is not None and slot.loss_done is not None:
-            torch.cuda.current_stream().wait_event(slot.loss_done)
+        """Orders the current stream behind the loss halves of the overlapped owned steps so far (no host synchronisation)."""
+        for slot in self._owned_ring:              # (the slots' loss streams run side by side: every one of them)
+            if slot.loss_done is not None:
+                torch.cuda.current_stream().wait_event(slot.loss_done)
 
     def bank_only_step(self, text_feat, video_feat, text_mask, video_mask, idx):
         """A step this rank does not own (interleave_steps): everything of loss_step that outlives the step -- the ring head and

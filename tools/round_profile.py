@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Replays rank 0's overlapped round graph (interleave.overlapped_round) of the emulated W-rank job a few times: run under
-`rocprofv3 --kernel-trace` (tools/round_timeline.sh) to see which kernels of a round run beside which."""
+"""Rank 0's round of the emulated W-rank step-interleaved job, replayed a few times -- `W serial`: the serial round as one graph;
+`W two [single|fused] [slots] [AB|AO] [one|own|chain]`: the overlapped owned step as two graphs on two streams with the knobs
+tools/ovl_probe.sh sweeps.  Run under `rocprofv3 --kernel-trace` (tools/round_timeline.sh) to see which kernels run beside which."""
 import os
 import sys
 
@@ -9,7 +10,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from neighborretr_amd import comm  # noqa: E402
-from neighborretr_amd.interleave import overlapped_round  # noqa: E402
 from tools import rank_local_times as RL  # noqa: E402
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -53,11 +53,9 @@ def other_step(j):
 
 
 def a_round():
-    if serial:
-        for j in range(W):
-            other_step(j)
-        return None
-    return overlapped_round(model, W, own_exchange, other_step)
+    """The serial round: the rank's own step and the W - 1 behind it, one after the other."""
+    for j in range(W):
+        other_step(j)
 
 
 if len(sys.argv) > 2 and sys.argv[2] == "two":
@@ -67,6 +65,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "two":
     fused = len(sys.argv) > 3 and sys.argv[3] == "fused"
     n_slots = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     order = sys.argv[5] if len(sys.argv) > 5 else "AB"
+    sides_mode = sys.argv[6] if len(sys.argv) > 6 else "one"      # "one": every loss graph on one stream; "own": a stream per slot; "chain": ... and B(k+1) behind B(k)
     model.owned_slots = n_slots
     with comm.use(c):
         def exch(k):
@@ -80,9 +79,12 @@ if len(sys.argv) > 2 and sys.argv[2] == "two":
                 other_step(j)
         gO, _ = RL.capture(others if fused else (lambda: other_step(1)))
         side = torch.cuda.Stream()
+        sides = [side] + [torch.cuda.Stream() if sides_mode != "one" else side for _ in range(n_slots - 1)]
         main = torch.cuda.Stream()
         pairs = []
+        last_b = [None]
         for k in range(n_slots):
+            side = sides[k]
             gA, _ = RL.capture(lambda k=k: exch(k))
             slot = model._owned_ring[k]
             side.wait_stream(torch.cuda.current_stream())
@@ -97,6 +99,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "two":
 
         def rnd():
             gA, gB, evA, evB = pairs[turn[0] % n_slots]
+            side = sides[turn[0] % n_slots]
             first = turn[0] < n_slots
             turn[0] += 1
             with torch.cuda.stream(main):
@@ -108,9 +111,12 @@ if len(sys.argv) > 2 and sys.argv[2] == "two":
                     for _ in range(1 if fused else W - 1):
                         gO.replay()
                 side.wait_event(evA)
+                if sides_mode == "chain" and last_b[0] is not None:
+                    side.wait_event(last_b[0])
                 with torch.cuda.stream(side):
                     gB.replay()
                     evB.record(side)
+                last_b[0] = evB
                 if order != "AO":
                     for _ in range(1 if fused else W - 1):
                         gO.replay()

@@ -2,7 +2,7 @@
 # Kernel timeline of ONE replay of rank 0's overlapped round graph (W = 8 emulated): bash tools/round_timeline.sh [W] [serial]
 repo="$(pwd)"; out="$repo/gpurun_out/round_prof"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d "$out" -o rt -- python3 "$repo/tools/round_profile.py" "${1:-8}" $2 $3 $4 $5 > "$out.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$out" -o rt -- python3 "$repo/tools/round_profile.py" "${1:-8}" $2 $3 $4 $5 $6 > "$out.log" 2>&1
 f=$(find "$out" -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
