@@ -611,6 +611,7 @@ def main():
                 for _try in range(max(1, args.overlap_tries) if ov else 1):
                     if ov:
                         model._owned_ring, model._owned = [], None         # fresh slots: fresh loss streams
+                        model.owned_slots = 1 if _try == 2 else 2          # (the third draw: one slot -- sometimes the better one at W = 8)
                         for _ in range(n_round):
                             step()
                         torch.cuda.synchronize()
@@ -621,7 +622,7 @@ def main():
             if len(out_) > 1:
                 for c_ in out_:
                     c_[0] = probe(c_[2])
-                    probes.append({"owner_loss_beside": c_[1], "us_per_step": round(c_[0], 1)})
+                    probes.append({"owner_loss_beside": c_[1], "slots": len(getattr(c_[2][1][True], "pairs", ())) if c_[1] else None, "us_per_step": round(c_[0], 1)})
                 out_.sort(key=lambda c_: c_[0])
             return out_
         form = None

@@ -345,6 +345,7 @@ def measure_interleaved(model, full, W, rank, dev, lines):
                 draws = []
                 for _draw in range(3):
                     model._owned_ring, model._owned = [], None
+                    model.owned_slots = 1 if _draw == 2 else 2          # (the third draw: ONE slot, as bench.py tries it)
                     own = OverlappedOwnedStep(model, exchange_half, lambda fn: capture(fn)[0])
                     # NOT on the default stream: replayed there, the exchange graphs and the loss graph take turns (723 us per
                     # round at W = 8 against 524 on a stream of the pool)
@@ -379,6 +380,7 @@ def measure_interleaved(model, full, W, rank, dev, lines):
             out["overlap_note"] = str(e)
         finally:
             model.interleave_overlap = False
+            model.owned_slots = 2
         for key, k in (("graph", 0), ("segmented", 1)):
             per_round = times[True][k] + (W - 1) * times[False][k]
             out[key + "_us_per_round"] = per_round
@@ -401,7 +403,7 @@ def measure_interleaved(model, full, W, rank, dev, lines):
         return out
     lines.append(f"    owner's loss BESIDE the following steps (two graphs per owned step; replayed pair and eager form == the serial owner's losses, "
                  f"max |dL| {max(out['overlap_dL'], out['overlap_eager_dL']):.1e}): exchange half {out['owned_exchange_us']:6.1f} us, loss half "
-                 f"{out['owned_loss_us']:6.1f} us alone; three draws of streams: " + " / ".join(f"{d_:.0f}" for d_ in out["overlap_draws_us"]) + " us per round; best: "
+                 f"{out['owned_loss_us']:6.1f} us alone; three draws of streams (two slots, two slots, one slot): " + " / ".join(f"{d_:.0f}" for d_ in out["overlap_draws_us"]) + " us per round; best: "
                  f"W={W} consecutive steps cost a rank {out['overlap_us_per_round']:7.1f} us  ->  {out['overlap_steps_per_s']:8.0f} steps/s for the job")
     return out
 
