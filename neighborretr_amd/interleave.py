@@ -16,15 +16,17 @@ collective and is captured like any step with collectives (one graph with the RC
 B has none and is a plain graph.  Every step's losses and the bank after any number of steps are bit-identical to the serial
 forms (tools/rank_local_times.py raises otherwise; tests/test_sharded_gpu.py, tests/test_rank_local_gpu.py).
 
-Measured, W = 8 emulated on one MI355X (profiles/r04_rank_local.txt): serial round 502 us = 15.9 k steps/s; with the pair 420 us =
-19.1 k; a tie at W = 4, a loss at W = 2 (bench.py turns it on from 6 ranks).  What was tried on the way
-(profiles/r04_overlap_probe.txt; serial round at the time: 616 us):
-  * the pair as above, one slot: 517-530 us per round; a second slot (the next A not waiting for this B) is SLOWER, 577-603 us;
+Measured, emulated on one MI355X (profiles/r04_rank_local.txt, r04_overlap_probe.txt; us per round of W steps, serial form first): W = 2
+358 -> 333; W = 4 404 -> 343-384; W = 8 499 -> 448-460, and 362 in a process that has built nothing else.  How well the two kinds of
+graph overlap depends on the hardware queues their streams land on, so bench.py builds this form on several draws of fresh streams
+AND the serial form, validates each and keeps the fastest.  What else was tried (serial round at the time: 616 us at W = 8):
+  * ONE slot (the next A waits for this B): 420-560 us; two slots on ONE loss stream: 491-598 (two loss graphs queued on one stream hold
+    the exchange graphs up); three slots, a stream each: 432;
   * the pair replayed from the legacy DEFAULT stream: 723 us, the graphs take turns (bench.py runs N > 1 on a pool stream);
   * the whole round as ONE graph with the loss on forked streams: 719 us -- the runtime runs a graph's branches on two hardware
     queues, both of which the loss already uses; the exchange steps were appended to one of them whatever their capture order
     (kernel trace: every exchange kernel behind the loss's local chain on the same queue);
-  * stream priorities for either half: 1.0-2.4 ms per round; more hardware queues (GPU_MAX_HW_QUEUES=8): 1.1 ms.
+  * stream priorities for either half: 1.0-2.4 ms per round; 6 / 8 hardware queues (GPU_MAX_HW_QUEUES): up to 2 ms.
 """
 import torch
 
