@@ -590,15 +590,23 @@ def main():
 
         def probe(form_):
             """us per step of a validated form over 6 rounds (after 2 warm ones), maximum over the ranks."""
+            import gc
             replay_ = form_[0]
-            ctr[0] = 0
-            for _ in range(2 * n_round):
-                replay_()
-            sync()
-            t0_ = time.perf_counter()
-            for _ in range(6 * n_round):
-                replay_()
-            sync()
+            gc.collect()                     # (discarded forms own HIP graphs: destroying them mid-probe costs up to a second)
+            gc_on = gc.isenabled()
+            gc.disable()
+            try:
+                ctr[0] = 0
+                for _ in range(2 * n_round):
+                    replay_()
+                sync()
+                t0_ = time.perf_counter()
+                for _ in range(6 * n_round):
+                    replay_()
+                sync()
+            finally:
+                if gc_on:
+                    gc.enable()
             t_ = torch.tensor([(time.perf_counter() - t0_) / (6 * n_round) * 1e6], device=dev, dtype=torch.float64)
             dist.all_reduce(t_, op=dist.ReduceOp.MAX)
             return float(t_.item())
@@ -758,6 +766,12 @@ def main():
         while budget[0] > 0:
             run()
             budget[0] -= 1
+    # Everything has been built: drop what is unreachable NOW (the discarded forms of the attempts above own HIP graphs and
+    # streams; destroying them takes the runtime up to a second) and keep the collector out of the timed steps
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    gc.disable()
     t_ramp = time.perf_counter()
     if world == 1:
         while time.perf_counter() - t_ramp < 0.4:
