@@ -17,7 +17,7 @@ B has none and is a plain graph.  Every step's losses and the bank after any num
 forms (tools/rank_local_times.py raises otherwise; tests/test_sharded_gpu.py, tests/test_rank_local_gpu.py).
 
 Measured, emulated on one MI355X (profiles/r04_rank_local.txt, r04_overlap_probe.txt; us per round of W steps, serial form first): W = 2
-358 -> 333; W = 4 404 -> 343-384; W = 8 499 -> 448-460, and 362 in a process that has built nothing else.  How well the two kinds of
+358 -> 333; W = 4 402 -> 341-378; W = 8 499 -> 360-366 (450 in a process that has built and dropped many other graphs first).  How well the two kinds of
 graph overlap depends on the hardware queues their streams land on, so bench.py builds this form on several draws of fresh streams
 AND the serial form, validates each and keeps the fastest.  What else was tried (serial round at the time: 616 us at W = 8):
   * ONE slot (the next A waits for this B): 420-560 us; two slots on ONE loss stream: 491-598 (two loss graphs queued on one stream hold

@@ -357,6 +357,10 @@ def measure_interleaved(model, full, W, rank, dev, lines):
                             own.replay()
                             for _ in range(W - 1):
                                 g_other.replay()
+                    import gc
+                    gc.collect()                      # (no destruction of discarded graphs in the middle of a timed loop)
+                    torch.cuda.synchronize()
+                    gc.disable()
                     for _ in range(5):
                         one_round_overlapped()
                     ts = []
@@ -367,6 +371,7 @@ def measure_interleaved(model, full, W, rank, dev, lines):
                             one_round_overlapped()
                         torch.cuda.synchronize()
                         ts.append((time.perf_counter() - t0) / 60 * 1e6)
+                    gc.enable()
                     draws.append(float(np.median(ts)))
                     # the two halves alone: exchange (pack, all-gather, unpack into the slot, bank copy, absorb) and loss
                     out["owned_exchange_us"] = replay_time(own.A.replay)
