@@ -101,7 +101,7 @@ def parse():
                          "sizes (default 2 4 8), emulated on this GPU -- its own messages through a 1-rank RCCL communicator, the peers' "
                          "parts pre-filled (tools/rank_local_times.py; no wire time)")
     ap.add_argument("--overlap", action="store_true", help="(accepted for older command lines: the overlapped owned step is always tried now)")
-    ap.add_argument("--overlap_tries", type=int, default=3,
+    ap.add_argument("--overlap_tries", type=int, default=4,
                     help="step-interleaved job: how many times the overlapped owned step is built (on fresh streams) before the fastest "
                          "validated form -- overlapped or serial -- is kept")
     ap.add_argument("--no_overlap", action="store_true",
@@ -619,7 +619,7 @@ def main():
                 for _try in range(max(1, args.overlap_tries) if ov else 1):
                     if ov:
                         model._owned_ring, model._owned = [], None         # fresh slots: fresh loss streams
-                        model.owned_slots = 1 if _try == 2 else 2          # (the third draw: one slot -- sometimes the better one at W = 8)
+                        model.owned_slots = 1 if _try == 3 else 2          # (the fourth draw: one slot -- sometimes the better one at W = 8)
                         for _ in range(n_round):
                             step()
                         torch.cuda.synchronize()
