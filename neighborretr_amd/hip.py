@@ -258,7 +258,15 @@ def _check(name, rc):
         raise NrHipError(f"{name} failed with status {rc} ({kind})")
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
+    """The current stream's hipStream_t.  (torch.cuda.current_stream() builds a Stream object per call, ~10 us: at 40-80 C-ABI
+    calls per step that was 0.4 ms of an eager training step's host time; the raw getter costs well under 1 us.)"""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return ctypes.c_void_p(_RAW_STREAM(_RAW_DEVICE()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
