@@ -349,6 +349,12 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit(launch_ranks(args.gpus))
     import torch.distributed as dist
+    t_start = time.perf_counter()
+
+    def progress(msg):
+        """N > 1: a line per phase on stderr (rank 0 and the last rank), so that a run that stops shows where."""
+        if world > 1 and rank in (0, world - 1):
+            print(f"[bench] rank {rank} +{time.perf_counter() - t_start:6.1f} s: {msg}", file=sys.stderr, flush=True)
     watchdog = None
     if world > 1:
         # a multi-rank run that stops making progress (a collective one rank never joins) would otherwise sit there until the
@@ -460,9 +466,11 @@ def main():
             with torch.no_grad():
                 gather()
             (graph.replay if graph is not None else after_gather)()
+    progress("process group up, model built; eager warm-up steps")
     for _ in range(3 * n_round):
         step()
     torch.cuda.synchronize()
+    progress("eager steps done")
     # launches of one eager step: C-ABI entry-point calls (a grouped stage call = up to 7 kernels); interleaved: of one round
     # of W steps on this rank (one loss evaluation + W - 1 exchange-and-push steps), divided by W
     before = hip.N_CALLS
@@ -623,7 +631,9 @@ def main():
                         for _ in range(n_round):
                             step()
                         torch.cuda.synchronize()
+                    progress(f"building the {what} form" + (f", owner's loss beside the following steps (draw {_try + 1})" if ov else ""))
                     f_ = attempt(make, what + (" (loss beside the following steps)" if ov else ""))
+                    progress("  ... " + ("validated" if f_ is not None else "not available"))
                     if f_ is None:
                         break
                     out_.append([None, ov, f_])
@@ -632,6 +642,7 @@ def main():
                     c_[0] = probe(c_[2])
                     probes.append({"owner_loss_beside": c_[1], "slots": len(getattr(c_[2][1][True], "pairs", ())) if c_[1] else None, "us_per_step": round(c_[0], 1)})
                 out_.sort(key=lambda c_: c_[0])
+                progress("probed: " + ", ".join(f"{c_[0]:.0f} us/step" + (" (beside)" if c_[1] else " (serial)") for c_ in out_))
             return out_
         form = None
         if args.backend == "nccl" or args.fail_whole_capture:
@@ -780,6 +791,7 @@ def main():
     else:                                   # the SAME number of steps on every rank: a clock-bounded loop would let the ranks disagree
         run_steps(1200)
         torch.cuda.synchronize()
+    progress(f"form: {step_form}; clock ramp done; timing {args.steps} steps")
     run_steps(args.warmup)
     if interleaved:                         # the timed steps start at a round's start on every rank
         run_steps((-ctr[0]) % world)
