@@ -14,7 +14,11 @@ For N>1 the GLOBAL batch stays 128 (the metric is quoted at global B=128; `scali
 every step.  Three forms of the job:
   default        step-interleaved: every step is gathered (one packed RCCL all-gather) and pushed into the bank replica on EVERY
                  rank; its LOSS is evaluated on rank (step mod N) with the single-rank kernels -- loss-only steps depend on each
-                 other through the bank alone.  Losses and bank are bit-identical to the single-rank run.
+                 other through the bank alone.  Losses and bank are bit-identical to the single-rank run.  The owner's loss
+                 can run BESIDE the following steps (a copy of the bank, a second graph on a second stream:
+                 neighborretr_amd/interleave.py): that form is built on a few draws of fresh streams next to the serial one,
+                 every form is validated against the eager steps, a few rounds of each are timed and the fastest is kept --
+                 by all ranks together (`config.owner_loss`, `config.form_probes`; `--no_overlap`: the serial form only).
   --sync_step    the synchronous sharded step: every rank takes part in every loss (five collectives per step).
   --replicated_loss   the reference's semantics (modeling.py:274-298): every rank evaluates every loss.
 A step that contains collectives is replayed as ONE graph with the RCCL collectives inside, or as the graphs of its rank-local
