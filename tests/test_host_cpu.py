@@ -141,6 +141,33 @@ def test_round3_entry_points_refuse_bad_arguments_before_any_launch():
     assert lib.nr_token_mlp_bwd_part_rows(3072, 1024, hip.PREC_BF16X3, 0) == 2 * 24
 
 
+def test_round4_entry_points_refuse_bad_arguments_before_any_launch():
+    """nr_pack_shard_convert / nr_copy_group / nr_bank_absorb_gathered: argument checks on the host; the ticket words the absorb
+    launch asks for; the mask kinds the host side hands to the pack launch; bench.py knows its round-4 switches (no GPU needed)."""
+    import subprocess
+    import sys
+    lib = hip.lib()
+    EINVAL = -1
+    buf = ctypes.create_string_buffer(4096)
+    ptr = ctypes.addressof(buf)
+    one = (ctypes.c_void_p * 1)(ptr)
+    sz = (ctypes.c_size_t * 1)(16)
+    off = (ctypes.c_size_t * 1)(0)
+    assert lib.nr_pack_shard_convert(1, one, sz, off, (ctypes.c_int * 1)(3), ptr, None) == EINVAL        # unknown kind
+    assert lib.nr_pack_shard_convert(9, one, sz, off, None, ptr, None) == EINVAL                          # > 8 pieces
+    assert lib.nr_copy_group(13, one, one, sz, None) == EINVAL                                            # > 12 copies
+    assert lib.nr_copy_group(1, (ctypes.c_void_p * 1)(None), one, sz, None) == EINVAL                     # null source
+    assert lib.nr_bank_absorb_gathered(None, None) == EINVAL
+    assert lib.nr_bank_absorb_counter_words() == 16 * (1 + 2048 // 32)        # the launch's word + one per group of 32 workgroups, 64 B apart
+    from neighborretr_amd import ops
+    assert ops.mask_piece(torch.ones(2, 3, dtype=torch.int64))[1] == 1 and ops.mask_piece(torch.ones(2, 3))[1] == 2
+    m8, k8 = ops.mask_piece(torch.ones(2, 3, dtype=torch.bool))
+    assert k8 == 0 and m8.dtype == torch.uint8
+    import neighborretr_amd.interleave  # noqa: F401  (importable without a GPU)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and all(f in r.stdout for f in ("--no_overlap", "--overlap_tries", "--sync_step", "--unroll"))
+
+
 def test_k_slicing_of_a_weight_gradient():
     from neighborretr_amd.backward import _apportion
     assert _apportion([3072, 1536], 8) == [5, 3]
