@@ -624,6 +624,60 @@ def test_pack_and_unpack_of_the_exchange_step():
         assert torch.equal(again, recv)
 
 
+@pytest.mark.parametrize("B,M,W", [(128, 512, 8), (32, 64, 2), (24, 40, 3)])
+def test_bank_absorb_gathered_equals_unpack_prepare_and_ring_push(B, M, W):
+    """nr_bank_absorb_gathered (a step of the step-interleaved job that this rank does not own): from the receive buffer of the
+    packed exchange, in ONE launch, what the eager path does in four -- unpack, prepare the batch's tokens, move the ring head,
+    push fp32 rows / masks / ids and the prepared rows -- bit for bit; the noise counter advances by one step; the launch's
+    two-level ticket (one word per group of 32 workgroups + its own) is all zero again afterwards.  Three launches in a row
+    (the head wraps at M = 40)."""
+    from types import SimpleNamespace
+    from neighborretr_amd import comm, synth
+    from neighborretr_amd.dist import packed_gather_raw, unpack_raw
+    Nt, Nv, b = 24, 12, B // W
+    p = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_problem(31, B, Nt, Nv, M).items()}
+    world = comm.EmulatedWorld(W, real_collectives=False)
+    cfg = SimpleNamespace(world_size=W)
+    recv = lay = None
+    for _sweep in range(2):                                       # settle the emulated peers' parts, then read rank 0's buffer
+        for r in range(W):
+            sl = slice(r * b, (r + 1) * b)
+            c = world.comm(r)
+            with comm.use(c):
+                c.begin_step()
+                rv, ly = packed_gather_raw(p["text_feat"][sl].contiguous(), p["video_feat"][sl].contiguous(), p["idx"][sl].contiguous(),
+                                           p["text_mask"][sl].contiguous(), p["video_mask"][sl].contiguous(), cfg)
+            if r == 0:
+                recv, lay = rv, ly
+    tf, vf, ix, tm, vm = unpack_raw(recv, lay)
+    assert torch.equal(tf, p["text_feat"]) and torch.equal(ix, p["idx"]) and torch.equal(vm, p["video_mask"].float())
+
+    def bank():
+        d = {"mb_feat_t": p["mb_feat_t"].clone(), "mb_feat_v": p["mb_feat_v"].clone(), "mb_mask_t": p["mb_mask_t"].float().clone(),
+             "mb_mask_v": p["mb_mask_v"].float().clone(), "mb_ind": torch.arange(7000, 7000 + M, device=DEV)}
+        sh = (ops.prepare_tokens(d["mb_feat_t"], d["mb_mask_t"], want_lo=True), ops.prepare_tokens(d["mb_feat_v"], d["mb_mask_v"], want_lo=True))
+        return d, sh, torch.tensor([3], dtype=torch.int32, device=DEV), torch.tensor([5, 40], dtype=torch.int64, device=DEV)
+    got, sh_g, head_g, rng_g = bank()
+    ref, sh_r, head_r, rng_r = bank()
+    pt, pv = ops.prepare_tokens_pair(tf, tm, vf, vm, want_lo=True)
+    names = list(ref)
+    for launch in range(3):
+        ops.bank_absorb_gathered(recv, lay, got, sh_g, head_g, M, rng_g)
+        head_r.sub_(B).remainder_(M)
+        banks = [ref[k] for k in names] + [t_ for q, N in ((sh_r[0], Nt), (sh_r[1], Nv)) for t_ in (q.hi.view(M, -1), q.lo.view(M, -1), q.norm.view(M, N))]
+        rows = [dict(mb_feat_t=tf, mb_feat_v=vf, mb_mask_t=tm, mb_mask_v=vm, mb_ind=ix)[k] for k in names]
+        rows += [t_ for q, N in ((pt, Nt), (pv, Nv)) for t_ in (q.hi.view(B, -1), q.lo.view(B, -1), q.norm.view(B, N))]
+        ops.bank_ring_push(banks, rows, 0, head_dev=head_r)
+        torch.cuda.synchronize()
+        assert int(head_g) == int(head_r), launch
+        for k in names:
+            assert torch.equal(got[k], ref[k]), (launch, k)
+        for a, c in zip(sh_g, sh_r):
+            assert torch.equal(a.hi, c.hi) and torch.equal(a.lo, c.lo) and torch.equal(a.norm, c.norm), launch
+        assert rng_g.tolist() == [5, 41 + launch]
+        assert int((ops._COUNTERS[("absorb", torch.device(DEV, 0))] != 0).sum()) == 0
+
+
 def test_copy_group_copies_every_piece():
     """nr_copy_group: several tensors of different dtypes and sizes (16-byte multiples and odd byte counts) in one launch."""
     g = torch.Generator().manual_seed(9)
