@@ -666,7 +666,9 @@ int nr_bank_ring_push(int n_tensors, void* const* banks, const void* const* batc
  *   shadow_* (hi / lo [capacity * N, d], norm [capacity * N]; all six NULL: no shadow kept);
  *   rng_state (optional): the noise stream's step counter advances by one, as a step's nr_step_prologue advances it.
  * counter: nr_bank_absorb_counter_words() zeroed device words (a two-level ticket: one word per group of workgroups, 64 B
- *   apart, and the launch's own), all zero again when the launch ends.  world * per_rank < capacity; d % 256 == 0, d <= 1024. */
+ *   apart, and the launch's own), all zero again when the launch ends.
+ * world * per_rank >= capacity: the batch's first `capacity` samples become the bank and the head 0 (the reference's
+ *   cat(batch, bank)[:capacity], modeling.py:244-249).  d % 256 == 0, d <= 1024. */
 typedef struct NrBankAbsorbDesc {
     const void* gathered;
     uint64_t record_bytes, off_text, off_video, off_index, off_text_mask, off_video_mask;

@@ -180,10 +180,13 @@ template <int CH>
 __global__ __launch_bounds__(256) void nr_bank_absorb_kernel(NrBankAbsorbDesc a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int B = a.world * a.per_rank, d = a.d;
-    const int rows_t = B * a.Nt, total = rows_t + B * a.Nv;
+    // B >= capacity (modeling.py:244-249: the bank becomes cat(batch, bank)[:capacity]): the batch's first `capacity` samples, head 0
+    const bool whole = B >= a.capacity;
+    const int Be = whole ? a.capacity : B;
+    const int rows_t = Be * a.Nt, total = rows_t + Be * a.Nv;
     const int old_head = __hip_atomic_load(a.ring_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old_head < 0 || old_head >= a.capacity) return;    // (a head outside the ring never becomes a wild write; the counter stays zero)
-    int nh = (old_head - B) % a.capacity;
+    int nh = whole ? 0 : (old_head - B) % a.capacity;
     if (nh < 0) nh += a.capacity;
     const char* recv = reinterpret_cast<const char*>(a.gathered);
     for (int row = blockIdx.x * 4 + wave; row < total; row += gridDim.x * 4) {
@@ -261,12 +264,11 @@ extern "C" int nr_bank_absorb_gathered(const NrBankAbsorbDesc* desc, void* strea
         return NR_EINVAL;
     if (a.world <= 0 || a.per_rank <= 0 || a.Nt <= 0 || a.Nv <= 0 || a.d <= 0 || a.capacity <= 0) return NR_EINVAL;
     const long long B = (long long)a.world * a.per_rank;
-    if (B >= a.capacity) return NR_EUNSUPPORTED;            // (the batch would wrap onto itself: the caller's cat-and-cut path)
     if ((a.d % 256) != 0 || a.d / 256 > NR_PREP_MAX_CHUNKS || a.Nt > 64 || a.Nv > 64) return NR_EUNSUPPORTED;
     const bool shadow = a.shadow_text_hi != nullptr;
     if (shadow != (a.shadow_text_lo && a.shadow_text_norm && a.shadow_video_hi && a.shadow_video_lo && a.shadow_video_norm)) return NR_EINVAL;
     if ((a.off_text % 16) != 0 || (a.off_video % 16) != 0 || (a.off_index % 8) != 0 || (a.record_bytes % 16) != 0) return NR_EINVAL;
-    const long long rows = B * ((long long)a.Nt + a.Nv);
+    const long long rows = (B < a.capacity ? B : (long long)a.capacity) * ((long long)a.Nt + a.Nv);
     int grid = (int)((rows + 3) / 4);
     if (grid > NR_PREP_MAX_GRID) grid = NR_PREP_MAX_GRID;
     hipStream_t st = (hipStream_t)stream;

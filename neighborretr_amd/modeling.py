@@ -295,11 +295,12 @@ class NeighborRetr(nn.Module):
             self._mb_head = 0
             self._mb_gen += 1
 
-    def _ring_ready(self, b):
-        """(head tensor, advance, capacity) for the step prologue when the coming push takes the ring path, else None."""
+    def _ring_ready(self, b, whole=False):
+        """(head tensor, advance, capacity) for the step prologue when the coming push takes the ring path, else None.
+        whole: a batch that replaces the bank (b >= capacity) counts too -- nr_bank_absorb_gathered takes it, at head 0."""
         mb = self._mb
         cap = mb["mb_feat_v"].size(0)
-        if cap == 0 or b >= cap or not all(t.is_cuda and t.is_contiguous() for t in mb.values()):
+        if cap == 0 or (b >= cap and not whole) or not all(t.is_cuda and t.is_contiguous() for t in mb.values()):
             return None
         if self._mb_head_dev is None or self._mb_head_dev.device != mb["mb_feat_v"].device:
             self._mb_head_dev = torch.tensor([self._mb_head], dtype=torch.int32, device=mb["mb_feat_v"].device)
@@ -369,16 +370,34 @@ class NeighborRetr(nn.Module):
         on_gpu = all(t.is_cuda and t.is_contiguous() for t in mb.values())
         if b >= cap or not on_gpu:
             # B >= capacity: the bank becomes the first rows of the batch (:244-249); CPU banks: plain cat
-            self._bank_fifo()
             if b >= cap:                           # (cat(batch, bank)[:cap] without the cat: the batch's first `cap` rows)
                 rows = {k: new[k][:cap] for k in self._mb}
                 if on_gpu and all(rows[k].is_cuda and rows[k].is_contiguous() and rows[k].dtype == v.dtype and rows[k].shape == v.shape
                                   for k, v in self._mb.items()):
-                    ops.copy_group(list(self._mb.values()), [rows[k] for k in self._mb])      # in place, one launch: the storage stays
-                    self._mb_shadow = None
+                    # in place, one launch: the storage, the device ring head (now 0; no read-back -- this runs inside captured
+                    # steps) and the prepared shadow stay, the shadow taking the batch's own prepared rows as on the ring path
+                    if self._mb_head_dev is not None:
+                        self._mb_head_dev.zero_()
+                    self._mb_head = 0
+                    dsts, srcs = list(self._mb.values()), [rows[k] for k in self._mb]
+                    sh, lp = self._mb_shadow, self._last_prepared
+                    if sh is not None and lp.get("pt") is not None and lp["pt"].lo is not None and lp["pv"].lo is not None \
+                            and sh[0].lo is not None and sh[1].lo is not None:
+                        for prep_b, prep_n, N in ((sh[0], lp["pt"], text_feat.shape[1]), (sh[1], lp["pv"], video_feat.shape[1])):
+                            n = cap * N
+                            dsts += [prep_b.hi, prep_b.lo, prep_b.norm]
+                            srcs += [prep_n.hi.view(-1, prep_b.d)[:n], prep_n.lo.view(-1, prep_b.d)[:n], prep_n.norm.view(-1)[:n]]
+                        dsts = [t.view(-1) for t in dsts]
+                        srcs = [t.reshape(-1) for t in srcs]
+                    else:
+                        self._mb_shadow = None
+                    self._last_prepared = {}
+                    ops.copy_group(dsts, srcs)
                     return
+                self._bank_fifo()
                 self._mb = {k: rows[k].to(v.dtype, copy=True).contiguous() for k, v in self._mb.items()}
             else:
+                self._bank_fifo()
                 self._mb = {k: torch.cat((new[k].to(v.dtype), v), 0)[:cap].contiguous() for k, v in self._mb.items()}
             self._mb_shadow = None
             self._mb_gen += 1
@@ -453,7 +472,7 @@ class NeighborRetr(nn.Module):
 
     def _absorb_ready(self, lay):
         """(ring, shadow) when a gathered batch of this layout can go into the bank through nr_bank_absorb_gathered -- the bank is
-        a device ring of fp32 tensors that holds more than a batch, of the batch's token shapes -- else None.  Does not look at
+        a device ring of fp32 tensors of the batch's token shapes -- else None.  Does not look at
         `bank_frozen`."""
         (Nt, d), (Nv, _) = lay["shapes"][0], lay["shapes"][1]
         B = lay["W"] * lay["b"]
@@ -464,7 +483,7 @@ class NeighborRetr(nn.Module):
             return None
         if any(mb[k].dtype != torch.float32 for k in ("mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v")):
             return None
-        ring = self._ring_ready(B)
+        ring = self._ring_ready(B, whole=True)
         if ring is None:
             return None
         shadow = self._bank_shadow()                       # (built before the first push, like the owner's step does)
@@ -474,8 +493,8 @@ class NeighborRetr(nn.Module):
 
     def _absorb_gathered(self, recv, lay):
         """A step this rank does not own, from the exchange step's receive buffer in ONE launch (nr_bank_absorb_gathered): ring
-        head, noise counter, fp32 bank rows and the prepared shadow rows.  False when the bank is not a device ring that holds
-        more than a batch, or frozen (the caller then unpacks and takes bank_only_step)."""
+        head, noise counter, fp32 bank rows and the prepared shadow rows.  False when the bank is not a device ring of the
+        batch's shapes, or frozen (the caller then unpacks and takes bank_only_step)."""
         pre = None if self.bank_frozen else self._absorb_ready(lay)
         if pre is None:
             return False
@@ -535,7 +554,7 @@ class NeighborRetr(nn.Module):
             slot = self._owned_prepare(recv, lay, slot_index)
         if slot is None:
             raise RuntimeError("overlapped owned step: the memory bank cannot absorb a gathered batch (not a device ring of fp32 "
-                               "tensors larger than the batch, or no prepared shadow)")
+                               "tensors of the batch's token shapes, or no prepared shadow)")
         return slot
 
     def owned_loss(self, slot=None):

@@ -678,6 +678,48 @@ def test_bank_absorb_gathered_equals_unpack_prepare_and_ring_push(B, M, W):
         assert int((ops._COUNTERS[("absorb", torch.device(DEV, 0))] != 0).sum()) == 0
 
 
+@pytest.mark.parametrize("B,M,W", [(64, 64, 2), (128, 48, 4), (1024, 512, 8)])
+def test_bank_absorb_gathered_of_a_batch_as_large_as_the_bank(B, M, W):
+    """world * per_rank >= capacity: the batch's first `capacity` samples become the bank, oldest-first order irrelevant, head 0
+    (the reference's cat(batch, bank)[:capacity], modeling.py:244-249) -- fp32 rows, masks, ids and the prepared shadow rows bit for
+    bit what unpack + prepare + a plain copy leave; the noise counter advances; the ticket words are zero again."""
+    from types import SimpleNamespace
+    from neighborretr_amd import comm, synth
+    from neighborretr_amd.dist import packed_gather_raw, unpack_raw
+    Nt, Nv, b = 24, 12, B // W
+    p = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_problem(37, B, Nt, Nv, M).items()}
+    world = comm.EmulatedWorld(W, real_collectives=False)
+    cfg = SimpleNamespace(world_size=W)
+    recv = lay = None
+    for _sweep in range(2):
+        for r in range(W):
+            sl = slice(r * b, (r + 1) * b)
+            c = world.comm(r)
+            with comm.use(c):
+                c.begin_step()
+                rv, ly = packed_gather_raw(p["text_feat"][sl].contiguous(), p["video_feat"][sl].contiguous(), p["idx"][sl].contiguous(),
+                                           p["text_mask"][sl].contiguous(), p["video_mask"][sl].contiguous(), cfg)
+            if r == 0:
+                recv, lay = rv, ly
+    tf, vf, ix, tm, vm = unpack_raw(recv, lay)
+    got = {"mb_feat_t": p["mb_feat_t"].clone(), "mb_feat_v": p["mb_feat_v"].clone(), "mb_mask_t": p["mb_mask_t"].float().clone(),
+           "mb_mask_v": p["mb_mask_v"].float().clone(), "mb_ind": torch.arange(7000, 7000 + M, device=DEV)}
+    sh = (ops.prepare_tokens(got["mb_feat_t"], got["mb_mask_t"], want_lo=True), ops.prepare_tokens(got["mb_feat_v"], got["mb_mask_v"], want_lo=True))
+    head = torch.tensor([min(5, M - 1)], dtype=torch.int32, device=DEV)
+    rng = torch.tensor([5, 40], dtype=torch.int64, device=DEV)
+    ops.bank_absorb_gathered(recv, lay, got, sh, head, M, rng)
+    torch.cuda.synchronize()
+    pt, pv = ops.prepare_tokens_pair(tf, tm, vf, vm, want_lo=True)
+    assert int(head) == 0 and rng.tolist() == [5, 41]
+    want = dict(mb_feat_t=tf, mb_feat_v=vf, mb_mask_t=tm, mb_mask_v=vm, mb_ind=ix)
+    for k, v in got.items():
+        assert torch.equal(v, want[k][:M]), k
+    for a, c, N in ((sh[0], pt, Nt), (sh[1], pv, Nv)):
+        assert torch.equal(a.hi.view(-1), c.hi.view(-1)[:M * N * a.d]) and torch.equal(a.lo.view(-1), c.lo.view(-1)[:M * N * a.d])
+        assert torch.equal(a.norm.view(-1), c.norm.view(-1)[:M * N])
+    assert int((ops._COUNTERS[("absorb", torch.device(DEV, 0))] != 0).sum()) == 0
+
+
 def test_copy_group_copies_every_piece():
     """nr_copy_group: several tensors of different dtypes and sizes (16-byte multiples and odd byte counts) in one launch."""
     g = torch.Generator().manual_seed(9)

@@ -208,7 +208,7 @@ def test_slab_row_losses_on_hip_match_the_torch_restatement():
         assert err < 2e-4 * scale + 1e-9, (name, err, scale)
 
 
-def _interleaved_worker(rank, world, port, out_path, overlap=False):
+def _interleaved_worker(rank, world, port, out_path, overlap=False, M=64):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from neighborretr_amd import modeling, synth
@@ -216,7 +216,7 @@ def _interleaved_worker(rank, world, port, out_path, overlap=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    B, Nt, Nv, M, K, steps = 32, 24, 12, 64, 8, 6
+    B, Nt, Nv, K, steps = 32, 24, 12, 8, 6
     b = B // world
     torch.manual_seed(11)                           # the noise stream's seed: the same on every rank, as in the entry point
 
@@ -258,7 +258,7 @@ def _interleaved_worker(rank, world, port, out_path, overlap=False):
     sh, sh1 = m._mb_shadow, m1._mb_shadow
     had_shadow = sh is not None and sh1 is not None
     shadow_same = had_shadow and all(torch.equal(getattr(a, f), getattr(b_, f)) for a, b_ in zip(sh, sh1) for f in ("hi", "lo", "norm"))
-    heads = (int(m._mb_head_dev.item()), int(m1._mb_head_dev.item()))
+    heads = tuple(int(x._mb_head_dev.item()) if x._mb_head_dev is not None else x._mb_head for x in (m, m1))
     bank_same = all(torch.equal(getattr(m, k), getattr(m1, k)) for k in ("mb_ind", "mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v"))
     torch.save({"ref": ref, "mine": mine, "bank_same": bank_same, "had_shadow": had_shadow, "shadow_same": shadow_same, "heads": heads},
                f"{out_path}.{rank}")
@@ -266,18 +266,20 @@ def _interleaved_worker(rank, world, port, out_path, overlap=False):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("M", [64, 16], ids=["bank-of-64", "bank-of-16"])
 @pytest.mark.parametrize("overlap", [False, True], ids=["loss-in-front", "loss-beside"])
-def test_step_interleaved_job_equals_the_single_rank_run_bit_for_bit(tmp_path, overlap):
+def test_step_interleaved_job_equals_the_single_rank_run_bit_for_bit(tmp_path, overlap, M):
     """model.interleave_steps on two ranks (gloo, one card): every step is gathered and pushed on both ranks, its loss evaluated
     on rank (step mod 2).  The losses of every step and the memory bank after the last one are those of the single-rank run on
     the same stream of batches -- identical bits: same kernels, same ring, same noise stream (the reference's semantics:
     modeling.py:274-312, every step sees the bank left by the steps before it).  overlap: model.interleave_overlap -- the owner
     copies the bank's prepared shadow, pushes the batch at once and evaluates its loss from the copy on a second stream while
-    the following steps' exchanges and pushes already run (modeling.OwnedSlot); the same bits again."""
+    the following steps' exchanges and pushes already run (modeling.OwnedSlot); the same bits again.  Bank of 16: every gathered
+    batch (32) replaces the bank (modeling.py:244-249) -- the same launches with the ring head at 0."""
     import torch.multiprocessing as mp
-    world, port = 2, 29641 + int(overlap)
+    world, port = 2, 29641 + int(overlap) + (2 if M == 16 else 0)
     out = str(tmp_path / "res")
-    mp.spawn(_interleaved_worker, args=(world, port, out, overlap), nprocs=world, join=True)
+    mp.spawn(_interleaved_worker, args=(world, port, out, overlap, M), nprocs=world, join=True)
     res = [torch.load(f"{out}.{r}") for r in range(world)]
     steps = len(res[0]["ref"])
     for s in range(steps):

@@ -308,7 +308,7 @@ def measure_interleaved(model, full, W, rank, dev, lines):
         try:
             s = rl.shards[rank]
             if model._absorb_ready(dict(W=W, b=rl.b, shapes=[tuple(s["text_feat"].shape[1:]), tuple(s["video_feat"].shape[1:])])) is None:
-                raise LookupError("the bank cannot absorb a gathered batch (B >= its capacity): no overlapped form")
+                raise LookupError("the bank cannot absorb a gathered batch (not a device ring of its shapes): no overlapped form")
 
             def exchange_half(slot_index):
                 model._step_index = rank
@@ -583,7 +583,8 @@ def main():
     dev = torch.device("cuda", 0)
     init_one_rank_group()
     model, full = build(dev)
-    lines = [f"rank-local times of the sharded loss-only step, configs[1] (B={CFG['B']}, Nt={CFG['Nt']}, Nv={CFG['Nv']}, M={CFG['M']}), emulated "
+    which = {128: "configs[1]", 1024: "configs[2]'s global batch"}.get(CFG["B"], "configs[1]'s token shapes")
+    lines = [f"rank-local times of the sharded loss-only step, {which} (B={CFG['B']}, Nt={CFG['Nt']}, Nv={CFG['Nv']}, M={CFG['M']}), emulated "
              f"on one MI355X: this rank's messages through a 1-rank RCCL communicator, peers' parts pre-filled (no wire time)"]
     # the single-rank step for scale
     model.config.world_size = 1
