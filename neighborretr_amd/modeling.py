@@ -797,12 +797,18 @@ class NeighborRetr(nn.Module):
             # branches) and are joined right before the global logits need them.
             cur = torch.cuda.current_stream()
             s_t, s_v = self._side_streams(text_feat.device)
+            tf_c, vf_c = text_feat, video_feat
+            if torch.is_grad_enabled():
+                # leaf features enter the side streams through an identity node of THIS stream: the head's local branch uses
+                # them on this stream as well, and their AccumulateGrad nodes then see one stream (cluster_fused.route_on_this_stream)
+                from .cluster_fused import route_on_this_stream
+                _, (tf_c, vf_c) = route_on_this_stream([], (text_feat, video_feat))
             wait_stream(s_t, cur)
             wait_stream(s_v, cur)
             with torch.cuda.stream(s_t):
-                gt = self._merge_one("text", text_feat, text_mask, nz.get("t0"), nz.get("t1"))
+                gt = self._merge_one("text", tf_c, text_mask, nz.get("t0"), nz.get("t1"))
             with torch.cuda.stream(s_v):
-                gv = self._merge_one("video", video_feat, video_mask, nz.get("v0"), nz.get("v1"))
+                gv = self._merge_one("video", vf_c, video_mask, nz.get("v0"), nz.get("v1"))
             gt.record_stream(cur)
             gv.record_stream(cur)
 

@@ -80,7 +80,7 @@ def test_graphed_training_step_keeps_the_reference_fifo():
             le[0].backward()
             lg = step.run(bt)
             torch.cuda.synchronize()
-            assert abs(float(lg[0]) - float(le[0])) < 1e-3 * abs(float(le[0])), (epoch, r, float(lg[0]), float(le[0]))
+            assert abs(float(lg[0]) - float(le[0].detach())) < 1e-3 * abs(float(le[0].detach())), (epoch, r, float(lg[0]), float(le[0].detach()))
         torch.cuda.synchronize()
         gen = graphed._mb_gen
         assert torch.equal(graphed.mb_ind, eager.mb_ind), (epoch, graphed.mb_ind[:3 * B], eager.mb_ind[:3 * B])

@@ -257,7 +257,7 @@ def test_until_module_classes_forward_and_backward():
         gpu = [t.clone().to(DEV).requires_grad_(True) for t in (S, G, bank, w)]
         ref = ref_fn(*cpu)
         mine = mine_fn(*gpu)
-        assert abs(float(mine) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+        assert abs(float(mine.detach()) - float(ref.detach())) < 1e-4 * max(1.0, abs(float(ref.detach())))
         ref.backward()
         mine.backward()
         for a, b in zip(gpu, cpu):
