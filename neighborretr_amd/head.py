@@ -125,6 +125,9 @@ def precision_plan(prec):
 # finished, and one 32 us launch that owns every CU's LDS holds the clustering kernels up longer than two 16 us ones.
 # NR_PAIR_BANK=1 turns it on (developer A/B switch, tools/).
 PAIR_BANK_PRODUCTS = os.environ.get("NR_PAIR_BANK", "0") == "1"
+# Pipelined steps: the next step's bank chains wait for this step's row losses (see after_previous_push).  NR_TAIL_EDGE=0 turns
+# the edge off (developer A/B switch, tools/ab_tail.sh).
+TAIL_BEFORE_NEXT_BANK_READS = os.environ.get("NR_TAIL_EDGE", "1") == "1"
 
 
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
@@ -215,6 +218,15 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         """Pipelined steps: whatever reads the memory bank waits for the PREVIOUS step's push (on the stream it runs on)."""
         if pipeline is not None and pipeline.prev_push_done is not None:
             wait_event(torch.cuda.current_stream(), pipeline.prev_push_done)
+        if pipeline is not None and pipeline.prev_tail_done is not None and TAIL_BEFORE_NEXT_BANK_READS:
+            # ... and for the previous step's ROW LOSSES.  No data flows along this edge.  It is there because of how the ROCm 7.2
+            # runtime orders a graph's nodes: a node nothing depends on (the row-loss launch is the last of its step) is put at the
+            # END of the graph's hardware queues -- the row losses of all ten steps of a pipelined graph ran one after the other
+            # when everything else was done, 24 of every 298 us with 32 workgroups on the chip; with a dependent it is started
+            # before that dependent.  The bank chain starts ~150 us after the previous solve: nothing waits in practice
+            # (profiles/r04_step_timeline_pipelined.txt: 3350-3480 -> 3490-3560 steps/s, A/B per box).
+            wait_event(torch.cuda.current_stream(), pipeline.prev_tail_done)
+            pipeline.prev_tail_done = None
 
     def bank_video_steps():
         # text x bank-video, row mean  -> centrality of text j  (used by the v2t neighbour loss)
@@ -387,6 +399,8 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
                 wc_t, wc_v, cw_aux = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
                 ops.row_losses_no_uniform_final(S, G, c0, c1, 1.0 / M, wc_t, wc_v, ls, K, hp["temperature"], rowloss, counter,
                                                 *wts, losses)
+                if pipeline is not None:
+                    pipeline.tail_done = record_event(side)
         except BaseException:
             if not torch.cuda.is_current_stream_capturing():
                 torch.cuda.synchronize(G.device)

@@ -67,6 +67,8 @@ class StepPipeline:
         self.prev_push_done = prev.push_done if prev is not None else None    # the bank reads of THIS step wait for it
         self.head = None             # this step's own copy of the ring head (its push reads it; the next prologue moves the shared one)
         self.tail_stream = None
+        self.tail_done = None        # event: this step's five losses are written (head.head_forward, split tail)
+        self.prev_tail_done = prev.tail_done if prev is not None else None
         self.pending = []
 
 
@@ -1014,6 +1016,8 @@ class NeighborRetr(nn.Module):
         if ring is not None:
             for k in range(int(n_steps)):
                 self._head_slot(k, ring[0])
+            for k in range(int(n_steps)):          # (allocated inside the capture, each would cost a fill node on the origin stream)
+                ops.split_tail_counter(ring[0].device, k)
 
     def _pipeline_for_head(self, device):
         """The installed StepPipeline with its tail stream resolved (None: steps are not being captured overlapped)."""
