@@ -75,7 +75,8 @@ def parse():
                     help="consecutive steps captured per HIP graph, every dependency between them kept (the bank push of step k before "
                          "the bank products of step k+1): one replay then issues U steps and the ~10 us between two replays is paid "
                          "once per U steps (round 3: 312 / 306 / 304 us per step at U = 1 / 2 / 4).  A remainder of K mod U steps is "
-                         "replayed step by step.  0 (default) = the largest U <= 10 that divides --steps (20 -> 10), else 4.  "
+                         "replayed step by step.  0 (default) = the largest U <= 40 that divides --steps (20 -> 20, 200 -> 40), else 4: a graph's end costs ~90 us (the last step's tail "
+                         "runs alone), 3570 / 3640 / 3670 steps/s at U = 10 / 20 / 40.  "
                          "N > 1: one graph per step (see --round_graph).  1 = one step per graph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL; gloo only to rehearse ranks that share one GPU)")
@@ -121,11 +122,9 @@ def parse():
     args = ap.parse_args()
     CFG.update(CFGS[args.config])
     if args.unroll <= 0:
-        args.unroll = max([u for u in range(2, 11) if args.steps % u == 0] or [4])
-    if CFG["B"] >= CFG["M"]:
-        # a batch as large as the bank replaces it wholesale (modeling.py:244-249: new tensors every step, no ring): consecutive
-        # steps of one graph would not see each other's bank -- one step per graph there (configs[2] on one GPU)
-        args.unroll = 1
+        args.unroll = max([u for u in range(2, 41) if args.steps % u == 0] or [4])
+    # (a batch as large as the bank -- configs[2] on one GPU -- replaces it IN PLACE, modeling.update_memory_bank: consecutive
+    # steps of one graph see each other's bank there too; the unrolled graph is held against single-step replays like any other)
     return args
 
 

@@ -165,7 +165,7 @@ def test_bench_overlapped_steps_equal_single_step_replays():
     times it: every step's losses and the state left behind bit-identical.  Also the strictly sequential form (--no-pipeline)."""
     import json
     for extra, form in (([], "pipelined"), (["--no-pipeline"], "sequential")):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "2", "--no-cpu-baseline"] + extra,
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "2", "--unroll", "6", "--no-cpu-baseline"] + extra,
                            capture_output=True, text=True, timeout=600, cwd=ROOT)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
