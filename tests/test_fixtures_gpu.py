@@ -266,7 +266,7 @@ def test_c4_b8_backward_matches_oracle_autograd_under_mean_flag():
     ref = O.compute_losses(tfc, vfc, xc["text_mask"], xc["video_mask"], xc["mb_feat_t"], xc["mb_feat_v"], xc["mb_mask_t"],
                            xc["mb_mask_v"], P, dict(synth.DEFAULT_HP, num_neighbors=K), ls, nzc, centrality_multi_token="mean")
     ref[0].backward()
-    assert abs(float(losses[0]) - float(ref[0])) < 2e-4
+    assert abs(float(losses[0].detach()) - float(ref[0].detach())) < 2e-4
     for mine, want, name in ((tf.grad, tfc.grad, "text"), (vf.grad, vfc.grad, "video")):
         scale = float(want.abs().max())
         err = maxdiff(mine, want)
