@@ -199,6 +199,14 @@ static int nr_token_logits_go(const uint16_t* tok_hi, const uint16_t* tok_lo, co
         const long cost = ((wg + 255) / 256) * (bm + bn);
         if (best < 0 || cost < best_cost || (cost == best_cost && wg > best_wg)) { best = c; best_cost = cost; best_wg = wg; }
     }
+    // Crowded grids of the 192 x 256 block (>= 3 workgroups per CU): its 142 registers a lane keep every CU at ONE 8-wave
+    // workgroup, while two of the 128 x 256 block (108) share a CU and hide each other's load phases with a one-deep ring --
+    // configs[3], 65536 bank tokens per scorer launch: 485 steps/s with 192 x 256 one-deep, 497 two-deep, 515 with 128 x 256
+    // one-deep (tools/ab_c3.sh, A/B in one session)
+    if (best == 4 && best_wg >= 3 * 256 && H % 256 == 0 && !(sm.counters && 128 % sm.N != 0)) {
+        best = 3;
+        best_wg = (long)((n_tok + 127) / 128) * (H / 256);
+    }
     if (const char* e = nr_tune_env("NR_MLP_SHAPE")) {          // tuning hook: index into the candidate list
         int c = atoi(e);
         if (c >= 0 && c < 5 && H % (16 * cand[c].wc * cand[c].ni) == 0 && !(x3 && cand[c].wc == 4) &&
@@ -209,7 +217,9 @@ static int nr_token_logits_go(const uint16_t* tok_hi, const uint16_t* tok_lo, co
     }
     if (best < 0) return NR_EUNSUPPORTED;
     // ring depth: workgroups that sit alone on their CU prefetch for themselves (2 stages); crowded grids run 1
-    bool two = best_wg < 3 * 256;
+    // (the 192 x 256 block holds 142 registers a lane: never two of its 8-wave workgroups on a CU, however crowded the grid --
+    // one-stage launches of it ran load and MFMA phases strictly in turn: 150 us for the 65536 bank tokens of configs[3])
+    bool two = best_wg < 3 * 256 || (cand[best].mi == 6 && cand[best].wc == 4);
     if (nr_tune_env("NR_MLP_ONE_STAGE")) two = false;          // tuning hook: smallest LDS footprint
 #define NR_MLP_GO(MI_, NI_, WC_)                                                                                              \
     if (cand[best].mi == MI_ && cand[best].ni == NI_ && cand[best].wc == WC_) {                                               \
