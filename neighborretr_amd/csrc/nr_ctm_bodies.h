@@ -489,6 +489,61 @@ __device__ __forceinline__ void nr_tc_attention_body(const NrAttnArgs& a, const 
     }
 }
 
+// The same attention for HG of a sample's heads (a workgroup per (sample, head group), 64 * HG threads or more): only those
+// heads' k | v columns go to LDS -- N * (128 * HG + 4) floats instead of N * (2C + 4): 25 KB instead of 99 at N = 24, HG = 2, and
+// 67 KB at N = 64, where the whole rows (263 KB) do not fit and nr_tc_attention_body reads k and v from global memory job by
+// job.  Every (head, query) job is computed by one wave with the arithmetic of nr_tc_attention_body: identical bits.
+template <int HG>
+__device__ __forceinline__ void nr_tc_attention_heads_body(const NrAttnArgs& a, const int b, const int hg, float* skv) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int N = a.N, C = a.C, cnum = a.cnum, h0 = hg * HG;
+    const float scale = a.scale;
+    const float* kvb = a.kv + (size_t)b * N * 2 * C;
+    constexpr int HW = 64 * HG;                              // floats of k (and of v) per row kept
+    constexpr int ld = 2 * HW + 4;
+    constexpr int per_row = 2 * HW / 4;                      // float4 per row
+    for (int e = threadIdx.x; e < N * per_row; e += (int)blockDim.x) {
+        const int n = e / per_row, c4 = e - n * per_row;
+        const int c = c4 * 4;
+        const int src = c < HW ? h0 * 64 + c : C + h0 * 64 + (c - HW);
+        *reinterpret_cast<f32x4_t*>(skv + n * ld + c) = *reinterpret_cast<const f32x4_t*>(kvb + (size_t)n * 2 * C + src);
+    }
+    __syncthreads();
+    for (int job = wave; job < HG * cnum; job += (int)(blockDim.x >> 6)) {
+        const int hl = job / cnum, cl = job - hl * cnum, h = h0 + hl;
+        const float* qr = a.q + ((size_t)b * cnum + cl) * C + h * 64;
+        float logit = -INFINITY;
+        if (lane < N) {
+            const float* kr = skv + (size_t)lane * ld + hl * 64;
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 64; j += 4) {
+                f32x4_t kk = *reinterpret_cast<const f32x4_t*>(kr + j);
+                f32x4_t qq = *reinterpret_cast<const f32x4_t*>(qr + j);
+                dot += (qq[0] * scale) * kk[0] + (qq[1] * scale) * kk[1] + (qq[2] * scale) * kk[2] + (qq[3] * scale) * kk[3];
+            }
+            logit = dot + a.score[(size_t)b * N + lane];
+        }
+        const float m = nr_wave_max(logit);
+        float e = lane < N ? expf(logit - m) : 0.f;
+        const float den = nr_wave_sum(e);
+        const float p = e / den;
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) {
+            float pn = __shfl(p, n);
+            acc += pn * skv[(size_t)n * ld + HW + hl * 64 + lane];
+        }
+        const size_t o = ((size_t)b * cnum + cl) * C + h * 64 + lane;
+        if (a.out_hi) {
+            const uint16_t hh = nr_f2bf(acc);
+            a.out_hi[o] = hh;
+            a.out_lo[o] = nr_f2bf(acc - nr_bf2f(hh));
+        } else {
+            a.out[o] = acc;
+        }
+    }
+}
+
 // ---- x[n-1] | x[n] | x[n+1] of one token row, written as bf16 hi / lo (operand of the conv GEMM) ------------
 struct NrShiftArgs {
     const float* x;

@@ -69,6 +69,16 @@ __global__ __launch_bounds__(1024) void nr_group_attention_kernel(NrGroupOf<NrAt
     nr_tc_attention_body(g.p[gi], blockIdx.x - g.start[gi], use_lds ? skv : nullptr);
 }
 
+// a workgroup per (sample, pair of heads): see nr_tc_attention_heads_body.  g.start[] counts WORKGROUPS here.
+#define NR_ATTN_HG 2
+__global__ __launch_bounds__(256) void nr_group_attention_heads_kernel(NrGroupOf<NrAttnArgs> g) {
+    NR_CRITICAL_PATH();
+    extern __shared__ __attribute__((aligned(16))) float skv[];
+    const int gi = g.find(blockIdx.x);
+    const int idx = blockIdx.x - g.start[gi], per_sample = g.p[gi].H / NR_ATTN_HG;
+    nr_tc_attention_heads_body<NR_ATTN_HG>(g.p[gi], idx / per_sample, idx % per_sample, skv);
+}
+
 #ifdef NR_STAMP
 extern "C" int nr_debug_back_stamps(unsigned long long* host) {
     (void)hipDeviceSynchronize();
@@ -316,9 +326,35 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
         }
         int jobs_max = 0;                    // (head, query) jobs per sample: one wave each, 8 waves when that covers them
         for (int i = 0; i < n; ++i) jobs_max = d[i].heads * d[i].cnum > jobs_max ? d[i].heads * d[i].cnum : jobs_max;
-        const char* te = nr_tune_env("NR_CTM_THREADS");
-        hipLaunchKernelGGL(nr_group_attention_kernel, dim3(total), dim3((jobs_max <= 8 || (te && atoi(te) == 512)) ? 512 : 1024), lds, st, g, use_lds);
-        NR_LAUNCH_CHECK();
+        // More than a wave's worth of jobs per pair of heads: a 256-thread workgroup per (sample, pair of heads) with only those
+        // heads' k | v columns in LDS -- several share a CU (the whole-sample form: one 1024-thread workgroup with up to 128 KB),
+        // and 64-token samples get their k | v rows into LDS at all.  NR_ATTN_WHOLE=1 keeps the whole-sample form (A/B hook).
+        bool by_heads = jobs_max > 8 && !nr_tune_env("NR_ATTN_WHOLE");
+        size_t lds_h = 0;
+        for (int i = 0; i < n; ++i) {
+            by_heads = by_heads && d[i].heads % NR_ATTN_HG == 0;
+            size_t need = (size_t)d[i].N * (2 * 64 * NR_ATTN_HG + 4) * sizeof(float);
+            lds_h = need > lds_h ? need : lds_h;
+        }
+        if (by_heads && lds_h <= 72 * 1024) {
+            int blocks = 0;
+            for (int i = 0; i < n; ++i) {
+                g.start[i] = blocks;
+                blocks += d[i].n_samples * (d[i].heads / NR_ATTN_HG);
+            }
+            for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = blocks;
+            if (lds_h > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)nr_group_attention_heads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipLaunchKernelGGL(nr_group_attention_heads_kernel, dim3(blocks), dim3(256), lds_h, st, g);
+            NR_LAUNCH_CHECK();
+        } else {
+            const char* te = nr_tune_env("NR_CTM_THREADS");
+            hipLaunchKernelGGL(nr_group_attention_kernel, dim3(total), dim3((jobs_max <= 8 || (te && atoi(te) == 512)) ? 512 : 1024), lds, st, g,
+                               use_lds);
+            NR_LAUNCH_CHECK();
+        }
     }
     // 7. out = merged + proj(att) + proj.bias
     if (first <= 6 && 6 < last) {
