@@ -178,10 +178,16 @@ int nr_linear_group_launch(const NrLinearArgs* probs, int n, hipStream_t st, boo
     }
     if (conv) {                      // token convolutions: the two shapes the clustering stages use (and their neighbours)
         if (wcols == 4 || mi > 2) { mi = 2; ni = 2; stg = 1; }
+        if (const char* ov = nr_tune_env("NR_LINEAR_TILE_CONV")) {          // the convolutions only: "MI,NI,STAGES"
+            int a_, b_, c_;
+            if (sscanf(ov, "%d,%d,%d", &a_, &b_, &c_) == 3 && t32x64 > 256) { mi = a_; ni = b_; stg = c_; }
+        }
 #define NR_LGC_CASE(MI_, NI_, ST_) if (mi == MI_ && ni == NI_ && stg == ST_) return nr_linear_group_launch_s<MI_, NI_, ST_, 2, true>(probs, n, st)
         NR_LGC_CASE(2, 2, 1); NR_LGC_CASE(1, 2, 2); NR_LGC_CASE(1, 2, 4);
 #ifdef NR_TUNE
         NR_LGC_CASE(2, 2, 2);
+        NR_LGC_CASE(3, 4, 1); NR_LGC_CASE(3, 4, 2); NR_LGC_CASE(3, 2, 1); NR_LGC_CASE(3, 2, 2); NR_LGC_CASE(4, 4, 1); NR_LGC_CASE(4, 4, 2);
+        NR_LGC_CASE(4, 2, 1); NR_LGC_CASE(4, 2, 2); NR_LGC_CASE(2, 4, 1); NR_LGC_CASE(2, 4, 2); NR_LGC_CASE(6, 2, 1); NR_LGC_CASE(6, 2, 2);
 #endif
 #undef NR_LGC_CASE
         return NR_EUNSUPPORTED;
