@@ -136,6 +136,8 @@ def build_model(precision, device):
     m = m.to(device).train()
     with torch.no_grad():
         m.clip.logit_scale.fill_(float(np.log(100.0)))
+    if os.environ.get("NR_BANK_EARLY"):             # developer hook: how many bank chains start beside the clustering (0..2)
+        m.bank_early = int(os.environ["NR_BANK_EARLY"])
     if os.environ.get("NR_CAPTURE_ORDER"):          # developer hook (tools/ab_tail.sh): "7,5;7,inf"
         m.capture_order = tuple(tuple((1 << 30) if x == "inf" else int(x) for x in t.split(",")) for t in os.environ["NR_CAPTURE_ORDER"].split(";"))
     return m
