@@ -26,7 +26,7 @@ extern "C" {
 
 /* bumped whenever a signature or the layout of a descriptor struct changes (2: NrCtmStageDesc gained x_hi/x_lo/out_hi/out_lo in
  * round 3, nr_stream_create / nr_stream_destroy, NrBankAbsorbDesc in round 4; 3: nr_pack_shard_convert); a binding compares nr_version() with the value it was written for */
-#define NR_ABI_VERSION 3
+#define NR_ABI_VERSION 4
 
 /* precision of the MFMA contractions */
 #define NR_PREC_BF16 0   /* one bf16 pass (training path)                                   */
@@ -114,6 +114,22 @@ int nr_token_weights_fwd(const uint16_t* tok_hi, const uint16_t* tok_lo, const f
                          const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2, const float* b2,
                          int H, int prec, const float* mask, float* logit_part, unsigned int* counters, int n_counters,
                          float* w, float* logits, void* stream);
+
+/* Two nr_token_weights_fwd calls of one precision in ONE launch (round 4: the step's text and video tokens, from a few
+ * workgroups per CU on: configs[2] / [3]; smaller sets are faster as two launches).  Fields as the arguments of
+ * nr_token_weights_fwd; the two problems need separate `counters`.  NR_EUNSUPPORTED when the two do not run the same block
+ * shape (the caller issues them one by one then); results are bit-identical to the single calls.                        */
+typedef struct NrTokenWeightsProblem {
+    const uint16_t *tok_hi, *tok_lo;
+    const float* norm;
+    const uint16_t *w1_hi, *w1_lo;
+    const float *b1, *w2, *b2, *mask;
+    float* logit_part;
+    unsigned int* counters;
+    float *w, *logits;
+    int32_t n_samples, N, d, H, n_counters, reserved;
+} NrTokenWeightsProblem;
+int nr_token_weights_fwd_pair(const NrTokenWeightsProblem* a, const NrTokenWeightsProblem* b, int prec, void* stream);
 
 /* Fused local_level (modeling.py:499-512): token-token cosine products on MFMA, max-pool over
  * each token axis, weighted sums, (t2v+v2t)/2.  The [A,Bv,Nt,Nv] tensor is never materialised.

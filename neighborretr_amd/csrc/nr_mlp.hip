@@ -29,13 +29,32 @@ struct NrMlpSoftmax {
     float* logits;               // [n_tok] or nullptr
 };
 
+// one scorer call: what a workgroup needs to know about it
+struct NrMlpProblem {
+    const uint16_t *tok_hi, *tok_lo;
+    const float* norm;
+    int n_tok, d;
+    const uint16_t *w1_hi, *w1_lo;
+    const float *b1, *w2;
+    int H;
+    float* logit_part;
+    NrMlpSoftmax sm;
+};
+
+// wg: the workgroup's index INSIDE this problem's (8-padded) grid -- blockIdx.x, or blockIdx.x minus the grids of the problems
+// in front of it in a paired launch (multiples of 8: the XCD a workgroup lands on is the same either way)
 template <int MI, int NI, int WC, bool X3, int STAGES>
-__global__ __launch_bounds__(128 * WC) void nr_mlp_kernel(const uint16_t* __restrict__ tok_hi, const uint16_t* __restrict__ tok_lo,
-                                                          const float* __restrict__ norm, int n_tok, int d,
-                                                          const uint16_t* __restrict__ w1_hi, const uint16_t* __restrict__ w1_lo,
-                                                          const float* __restrict__ b1, const float* __restrict__ w2, int H,
-                                                          float* __restrict__ logit_part, NrMlpSoftmax sm) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void nr_mlp_body(const NrMlpProblem& q, const int wg, char* smem) {
+    const uint16_t* __restrict__ tok_hi = q.tok_hi;
+    const uint16_t* __restrict__ tok_lo = q.tok_lo;
+    const float* __restrict__ norm = q.norm;
+    const int n_tok = q.n_tok, d = q.d, H = q.H;
+    const uint16_t* __restrict__ w1_hi = q.w1_hi;
+    const uint16_t* __restrict__ w1_lo = q.w1_lo;
+    const float* __restrict__ b1 = q.b1;
+    const float* __restrict__ w2 = q.w2;
+    float* __restrict__ logit_part = q.logit_part;
+    const NrMlpSoftmax& sm = q.sm;
     using Tile = NrGemmTile<MI, NI, X3, 16, 16, STAGES, WC>;
     constexpr int BM = Tile::BM, BN = Tile::BN;
     constexpr int WCOLS = 16 * NI;                 // hidden units per wave
@@ -46,7 +65,7 @@ __global__ __launch_bounds__(128 * WC) void nr_mlp_kernel(const uint16_t* __rest
     // 1-D grid, tiles numbered column-fastest: the H/BN column tiles of one token-row tile are neighbours and
     // nr_xcd_chunk_tile keeps neighbours on one XCD, whose L2 then fetches those token rows once
     const int n_col = H / BN;
-    const int tile_id = nr_xcd_chunk_tile(blockIdx.x, n_col * ((n_tok + BM - 1) / BM));
+    const int tile_id = nr_xcd_chunk_tile(wg, n_col * ((n_tok + BM - 1) / BM));
     if (tile_id < 0) return;
     const int bx = tile_id % n_col, by = tile_id / n_col;
     const int row0 = by * BM, col0 = bx * BN;
@@ -152,42 +171,63 @@ __global__ __launch_bounds__(128 * WC) void nr_mlp_kernel(const uint16_t* __rest
     if (tid == 0) __hip_atomic_store(&sm.counters[by], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <int MI, int NI, int WC, bool X3, int STAGES>
+__global__ __launch_bounds__(128 * WC) void nr_mlp_kernel(NrMlpProblem q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    nr_mlp_body<MI, NI, WC, X3, STAGES>(q, blockIdx.x, smem);
+}
+
+// TWO scorer calls of one block shape in one grid (the step's text and video tokens): workgroups [0, grid_a) take `a`, the
+// rest `b`.  Pays from a few workgroups per CU on -- configs[3] (512 + 512 workgroups) 517 -> 530 steps/s, configs[2] 424 -> 427;
+// at configs[1] (256 + 128, one per CU with a two-deep ring) the two launches one after the other are FASTER (3725 vs 3605
+// steps/s, also with a one-deep ring for the pair): the host pairs only large token sets (head.PAIR_BATCH_SCORERS_FROM).
+template <int MI, int NI, int WC, bool X3, int STAGES>
+__global__ __launch_bounds__(128 * WC) void nr_mlp_pair_kernel(NrMlpProblem a, NrMlpProblem b, int grid_a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < grid_a) nr_mlp_body<MI, NI, WC, X3, STAGES>(a, blockIdx.x, smem);
+    else nr_mlp_body<MI, NI, WC, X3, STAGES>(b, (int)blockIdx.x - grid_a, smem);
+}
+
 namespace {
 struct MlpShape { int mi, ni, wc; };
 
 template <int MI, int NI, int WC, bool X3, int STAGES>
-int mlp_launch(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d, const uint16_t* w1_hi,
-               const uint16_t* w1_lo, const float* b1, const float* w2, int H, float* logit_part, hipStream_t st,
-               NrMlpSoftmax sm = NrMlpSoftmax{}) {
+int mlp_launch(const NrMlpProblem& q, hipStream_t st, const NrMlpProblem* second = nullptr) {
     using Tile = NrGemmTile<MI, NI, X3, 16, 16, STAGES, WC>;
     size_t lds = Tile::RING_BYTES;
     const size_t epi = 8192 + 16;                                 // sPart (<= 3 KiB) + the last-block flag at 8192
     static_assert((size_t)WC * Tile::BM * sizeof(float) <= 8192, "the flag sits behind sPart");
     if (lds < epi) lds = epi;
+    const int grid_a = nr_xcd_chunk_grid((q.H / Tile::BN) * ((q.n_tok + Tile::BM - 1) / Tile::BM));
+    if (second) {
+        auto kern = nr_mlp_pair_kernel<MI, NI, WC, X3, STAGES>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        const int grid_b = nr_xcd_chunk_grid((second->H / Tile::BN) * ((second->n_tok + Tile::BM - 1) / Tile::BM));
+        hipLaunchKernelGGL(kern, dim3(grid_a + grid_b), dim3(128 * WC), lds, st, q, *second, grid_a);
+        NR_LAUNCH_CHECK();
+        return NR_OK;
+    }
     auto kern = nr_mlp_kernel<MI, NI, WC, X3, STAGES>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid(nr_xcd_chunk_grid((H / Tile::BN) * ((n_tok + Tile::BM - 1) / Tile::BM)));
-    hipLaunchKernelGGL(kern, grid, dim3(128 * WC), lds, st, tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, sm);
+    hipLaunchKernelGGL(kern, dim3(grid_a), dim3(128 * WC), lds, st, q);
     NR_LAUNCH_CHECK();
     return NR_OK;
 }
 }  // namespace
 
-static int nr_token_logits_go(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d,
-                              const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2,
-                              int H, int prec, float* logit_part, void* stream, const NrMlpSoftmax& sm) {
-    if (!tok_hi || !norm || !w1_hi || !b1 || !w2 || !logit_part) return NR_EINVAL;
-    if (n_tok <= 0 || d <= 0 || (d % 64) != 0 || H <= 0 || (H % 128) != 0) return NR_EINVAL;
-    if (prec != NR_PREC_BF16 && prec != NR_PREC_BF16X3) return NR_EINVAL;
-    if (prec == NR_PREC_BF16X3 && (!tok_lo || !w1_lo)) return NR_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    const bool x3 = prec == NR_PREC_BF16X3;
+// block shape (index into `cand`) and workgroup count of one scorer call; -1: none fits
+static const MlpShape nr_mlp_cand[] = {{2, 4, 2}, {3, 4, 2}, {4, 4, 2}, {4, 4, 4}, {6, 4, 4}};
+
+static int nr_mlp_pick(int n_tok, int H, bool x3, const NrMlpSoftmax& sm, long* wg_out) {
     // candidate block shapes (MI, NI, WC): 64/96/128 x 128 on 4 waves, 128/192 x 256 on 8 waves (one-pass bf16
     // only: the split operands of a 256-wide block do not fit the LDS twice)
-    static const MlpShape cand[] = {{2, 4, 2}, {3, 4, 2}, {4, 4, 2}, {4, 4, 4}, {6, 4, 4}};
+    const MlpShape* cand = nr_mlp_cand;
     int best = -1;
     long best_cost = 0, best_wg = 0;
     for (int c = 0; c < 5; ++c) {
@@ -215,7 +255,34 @@ static int nr_token_logits_go(const uint16_t* tok_hi, const uint16_t* tok_lo, co
             best_wg = (long)((n_tok + 32 * cand[c].mi - 1) / (32 * cand[c].mi)) * (H / (16 * cand[c].wc * cand[c].ni));
         }
     }
+    if (wg_out) *wg_out = best_wg;
+    return best;
+}
+
+static int nr_mlp_check(const NrMlpProblem& q, int prec) {
+    if (!q.tok_hi || !q.norm || !q.w1_hi || !q.b1 || !q.w2 || !q.logit_part) return NR_EINVAL;
+    if (q.n_tok <= 0 || q.d <= 0 || (q.d % 64) != 0 || q.H <= 0 || (q.H % 128) != 0) return NR_EINVAL;
+    if (prec != NR_PREC_BF16 && prec != NR_PREC_BF16X3) return NR_EINVAL;
+    if (prec == NR_PREC_BF16X3 && (!q.tok_lo || !q.w1_lo)) return NR_EINVAL;
+    return NR_OK;
+}
+
+// one scorer call, or two of one block shape in one grid (`second`; NR_EUNSUPPORTED when their shapes differ)
+static int nr_mlp_go(const NrMlpProblem& q, const NrMlpProblem* second, int prec, void* stream) {
+    int rc = nr_mlp_check(q, prec);
+    if (rc == NR_OK && second) rc = nr_mlp_check(*second, prec);
+    if (rc != NR_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const bool x3 = prec == NR_PREC_BF16X3;
+    const MlpShape* cand = nr_mlp_cand;
+    long best_wg = 0;
+    const int best = nr_mlp_pick(q.n_tok, q.H, x3, q.sm, &best_wg);
     if (best < 0) return NR_EUNSUPPORTED;
+    if (second) {
+        long wg_b = 0;
+        if (nr_mlp_pick(second->n_tok, second->H, x3, second->sm, &wg_b) != best || second->d != q.d) return NR_EUNSUPPORTED;
+        best_wg += wg_b;
+    }
     // ring depth: workgroups that sit alone on their CU prefetch for themselves (2 stages); crowded grids run 1
     // (the 192 x 256 block holds 142 registers a lane: never two of its 8-wave workgroups on a CU, however crowded the grid --
     // one-stage launches of it ran load and MFMA phases strictly in turn: 150 us for the 65536 bank tokens of configs[3])
@@ -225,17 +292,22 @@ static int nr_token_logits_go(const uint16_t* tok_hi, const uint16_t* tok_lo, co
     if (cand[best].mi == MI_ && cand[best].ni == NI_ && cand[best].wc == WC_) {                                               \
         if (x3) {                                                                                                             \
             if constexpr (WC_ == 2) {                                                                                         \
-                return two ? mlp_launch<MI_, NI_, WC_, true, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st, sm) \
-                           : mlp_launch<MI_, NI_, WC_, true, 1>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st, sm); \
+                return two ? mlp_launch<MI_, NI_, WC_, true, 2>(q, st, second) : mlp_launch<MI_, NI_, WC_, true, 1>(q, st, second); \
             }                                                                                                                 \
         } else {                                                                                                              \
-            return two ? mlp_launch<MI_, NI_, WC_, false, 2>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st, sm)    \
-                       : mlp_launch<MI_, NI_, WC_, false, 1>(tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, st, sm);   \
+            return two ? mlp_launch<MI_, NI_, WC_, false, 2>(q, st, second) : mlp_launch<MI_, NI_, WC_, false, 1>(q, st, second);   \
         }                                                                                                                     \
     }
     NR_MLP_GO(2, 4, 2) NR_MLP_GO(3, 4, 2) NR_MLP_GO(4, 4, 2) NR_MLP_GO(4, 4, 4) NR_MLP_GO(6, 4, 4)
 #undef NR_MLP_GO
     return NR_EUNSUPPORTED;
+}
+
+static int nr_token_logits_go(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d,
+                              const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1, const float* w2,
+                              int H, int prec, float* logit_part, void* stream, const NrMlpSoftmax& sm) {
+    NrMlpProblem q{tok_hi, tok_lo, norm, n_tok, d, w1_hi, w1_lo, b1, w2, H, logit_part, sm};
+    return nr_mlp_go(q, nullptr, prec, stream);
 }
 
 extern "C" int nr_token_logits_fwd(const uint16_t* tok_hi, const uint16_t* tok_lo, const float* norm, int n_tok, int d,
@@ -257,6 +329,25 @@ extern "C" int nr_token_weights_fwd(const uint16_t* tok_hi, const uint16_t* tok_
     if (n_counters < (n_tok + 63) / 64) return NR_EINVAL;           // the smallest row tile is 64 tokens
     NrMlpSoftmax sm{counters, b2, mask, N, w, logits};
     return nr_token_logits_go(tok_hi, tok_lo, norm, (int)n_tok, d, w1_hi, w1_lo, b1, w2, H, prec, logit_part, stream, sm);
+}
+
+// Two nr_token_weights_fwd calls of one precision in ONE launch (the step's text and video tokens).  NR_EUNSUPPORTED when the
+// two do not run the same block shape (the caller then issues them one by one).
+extern "C" int nr_token_weights_fwd_pair(const NrTokenWeightsProblem* a, const NrTokenWeightsProblem* b, int prec, void* stream) {
+    if (!a || !b) return NR_EINVAL;
+    NrMlpProblem q[2];
+    const NrTokenWeightsProblem* src[2] = {a, b};
+    for (int i = 0; i < 2; ++i) {
+        const NrTokenWeightsProblem& t = *src[i];
+        if (!t.counters || !t.b2 || !t.w || t.n_samples <= 0 || t.N <= 0) return NR_EINVAL;
+        if (t.N > 256) return NR_EUNSUPPORTED;
+        const long n_tok = (long)t.n_samples * t.N;
+        if (t.n_counters < (n_tok + 63) / 64) return NR_EINVAL;
+        q[i] = NrMlpProblem{t.tok_hi, t.tok_lo, t.norm, (int)n_tok, t.d, t.w1_hi, t.w1_lo, t.b1, t.w2, t.H, t.logit_part,
+                            NrMlpSoftmax{t.counters, t.b2, t.mask, t.N, t.w, t.logits}};
+    }
+    if (a->counters == b->counters) return NR_EINVAL;               // (the two problems' row tiles count separately)
+    return nr_mlp_go(q[0], &q[1], prec, stream);
 }
 
 // ---- backward of the scorer MLP, hidden layer (no counterpart in the reference: autograd differentiates modeling.py:148-153) ----

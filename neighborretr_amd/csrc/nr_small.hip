@@ -15,6 +15,7 @@ extern "C" size_t nr_struct_size(const char* name) {
     NR_SIZE_OF(NrCtmStageDesc); NR_SIZE_OF(NrLocalLevelProblem); NR_SIZE_OF(NrSplitItem); NR_SIZE_OF(NrColsumItem);
     NR_SIZE_OF(NrLinearProblem); NR_SIZE_OF(NrCtmAttnBwdDesc); NR_SIZE_OF(NrCtmMidBwdDesc); NR_SIZE_OF(NrSimBwdItem);
     NR_SIZE_OF(NrSimBwdOperand); NR_SIZE_OF(NrSlabSum); NR_SIZE_OF(NrPoolWSrc); NR_SIZE_OF(NrPoolWJob); NR_SIZE_OF(NrBankAbsorbDesc);
+    NR_SIZE_OF(NrTokenWeightsProblem);
 #undef NR_SIZE_OF
     return 0;
 }

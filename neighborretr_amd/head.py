@@ -128,6 +128,11 @@ PAIR_BANK_PRODUCTS = os.environ.get("NR_PAIR_BANK", "0") == "1"
 # Pipelined steps: the next step's bank chains wait for this step's row losses (see after_previous_push).  NR_TAIL_EDGE=0 turns
 # the edge off (developer A/B switch, tools/ab_tail.sh).
 TAIL_BEFORE_NEXT_BANK_READS = os.environ.get("NR_TAIL_EDGE", "1") == "1"
+# Loss-only step: the batch's text and video scorers as one launch (nr_token_weights_fwd_pair).  NR_PAIR_SCORERS=0: two launches (A/B).
+PAIR_BATCH_SCORERS = os.environ.get("NR_PAIR_SCORERS", "1") == "1"
+# ... from this many tokens in the smaller set on (a few workgroups per CU): configs[3] 517 -> 530 steps/s, configs[2] 424 -> 427;
+# at configs[1] (3072 + 1536 tokens: one workgroup per CU) the two launches one after the other are faster, 3725 vs 3605
+PAIR_BATCH_SCORERS_FROM = int(os.environ.get("NR_PAIR_SCORERS_FROM", "8192"))
 
 
 def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_feat_v, mb_mask_t, mb_mask_v,
@@ -191,10 +196,17 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     def local_steps():
         L["pt"], L["pv"] = pt_, pv_ = ops.prepare_tokens_pair(text_feat, text_mask, video_feat, video_mask, want_lo=lo_b, want_colsum=True)
         yield
-        L["w_t"], L["lg_t"] = token_weights(pt_, text_mask, sw_t, B, Nt, p_mlp, keep)
-        yield
-        L["w_v"], L["lg_v"] = token_weights(pv_, video_mask, sw_v, B, Nv, p_mlp, keep)
-        yield
+        if PAIR_BATCH_SCORERS and not keep and B * min(Nt, Nv) >= PAIR_BATCH_SCORERS_FROM:
+            # the text and the video scorer in one grid; bit-identical to the two launches
+            (L["w_t"], L["lg_t"]), (L["w_v"], L["lg_v"]) = ops.token_weights_pair(
+                [(pt_, sw_t.w1_hi, sw_t.w1_lo, sw_t.b1, sw_t.w2, sw_t.b2, text_mask, B, Nt),
+                 (pv_, sw_v.w1_hi, sw_v.w1_lo, sw_v.b1, sw_v.w2, sw_v.b2, video_mask, B, Nv)], p_mlp)
+            yield
+        else:
+            L["w_t"], L["lg_t"] = token_weights(pt_, text_mask, sw_t, B, Nt, p_mlp, keep)
+            yield
+            L["w_v"], L["lg_v"] = token_weights(pv_, video_mask, sw_v, B, Nv, p_mlp, keep)
+            yield
         if not (bb_late and split_tail):
             L["S"], L["aux0"] = ops.local_level(pt_, pv_, L["w_t"], L["w_v"], B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
             yield

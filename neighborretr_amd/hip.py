@@ -17,7 +17,7 @@ PREC_BF16 = 0
 PREC_BF16X3 = 1
 OUT_FULL, OUT_ROWSUM, OUT_COLSUM = 0, 1, 2
 NR_EINVAL, NR_EUNSUPPORTED = -1, -2          # status codes of include/nr_hip.h
-ABI_VERSION = 3                              # NR_ABI_VERSION this binding was written for (checked at load)
+ABI_VERSION = 4                              # NR_ABI_VERSION this binding was written for (checked at load)
 
 _lib = None
 
@@ -108,7 +108,13 @@ class BankAbsorbDesc(ctypes.Structure):
                                      "ring_head", "rng_state", "counter")])
 
 
-STRUCTS = {"NrBankAbsorbDesc": BankAbsorbDesc, "NrCtmStageDesc": CtmStageDesc, "NrLocalLevelProblem": LocalLevelProblem, "NrSplitItem": SplitItem,
+class TokenWeightsProblem(ctypes.Structure):
+    """NrTokenWeightsProblem of include/nr_hip.h."""
+    _fields_ = ([(n, _P) for n in ("tok_hi", "tok_lo", "norm", "w1_hi", "w1_lo", "b1", "w2", "b2", "mask", "logit_part", "counters", "w", "logits")]
+                + [(n, ctypes.c_int32) for n in ("n_samples", "N", "d", "H", "n_counters", "reserved")])
+
+
+STRUCTS = {"NrTokenWeightsProblem": TokenWeightsProblem, "NrBankAbsorbDesc": BankAbsorbDesc, "NrCtmStageDesc": CtmStageDesc, "NrLocalLevelProblem": LocalLevelProblem, "NrSplitItem": SplitItem,
            "NrColsumItem": ColsumItem, "NrLinearProblem": LinearProblem, "NrCtmAttnBwdDesc": CtmAttnBwdDesc,
            "NrCtmMidBwdDesc": CtmMidBwdDesc, "NrSimBwdItem": SimBwdItem, "NrSimBwdOperand": SimBwdOperand, "NrSlabSum": SlabSum,
            "NrPoolWSrc": PoolWSrc, "NrPoolWJob": PoolWJob}
@@ -133,6 +139,7 @@ _SIGNATURES = {
     "nr_token_mlp_bwd_row_tiles": ([_I], _I),
     "nr_token_mlp_bwd_part_rows": ([_I, _I, _I, _I], _I),
     "nr_token_mlp_bwd_hidden": ([_P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P], _I),
+    "nr_token_weights_fwd_pair": ([ctypes.POINTER(TokenWeightsProblem), ctypes.POINTER(TokenWeightsProblem), _I, _P], _I),
     "nr_token_weights_fwd": ([_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P], _I),
     "nr_local_level_tiles": ([_I, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)], _I),
     "nr_local_level_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),

@@ -142,6 +142,43 @@ def token_weights(prep, w1_hi, w1_lo, b1, w2, b2, mask, n_samples, N, prec, want
     return token_softmax(parts, b2, mask, n_samples, N, want_logits)
 
 
+def token_weights_pair(calls, prec):
+    """Two token_weights calls of one precision in ONE launch (nr_token_weights_fwd_pair; bit-identical to the single calls).
+    calls: two tuples (prep, w1_hi, w1_lo, b1, w2, b2, mask, n_samples, N).  -> [(w, None), (w, None)]; falls back to two
+    launches when the two do not run the same block shape."""
+    import ctypes
+    dev = calls[0][0].hi.device
+    probs, outs, keep = [], [], []
+    for prep, w1_hi, w1_lo, b1, w2, b2, mask, n_samples, N in calls:
+        counters = _softmax_counters(dev, prep.n_tok) if FUSE_TOKEN_SOFTMAX else None
+        if counters is None:
+            probs = None
+            break
+        H = w1_hi.shape[0]
+        parts = torch.empty((H // 128, prep.n_tok), dtype=torch.float32, device=dev)
+        w = torch.empty((n_samples, N), dtype=torch.float32, device=dev)
+        m = _f32(mask).contiguous() if mask is not None else None
+        q = hip.TokenWeightsProblem()
+        q.tok_hi, q.tok_lo, q.norm = hip.ptr(prep.hi), hip.ptr(prep.lo, allow_none=True), hip.ptr(prep.norm)
+        q.w1_hi, q.w1_lo = hip.ptr(w1_hi), hip.ptr(w1_lo, allow_none=True)
+        q.b1, q.w2, q.b2 = hip.ptr(b1, torch.float32), hip.ptr(w2, torch.float32), hip.ptr(b2, torch.float32)
+        q.mask, q.logit_part, q.counters = hip.ptr(m, allow_none=True), hip.ptr(parts), hip.ptr(counters)
+        q.w, q.logits = hip.ptr(w), None
+        q.n_samples, q.N, q.d, q.H, q.n_counters = int(n_samples), int(N), int(prep.d), int(H), counters.numel()
+        probs.append(q)
+        outs.append((w, None))
+        keep += [parts, m]
+    if probs is not None:
+        hip.N_CALLS += 1
+        rc = hip.lib().nr_token_weights_fwd_pair(ctypes.byref(probs[0]), ctypes.byref(probs[1]), prec, hip.stream_ptr())
+        if rc == 0:
+            return outs
+        if rc != hip.NR_EUNSUPPORTED:
+            hip._check("nr_token_weights_fwd_pair", rc)
+        hip.N_CALLS -= 1
+    return [token_weights(*c, prec) for c in calls]
+
+
 def local_level(prep_t, prep_v, w_t, w_v, A, Nt, Bv, Nv, prec=hip.PREC_BF16, out_mode=hip.OUT_FULL, want_arg=False):
     """Fused token-token similarity (nr_local_level_fwd).  Returns (out, aux); aux = None or
     (arg_v, arg_t, pmax, qmax) kept for the backward pass."""

@@ -54,7 +54,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert declared == set(hip.exported_symbols()), declared ^ set(hip.exported_symbols())
-    assert lib.nr_version() == 3
+    assert lib.nr_version() == 4
     assert lib.nr_prepare_parts(10) == 1 and lib.nr_prepare_parts(3072) == 192 and lib.nr_prepare_parts(10 ** 6) == 256
 
 
@@ -158,6 +158,9 @@ def test_round4_entry_points_refuse_bad_arguments_before_any_launch():
     assert lib.nr_copy_group(13, one, one, sz, None) == EINVAL                                            # > 12 copies
     assert lib.nr_copy_group(1, (ctypes.c_void_p * 1)(None), one, sz, None) == EINVAL                     # null source
     assert lib.nr_bank_absorb_gathered(None, None) == EINVAL
+    assert lib.nr_token_weights_fwd_pair(None, None, hip.PREC_BF16, None) == EINVAL
+    tw = hip.TokenWeightsProblem()                                                                        # all-null problem
+    assert lib.nr_token_weights_fwd_pair(ctypes.byref(tw), ctypes.byref(tw), hip.PREC_BF16, None) == EINVAL
     assert lib.nr_bank_absorb_counter_words() == 16 * (1 + 2048 // 32)        # the launch's word + one per group of 32 workgroups, 64 B apart
     from neighborretr_amd import ops
     assert ops.mask_piece(torch.ones(2, 3, dtype=torch.int64))[1] == 1 and ops.mask_piece(torch.ones(2, 3))[1] == 2

@@ -24,7 +24,7 @@ def _tw(prep, mask, P, prefix, n, N, prec):
 
 
 def test_library_loads_and_version():
-    assert hip.version() == hip.ABI_VERSION == 3
+    assert hip.version() == hip.ABI_VERSION == 4
 
 
 @pytest.mark.parametrize("n,N,d", [(16, 24, 512), (5, 7, 256), (3, 64, 768)])
@@ -60,6 +60,34 @@ def test_token_weights(prec, tol):
         lg_ref = O.token_weight_logits(feat, P, prefix)
         valid = mask.bool()
         assert maxdiff(logits.cpu()[valid], lg_ref[valid]) < tol * 10
+
+
+@pytest.mark.parametrize("B,Nt,Nv,prec", [(128, 24, 12, hip.PREC_BF16X3), (128, 24, 12, hip.PREC_BF16), (16, 24, 12, hip.PREC_BF16X3),
+                                          (8, 64, 64, hip.PREC_BF16X3), (5, 7, 24, hip.PREC_BF16X3)])
+def test_token_weights_pair_equals_the_two_launches(B, Nt, Nv, prec):
+    """nr_token_weights_fwd_pair (the step's text and video scorers in one grid) against the two nr_token_weights_fwd launches:
+    identical bits, masks included; counters left zeroed.  (5, 7, 24): the two problems pick different block shapes -- the
+    entry point refuses, ops.token_weights_pair falls back to the single launches."""
+    x = problem(1001 + B, B, Nt, Nv, 16)
+    Pg = {k: v.to(DEV) for k, v in params().items()}
+    tm, vm = x["text_mask"].to(DEV), x["video_mask"].to(DEV)
+    pt = ops.prepare_tokens(x["text_feat"].to(DEV), tm)
+    pv = ops.prepare_tokens(x["video_feat"].to(DEV), vm)
+
+    def call(prep, mask, prefix, n, N):
+        w1 = Pg[prefix + ".0.weight"]
+        hi, lo = ops.split_bf16(w1)
+        return (prep, hi, lo, Pg[prefix + ".0.bias"], Pg[prefix + ".2.weight"].reshape(-1).contiguous(), Pg[prefix + ".2.bias"], mask, n, N)
+    calls = [call(pt, tm, "text_weight_fc", B, Nt), call(pv, vm, "video_weight_fc", B, Nv)]
+    single = [ops.token_weights(*c, prec)[0] for c in calls]
+    n0 = hip.N_CALLS
+    (w_t, _), (w_v, _) = ops.token_weights_pair(calls, prec)
+    torch.cuda.synchronize()
+    if (B, Nt, Nv) != (5, 7, 24):
+        assert hip.N_CALLS - n0 == 1
+    assert torch.equal(w_t, single[0]) and torch.equal(w_v, single[1])
+    assert maxdiff(w_t, _tw(pt, tm, Pg, "text_weight_fc", B, Nt, prec)[0]) < 1e-5
+    assert int((ops._COUNTERS[("softmax", w_t.device)][0] != 0).sum()) == 0
 
 
 SHAPES = [
