@@ -100,7 +100,10 @@ def parse():
                          "inside a multi-stream graph every node costs more than in the single-stream graph of a non-owned step")
     ap.add_argument("--decouple_push", action="store_true",
                     help="pipelined steps, A/B switch: the next step's prologue does not wait for this step's bank push (per-step copy "
-                         "of the ring head; only the bank chains wait).  Bit-identical and slower (0.355 vs 0.293 ms per step)")
+                         "of the ring head; only the bank chains wait).  Slower at every config (0.355 vs 0.293 ms per step at configs[1]; 454-510 vs 527 "
+                         "steps/s at configs[3]) and NOT protected like the default order: steps then run so far ahead of each other that a "
+                         "buffer freed on the origin stream can be handed out while a tail still reads it -- at configs[3] the graph failed "
+                         "its check against single-step replays once in two runs (the bench then takes the sequential form)")
     ap.add_argument("--emulate_world", type=int, nargs="*", default=None, metavar="W",
                     help="N=1 only, extra field `rank_local` (never the headline): what ONE rank of the sharded step does at these world "
                          "sizes (default 2 4 8), emulated on this GPU -- its own messages through a 1-rank RCCL communicator, the peers' "
