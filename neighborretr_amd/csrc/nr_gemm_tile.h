@@ -381,16 +381,29 @@ struct NrGemmTile {
         run_pp_segs<1>(sg, K, smem, [](int) {});
     }
 
-    template <int NSEG, typename Between>
+    // Split-bf16 product on a ONE-PASS tile (X3 = false: the ring holds hi halves only, so the block can be as large as the
+    // one-pass blocks): three passes over K through one loop, accumulated -- Ah Bh over all slices, then Ah Bl, then Al Bh
+    // (the three products the X3 tile adds up slice by slice; another summation order, the same ~16 mantissa bits).
+    __device__ __forceinline__ void run_pp3(const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
+                                            int a_row0, int a_rows,
+                                            const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo,
+                                            int b_row0, int b_rows, int K, char* smem) {
+        static_assert(!X3, "three passes: on the one-pass tile");
+        const Seg sg[1] = {{a_hi, a_lo, a_row0, a_rows, b_hi, b_lo, b_row0, b_rows}};
+        run_pp_segs<1, true>(sg, K, smem, [](int) {});
+    }
+
+    template <int NSEG, bool ACC3 = false, typename Between>
     __device__ __forceinline__ void run_pp_segs(const Seg (&sg)[NSEG], int K, char* smem, Between&& between) {
         static_assert(WC == 4 && STAGES == 2, "ping-pong loop: 2 x 4 waves, two-stage ring");
         static_assert(NSEG == 1 || NSEG == 2, "one tile, or two chained tiles");
+        static_assert(!ACC3 || (NSEG == 1 && !X3), "three accumulated passes: one tile, one-pass ring");
         const int tid = threadIdx.x;
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int grp = wave / WC, wc = wave % WC;        // group = wave row
         const int KS = K / BK;                            // slices per tile
-        const int KT = NSEG * KS;                         // slices of the whole loop
+        const int KT = (ACC3 ? 3 : NSEG) * KS;            // slices of the whole loop
 
         // The pieces go out as buffer loads to LDS: per lane ONE row offset ((lane / 8) rows) and the piece's swizzled
         // 16-byte chunk (3 bits per slot, packed); operand, first row of the piece, K offset of the slice and LDS
@@ -404,6 +417,9 @@ struct NrGemmTile {
         const __amdgpu_buffer_rsrc_t rt_bh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(sg[SEC].b_hi), 0, sg[SEC].b_rows * K * 2, 0x00020000);
         const __amdgpu_buffer_rsrc_t rt_al = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X3 ? sg[SEC].a_lo : sg[SEC].a_hi), 0, sg[SEC].a_rows * K * 2, 0x00020000);
         const __amdgpu_buffer_rsrc_t rt_bl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X3 ? sg[SEC].b_lo : sg[SEC].b_hi), 0, sg[SEC].b_rows * K * 2, 0x00020000);
+        // (three passes: the lo halves as operands of their own, slices [KS, 2 KS) = Ah Bl, [2 KS, 3 KS) = Al Bh)
+        const __amdgpu_buffer_rsrc_t r3_al = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ACC3 ? sg[0].a_lo : sg[0].a_hi), 0, sg[0].a_rows * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r3_bl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ACC3 ? sg[0].b_lo : sg[0].b_hi), 0, sg[0].b_rows * K * 2, 0x00020000);
         const int a_row0 = sg[0].a_row0, b_row0 = sg[0].b_row0, a_row1 = sg[SEC].a_row0, b_row1 = sg[SEC].b_row0;
         const int row_off = (lane >> 3) * K * 2;
         // slot s of a group-1 wave: B piece BS wc + s (s < PC1 + PA1); of a group-0 wave: s < NA_P/4: A piece
@@ -426,9 +442,11 @@ struct NrGemmTile {
             constexpr int G = decltype(g_c)::value, S0 = decltype(s0_c)::value, S1 = decltype(s1_c)::value;
             char* st = smem + (kt & 1) * STAGE_BYTES;
             const bool second = NSEG > 1 && kt >= KS;         // slice of the second tile (wave-uniform)
-            const int kb = (second ? kt - KS : kt) * BK * 2;
+            const int pass = ACC3 ? (kt >= 2 * KS ? 2 : (kt >= KS ? 1 : 0)) : 0;      // (wave-uniform)
+            const int kb = (ACC3 ? kt - pass * KS : (second ? kt - KS : kt)) * BK * 2;
             const int ar0 = second ? a_row1 : a_row0, br0 = second ? b_row1 : b_row0;
-            const __amdgpu_buffer_rsrc_t r_ah = second ? rt_ah : rs_ah, r_bh = second ? rt_bh : rs_bh;
+            const __amdgpu_buffer_rsrc_t r_ah = ACC3 ? (pass == 2 ? r3_al : rs_ah) : (second ? rt_ah : rs_ah);
+            const __amdgpu_buffer_rsrc_t r_bh = ACC3 ? (pass == 1 ? r3_bl : rs_bh) : (second ? rt_bh : rs_bh);
             const __amdgpu_buffer_rsrc_t r_al = second ? rt_al : rs_al, r_bl = second ? rt_bl : rs_bl;
             nr_static_for<S0, S1>([&](auto s_c) {
                 constexpr int s_ = decltype(s_c)::value;

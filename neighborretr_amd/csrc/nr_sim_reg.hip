@@ -75,8 +75,9 @@ __device__ __forceinline__ float nr_lanes_sum(float v) {
 // RT > 1 (TPS = 16 only: the strip is in memory order): a wave strip of 16*MI rows holds RT texts one behind the other, text
 // rt in sub-tiles [rt*MI/RT, (rt+1)*MI/RT) -- twice the rows per wave for the same columns, i.e. the operand bytes per MFMA of
 // the 192 x 384 blocks at 64 x 64 tokens: 256 x 256 blocks = 4 texts x 4 videos on 2 x 4 waves of 128 x 64 (MI, NI = 8, 4).
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false, int RT = 1>
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false, int RT = 1, bool P3 = false>
 __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int bid, char* smem) {
+    static_assert(!P3 || (PP && !X3), "three accumulated passes run on the one-pass tile's ping-pong loop");
     using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES, WC>;
     static_assert(MI % RT == 0 && (RT == 1 || TPS == 16), "texts stacked in a wave strip: whole sub-tiles each, strip in memory order");
     constexpr int MIE = MI / RT;                      // sub-tiles per text
@@ -292,7 +293,8 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
 
     // (group 0's pooling inside the loop's last phase, beside group 1's final MFMAs, was built and measured: 16.2 / 15.8 us
     // against 16.1 / 15.4 for the bank products -- nothing; the epilogue stays behind the loop.)
-    if constexpr (PP) tile.run_pp(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
+    if constexpr (P3) tile.run_pp3(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
+    else if constexpr (PP) tile.run_pp(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem);
     else tile.run(p.t_hi, p.t_lo, row0, p.A * Nt, p.v_hi, p.v_lo, col0, p.Bv * Nv, p.K, smem, rot, p.dma_front != 0);
     pool();
 #ifdef NR_STAMP
@@ -335,10 +337,10 @@ __device__ __forceinline__ void nr_sim_reg_body(const NrSimRegArgs& p, const int
     }
 }
 
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false, int RT = 1>
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false, int RT = 1, bool P3 = false>
 __global__ __launch_bounds__(128 * WC) void nr_sim_reg_kernel(NrSimRegArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    nr_sim_reg_body<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC, PP, RT>(p, blockIdx.x, smem);
+    nr_sim_reg_body<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC, PP, RT, P3>(p, blockIdx.x, smem);
 }
 
 // ---- two chained tiles per workgroup (the step's two bank products) ---------------------------------------------------
@@ -504,10 +506,10 @@ __global__ __launch_bounds__(512) void nr_sim_group_kernel(NrSimGroup g) {
     else nr_sim_reg_body<3, 3, 8, 4, true, false, 2, 4, true>(g.p[k], b - g.first[k], smem);
 }
 
-template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false, int RT = 1>
+template <int MI, int NI, int TPS, int FPS, bool X3, bool ARGS, int STAGES, int WC, bool PP = false, int RT = 1, bool P3 = false>
 static int nr_sim_reg_launch_s(NrSimRegArgs& a, hipStream_t st) {
     using Tile = NrGemmTile<MI, NI, X3, TPS, FPS, STAGES, WC>;
-    auto kern = nr_sim_reg_kernel<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC, PP, RT>;
+    auto kern = nr_sim_reg_kernel<MI, NI, TPS, FPS, X3, ARGS, STAGES, WC, PP, RT, P3>;
     size_t lds = Tile::RING_BYTES;
     if constexpr (MI * NI >= 32)          // the block's token weights, parked behind the ring (LATE_W in the kernel)
         lds += sizeof(float) * (2 * (16 / TPS) * MI * TPS + WC * (16 / FPS) * NI * FPS);
@@ -593,7 +595,10 @@ static int nr_sim_reg_big(int A, int Nt, int Bv, int Nv, int prec) {
     if (Nt == 64 && Nv == 64) {       // 4: 128 x 256 blocks (2 texts x 4 videos) on 8 waves, once they fill the chip
         const char* e64 = nr_tune_env("NR_SIM_BIG");
         if (e64 && atoi(e64) == 0) return 0;
-        if (prec == NR_PREC_BF16X3) return 0;             // split-bf16 would run a 1-stage ring there: measured slower
+        // split-bf16: its own tile would run a 1-stage ring on the 128 x 256 block (measured slower) -- but the ONE-PASS 256 x 256
+        // block takes it as three accumulated passes over K (NrGemmTile::run_pp3).  NR_SIM_BIG=4: the small blocks (A/B hook)
+        if (prec == NR_PREC_BF16X3)
+            return (!(e64 && atoi(e64) == 4) && (A % 4) == 0 && (long)(A / 4) * ((Bv + 3) / 4) >= 256) ? 5 : 0;
         // 5: 256 x 256 blocks (4 texts x 4 videos, two texts per wave strip) once THEY fill the chip: the operand bytes per
         // MFMA of the 192 x 384 blocks of the 24 x 12 shape.  NR_SIM_BIG=4 keeps the 128 x 256 blocks (A/B hook)
         if (!(e64 && atoi(e64) == 4) && (A % 4) == 0 && (long)(A / 4) * ((Bv + 3) / 4) >= 256) return 5;
@@ -644,8 +649,11 @@ int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16
         return args ? nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, false, true>(a, st)                      \
                     : nr_sim_reg_launch<MI_, NI_, TPS_, FPS_, false, false>(a, st);                    \
     }
-    if (nr_sim_reg_big(A, Nt, Bv, Nv, prec) == 5) {     // 64 x 64 tokens, 256 x 256 blocks on 2 x 4 waves (one bf16 pass only)
+    if (nr_sim_reg_big(A, Nt, Bv, Nv, prec) == 5) {     // 64 x 64 tokens, 256 x 256 blocks on 2 x 4 waves
         nr_sim_reg_plan<8, 4, 16, 16, 4, 2>(a);
+        if (x3)       // split-bf16 as three accumulated passes on the one-pass tile
+            return args ? nr_sim_reg_launch_s<8, 4, 16, 16, false, true, 2, 4, true, 2, true>(a, st)
+                        : nr_sim_reg_launch_s<8, 4, 16, 16, false, false, 2, 4, true, 2, true>(a, st);
         return args ? nr_sim_reg_launch_s<8, 4, 16, 16, false, true, 2, 4, true, 2>(a, st)
                     : nr_sim_reg_launch_s<8, 4, 16, 16, false, false, 2, 4, true, 2>(a, st);
     }

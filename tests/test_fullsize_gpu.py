@@ -175,6 +175,39 @@ def test_diag_ranks_at_1000():
         assert mine[k] == ref[k]
 
 
+@pytest.mark.parametrize("A,Bv", [(64, 64), (128, 128), (128, 70)])
+def test_split_bf16_64_token_products_on_the_one_pass_blocks(A, Bv):
+    """Split-bf16 products of 64 x 64-token samples (configs[3]'s batch x batch product, ActivityNet evaluation) run the ONE-PASS
+    256 x 256 blocks as three accumulated passes over K -- Ah Bh, then Ah Bl, then Al Bh (NrGemmTile::run_pp3) -- once those
+    fill the chip.  Same three products as the split tile adds up slice by slice, another summation order: against the small
+    blocks (a few texts alone) within 1e-6, against fp64 within 2e-6; row / column means; training form's pooled maxima."""
+    N = 64
+    t, tm, wt = _tokens(51, A, N)
+    v, vm, wv = _tokens(52, Bv, N)
+    pt, pv = ops.prepare_tokens(t, tm), ops.prepare_tokens(v, vm)
+    X3 = hip.PREC_BF16X3
+    assert hip.local_level_tiles(A, N, Bv, N, X3) == (A // 4, (Bv + 3) // 4)
+    S, _ = ops.local_level(pt, pv, wt, wv, A, N, Bv, N, X3)
+    Sa, aux = ops.local_level(pt, pv, wt, wv, A, N, Bv, N, X3, want_arg=True)
+    assert torch.equal(S, Sa) and torch.isfinite(S).all()
+    for a0 in (0, A // 2 + 1, A - 2):
+        sub = ops.prepare_tokens(t[a0:a0 + 2].contiguous(), tm[a0:a0 + 2].contiguous())
+        assert hip.local_level_tiles(2, N, Bv, N, X3)[0] == 1                                         # the split tile's own blocks
+        S2, aux2 = ops.local_level(sub, pv, wt[a0:a0 + 2].contiguous(), wv, 2, N, Bv, N, X3, want_arg=True)
+        assert maxdiff(S2, S[a0:a0 + 2]) < 1e-6, a0
+        assert maxdiff(aux2[2], aux[2][a0:a0 + 2]) < 1e-6 and maxdiff(aux2[3], aux[3][a0:a0 + 2]) < 1e-6       # pooled maxima
+    rs, _ = ops.local_level(pt, pv, wt, wv, A, N, Bv, N, X3, hip.OUT_ROWSUM)
+    cs, _ = ops.local_level(pt, pv, wt, wv, A, N, Bv, N, X3, hip.OUT_COLSUM)
+    assert maxdiff(ops.reduce_parts(rs, 1.0 / Bv), S.double().mean(1)) < 1e-6
+    assert maxdiff(ops.reduce_parts(cs, 1.0 / A), S.double().mean(0)) < 1e-6
+    ia, ib = torch.tensor([0, 1, A // 2, A - 1]), torch.tensor([0, Bv // 3, Bv - 1])
+    tn = torch.nn.functional.normalize(t[ia].cpu().double(), dim=-1) * tm[ia].cpu().double()[..., None]
+    vn = torch.nn.functional.normalize(v[ib].cpu().double(), dim=-1) * vm[ib].cpu().double()[..., None]
+    R = torch.einsum("atd,bvd->abtv", tn, vn)
+    ref = 0.5 * ((R.max(-1)[0] * wt[ia].cpu().double()[:, None]).sum(-1) + (R.max(-2)[0] * wv[ib].cpu().double()[None]).sum(-1))
+    assert maxdiff(S[ia][:, ib], ref) < 2e-6
+
+
 @pytest.mark.parametrize("B,M,all_groupable", [(128, 512, True), (130, 520, True), (256, 1024, False)])
 def test_grouped_products_equal_the_single_launches(B, M, all_groupable):
     """nr_local_level_group: the step's three products (two bank products in bf16, batch x batch in split-bf16) in one grid

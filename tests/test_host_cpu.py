@@ -184,7 +184,8 @@ def test_tile_query_no_gpu_needed():
     assert hip.local_level_tiles(128, 24, 128, 12) == (32, 16)      # 4 texts x 8 videos per 96x96 block
     assert hip.local_level_tiles(128, 64, 1024, 64) == (32, 256)    # one pass: 4 x 4 per 256x256 block on 8 waves (two texts per wave strip)
     assert hip.local_level_tiles(130, 64, 1024, 64) == (65, 256)    # ... 2 x 4 per 128x256 block when the texts do not come in fours
-    assert hip.local_level_tiles(128, 64, 1024, 64, hip.PREC_BF16X3) == (64, 512)    # split-bf16: 2 x 2 per 128x128 block
+    assert hip.local_level_tiles(128, 64, 1024, 64, hip.PREC_BF16X3) == (32, 256)    # split-bf16: the same blocks, three accumulated passes
+    assert hip.local_level_tiles(6, 64, 10, 64, hip.PREC_BF16X3) == (3, 5)           # ... too few of them: 2 x 2 per 128x128 split block
     assert hip.local_level_tiles(128, 24, 512, 12, hip.PREC_BF16) == (16, 16)      # bank product: 8 x 32 per 192x384 block
     assert hip.local_level_tiles(128, 24, 512, 12, hip.PREC_BF16X3) == (16, 32)    # split-bf16: 8 x 16 per 192x192 block
     with pytest.raises(hip.NrHipError):
