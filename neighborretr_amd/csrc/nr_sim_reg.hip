@@ -611,6 +611,9 @@ static int nr_sim_reg_big(int A, int Nt, int Bv, int Nv, int prec) {
     const int env = e ? atoi(e) : -1;
     if (env >= 0 && env <= 2) cap = std::min(cap, env);
     const long wg3 = (long)((A + 3) / 4) * ((Bv + 15) / 16);
+    // split-bf16 once the 192 x 384 blocks fill the chip: those ONE-PASS blocks, three accumulated passes over K (run_pp3) -- the
+    // split tile's own largest block there (192 x 192) runs a one-deep ring.  NR_SIM_BIG=1 keeps the latter (A/B hook)
+    if (x3 && env < 0 && (long)((A + 7) / 8) * ((Bv + 31) / 32) >= 256) return 2;
     if (x3 && env == 3 && wg3 >= 256) return 3;
     // (96 x 192 on the two-stage ping-pong loop only while the 192 x 192 blocks would not fill the chip: at B = 1024 the latter win
     // although they can only run a ONE-stage ring -- batch x batch product of configs[2] 1372 us against ~1510, step 2.638 vs
@@ -666,6 +669,12 @@ int nr_sim_reg_dispatch(const uint16_t* t_hi, const uint16_t* t_lo, const uint16
         if (const char* e = nr_tune_env("NR_SIM_X3PP"); !(e && atoi(e) == 0) && d >= 128)
             return args ? nr_sim_reg_launch<3, 3, 8, 4, true, true, 4>(a, st) : nr_sim_reg_launch<3, 3, 8, 4, true, false, 4>(a, st);
         return args ? nr_sim_reg_launch<3, 6, 8, 2, true, true, 2>(a, st) : nr_sim_reg_launch<3, 6, 8, 2, true, false, 2>(a, st);
+    }
+    if (nr_sim_reg_big(A, Nt, Bv, Nv, prec) == 2 && x3) {     // ... split-bf16: three accumulated passes on the one-pass blocks
+        if (d < 128) return NR_EUNSUPPORTED;
+        nr_sim_reg_plan<6, 6, 4, 2, 4>(a);
+        return args ? nr_sim_reg_launch_s<6, 6, 4, 2, false, true, 2, 4, true, 1, true>(a, st)
+                    : nr_sim_reg_launch_s<6, 6, 4, 2, false, false, 2, 4, true, 1, true>(a, st);
     }
     if (nr_sim_reg_big(A, Nt, Bv, Nv, prec) == 2) {     // 24 x 12 tokens, 192 x 384 blocks on 2 x 4 waves
         return args ? nr_sim_reg_launch<6, 6, 4, 2, false, true, 4>(a, st) : nr_sim_reg_launch<6, 6, 4, 2, false, false, 4>(a, st);
