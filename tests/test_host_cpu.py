@@ -187,7 +187,7 @@ def test_tile_query_no_gpu_needed():
     assert hip.local_level_tiles(128, 64, 1024, 64, hip.PREC_BF16X3) == (32, 256)    # split-bf16: the same blocks, three accumulated passes
     assert hip.local_level_tiles(6, 64, 10, 64, hip.PREC_BF16X3) == (3, 5)           # ... too few of them: 2 x 2 per 128x128 split block
     assert hip.local_level_tiles(128, 24, 512, 12, hip.PREC_BF16) == (16, 16)      # bank product: 8 x 32 per 192x384 block
-    assert hip.local_level_tiles(128, 24, 512, 12, hip.PREC_BF16X3) == (16, 32)    # split-bf16: 8 x 16 per 192x192 block
+    assert hip.local_level_tiles(128, 24, 512, 12, hip.PREC_BF16X3) == (16, 16)    # split-bf16: the same blocks, three accumulated passes
     with pytest.raises(hip.NrHipError):
         hip.local_level_tiles(4, 200, 4, 12)                         # > 128 tokens per sample: unsupported
 
