@@ -200,6 +200,9 @@ int mlp_launch(const NrMlpProblem& q, hipStream_t st, const NrMlpProblem* second
     if (lds < epi) lds = epi;
     const int grid_a = nr_xcd_chunk_grid((q.H / Tile::BN) * ((q.n_tok + Tile::BM - 1) / Tile::BM));
     if (second) {
+        // (pairs pay only for crowded grids -- a one-deep ring on 4-wave blocks: the other forms are not built)
+        if constexpr (!(WC == 2 && STAGES == 1)) return NR_EUNSUPPORTED;
+        else {
         auto kern = nr_mlp_pair_kernel<MI, NI, WC, X3, STAGES>;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -209,6 +212,7 @@ int mlp_launch(const NrMlpProblem& q, hipStream_t st, const NrMlpProblem* second
         hipLaunchKernelGGL(kern, dim3(grid_a + grid_b), dim3(128 * WC), lds, st, q, *second, grid_a);
         NR_LAUNCH_CHECK();
         return NR_OK;
+        }
     }
     auto kern = nr_mlp_kernel<MI, NI, WC, X3, STAGES>;
     if (lds > 64 * 1024) {

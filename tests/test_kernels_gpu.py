@@ -62,12 +62,12 @@ def test_token_weights(prec, tol):
         assert maxdiff(logits.cpu()[valid], lg_ref[valid]) < tol * 10
 
 
-@pytest.mark.parametrize("B,Nt,Nv,prec", [(128, 24, 12, hip.PREC_BF16X3), (128, 24, 12, hip.PREC_BF16), (16, 24, 12, hip.PREC_BF16X3),
-                                          (8, 64, 64, hip.PREC_BF16X3), (5, 7, 24, hip.PREC_BF16X3)])
+@pytest.mark.parametrize("B,Nt,Nv,prec", [(512, 24, 12, hip.PREC_BF16X3), (128, 64, 64, hip.PREC_BF16X3), (128, 24, 12, hip.PREC_BF16X3),
+                                          (128, 24, 12, hip.PREC_BF16), (5, 7, 24, hip.PREC_BF16X3)])
 def test_token_weights_pair_equals_the_two_launches(B, Nt, Nv, prec):
     """nr_token_weights_fwd_pair (the step's text and video scorers in one grid) against the two nr_token_weights_fwd launches:
-    identical bits, masks included; counters left zeroed.  (5, 7, 24): the two problems pick different block shapes -- the
-    entry point refuses, ops.token_weights_pair falls back to the single launches."""
+    identical bits, masks included; counters left zeroed.  Built for crowded grids only (4-wave blocks on a one-deep ring: the
+    first two cases); otherwise the entry point refuses and ops.token_weights_pair falls back to the single launches."""
     x = problem(1001 + B, B, Nt, Nv, 16)
     Pg = {k: v.to(DEV) for k, v in params().items()}
     tm, vm = x["text_mask"].to(DEV), x["video_mask"].to(DEV)
@@ -83,7 +83,7 @@ def test_token_weights_pair_equals_the_two_launches(B, Nt, Nv, prec):
     n0 = hip.N_CALLS
     (w_t, _), (w_v, _) = ops.token_weights_pair(calls, prec)
     torch.cuda.synchronize()
-    if (B, Nt, Nv) != (5, 7, 24):
+    if (B, Nt, Nv) in ((512, 24, 12), (128, 64, 64)):
         assert hip.N_CALLS - n0 == 1
     assert torch.equal(w_t, single[0]) and torch.equal(w_v, single[1])
     assert maxdiff(w_t, _tw(pt, tm, Pg, "text_weight_fc", B, Nt, prec)[0]) < 1e-5
