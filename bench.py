@@ -254,13 +254,15 @@ def parity_gates(model, dev):
     path.  The reference's cols are recomputed here from ITS similarity matrix with its own three numpy lines."""
     from neighborretr_amd import head, synth
     from neighborretr_amd.metrics import RetrievalMetrics
+    c = CFG
+    if (c["B"], c["Nt"]) != (128, 24):
+        return parity_gates_full_size(model, dev)        # --config 2 / 3: the reduced full-size fixtures
     path = os.path.join(ROOT, "tests", "golden", "c2_b128.npz")
     if not os.path.exists(path):
         return None
     g = np.load(path)
-    c = CFG
     if (int(g["B"]), int(g["Nt"]), int(g["Nv"]), int(g["M"]), int(g["K"])) != (c["B"], c["Nt"], c["Nv"], c["M"], c["K"]):
-        return None                          # --config 2 / 3: the reference fixture is of configs[1]
+        return None
     assert (int(g["B"]), int(g["Nt"]), int(g["Nv"]), int(g["M"]), int(g["K"])) == (c["B"], c["Nt"], c["Nv"], c["M"], c["K"])
     prob = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_problem(int(g["seed"]), c["B"], c["Nt"], c["Nv"], c["M"]).items()}
     nz = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_noise(int(g["seed"]), c["B"], c["Nt"], c["Nv"]).items()}
@@ -287,6 +289,63 @@ def parity_gates(model, dev):
             "losses": [round(float(x), 5) for x in losses], "ref_losses": [round(float(x), 5) for x in g["losses"]],
             "cols_identical": bool(np.array_equal(np.asarray(mine["cols"]), ref_cols)),
             "R1": mine["R1"], "tol_losses": 1e-3, "pass": bool(dL.max() < 1e-3 and np.array_equal(np.asarray(mine["cols"]), ref_cols))}
+
+
+def parity_gates_full_size(model, dev):
+    """The same gates at configs[2] / configs[3]: one extra UN-TIMED step on the inputs of the full-size reference fixtures
+    (tests/golden/c3_b1024.npz: B=1024; c4_b128_full.npz: ActivityNet token counts, M=1024 -- outputs of the unmodified
+    reference, oracle/capture_golden_large.py).  The fixtures hold reduced forms of the big matrices (row / column sums,
+    diagonal, a 64 x 64 corner) plus the losses and `cols`.  At configs[3] the reference's centrality term raises
+    (until_module.py:321): the three terms it does evaluate are compared, the other two are reported as unpinned."""
+    from neighborretr_amd import head, synth
+    from neighborretr_amd.metrics import RetrievalMetrics
+    c = CFG
+    name = "c3_b1024" if c["Nt"] == 24 else "c4_b128_full"
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if (int(g["B"]), int(g["Nt"]), int(g["Nv"]), int(g["M"]), int(g["K"])) != (c["B"], c["Nt"], c["Nv"], c["M"], c["K"]):
+        return None
+    prob = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_problem(int(g["seed"]), c["B"], c["Nt"], c["Nv"], c["M"]).items()}
+    nz = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_noise(int(g["seed"]), c["B"], c["Nt"], c["Nv"]).items()}
+    cfg = model.config
+    with torch.no_grad():
+        losses = torch.stack(model._compute_losses(
+            prob["text_feat"], prob["video_feat"], prob["text_mask"], prob["video_mask"], prob["mb_feat_t"], prob["mb_feat_v"],
+            prob["mb_mask_t"], prob["mb_mask_v"], cfg.centrality_scale, cfg.beta, c["K"], cfg.temperature,
+            torch.tensor(100.0, device=dev), noise=nz)).cpu().numpy()
+        sw_t, sw_v = model.scorer_weights("text_weight_fc"), model.scorer_weights("video_weight_fc")
+        p_bb = head.precision_plan(model._prec())[0]
+        S_plan = head.similarity_matrix(prob["text_feat"], prob["video_feat"], prob["text_mask"].float(),
+                                        prob["video_mask"].float(), sw_t, sw_v, p_bb)
+        S_exact, _ = model.get_similarity_logits(prob["text_feat"], prob["video_feat"], prob["text_mask"], prob["video_mask"])
+        mine = RetrievalMetrics.compute_metrics(S_exact)
+
+    def corner_diag(S):
+        S = S.double().cpu()
+        return max(float((S[:64, :64] - torch.from_numpy(g["S_corner"]).double()).abs().max()),
+                   float((torch.diagonal(S) - torch.from_numpy(g["S_diag"]).double()).abs().max()))
+
+    def sums(S):
+        S = S.double().cpu()
+        return max(float((S.sum(1) - torch.from_numpy(g["S_rowsum"])).abs().max()), float((S.sum(0) - torch.from_numpy(g["S_colsum"])).abs().max()))
+    cols_same = bool(np.array_equal(np.asarray(mine["cols"]), g["cols"]))
+    out = {"fixture": f"tests/golden/{name}.npz (reference outputs on this workload; reduced forms of the {c['B']} x {c['B']} matrices)",
+           "max_dS_corner_and_diagonal": corner_diag(S_plan), "max_dS_corner_and_diagonal_rank_exact_path": corner_diag(S_exact),
+           "max_d_rowcol_sums_rank_exact_path": sums(S_exact), "cols_identical": cols_same, "R1": mine["R1"], "tol_losses": 1e-3,
+           "losses": [round(float(x), 5) for x in losses], "dL_order": ["total", "centrality", "uniform", "neighbor", "kl"]}
+    if "losses" in g:
+        dL = np.abs(losses - g["losses"])
+        out.update(dL=[float(f"{x:.3e}") for x in dL], ref_losses=[round(float(x), 5) for x in g["losses"]])
+    else:
+        dL = np.abs(losses[2:] - np.array([float(g["L_uniform_direct"]), float(g["L_neighbor_direct"]), float(g["L_kl_direct"])]))
+        out.update(dL=[None, None] + [float(f"{x:.3e}") for x in dL],
+                   ref_losses=[None, None] + [round(float(g[k]), 5) for k in ("L_uniform_direct", "L_neighbor_direct", "L_kl_direct")],
+                   unpinned="total and centrality: the reference raises on 3 / 6 global tokens per sample (until_module.py:321); the "
+                            "step runs config.centrality_multi_token='mean'")
+    out["pass"] = bool(dL.max() < 1e-3 and cols_same)
+    return out
 
 
 def e2e_bench(dev, B=128, steps=5):

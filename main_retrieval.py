@@ -359,11 +359,16 @@ class GraphedStep:
                 seg.replay()
             return replay_pass, seg
         freeze = lambda on: setattr(model, "bank_frozen", on)      # noqa: E731
+        # the validation passes pin the DPC-KNN noise counter to one value; the run continues from where it stood before them
+        # (otherwise every re-capture -- one per epoch -- restarts the same noise sequence and a --hip_graph 1 run diverges
+        # from the eager run with the same seed)
+        rng_before = rng.clone()
         form = self.cc.attempt("whole-step", eager_pass, whole, result, same, freeze) if self.backend == "nccl" else None
         self.form = "whole"
         if form is None:
             form = self.cc.attempt("segmented", eager_pass, segmented, result, same, freeze)
             self.form = "segmented"
+        rng.copy_(rng_before)
         if form is None:
             self.form, self.replay, self.keep = "eager", step, None
         else:

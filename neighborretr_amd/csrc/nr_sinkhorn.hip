@@ -18,6 +18,7 @@
 // and a = b = 1, so nothing can overflow.
 // B > 128: the matrix stays in L2/MALL; one launch per half-iteration (wave per row, coalesced),
 // the column pass running on a transposed copy held in the workspace (log domain throughout).
+#include <atomic>
 #include <cstdlib>
 #include "nr_common.h"
 #include "nr_finalize.h"
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(512) void nr_sinkhorn_coop_kernel(NrSkCoopArgs p) {
     unsigned int* dead_flag = p.counter + 16;         // shared by both directions: one timeout ends every workgroup of the launch
     __shared__ int s_dead;
     if (tid == 0) s_dead = 0;
+    __syncthreads();                                  // every wave reads s_dead at the top of its first barrier(): LDS is not zeroed between workgroups
     const float norm = -logf((float)(2 * B));
     const float mass = 1.0f / (float)(2 * B);
     // X[i][j] = G[i][j] (dir 0) or G[j][i] (dir 1);  pr(q, e) = X[line q][64 e + lane],  pc(q, e) = X[64 e + lane][line q]
@@ -509,20 +511,27 @@ extern "C" int nr_sinkhorn_cooperative_gate(int B, int blocks_per_cu, int n_cus,
 // form (B outside 192..1024 / not a multiple of 64, or the device cannot hold a direction's workgroups together: a CU-masked
 // or partitioned device).  Queried once per B (occupancy of the kernel variant x the device's CU count).
 extern "C" int nr_sinkhorn_cooperative_ok(int B) {
-    static int cache[17];                              // by B / 64: 0 unknown, 1 no, 2 yes
+    // by device and B / 64: 0 unknown, 1 no, 2 yes.  Per DEVICE: the occupancy answer and the dynamic-LDS grant
+    // (hipFuncSetAttribute applies to the current device's copy of the kernel) are both per device.  Words are written
+    // whole with the same value by whoever asks first: two host threads racing here compute the same answer.
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> cache[kMaxDev][17];
     if (B <= 128 || B > 1024 || (B % 64) != 0) return 0;
-    int& c = cache[B / 64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+    std::atomic<int>* slot = dev < kMaxDev ? &cache[dev][B / 64] : nullptr;
+    int c = slot ? slot->load(std::memory_order_acquire) : 0;
     if (c == 0) {
-        int dev = 0, cus = 0, per_cu = 0;
+        int cus = 0, per_cu = 0;
         const void* fn = nr_sinkhorn_coop_fn(B);
         const size_t lds = nr_sinkhorn_coop_lds(B);
-        bool ok = fn && hipGetDevice(&dev) == hipSuccess &&
-                  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        bool ok = fn && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
                   (lds <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
                   hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, lds) == hipSuccess;
         // MI355X in SPX mode: 256 CUs in 8 XCDs; a partition / mask reports fewer CUs and is priced as ONE XCD's worth per 32
         const int n_xcd = cus >= 64 ? 8 : 1;
         c = (ok && nr_sinkhorn_cooperative_gate(B, per_cu, cus, n_xcd)) ? 2 : 1;
+        if (slot) slot->store(c, std::memory_order_release);
     }
     return c == 2;
 }

@@ -55,6 +55,15 @@ class OverlappedOwnedStep:
                                torch.cuda.Event(), torch.cuda.Event(), slot.stream))
         self.turn = 0
         self.pending = [False] * n
+        # B > 128 solves Sinkhorn as ONE cooperative launch whose workgroups of a direction must all be resident together
+        # (nr_sinkhorn_coop_kernel).  The host gate prices that for a launch that has the XCDs to itself: two loss halves on two
+        # streams could each hold part of the CUs and starve each other until the bounded spin gives up (NaN losses).  So the
+        # loss halves of such a batch run one BEHIND the other (an event edge between consecutive loss halves, whatever their
+        # slot); they still run beside the exchange halves, which have no solve.
+        from . import hip
+        B_glob = int(self.slots[0].batch[0].shape[0]) if self.slots else 0
+        self.serial_losses = bool(B_glob > 128 and hip.lib().nr_sinkhorn_cooperative_ok(B_glob))
+        self._last_loss = None
         self.losses = self.pairs[0][2]             # of the LAST replayed owned step (valid once its loss half has finished)
 
     @property
@@ -76,9 +85,12 @@ class OverlappedOwnedStep:
         A.replay()
         ev_a.record(cur)
         side.wait_event(ev_a)
+        if self.serial_losses and self._last_loss is not None and self._last_loss is not ev_b:
+            side.wait_event(self._last_loss)       # the previous loss half (another slot's stream) has finished its solve
         with torch.cuda.stream(side):
             B.replay()
             ev_b.record(side)
+        self._last_loss = ev_b
         self.pending[k] = True
         self.losses = losses
 

@@ -1018,6 +1018,8 @@ class NeighborRetr(nn.Module):
                 self._head_slot(k, ring[0])
             for k in range(int(n_steps)):          # (allocated inside the capture, each would cost a fill node on the origin stream)
                 ops.split_tail_counter(ring[0].device, k)
+        from . import streams
+        streams.reserve(8 * int(n_steps) + 8)      # a pipelined step forks up to seven streams: none is created while the capture is open
 
     def _pipeline_for_head(self, device):
         """The installed StepPipeline with its tail stream resolved (None: steps are not being captured overlapped)."""

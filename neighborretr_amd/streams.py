@@ -47,9 +47,22 @@ def _retire_old(current_cid):
 
 def _fresh_raw_stream():
     if STATS["created"] >= MAX_LIVE and _RETIRED:
+        if STATS["reused"] == 0:
+            import warnings
+            warnings.warn(f"neighborretr_amd.streams: {MAX_LIVE} capture streams exist; the oldest retired ones are handed to new "
+                          "captures from here on (see the module docstring: the condition earlier runtime crashes had in common)")
         STATS["reused"] += 1
         return _RETIRED.pop(0)
     return _new_raw_stream()
+
+
+def reserve(n):
+    """Tops the spare list up to `n` streams NOW (eager code): a capture that forks many streams -- a pipelined capture of U
+    loss-only steps forks ~7 U -- must not create streams while it is open.  Raises inside a capture."""
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("streams.reserve() inside a capture: reserve the capture's side streams before opening it")
+    while len(_SPARE) < int(n):
+        _SPARE.append(_fresh_raw_stream())
 
 
 def side(owner, name, device):

@@ -207,3 +207,24 @@ def test_multi_sentence_metrics_against_reference_vector():
     assert np.allclose([t2v[k] for k in keys_t], g["t2v"], rtol=1e-6)
     assert np.array_equal(np.array(v2t["cols"]), g["v2t_cols"])
     assert np.allclose([v2t[k] for k in ("R1", "R5", "R10", "R50", "MR", "MeanR")], g["v2t"])
+
+
+def test_c3_b1024_losses_at_full_size():
+    """BASELINE configs[2] (global B = 1024): the oracle's five losses and the reduced forms of its batch similarity against
+    the reference's own (oracle/capture_golden_large.py).  ~10 s of CPU."""
+    g = golden("c3_b1024")
+    B, Nt, Nv, M, K = (int(g[k]) for k in ("B", "Nt", "Nv", "M", "K"))
+    x, P, nz = problem(int(g["seed"]), B, Nt, Nv, M), params(int(g["param_seed"])), noise(int(g["seed"]), B, Nt, Nv)
+    hp = dict(synth.DEFAULT_HP, num_neighbors=K)
+    with torch.no_grad():
+        losses, parts = O.compute_losses(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"], x["mb_feat_t"],
+                                         x["mb_feat_v"], x["mb_mask_t"], x["mb_mask_v"], P, hp, torch.tensor(100.0), nz,
+                                         return_parts=True)
+    assert maxdiff(torch.stack(losses), g["losses"]) < 1e-4
+    S, G = parts["S"].double(), parts["G"].double()
+    assert maxdiff(S.sum(1), g["S_rowsum"]) < 1e-4 and maxdiff(S.sum(0), g["S_colsum"]) < 1e-4
+    assert maxdiff(torch.diagonal(S), g["S_diag"]) < TOL and maxdiff(S[:64, :64], g["S_corner"]) < TOL
+    assert maxdiff(G[:64, :64], g["G_corner"]) < 1e-3 * float(np.abs(g["G_corner"]).max())
+    assert maxdiff(parts["bank_t2v"].mean(-1), g["bank_c_t2v"]) < TOL and maxdiff(parts["bank_v2t"].mean(-1), g["bank_c_v2t"]) < TOL
+    ref = O.compute_metrics(parts["S"].numpy())
+    assert np.array_equal(np.asarray(ref["cols"]), g["cols"])
