@@ -580,6 +580,39 @@ class GlobalLogitsFn(torch.autograd.Function):
         return (dG @ b).reshape(ctx.shapes[0]), (dG.t() @ a).reshape(ctx.shapes[1])
 
 
+class GlobalLevelMultiFn(torch.autograd.Function):
+    """global_level with SEVERAL global tokens per sample (ActivityNet token counts; modeling.py:516-539): the fused product on
+    the un-normalised global tokens with the softmax weights of the *_weight_fc1 scorers, no masks.  Backward: arg-max-routed
+    token gradients (nr_local_level_bwd), softmax and scorer-MLP backward -- the arithmetic of the loss head's own multi-token
+    branch (_global_backward), as a node of its own for the public `NeighborRetr.global_level`."""
+
+    @staticmethod
+    def forward(ctx, model, gt, gv, w1t, b1t, w2t, b2t, w1v, b1v, w2v, b2v):
+        G, saved = head.global_logits(gt.detach().float().contiguous(), gv.detach().float().contiguous(),
+                                      model.scorer_weights("text_weight_fc1"), model.scorer_weights("video_weight_fc1"), keep=True)
+        ctx.st = saved
+        ctx.save_for_backward(gt, gv, w1t, b1t, w2t, w1v, b1v, w2v)
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        gs_ = ctx.st
+        gt, gv, w1t, b1t, w2t, w1v, b1v, w2v = ctx.saved_tensors
+        B, Gt, d = gt.shape
+        Bv, Gv, _ = gv.shape
+        dG = dG.float().contiguous()
+        gt2, gv2 = gt.detach().float().contiguous(), gv.detach().float().contiguous()
+        d_gt, d_wgt = ops.local_level_bwd(0, dG, 0, 1.0, gs_["pv"], gs_["w_t"], gs_["w_v"], gs_["aux"], B, Gt, Bv, Gv, use_lo=True)
+        d_gv, d_wgv = ops.local_level_bwd(1, dG, 0, 1.0, gs_["pt"], gs_["w_v"], gs_["w_t"], gs_["aux"], B, Gt, Bv, Gv, use_lo=True)
+        dl_gt = ops.token_softmax_bwd(gs_["w_t"], d_wgt.view(B, Gt))
+        dl_gv = ops.token_softmax_bwd(gs_["w_v"], d_wgv.view(Bv, Gv))
+        gW1t, gb1t, gW2t, gb2t, gXt = _mlp_backward([gt2], [dl_gt], w1t, b1t, w2t, B * Gt, True)
+        gW1v, gb1v, gW2v, gb2v, gXv = _mlp_backward([gv2], [dl_gv], w1v, b1v, w2v, Bv * Gv, True)
+        ctx.st = None
+        return (None, (d_gt.view_as(gt2) + gXt.view_as(gt2)).to(gt.dtype), (d_gv.view_as(gv2) + gXv.view_as(gv2)).to(gv.dtype),
+                gW1t, gb1t, gW2t, gb2t, gW1v, gb1v, gW2v, gb2v)
+
+
 class RowLossFn(torch.autograd.Function):
     """Raw per-row loss terms [2,4,B] with the HIP backward (used by the until_module classes)."""
 

@@ -49,14 +49,26 @@ static inline const char* nr_tune_env(const char*) { return nullptr; }
         if (e__ != hipSuccess) return (int)e__;        \
     } while (0)
 
-// round-to-nearest-even f32 -> bf16 bits (finite inputs)
+// round-to-nearest-even f32 -> bf16 bits: the plain cast, which hipcc lowers to v_cvt_pk_bf16_f32 on gfx950 (one instruction
+// where the integer form -- u += 0x7FFF + ((u >> 16) & 1) -- took five; the same bits for every finite input, and a NaN
+// stays a NaN)
 __device__ __forceinline__ uint16_t nr_f2bf(float f) {
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
 }
 __device__ __forceinline__ float nr_bf2f(uint16_t h) {
     return __builtin_bit_cast(float, ((uint32_t)h) << 16);
+}
+// two values at once: {bf16(a) in the low half, bf16(b) in the high half} -- ONE v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) float nr_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 nr_bf16x2_t;
+__device__ __forceinline__ uint32_t nr_f2bf_pk(float a, float b) {
+    const nr_f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, nr_bf16x2_t));
+}
+// split-bf16 pair of two values: hi = packed bf16(a), bf16(b); lo = packed bf16 of the remainders
+__device__ __forceinline__ void nr_split_pk(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = nr_f2bf_pk(a, b);
+    lo = nr_f2bf_pk(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xFFFF0000u));
 }
 
 // ---- cross-lane reductions on DPP (data-parallel primitives): VALU-latency steps instead of the

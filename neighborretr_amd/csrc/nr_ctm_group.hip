@@ -12,20 +12,6 @@
 #include "nr_linear.h"
 #include "../../include/nr_hip.h"
 
-template <typename A>
-struct NrGroupOf {
-    A p[NR_CTM_MAX_GROUP];
-    int start[NR_CTM_MAX_GROUP + 1];     // first workgroup of every problem
-    int n;
-    __device__ __forceinline__ int find(int wg) const {
-        int g = 0;
-#pragma unroll
-        for (int i = 1; i < NR_CTM_MAX_GROUP; ++i)
-            if (i < n && wg >= start[i]) g = i;
-        return g;
-    }
-};
-
 __global__ __launch_bounds__(256) void nr_group_shift_kernel(NrGroupOf<NrShiftArgs> g) {
     NR_CRITICAL_PATH();
     const int gi = g.find(blockIdx.x);
@@ -54,6 +40,36 @@ __global__ __launch_bounds__(THREADS) void nr_group_front_back_kernel(NrGroupOf<
     nr_ctm_back_body<true, THREADS>(gb.p[gi], b, sx);
 }
 
+// second form of the bodies (nr_ctm_bodies.h): C % 256 == 0, 512-thread workgroups (256 for a handful of tokens)
+template <int V4, int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS / 128) void nr_group_front2_kernel(NrGroupOf<NrCtmFrontArgs> g) {
+    NR_CRITICAL_PATH();
+    extern __shared__ __attribute__((aligned(16))) float sx[];
+    const int gi = g.find(blockIdx.x);
+    nr_ctm_front_body2<V4, THREADS>(g.p[gi], blockIdx.x - g.start[gi], sx);
+}
+
+// (the 16-cluster / 64-token form keeps a 64-entry distance row per lane: one workgroup per CU, up to 256 registers)
+template <int V4, int THREADS, int MAXC>
+__global__ __launch_bounds__(THREADS, MAXC <= 4 ? THREADS / 128 : THREADS / 256) void nr_group_front_back2_kernel(NrGroupOf<NrCtmFrontArgs> gf, NrGroupOf<NrCtmBackArgs> gb) {
+    NR_CRITICAL_PATH();
+    extern __shared__ __attribute__((aligned(16))) float sx[];
+    const int gi = gf.find(blockIdx.x);
+    const int b = blockIdx.x - gf.start[gi];
+    const NrCtmFrontArgs& f = gf.p[gi];
+    nr_ctm_front_body2<V4, THREADS>(f, b, sx);
+    __syncthreads();
+    nr_ctm_back_body2<true, THREADS, MAXC, (256 * V4) / THREADS, MAXC <= 4 ? 32 : 64>(gb.p[gi], b, sx, sx + (size_t)f.N * f.C, sx + (size_t)f.N * f.C + (size_t)f.N * f.N);
+}
+
+template <int THREADS, int MAXC, int CPT>
+__global__ __launch_bounds__(THREADS, MAXC <= 4 ? THREADS / 128 : THREADS / 256) void nr_group_back2_kernel(NrGroupOf<NrCtmBackArgs> g, int use_lds) {
+    NR_CRITICAL_PATH();
+    extern __shared__ __attribute__((aligned(16))) float sxn[];
+    const int gi = g.find(blockIdx.x);
+    nr_ctm_back_body2<false, THREADS, MAXC, CPT, MAXC <= 4 ? 32 : 64>(g.p[gi], blockIdx.x - g.start[gi], use_lds ? sxn : nullptr, nullptr, nullptr);
+}
+
 template <int THREADS = BK_THREADS>
 __global__ __launch_bounds__(THREADS) void nr_group_back_kernel(NrGroupOf<NrCtmBackArgs> g, int use_lds) {
     NR_CRITICAL_PATH();
@@ -80,6 +96,11 @@ __global__ __launch_bounds__(256) void nr_group_attention_heads_kernel(NrGroupOf
 }
 
 #ifdef NR_STAMP
+extern "C" int nr_debug_front_stamps(unsigned long long* host) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(nr_front_stamps), sizeof(unsigned long long) * 16);
+    return 5;
+}
 extern "C" int nr_debug_back_stamps(unsigned long long* host) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(nr_back_stamps), sizeof(unsigned long long) * 16);
@@ -221,6 +242,12 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
     //        is empty.
     bool fusable = true;
     for (int i = 0; i < n; ++i) fusable = fusable && d[i].mask == nullptr;
+    bool small_c = true;                     // (`small` below: registers sized for C <= 512 unless a problem is wider)
+    for (int i = 0; i < n; ++i) small_c = small_c && d[i].C <= 512;
+    // Stages whose back half is a launch of its own (a mask: the back half needs the maximum distance over all samples): the kv
+    // projection rides in that launch (launch 3), launch 4 is the q projection alone.  NR_KV_APART=1 (tuning builds): as before.
+    bool kv_beside_back = !(fusable && small_c) && small_c && !nr_tune_env("NR_KV_APART");
+    for (int i = 0; i < n; ++i) kv_beside_back = kv_beside_back && d[i].cnum * (d[i].C / 128) <= 8 * BK_MAXJ;
     if ((first <= 2 && 2 < last) || (first <= 3 && 3 < last)) {
         NrGroupOf<NrCtmFrontArgs> gf;
         NrGroupOf<NrCtmBackArgs> gb;
@@ -239,7 +266,64 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
         for (int i = n; i <= NR_CTM_MAX_GROUP; ++i) gf.start[i] = gb.start[i] = total;
         bool small = true;                   // registers sized for C <= 512 unless a problem is wider
         for (int i = 0; i < n; ++i) small = small && d[i].C <= 512;
-        if (first <= 2 && 2 < last) {
+        // The second form of the two bodies (nr_ctm_bodies.h): every problem 512 channels wide (the model's width), at most 16
+        // clusters.  NR_CTM_V1=1 (tuning builds) keeps the first form.
+        bool v2 = !nr_tune_env("NR_CTM_V1");
+        int maxc = 0, maxn = 0;
+        size_t lds2 = 0;
+        for (int i = 0; i < n; ++i) {
+            v2 = v2 && d[i].C == 512 && d[i].cnum <= 16;
+            maxc = d[i].cnum > maxc ? d[i].cnum : maxc;
+            maxn = d[i].N > maxn ? d[i].N : maxn;
+            const size_t need = nr_ctm_front2_lds_floats(d[i].N, d[i].C) * sizeof(float);
+            lds2 = need > lds2 ? need : lds2;
+        }
+        // the back half's registers: 4 cluster accumulators and a 32-entry distance row per token, or 16 and 64
+        const int back_form = (maxc <= 4 && maxn <= 32) ? 4 : 16;
+        if (v2 && first <= 2 && 2 < last) {
+            bool few = maxc <= 4;                // a handful of tokens per sample (stage 1 of the step): 256-thread workgroups
+            for (int i = 0; i < n; ++i) few = few && d[i].N <= 8;
+            const void* k = !fusable ? (const void*)nr_group_front2_kernel<2, 512>
+                            : few    ? (const void*)nr_group_front_back2_kernel<2, 256, 4>
+                                     : (const void*)nr_group_front_back2_kernel<2, 512, 16>;
+            if (lds2 > 40 * 1024) {
+                hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                if (e != hipSuccess) return (int)e;
+            }
+            if (!fusable) hipLaunchKernelGGL((nr_group_front2_kernel<2, 512>), dim3(total), dim3(512), lds2, st, gf);
+            else if (few) hipLaunchKernelGGL((nr_group_front_back2_kernel<2, 256, 4>), dim3(total), dim3(256), lds2, st, gf, gb);
+            else hipLaunchKernelGGL((nr_group_front_back2_kernel<2, 512, 16>), dim3(total), dim3(512), lds2, st, gf, gb);
+            NR_LAUNCH_CHECK();
+        }
+        if (v2 && first <= 3 && 3 < last && !fusable) {
+            size_t lds = 0;                      // token rows of the largest problem: in LDS when two workgroups still fit a CU
+            for (int i = 0; i < n; ++i) {
+                size_t need = (size_t)d[i].N * d[i].C * sizeof(float);
+                lds = need > lds ? need : lds;
+            }
+            const int use_lds = lds <= 56 * 1024;
+            if (!use_lds) lds = 0;
+            if (kv_beside_back) {
+                // the kv projections need the front launch alone, like the back half: one grid carries both (nr_linear.h)
+                NrLinearArgs p[NR_CTM_MAX_GROUP];
+                for (int i = 0; i < n; ++i) {
+                    const NrCtmStageDesc& s = d[i];
+                    p[i] = NrLinearArgs{w[i].kvn_hi, w[i].kvn_lo, s.wkv_hi, s.wkv_lo, s.kv_bias, nullptr, w[i].kv, s.n_samples * s.N, 2 * s.C, s.C};
+                }
+                rc = nr_linear_group_launch_beside_back(p, n, gb, lds, use_lds, back_form, st);
+                if (rc != NR_OK) return rc;
+            } else {
+                const void* k = back_form == 4 ? (const void*)nr_group_back2_kernel<512, 4, 1> : (const void*)nr_group_back2_kernel<512, 16, 1>;
+                if (lds > 40 * 1024) {
+                    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) return (int)e;
+                }
+                if (back_form == 4) hipLaunchKernelGGL((nr_group_back2_kernel<512, 4, 1>), dim3(total), dim3(512), lds, st, gb, use_lds);
+                else hipLaunchKernelGGL((nr_group_back2_kernel<512, 16, 1>), dim3(total), dim3(512), lds, st, gb, use_lds);
+                NR_LAUNCH_CHECK();
+            }
+        }
+        if (!v2 && first <= 2 && 2 < last) {
             bool few = small;                    // a handful of tokens per sample (stage 1 of the step): 256-thread workgroups
             for (int i = 0; i < n; ++i) few = few && d[i].N <= 8 && d[i].cnum * (d[i].C / 128) <= 4 * BK_MAXJ;
             if (fusable && few) {
@@ -265,7 +349,7 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
             }
             NR_LAUNCH_CHECK();
         }
-        if (first <= 3 && 3 < last && !(fusable && small)) {
+        if (!v2 && first <= 3 && 3 < last && !(fusable && small)) {
             size_t lds = 0;                      // token rows of the largest problem, if every problem's rows fit
             bool fits = true;
             for (int i = 0; i < n; ++i) {
@@ -275,6 +359,16 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
             }
             const int use_lds = fits && lds <= 96 * 1024;
             if (!use_lds) lds = 0;
+            if (kv_beside_back) {
+                // the kv projections need the front launch alone, like the back half: one grid carries both (nr_linear.h)
+                NrLinearArgs p[NR_CTM_MAX_GROUP];
+                for (int i = 0; i < n; ++i) {
+                    const NrCtmStageDesc& s = d[i];
+                    p[i] = NrLinearArgs{w[i].kvn_hi, w[i].kvn_lo, s.wkv_hi, s.wkv_lo, s.kv_bias, nullptr, w[i].kv, s.n_samples * s.N, 2 * s.C, s.C};
+                }
+                rc = nr_linear_group_launch_beside_back(p, n, gb, lds, use_lds, 0, st);
+                if (rc != NR_OK) return rc;
+            } else {
             if (lds > 40 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void*)nr_group_back_kernel<BK_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #ifdef NR_TUNE
@@ -289,17 +383,22 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
 #endif
             hipLaunchKernelGGL(nr_group_back_kernel<BK_THREADS>, dim3(total), dim3(BK_THREADS), lds, st, gb, use_lds);
             NR_LAUNCH_CHECK();
+            }
         }
     }
     // 5. q = norm1(merged) Wq^T (+b), kv = norm1(xn) Wkv^T (+b): 2n problems, one launch
     if (first <= 4 && 4 < last) {
         NrLinearArgs p[2 * NR_CTM_MAX_GROUP];
+        int np = 0;
+        for (int i = 0; i < n && !kv_beside_back; ++i) {
+            const NrCtmStageDesc& s = d[i];
+            p[np++] = NrLinearArgs{w[i].kvn_hi, w[i].kvn_lo, s.wkv_hi, s.wkv_lo, s.kv_bias, nullptr, w[i].kv, s.n_samples * s.N, 2 * s.C, s.C};
+        }
         for (int i = 0; i < n; ++i) {
             const NrCtmStageDesc& s = d[i];
-            p[i] = NrLinearArgs{w[i].kvn_hi, w[i].kvn_lo, s.wkv_hi, s.wkv_lo, s.kv_bias, nullptr, w[i].kv, s.n_samples * s.N, 2 * s.C, s.C};
-            p[n + i] = NrLinearArgs{w[i].qn_hi, w[i].qn_lo, s.wq_hi, s.wq_lo, s.q_bias, nullptr, w[i].q, s.n_samples * s.cnum, s.C, s.C};
+            p[np++] = NrLinearArgs{w[i].qn_hi, w[i].qn_lo, s.wq_hi, s.wq_lo, s.q_bias, nullptr, w[i].q, s.n_samples * s.cnum, s.C, s.C};
         }
-        if ((rc = nr_linear_group_launch(p, 2 * n, st)) != NR_OK) return rc;
+        if ((rc = nr_linear_group_launch(p, np, st)) != NR_OK) return rc;
     }
     // 6. score-biased attention of the merged tokens over the un-merged ones
     if (first <= 5 && 5 < last) {

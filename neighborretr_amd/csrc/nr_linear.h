@@ -24,3 +24,15 @@ struct NrLinearArgs {
 // selects the one-pass bf16 product (hi halves only) instead of the three-pass split-bf16 one.
 // conv = true: every problem is a token convolution (conv_n > 0 each).
 int nr_linear_group_launch(const NrLinearArgs* probs, int n_probs, hipStream_t stream, bool conv = false);
+
+// The same grouped launch with the clustering stage's DPC-KNN / merge workgroups ("back", nr_ctm_back_body) in FRONT of the GEMM
+// tiles in one grid of 512-thread workgroups: the kv projection depends on the stage's front launch alone, like the back half,
+// so the two run beside each other instead of one behind the other (the back half is a latency chain on a few waves per
+// sample, the GEMM tiles are LDS-DMA bound: they share CUs well).  gb: the back problems (start[] = first workgroup of each,
+// start[NR_CTM_MAX_GROUP] = their total); back_lds: dynamic LDS of a back workgroup when use_lds.  Tile shape fixed: 64 x 128
+// on 8 waves, one-deep ring.  NR_EUNSUPPORTED when a problem does not fit that form (the caller then launches the two apart).
+struct NrCtmBackArgs;
+template <typename A> struct NrGroupOf;
+// back_form: 0 = nr_ctm_back_body (first form); 4 / 16 = nr_ctm_back_body2 with accumulators for that many clusters (C = 512).
+int nr_linear_group_launch_beside_back(const NrLinearArgs* probs, int n_probs, const NrGroupOf<NrCtmBackArgs>& gb, size_t back_lds,
+                                       int use_lds, int back_form, hipStream_t stream);

@@ -76,6 +76,73 @@ __global__ __launch_bounds__(128 * WC) void nr_linear_group_kernel(NrLinearGroup
     nr_linear_tile<MI, NI, STAGES, WC, CONV, X3>(p, t / ncol, t % ncol, smem);
 }
 
+// back workgroups of a clustering stage in front of the GEMM tiles of its kv projection, one grid (nr_linear.h)
+template <int MI, int NI, int STAGES, int WC, int BACK_FORM>
+__global__ __launch_bounds__(128 * WC, (256 * WC) / 256) void nr_back_beside_linear_kernel(NrGroupOf<NrCtmBackArgs> gb, int n_back_pad, int use_lds,
+                                                                                         NrLinearGroup g) {
+    NR_CRITICAL_PATH();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < n_back_pad) {
+        if ((int)blockIdx.x >= gb.start[NR_CTM_MAX_GROUP]) return;          // padding up to a multiple of 8 (XCD order of the tiles)
+        const int gi = gb.find(blockIdx.x);
+        float* rows = use_lds ? reinterpret_cast<float*>(smem) : nullptr;
+        if constexpr (BACK_FORM == 0) nr_ctm_back_body<false, 128 * WC>(gb.p[gi], blockIdx.x - gb.start[gi], rows);
+        else nr_ctm_back_body2<false, 128 * WC, BACK_FORM, 512 / (128 * WC), BACK_FORM <= 4 ? 32 : 64>(gb.p[gi], blockIdx.x - gb.start[gi], rows, nullptr, nullptr);
+        return;
+    }
+    const int wg = nr_xcd_chunk_tile(blockIdx.x - n_back_pad, g.tile_start[NR_LINEAR_MAX_GROUP]);
+    if (wg < 0) return;
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < NR_LINEAR_MAX_GROUP; ++i)
+        if (i < g.n && wg >= g.tile_start[i]) gi = i;
+    const NrLinearArgs& p = g.p[gi];
+    const int t = wg - g.tile_start[gi];
+    const int ncol = (p.N + 16 * WC * NI - 1) / (16 * WC * NI);
+    nr_linear_tile<MI, NI, STAGES, WC, false, true>(p, t / ncol, t % ncol, smem);
+}
+
+int nr_linear_group_launch_beside_back(const NrLinearArgs* probs, int n, const NrGroupOf<NrCtmBackArgs>& gb, size_t back_lds, int use_lds,
+                                       int back_form, hipStream_t st) {
+    constexpr int MI = 2, NI = 2, STAGES = 1, WC = 4;
+    using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES, WC>;
+    if (!probs || n <= 0 || n > NR_LINEAR_MAX_GROUP) return NR_EINVAL;
+    NrLinearGroup g;
+    g.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const NrLinearArgs& a = probs[i];
+        if (!a.x_hi || !a.x_lo || !a.w_hi || !a.w_lo || !a.out || a.M <= 0 || a.N <= 0 || a.K <= 0) return NR_EINVAL;
+        if ((a.K % 64) != 0 || a.conv_n != 0 || a.ld != 0 || a.out_hi || a.out_lo) return NR_EUNSUPPORTED;
+        g.p[i] = a;
+        g.tile_start[i] = total;
+        total += ((a.M + Tile::BM - 1) / Tile::BM) * ((a.N + Tile::BN - 1) / Tile::BN);
+    }
+    for (int i = n; i <= NR_LINEAR_MAX_GROUP; ++i) g.tile_start[i] = total;
+    if (back_form != 0 && back_form != 4 && back_form != 16) return NR_EINVAL;
+    for (int i = 0; i < gb.n; ++i) {
+        if (gb.p[i].N > 64) return NR_EUNSUPPORTED;
+        // first form: the 8-wave body spreads cnum * C/128 merge jobs over 8 waves; second form: C = 512, cnum <= back_form
+        if (back_form == 0 ? gb.p[i].cnum * (gb.p[i].C / 128) > 8 * BK_MAXJ : (gb.p[i].C != 512 || gb.p[i].cnum > back_form)) return NR_EUNSUPPORTED;
+    }
+    const int n_back = gb.start[NR_CTM_MAX_GROUP], n_back_pad = (n_back + 7) & ~7;
+    size_t lds = Tile::RING_BYTES;
+    if (use_lds && back_lds > lds) lds = back_lds;
+    const void* k = back_form == 0 ? (const void*)nr_back_beside_linear_kernel<MI, NI, STAGES, WC, 0>
+                    : back_form == 4 ? (const void*)nr_back_beside_linear_kernel<MI, NI, STAGES, WC, 4>
+                                     : (const void*)nr_back_beside_linear_kernel<MI, NI, STAGES, WC, 16>;
+    if (lds > 40 * 1024) {
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const dim3 grid(n_back_pad + nr_xcd_chunk_grid(total)), block(128 * WC);
+    if (back_form == 0) hipLaunchKernelGGL((nr_back_beside_linear_kernel<MI, NI, STAGES, WC, 0>), grid, block, lds, st, gb, n_back_pad, use_lds, g);
+    else if (back_form == 4) hipLaunchKernelGGL((nr_back_beside_linear_kernel<MI, NI, STAGES, WC, 4>), grid, block, lds, st, gb, n_back_pad, use_lds, g);
+    else hipLaunchKernelGGL((nr_back_beside_linear_kernel<MI, NI, STAGES, WC, 16>), grid, block, lds, st, gb, n_back_pad, use_lds, g);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+}
+
 template <int MI, int NI, int STAGES>
 static int nr_linear_launch_s(NrLinearArgs& a, hipStream_t st) {
     using Tile = NrGemmTile<MI, NI, true, 16, 16, STAGES>;

@@ -5,9 +5,10 @@
     global_level_sim(...) global_level (modeling.py:516-539)
     row_loss_terms(...)   the raw [2,4,B] per-row loss terms (used by the until_module classes)
 
-Forward and backward both run on the HIP kernels (the token-scorer MLP backward on nr_linear_x3); the only library
-GEMMs left on the training path are the tiny dG products of the global logits and the torch-op recompute of the
-clustering stage's backward (cluster_fused.ClusterStagesFn).
+Forward and backward both run on the HIP kernels: the token-scorer MLP backward on the grouped split-bf16 GEMMs, the
+clustering stage's backward on nr_ctm_bwd.hip (cluster_backward_hip; widths above 512 channels: the same arithmetic as torch ops
+on the GPU, cluster_backward.py).  The only library GEMMs left on the training path are the tiny dG products of the one-token
+global logits.
 """
 import torch
 
@@ -59,11 +60,16 @@ def local_level_sim(model, text_feat, video_feat, text_mask, video_mask):
 
 
 def global_level_sim(model, gt, gv):
-    if _needs_grad(gt, gv):
-        from .backward import GlobalLogitsFn
-        if gt.shape[1] == 1 and gv.shape[1] == 1:
+    if gt.shape[1] == 1 and gv.shape[1] == 1:
+        if _needs_grad(gt, gv):
+            from .backward import GlobalLogitsFn
             return GlobalLogitsFn.apply(gt, gv)
-        raise NotImplementedError("gradient of the multi-token global level is not implemented")
+    else:
+        pt_params = _mlp_params(model, "text_weight_fc1")
+        pv_params = _mlp_params(model, "video_weight_fc1")
+        if _needs_grad(gt, gv, *pt_params, *pv_params):
+            from .backward import GlobalLevelMultiFn
+            return GlobalLevelMultiFn.apply(model, gt, gv, *pt_params, *pv_params)
     return head.global_logits(gt, gv, model.scorer_weights("text_weight_fc1"), model.scorer_weights("video_weight_fc1"))
 
 

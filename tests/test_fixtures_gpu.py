@@ -286,3 +286,32 @@ def test_c4_b8_backward_matches_oracle_autograd_under_mean_flag():
     # the *_weight_fc1 scorers of the global level DO get a gradient at this shape (zero with one global token)
     assert float(named["text_weight_fc1.0.weight"].grad.abs().max()) > 0 and float(named["video_weight_fc1.2.weight"].grad.abs().max()) > 0
     assert checked > 60
+
+
+def test_c4_b8_public_global_level_gradient_matches_oracle_autograd():
+    """`NeighborRetr.global_level` with several global tokens per sample (modeling.py:516-539) as a differentiable call of its
+    own (backward.GlobalLevelMultiFn): gradients w.r.t. both token sets and the *_weight_fc1 scorers against the oracle's
+    autograd on the reference's own global tokens (fixture c4_b8: 3 text / 6 video tokens per sample)."""
+    g, _, _, (B, Nt, Nv, M, K) = _case("c4_b8")
+    m = _model("bf16x3", K)
+    gt = torch.from_numpy(g["gt"]).to(DEV).requires_grad_(True)
+    gv = torch.from_numpy(g["gv"]).to(DEV).requires_grad_(True)
+    G, Gt = m.global_level(gt, gv)
+    gmax = float(np.abs(g["G"]).max())
+    assert maxdiff(G, g["G"]) < 1e-5 * gmax and G.requires_grad
+    up = torch.from_numpy(synth.normal(77, "dG", (B, B)).astype(np.float32)).to(DEV)
+    ((G * up).sum() + 0.5 * (Gt * up).sum()).backward()
+    P = {k: v.clone().requires_grad_(True) for k, v in params().items()}
+    gtc = torch.from_numpy(g["gt"]).clone().requires_grad_(True)
+    gvc = torch.from_numpy(g["gv"]).clone().requires_grad_(True)
+    Gc, _ = O.global_level(gtc, gvc, P)
+    ((Gc * up.cpu()).sum() + 0.5 * (Gc.T * up.cpu()).sum()).backward()
+    for mine, want, name in ((gt.grad, gtc.grad, "gt"), (gv.grad, gvc.grad, "gv")):
+        scale = float(want.abs().max())
+        print(f"\n[global_level backward] d{name}: max|err| {maxdiff(mine, want):.2e} of {scale:.2e}")
+        assert maxdiff(mine, want) < 3e-3 * scale
+    named = dict(m.named_parameters())
+    for n in ("text_weight_fc1.0.weight", "text_weight_fc1.0.bias", "text_weight_fc1.2.weight", "video_weight_fc1.0.weight",
+              "video_weight_fc1.2.weight"):
+        scale = float(P[n].grad.abs().max())
+        assert scale > 0 and maxdiff(named[n].grad, P[n].grad) < 5e-3 * scale + 2e-6, (n, maxdiff(named[n].grad, P[n].grad), scale)

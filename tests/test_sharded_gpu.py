@@ -165,10 +165,11 @@ def test_sharded_training_loss_gradients_equal_replicated(tmp_path, precision, p
 
 
 def test_slab_row_losses_on_hip_match_the_torch_restatement():
-    """SlabRowLossFn (nr_row_losses_fwd_slab / nr_row_losses_bwd_slab) against sharded._direction_terms -- the row terms restated
+    """SlabRowLossFn (nr_row_losses_fwd_slab / nr_row_losses_bwd_slab) against tests/slab_terms_torch.direction_terms -- the row terms restated
     in torch ops -- for one rank's slab: the partial losses and the gradients w.r.t. both S slabs, G, both bank centrality
     vectors, the centrality weights and the logit scale.  Single process (no collective involved)."""
     import numpy as np
+    import slab_terms_torch
     from neighborretr_amd import ops, sharded, synth
     dev = "cuda"
     B, b, r0, K, T = 64, 16, 32, 8, 3.0
@@ -188,8 +189,8 @@ def test_slab_row_losses_on_hip_match_the_torch_restatement():
     # torch restatement (normalised like the full loss)
     a = leaves()
     diag = torch.arange(r0, r0 + b, device=dev)
-    ct, ut, nt, kt = sharded._direction_terms(a[0], a[2][sl], tgt_r[sl], a[3], a[5], a[7].reshape(()), K, T, diag)
-    cv, uv, nv, kv = sharded._direction_terms(a[1].t(), a[2].t()[sl], tgt_c[sl], a[4], a[6], a[7].reshape(()), K, T, diag)
+    ct, ut, nt, kt = slab_terms_torch.direction_terms(a[0], a[2][sl], tgt_r[sl], a[3], a[5], a[7].reshape(()), K, T, diag)
+    cv, uv, nv, kv = slab_terms_torch.direction_terms(a[1].t(), a[2].t()[sl], tgt_c[sl], a[4], a[6], a[7].reshape(()), K, T, diag)
     cent, unif, neigh = ((x + y) / (2 * B) for x, y in ((ct, cv), (ut, uv), (nt, nv)))
     kl = (kt + kv) / (2 * B * B)
     ref = torch.stack((cent + unif * hp["uniform_weight"] + neigh * hp["neighbor_weight"] + kl * hp["kl_weight"], cent, unif, neigh, kl))

@@ -28,6 +28,12 @@ def main():
             ctm_stage_group([("t0", p["text_feat"], p["text_mask"].float(), m.text_ctm0, m.text_block0, nz["t0"]),
                              ("v0", p["video_feat"], p["video_mask"].float(), m.video_ctm0, m.video_block0, nz["v0"])], {})
     buf = (ctypes.c_ulonglong * 16)()
+    if hasattr(hip.lib(), "nr_debug_front_stamps"):
+        n = hip.lib().nr_debug_front_stamps(buf)
+        prev = 0
+        for i, name in zip(range(n), ["start", "own rows normalised (issue side)", "all rows (barrier)", "own distances", "end"]):
+            print(f"front {buf[i]:8d}  +{buf[i] - prev:6d}  {name}")
+            prev = buf[i]
     n = hip.lib().nr_debug_back_stamps(buf)
     prev = 0
     for i in range(n):
