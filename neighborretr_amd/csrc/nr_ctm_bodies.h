@@ -493,7 +493,7 @@ __device__ __forceinline__ void nr_wave_sum_n(float (&v)[R]) {
 }
 
 // dynamic LDS of the second form's front body (and of the fused front + back): rows, distance matrix, token weights
-__host__ __device__ __forceinline__ size_t nr_ctm_front2_lds_floats(int N, int C) { return (size_t)N * C + (size_t)N * N + 64; }
+__host__ __device__ __forceinline__ size_t nr_ctm_front2_lds_floats(int N, int C) { return (size_t)N * C + (size_t)N * N + 128; }     // (+ token weights, + the fused form's noise draws)
 
 // b = sample; smem = nr_ctm_front2_lds_floats(N, C) floats.  V4 = C / 256 chunks of four channels per lane.
 template <int V4, int THREADS>
@@ -740,7 +740,7 @@ __device__ __forceinline__ void nr_ctm_back_body2(const NrCtmBackArgs& p, const 
     }
     if (tid < N) {
         s_tokw[tid] = FUSED ? s_tokw_in[tid] : p.tokw[(size_t)b * N + tid];
-        s_noise[tid] = p.noise[(size_t)b * N + tid];
+        s_noise[tid] = FUSED ? s_tokw_in[64 + tid] : p.noise[(size_t)b * N + tid];     // (fused form: requested before the front half ran)
         s_mask[tid] = masked ? p.mask[(size_t)b * N + tid] : 1.f;
     }
     float g = 0.f;                                    // global maximum over all samples (cluster.py:473-475)
@@ -1002,11 +1002,19 @@ struct NrAttnArgs {
 __device__ __forceinline__ int nr_tc_attention_lds_floats(int N, int C) { return N * (2 * C + 4); }
 
 __device__ __forceinline__ void nr_tc_attention_body(const NrAttnArgs& a, const int b, float* skv) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (int)(blockDim.x >> 6);
     const int N = a.N, C = a.C, cnum = a.cnum;
     const float scale = a.scale;
     const float* kvb = a.kv + (size_t)b * N * 2 * C;
     const int ld = skv ? 2 * C + 4 : 2 * C;
+    // the wave's first query vector (lane = channel) and the score bias: requested together with the k | v rows
+    const int job0 = wave;
+    float q0 = 0.f;
+    if (job0 < a.H * cnum) {
+        const int h = job0 / cnum, cl = job0 - h * cnum;
+        q0 = a.q[((size_t)b * cnum + cl) * C + h * 64 + lane] * scale;
+    }
+    const float bias = lane < N ? a.score[(size_t)b * N + lane] : 0.f;
     if (skv) {
         const int per_row = 2 * C / 4;                       // float4 per row
         for (int e = threadIdx.x; e < N * per_row; e += (int)blockDim.x) {
@@ -1016,20 +1024,21 @@ __device__ __forceinline__ void nr_tc_attention_body(const NrAttnArgs& a, const 
         __syncthreads();
     }
     const float* kvs = skv ? skv : kvb;
-    for (int job = wave; job < a.H * cnum; job += (int)(blockDim.x >> 6)) {
+    for (int job = wave; job < a.H * cnum; job += nwave) {
         const int h = job / cnum, cl = job - h * cnum;
-        const float* qr = a.q + ((size_t)b * cnum + cl) * C + h * 64;
+        const float qs = job == job0 ? q0 : a.q[((size_t)b * cnum + cl) * C + h * 64 + lane] * scale;
         float logit = -INFINITY;
-        if (lane < N) {
-            const float* kr = kvs + (size_t)lane * ld + h * 64;
+        {
+            const float* kr = kvs + (size_t)min(lane, N - 1) * ld + h * 64;
             float dot = 0.f;
 #pragma unroll
             for (int j = 0; j < 64; j += 4) {
-                f32x4_t kk = *reinterpret_cast<const f32x4_t*>(kr + j);
-                f32x4_t qq = *reinterpret_cast<const f32x4_t*>(qr + j);
-                dot += (qq[0] * scale) * kk[0] + (qq[1] * scale) * kk[1] + (qq[2] * scale) * kk[2] + (qq[3] * scale) * kk[3];
+                const f32x4_t kk = *reinterpret_cast<const f32x4_t*>(kr + j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    dot = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qs), j + e)), kk[e], dot);
             }
-            logit = dot + a.score[(size_t)b * N + lane];
+            if (lane < N) logit = dot + bias;
         }
         const float m = nr_wave_max(logit);
         float e = lane < N ? expf(logit - m) : 0.f;
@@ -1037,8 +1046,8 @@ __device__ __forceinline__ void nr_tc_attention_body(const NrAttnArgs& a, const 
         const float p = e / den;
         float acc = 0.f;
         for (int n = 0; n < N; ++n) {
-            float pn = __shfl(p, n);
-            acc += pn * kvs[(size_t)n * ld + C + h * 64 + lane];
+            const float pn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), n));
+            acc = fmaf(pn, kvs[(size_t)n * ld + C + h * 64 + lane], acc);
         }
         const size_t o = ((size_t)b * cnum + cl) * C + h * 64 + lane;
         if (a.out_hi) {
@@ -1054,16 +1063,27 @@ __device__ __forceinline__ void nr_tc_attention_body(const NrAttnArgs& a, const 
 // The same attention for HG of a sample's heads (a workgroup per (sample, head group), 64 * HG threads or more): only those
 // heads' k | v columns go to LDS -- N * (128 * HG + 4) floats instead of N * (2C + 4): 25 KB instead of 99 at N = 24, HG = 2, and
 // 67 KB at N = 64, where the whole rows (263 KB) do not fit and nr_tc_attention_body reads k and v from global memory job by
-// job.  Every (head, query) job is computed by one wave with the arithmetic of nr_tc_attention_body: identical bits.
+// job.  Every (head, query) job is computed by one wave with the arithmetic of nr_tc_attention_body.
 template <int HG>
 __device__ __forceinline__ void nr_tc_attention_heads_body(const NrAttnArgs& a, const int b, const int hg, float* skv) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (int)(blockDim.x >> 6);
     const int N = a.N, C = a.C, cnum = a.cnum, h0 = hg * HG;
     const float scale = a.scale;
     const float* kvb = a.kv + (size_t)b * N * 2 * C;
     constexpr int HW = 64 * HG;                              // floats of k (and of v) per row kept
     constexpr int ld = 2 * HW + 4;
     constexpr int per_row = 2 * HW / 4;                      // float4 per row
+    constexpr int QJ = 4;                                    // (head, query) jobs whose query vectors a wave requests up front
+    // this wave's first query vectors (lane = channel) and the sample's score bias, requested together with the k | v rows: one
+    // global round trip for everything (the q loads used to sit inside the per-key dot product, a round trip per job)
+    float qv[QJ];
+#pragma unroll
+    for (int u = 0; u < QJ; ++u) {
+        const int job = wave + nwave * u;
+        const int hl = job / cnum, cl = job - hl * cnum;
+        qv[u] = job < HG * cnum ? a.q[((size_t)b * cnum + cl) * C + (h0 + hl) * 64 + lane] * scale : 0.f;
+    }
+    const float bias = lane < N ? a.score[(size_t)b * N + lane] : 0.f;
     for (int e = threadIdx.x; e < N * per_row; e += (int)blockDim.x) {
         const int n = e / per_row, c4 = e - n * per_row;
         const int c = c4 * 4;
@@ -1071,20 +1091,28 @@ __device__ __forceinline__ void nr_tc_attention_heads_body(const NrAttnArgs& a, 
         *reinterpret_cast<f32x4_t*>(skv + n * ld + c) = *reinterpret_cast<const f32x4_t*>(kvb + (size_t)n * 2 * C + src);
     }
     __syncthreads();
-    for (int job = wave; job < HG * cnum; job += (int)(blockDim.x >> 6)) {
+    for (int job = wave, u = 0; job < HG * cnum; job += nwave, ++u) {
         const int hl = job / cnum, cl = job - hl * cnum, h = h0 + hl;
-        const float* qr = a.q + ((size_t)b * cnum + cl) * C + h * 64;
+        float qs;                                            // this job's scaled query, lane = channel
+        if (u < QJ) {
+            qs = 0.f;
+#pragma unroll
+            for (int w = 0; w < QJ; ++w) qs = u == w ? qv[w] : qs;
+        } else {
+            qs = a.q[((size_t)b * cnum + cl) * C + h * 64 + lane] * scale;
+        }
         float logit = -INFINITY;
-        if (lane < N) {
-            const float* kr = skv + (size_t)lane * ld + hl * 64;
+        {
+            const float* kr = skv + (size_t)min(lane, N - 1) * ld + hl * 64;
             float dot = 0.f;
 #pragma unroll
             for (int j = 0; j < 64; j += 4) {
-                f32x4_t kk = *reinterpret_cast<const f32x4_t*>(kr + j);
-                f32x4_t qq = *reinterpret_cast<const f32x4_t*>(qr + j);
-                dot += (qq[0] * scale) * kk[0] + (qq[1] * scale) * kk[1] + (qq[2] * scale) * kk[2] + (qq[3] * scale) * kk[3];
+                const f32x4_t kk = *reinterpret_cast<const f32x4_t*>(kr + j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    dot = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qs), j + e)), kk[e], dot);
             }
-            logit = dot + a.score[(size_t)b * N + lane];
+            if (lane < N) logit = dot + bias;
         }
         const float m = nr_wave_max(logit);
         float e = lane < N ? expf(logit - m) : 0.f;
@@ -1092,8 +1120,8 @@ __device__ __forceinline__ void nr_tc_attention_heads_body(const NrAttnArgs& a, 
         const float p = e / den;
         float acc = 0.f;
         for (int n = 0; n < N; ++n) {
-            float pn = __shfl(p, n);
-            acc += pn * skv[(size_t)n * ld + HW + hl * 64 + lane];
+            const float pn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), n));
+            acc = fmaf(pn, skv[(size_t)n * ld + HW + hl * 64 + lane], acc);
         }
         const size_t o = ((size_t)b * cnum + cl) * C + h * 64 + lane;
         if (a.out_hi) {

@@ -12,10 +12,21 @@
 #include "nr_linear.h"
 #include "../../include/nr_hip.h"
 
+// plain rows as bf16 pairs: NR_SHIFT_ROWS rows per 256-thread workgroup, a float4 (one 8-byte pair store each) per thread and turn
+#define NR_SHIFT_ROWS 8
 __global__ __launch_bounds__(256) void nr_group_shift_kernel(NrGroupOf<NrShiftArgs> g) {
     NR_CRITICAL_PATH();
     const int gi = g.find(blockIdx.x);
-    nr_shift_split_body(g.p[gi], blockIdx.x - g.start[gi]);
+    const NrShiftArgs& a = g.p[gi];
+    const size_t e0 = (size_t)(blockIdx.x - g.start[gi]) * NR_SHIFT_ROWS * a.C, e1 = (size_t)a.N * a.C;      // (a.N: ALL rows of the problem here)
+    for (size_t e = e0 + 4 * threadIdx.x; e < e0 + (size_t)NR_SHIFT_ROWS * a.C && e < e1; e += 1024) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(a.x + e);
+        uint32_t h0, l0, h1, l1;
+        nr_split_pk(v[0], v[1], h0, l0);
+        nr_split_pk(v[2], v[3], h1, l1);
+        *reinterpret_cast<uint2*>(a.hi + e) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(a.lo + e) = make_uint2(l0, l1);
+    }
 }
 
 template <int CPL, int THREADS = CF_THREADS>
@@ -50,16 +61,18 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void nr_group_front2_kernel
 }
 
 // (the 16-cluster / 64-token form keeps a 64-entry distance row per lane: one workgroup per CU, up to 256 registers)
-template <int V4, int THREADS, int MAXC>
+template <int V4, int THREADS, int MAXC, int MAXN>
 __global__ __launch_bounds__(THREADS, MAXC <= 4 ? THREADS / 128 : THREADS / 256) void nr_group_front_back2_kernel(NrGroupOf<NrCtmFrontArgs> gf, NrGroupOf<NrCtmBackArgs> gb) {
     NR_CRITICAL_PATH();
     extern __shared__ __attribute__((aligned(16))) float sx[];
     const int gi = gf.find(blockIdx.x);
     const int b = blockIdx.x - gf.start[gi];
     const NrCtmFrontArgs& f = gf.p[gi];
+    // the back half's tie-break draws: requested now, in LDS by the time it starts (a round trip less behind the front half)
+    if ((int)threadIdx.x < f.N) sx[(size_t)f.N * f.C + (size_t)f.N * f.N + 64 + threadIdx.x] = gb.p[gi].noise[(size_t)b * f.N + threadIdx.x];
     nr_ctm_front_body2<V4, THREADS>(f, b, sx);
     __syncthreads();
-    nr_ctm_back_body2<true, THREADS, MAXC, (256 * V4) / THREADS, MAXC <= 4 ? 32 : 64>(gb.p[gi], b, sx, sx + (size_t)f.N * f.C, sx + (size_t)f.N * f.C + (size_t)f.N * f.N);
+    nr_ctm_back_body2<true, THREADS, MAXC, (256 * V4) / THREADS, MAXN>(gb.p[gi], b, sx, sx + (size_t)f.N * f.C, sx + (size_t)f.N * f.C + (size_t)f.N * f.N);
 }
 
 template <int THREADS, int MAXC, int CPT>
@@ -218,9 +231,10 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
         int total = 0;
         for (int i = 0; i < n; ++i) {
             if (d[i].x_hi) continue;
-            g.p[g.n] = NrShiftArgs{d[i].x, d[i].N, d[i].C, w[i].cat_hi, w[i].cat_lo, 1};
+            const int rows = d[i].n_samples * d[i].N;
+            g.p[g.n] = NrShiftArgs{d[i].x, rows, d[i].C, w[i].cat_hi, w[i].cat_lo, 1};       // (N = all rows: see the kernel)
             g.start[g.n++] = total;
-            total += d[i].n_samples * d[i].N;
+            total += (rows + NR_SHIFT_ROWS - 1) / NR_SHIFT_ROWS;
         }
         for (int i = g.n; i <= NR_CTM_MAX_GROUP; ++i) g.start[i] = total;
         hipLaunchKernelGGL(nr_group_shift_kernel, dim3(total), dim3(256), 0, st, g);
@@ -284,15 +298,15 @@ extern "C" int nr_ctm_stage_fwd_range(const NrCtmStageDesc* d, int n, int first,
             bool few = maxc <= 4;                // a handful of tokens per sample (stage 1 of the step): 256-thread workgroups
             for (int i = 0; i < n; ++i) few = few && d[i].N <= 8;
             const void* k = !fusable ? (const void*)nr_group_front2_kernel<2, 512>
-                            : few    ? (const void*)nr_group_front_back2_kernel<2, 256, 4>
-                                     : (const void*)nr_group_front_back2_kernel<2, 512, 16>;
+                            : few    ? (const void*)nr_group_front_back2_kernel<2, 256, 4, 8>
+                                     : (const void*)nr_group_front_back2_kernel<2, 512, 16, 64>;
             if (lds2 > 40 * 1024) {
                 hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
                 if (e != hipSuccess) return (int)e;
             }
             if (!fusable) hipLaunchKernelGGL((nr_group_front2_kernel<2, 512>), dim3(total), dim3(512), lds2, st, gf);
-            else if (few) hipLaunchKernelGGL((nr_group_front_back2_kernel<2, 256, 4>), dim3(total), dim3(256), lds2, st, gf, gb);
-            else hipLaunchKernelGGL((nr_group_front_back2_kernel<2, 512, 16>), dim3(total), dim3(512), lds2, st, gf, gb);
+            else if (few) hipLaunchKernelGGL((nr_group_front_back2_kernel<2, 256, 4, 8>), dim3(total), dim3(256), lds2, st, gf, gb);
+            else hipLaunchKernelGGL((nr_group_front_back2_kernel<2, 512, 16, 64>), dim3(total), dim3(512), lds2, st, gf, gb);
             NR_LAUNCH_CHECK();
         }
         if (v2 && first <= 3 && 3 < last && !fusable) {
