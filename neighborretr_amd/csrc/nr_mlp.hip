@@ -9,6 +9,11 @@
 #include <cstdlib>
 #include "nr_gemm_tile.h"
 #include "../../include/nr_hip.h"
+// ping-pong K loop for the 8-wave one-pass blocks: measured 16.7 vs 16.8 us for the 12288 bank text tokens (the loop is not
+// what bounds a scorer launch of eight K slices: its start and its epilogue are) -- off; -DNR_MLP_PP=1 builds it in
+#ifndef NR_MLP_PP
+#define NR_MLP_PP 0
+#endif
 
 // Block shapes: BM = 32*MI token rows x BN = 16*WC*NI hidden units with BN a multiple of 128 (one partial-logit row
 // per 128 hidden units, the granularity nr_token_softmax sums).  The main loop is bound by the operand bytes a CU
@@ -72,7 +77,14 @@ __device__ __forceinline__ void nr_mlp_body(const NrMlpProblem& q, const int wg,
 
     Tile tile;
     tile.zero();
-    tile.run(tok_hi, tok_lo, row0, n_tok, w1_hi, w1_lo, col0, H, d, smem);
+    // 8-wave blocks on a two-deep ring walk K with the ping-pong loop of the similarity kernel (the two wave rows alternate
+    // between an MFMA phase and a memory phase: nr_gemm_tile.h); NR_MLP_PLAIN=1 (tuning builds): the plain loop
+    if constexpr (WC == 4 && STAGES == 2 && !X3) {
+        if (NR_MLP_PP) tile.run_pp(tok_hi, tok_lo, row0, n_tok, w1_hi, w1_lo, col0, H, d, smem);
+        else tile.run(tok_hi, tok_lo, row0, n_tok, w1_hi, w1_lo, col0, H, d, smem);
+    } else {
+        tile.run(tok_hi, tok_lo, row0, n_tok, w1_hi, w1_lo, col0, H, d, smem);
+    }
 
     float bb[NI], ww[NI];
 #pragma unroll

@@ -196,6 +196,14 @@ def test_bench_launches_its_own_ranks(tmp_path):
     # what is left of a step besides gloo's own data path (the packed gather goes device -> host -> TCP -> device here: ~3 ms for
     # 9.4 MB; on RCCL it is a device-side collective): replaying two graphs instead of ~35 eager launches
     assert d["ms_per_step"] - d["exchange_step_ms"] < 1.5, (d["ms_per_step"], d["exchange_step_ms"])
+    # both forms of the job in ONE line: `value` = the step-interleaved job, `sync_step` = the synchronous sharded
+    # step (six rank-local segments between its five collectives) timed in the same job; the ranks the collective
+    # backend really joined, by an all-reduce of ones
+    assert d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo"
+    ss = d["sync_step"]
+    assert "error" not in ss, ss
+    assert ss["value"] > 0 and ss["step_form"] == "segmented" and ss["graph_segments"] == 6, ss
+    assert all(x == x and abs(x) < 1e4 for x in ss["losses"])
 
 
 def test_bench_overlapped_owned_step_on_two_ranks():
