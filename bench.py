@@ -1256,6 +1256,14 @@ def main():
                     roofline["avg_launch_us_alone"] = round(a_us, 2)
                     roofline["alone_source"] = ("gpurun_out/bench_alone_kernel_stats.csv: rocprofv3 --kernel-trace --stats of "
                                                 "tools/roofline_launches.py (the three products alone, 1650 launches)")
+                    # `frac` / `achieved` / `avg_launch_us` = the profiler's per-kernel average of the launches alone: the figure a
+                    # reader recomputes from the committed kernel_stats.csv (profiles/); the HIP-event figure stays beside it
+                    roofline["hip_events_avg_launch_us"] = roofline["avg_launch_us"]
+                    roofline["frac"], roofline["avg_launch_us"] = roofline["frac_alone"], roofline["avg_launch_us_alone"]
+                    roofline["achieved"] = round(roofline["frac_alone"] * PEAK_BF16_TFLOPS, 2)
+                    roofline["timing"] = ("frac / achieved / avg_launch_us: rocprofv3 per-kernel average of the step's three similarity launches "
+                                          "ALONE (alone_source); frac_in_step: the same kernels inside the timed step loop (in_step_source); "
+                                          "frac_hip_events_graph_of_30: HIP events around 50 replays of a graph of 10 x the three launches")
 
     if rank == 0:
         line = {
