@@ -846,6 +846,7 @@ def main():
                 if args.unroll > 1:              # U consecutive steps as one graph (their dependencies kept), K mod U singly
                     out1 = result["losses"]
                     outs_u = []
+                    pipes_u = []
 
                     def unrolled(pipelined):
                         """U steps into the running capture.  pipelined: a step's tail (Sinkhorn solve, row losses, bank push) stays
@@ -860,11 +861,13 @@ def main():
                                 outs_u.append(result["losses"])
                             return
                         origin, prev, pending = torch.cuda.current_stream(), None, []
+                        del pipes_u[:]
                         try:
                             for k in range(args.unroll):
                                 if prev is not None and prev.push_done is not None and not args.decouple_push:
                                     wait_event(origin, prev.push_done)       # ring head and bank rows: the one dependency between two steps
                                 model._pipeline = prev = StepPipeline(k, prev, decoupled=args.decouple_push)
+                                pipes_u.append(prev)                         # (owns its step's buffers until the capture has ended)
                                 step()                                       # prologue -> clustering -> logits on the origin; the rest forked
                                 outs_u.append(result["losses"])
                                 pending += prev.pending
@@ -878,6 +881,7 @@ def main():
                         gu = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(gu):
                             unrolled(pipelined)
+                        del pipes_u[:]                 # the capture has ended: the steps' buffers go back to the graph's own pool
                         return gu, list(outs_u)
 
                     def state():

@@ -421,6 +421,10 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
                 ops.forget_split_tail_counter(G.device, slot)   # an aborted capture: the next step takes a fresh zeroed word
             raise
         if pipeline is not None:
+            # everything this step allocated stays referenced until the capture ends (StepPipeline.own): its forked streams are
+            # not joined here, and the next step allocates on this stream right away
+            pipeline.own(L, early, gt, gv, gt2, gv2, ls, G, rowloss, losses, S, aux0, c0, c1, wc_t, wc_v, cw_aux,
+                         pbt, w_bt, lg_bt, aux2, pbv, w_bv, lg_bv, aux1, text_mask, video_mask, mb_mask_t, mb_mask_v)
             pipeline.pending += [tail, side] + ([push_stream] if (push_stream is not None and bank_push is not None) else [])
             # Nothing is joined into this stream, which goes straight on to the NEXT step: whatever was allocated on it and is
             # still read by this step's forked streams must not go back to its free list when this function returns

@@ -70,6 +70,33 @@ class StepPipeline:
         self.tail_done = None        # event: this step's five losses are written (head.head_forward, split tail)
         self.prev_tail_done = prev.tail_done if prev is not None else None
         self.pending = []
+        # OWNERSHIP: every tensor this step allocates that a forked stream (tail, bank chains, push) may still read when the origin
+        # stream has moved on to the next step is referenced from here until the capture ends -- whoever captures the steps keeps
+        # the StepPipeline objects alive that long.  A block that is never freed inside the capture is never handed out again
+        # inside it, so no wait edge and no record_stream() call has to be right for a tail's operands to stay intact
+        # (bench.py --decouple_push, whose steps run far ahead of each other, relied on exactly those).
+        self.owned = []
+
+    def own(self, *objs):
+        """Takes ownership of every CUDA tensor reachable from `objs` (dicts, sequences, objects with fields)."""
+        seen = set()
+        stack = list(objs)
+        while stack:
+            o = stack.pop()
+            if o is None or isinstance(o, (int, float, str, bool, bytes)) or id(o) in seen:
+                continue
+            seen.add(id(o))
+            if torch.is_tensor(o):
+                if o.is_cuda:
+                    self.owned.append(o)
+            elif isinstance(o, dict):
+                stack.extend(o.values())
+            elif isinstance(o, (list, tuple, set)):
+                stack.extend(o)
+            elif hasattr(o, "_fields"):                        # namedtuple-like (ops.Prepared)
+                stack.extend(getattr(o, f) for f in o._fields)
+            elif hasattr(o, "__dict__") and type(o).__module__.startswith("neighborretr_amd") and not isinstance(o, nn.Module):
+                stack.extend(vars(o).values())
 
 
 class OwnedSlot:
@@ -661,6 +688,8 @@ class NeighborRetr(nn.Module):
         if not self.bank_frozen and not self._pushed:
             with torch.no_grad():
                 push()
+        if self._pipeline is not None:
+            self._pipeline.own(text_mask, video_mask, logit_scale, noise, losses, self._last_prepared)
         return losses
 
     # ------------------------------------------------------------------ losses (modeling.py:314-360)
