@@ -852,7 +852,7 @@ def main():
                         """U steps into the running capture.  pipelined: a step's tail (Sinkhorn solve, row losses, bank push) stays
                         forked until the capture ends; the next step starts behind this step's logits and bank push
                         (modeling.StepPipeline)."""
-                        from neighborretr_amd.capture_guard import wait_event, wait_stream
+                        from neighborretr_amd.capture_guard import record_event, wait_event, wait_stream
                         from neighborretr_amd.modeling import StepPipeline
                         del outs_u[:]
                         if not pipelined:
@@ -864,9 +864,11 @@ def main():
                         del pipes_u[:]
                         try:
                             for k in range(args.unroll):
+                                early = record_event(origin)                 # where this step's local branch forks from: in front of ...
                                 if prev is not None and prev.push_done is not None and not args.decouple_push:
                                     wait_event(origin, prev.push_done)       # ring head and bank rows: the one dependency between two steps
                                 model._pipeline = prev = StepPipeline(k, prev, decoupled=args.decouple_push)
+                                prev.early_fork = early
                                 pipes_u.append(prev)                         # (owns its step's buffers until the capture has ended)
                                 step()                                       # prologue -> clustering -> logits on the origin; the rest forked
                                 outs_u.append(result["losses"])

@@ -44,6 +44,7 @@ def head_losses(model, text_feat, video_feat, text_mask, video_mask, mb_feat_t, 
                                   bank_early=model.bank_early, capture_order=model.capture_order, bb_late=getattr(model, "bb_late", False),
                                   bank_prepared=model._bank_shadow(mb_feat_t, mb_feat_v), prepared_out=model._last_prepared,
                                   bank_push=getattr(model, "_push_fn", None), slot=model._slot(), pipeline=model._pipeline_for_head(text_feat.device),
+                                  local_masks=getattr(model, "_raw_masks", None),
                                   **model._global_scorers(text_feat, video_feat))
     return losses
 

@@ -128,6 +128,15 @@ PAIR_BANK_PRODUCTS = os.environ.get("NR_PAIR_BANK", "0") == "1"
 # Pipelined steps: the next step's bank chains wait for this step's row losses (see after_previous_push).  NR_TAIL_EDGE=0 turns
 # the edge off (developer A/B switch, tools/ab_tail.sh).
 TAIL_BEFORE_NEXT_BANK_READS = os.environ.get("NR_TAIL_EDGE", "1") == "1"
+# NR_TAIL_EDGE=2 (A/B hook): the edge goes to the next step's bank PUSH instead (the row losses then only have to end before
+# the next push, beside the next step's bank chain instead of in front of it)
+TAIL_BEFORE_NEXT_PUSH = os.environ.get("NR_TAIL_EDGE", "1") == "2"
+# Pipelined steps: the batch half of the local branch forked from the origin stream IN FRONT of the step's prologue
+# (StepPipeline.early_fork), i.e. beside the previous step's bank chain instead of behind its push.  OFF: bit-identical, and
+# 36 % SLOWER (0.354 vs 0.260 ms per step, two A/B pairs in one session, tools/ab_early_fork.sh) -- the same figure round 4 got
+# from --decouple_push: whenever a step's chip-filling launches are released ahead of the previous step's push, the replayed
+# graph runs slower, whatever the edges say.  NR_EARLY_FORK=1 turns it on (developer A/B switch).
+EARLY_LOCAL_FORK = os.environ.get("NR_EARLY_FORK", "0") == "1"
 # Loss-only step: the batch's text and video scorers as one launch (nr_token_weights_fwd_pair).  NR_PAIR_SCORERS=0: two launches (A/B).
 PAIR_BATCH_SCORERS = os.environ.get("NR_PAIR_SCORERS", "1") == "1"
 # ... from this many tokens in the smaller set on (a few workgroups per CU): configs[3] 517 -> 530 steps/s, configs[2] 424 -> 427;
@@ -139,7 +148,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
                  gt, gv, sw_t, sw_v, hp, logit_scale, prec=hip.PREC_BF16, keep=False, sw_t1=None, sw_v1=None, join=None,
                  bank_streams=None, local_stream=None, bank_early=0,
                  capture_order=((7, 5), (7, 1 << 30)), bank_prepared=None, prepared_out=None, bank_push=None, bb_late=False, slot=0,
-                 pipeline=None):
+                 pipeline=None, local_masks=None):
     """Forward of the head.  Returns (losses[5] device tensor, saved-state dict or None).
 
     `join`: optional callable run right before the first use of gt / gv.  Either the caller produces the
@@ -192,20 +201,35 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     # with the clustering -- see below); its results land in `L`.
     L = {}
     early = [None, None]
+    # Pipelined steps with an early fork (modeling.StepPipeline.early_fork): the local branch starts from a point of the origin
+    # stream that lies BEFORE this step's prologue, so it converts its own copy of the caller's masks instead of reading the
+    # prologue's (the same values: 0 / 1 as fp32)
+    early_fork = (pipeline.early_fork if (pipeline is not None and EARLY_LOCAL_FORK and local_masks is not None and local_stream is not None
+                                          and all(m is not None for m in local_masks)) else None)
+
+    def fork_local():
+        if early_fork is not None:
+            wait_event(local_stream, early_fork)
+        else:
+            wait_stream(local_stream, cur)
 
     def local_steps():
-        L["pt"], L["pv"] = pt_, pv_ = ops.prepare_tokens_pair(text_feat, text_mask, video_feat, video_mask, want_lo=lo_b, want_colsum=True)
+        tm_l, vm_l = text_mask, video_mask
+        if early_fork is not None:
+            tm_l, vm_l = (m if m.dtype == torch.float32 else m.float() for m in local_masks)
+            L["masks"] = (tm_l, vm_l)
+        L["pt"], L["pv"] = pt_, pv_ = ops.prepare_tokens_pair(text_feat, tm_l, video_feat, vm_l, want_lo=lo_b, want_colsum=True)
         yield
         if PAIR_BATCH_SCORERS and not keep and B * min(Nt, Nv) >= PAIR_BATCH_SCORERS_FROM:
             # the text and the video scorer in one grid; bit-identical to the two launches
             (L["w_t"], L["lg_t"]), (L["w_v"], L["lg_v"]) = ops.token_weights_pair(
-                [(pt_, sw_t.w1_hi, sw_t.w1_lo, sw_t.b1, sw_t.w2, sw_t.b2, text_mask, B, Nt),
-                 (pv_, sw_v.w1_hi, sw_v.w1_lo, sw_v.b1, sw_v.w2, sw_v.b2, video_mask, B, Nv)], p_mlp)
+                [(pt_, sw_t.w1_hi, sw_t.w1_lo, sw_t.b1, sw_t.w2, sw_t.b2, tm_l, B, Nt),
+                 (pv_, sw_v.w1_hi, sw_v.w1_lo, sw_v.b1, sw_v.w2, sw_v.b2, vm_l, B, Nv)], p_mlp)
             yield
         else:
-            L["w_t"], L["lg_t"] = token_weights(pt_, text_mask, sw_t, B, Nt, p_mlp, keep)
+            L["w_t"], L["lg_t"] = token_weights(pt_, tm_l, sw_t, B, Nt, p_mlp, keep)
             yield
-            L["w_v"], L["lg_v"] = token_weights(pv_, video_mask, sw_v, B, Nv, p_mlp, keep)
+            L["w_v"], L["lg_v"] = token_weights(pv_, vm_l, sw_v, B, Nv, p_mlp, keep)
             yield
         if not (bb_late and split_tail):
             L["S"], L["aux0"] = ops.local_level(pt_, pv_, L["w_t"], L["w_v"], B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
@@ -297,7 +321,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         # the nodes captured ahead of it have started (profiled step: a branch captured after 7 clustering nodes
         # began 120 us late and ended up the critical path).  So the two branches are captured interleaved:
         # `capture_order` = [(clustering launches, local launches), ...] per turn, the last pair repeating.
-        wait_stream(local_stream, cur)
+        fork_local()
         loc = local_steps()
         loc_alive, clu_alive = True, True
         produced = None
@@ -325,7 +349,7 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     else:
         # `join`: one callable run right before gt / gv are needed (may return them); generators are run through
         if local_stream is not None:
-            wait_stream(local_stream, cur)
+            fork_local()
             if join is not None:
                 produced = exhaust(join) if stepwise_join else join()
                 if produced is not None:
@@ -405,6 +429,11 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
                     with torch.cuda.stream(pst):
                         for t_ in (pt.hi, pt.norm, pv.hi, pv.norm) + ((pt.lo, pv.lo) if pt.lo is not None else ()):
                             t_.record_stream(pst)
+                        if early_fork is not None and pipeline.prologue_done is not None:
+                            wait_event(pst, pipeline.prologue_done)      # the push writes at the ring head this step's prologue has moved
+                        if pipeline is not None and pipeline.prev_tail_done is not None and TAIL_BEFORE_NEXT_PUSH:
+                            wait_event(pst, pipeline.prev_tail_done)
+                            pipeline.prev_tail_done = None
                         with torch.no_grad():
                             bank_push()
                 wait_event(side, g_ready)

@@ -70,6 +70,13 @@ class StepPipeline:
         self.tail_done = None        # event: this step's five losses are written (head.head_forward, split tail)
         self.prev_tail_done = prev.tail_done if prev is not None else None
         self.pending = []
+        # EARLY FORK of the local branch: an event recorded on the origin stream BEFORE it waits for the previous step's push
+        # (set by whoever captures the steps).  The batch half of the local branch -- prepare, batch scorers, batch x batch
+        # product -- reads neither the bank nor anything the prologue writes, so it forks from there and runs beside the previous
+        # step's bank chain instead of behind its push; `prologue_done` (recorded behind this step's prologue) is what this
+        # step's push then waits for explicitly (it writes at the ring head the prologue has just moved).
+        self.early_fork = None
+        self.prologue_done = None
         # OWNERSHIP: every tensor this step allocates that a forked stream (tail, bank chains, push) may still read when the origin
         # stream has moved on to the next step is referenced from here until the capture ends -- whoever captures the steps keeps
         # the StepPipeline objects alive that long.  A block that is never freed inside the capture is never handed out again
@@ -647,6 +654,7 @@ class NeighborRetr(nn.Module):
         memory-bank push (modeling.py:283-312).  Collective-free, so it captures into a HIP graph."""
         noise = None
         raw_scale = self.clip.logit_scale
+        self._raw_masks = (text_mask, video_mask)      # as the caller handed them over (the early-forked local branch converts its own copy)
         if text_feat.is_cuda:
             # masks as fp32 multipliers, exp(logit_scale) and the DPC-KNN tie-break noise in ONE launch
             scale_in_kernel = not (torch.is_grad_enabled() and raw_scale.requires_grad)
@@ -657,6 +665,9 @@ class NeighborRetr(nn.Module):
                 text_mask, video_mask, raw_scale if scale_in_kernel else None,
                 self._rng_state_on(text_feat.device), B * sum(sizes.values()), ring=ring)
             self._ring_advanced = ring is not None
+            if self._pipeline is not None:
+                from .capture_guard import record_event as _rec
+                self._pipeline.prologue_done = _rec(torch.cuda.current_stream())
             if self._pipeline is not None and self._pipeline.decoupled and ring is not None:
                 # this step's own copy of the ring head, in a PERSISTENT word per slot: the push reads it late, on its own stream --
                 # a per-step allocation of this stream would be handed out again to the next step before the push has run
@@ -685,6 +696,7 @@ class NeighborRetr(nn.Module):
                                       cfg.centrality_scale, cfg.beta, cfg.num_neighbors, cfg.temperature,
                                       logit_scale, noise=noise)
         self._push_fn = None
+        self._raw_masks = None
         if not self.bank_frozen and not self._pushed:
             with torch.no_grad():
                 push()
