@@ -26,7 +26,7 @@ extern "C" {
 
 /* bumped whenever a signature or the layout of a descriptor struct changes (2: NrCtmStageDesc gained x_hi/x_lo/out_hi/out_lo in
  * round 3, nr_stream_create / nr_stream_destroy, NrBankAbsorbDesc in round 4; 3: nr_pack_shard_convert); a binding compares nr_version() with the value it was written for */
-#define NR_ABI_VERSION 4
+#define NR_ABI_VERSION 5
 
 /* precision of the MFMA contractions */
 #define NR_PREC_BF16 0   /* one bf16 pass (training path)                                   */
@@ -432,6 +432,16 @@ int nr_row_losses_fwd_no_uniform_final(const float* S, const float* G, const flo
                                        const float* wc_video, const float* logit_scale, int B, int K, float temperature,
                                        float* rowloss, uint32_t* counter, float uniform_weight, float neighbor_weight,
                                        float kl_weight, float* losses, void* stream);
+/* nr_row_losses_fwd_no_uniform_final computing the centrality weights itself (compute_centrality_weights, modeling.py:403-430,
+ * ONE global token per sample): g_text / g_video [B,d] global tokens, mean_text / mean_video [d] means of the normalised
+ * batch tokens, w_i = exp(centrality_scale * <g_i, mean> / max(|g_i|, 1e-12)) -- the arithmetic of
+ * nr_centrality_weights_pair, whose launch this form saves in the loss-only step. */
+int nr_row_losses_fwd_no_uniform_final_cw(const float* S, const float* G, const float* c0_parts, int n_c0,
+                                          const float* c1_parts, int n_c1, float c_scale, const float* g_text,
+                                          const float* g_video, const float* mean_text, const float* mean_video, int d,
+                                          float centrality_scale, const float* logit_scale, int B, int K, float temperature,
+                                          float* rowloss, uint32_t* counter, float uniform_weight, float neighbor_weight,
+                                          float kl_weight, float* losses, void* stream);
 /* nr_row_losses_fwd without the uniform term: rowloss[dir][0,2,3][i] only, no dependence on the Sinkhorn targets. */
 int nr_row_losses_fwd_no_uniform(const float* S, const float* G, const float* bank_c0, const float* bank_c1,
                                  const float* wc_text, const float* wc_video, const float* logit_scale, int B, int K,

@@ -30,6 +30,12 @@ struct NrRowArgs {
     // launches of the bank chains disappear.  0: bank_c0 / bank_c1 are the finished [B] vectors.
     int n_c0, n_c1;
     float c_scale;
+    // Centrality weights computed HERE (one global token per sample): wc_i = exp(cw_scale * <g_i, mean> / max(|g_i|, 1e-12)),
+    // the arithmetic of nr_centrality_pair_kernel (modeling.py:403-430) -- the weights' own launch disappears from the split
+    // tail.  nullptr: wc_text / wc_video hold the finished weights.
+    const float *cw_g_text, *cw_g_video, *cw_mean_text, *cw_mean_video;
+    int cw_d;
+    float cw_scale;
 };
 
 // Everything the forward and the backward need about one row, recomputed identically in both.
@@ -52,7 +58,22 @@ struct NrRowState {
     __device__ __forceinline__ void load(const NrRowArgs& a, int row, int dir, int lane) {
         i = row; B = a.B; T = a.T;
         ls = a.logit_scale[0];
-        wci = dir == 0 ? a.wc_text[row] : a.wc_video[row];
+        if (a.cw_g_text) {
+            const float* gi = (dir == 0 ? a.cw_g_text : a.cw_g_video) + (size_t)row * a.cw_d;
+            const float* mean = dir == 0 ? a.cw_mean_text : a.cw_mean_video;
+            float dot = 0.f, ss = 0.f;
+            for (int k = lane * 4; k < a.cw_d; k += 256) {
+                f32x4_t x = *reinterpret_cast<const f32x4_t*>(gi + k);
+                f32x4_t m = *reinterpret_cast<const f32x4_t*>(mean + k);
+                dot += x[0] * m[0] + x[1] * m[1] + x[2] * m[2] + x[3] * m[3];
+                ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+            }
+            dot = nr_wave_sum(dot);
+            ss = nr_wave_sum(ss);
+            wci = expf(dot / fmaxf(sqrtf(ss), 1e-12f) * a.cw_scale);
+        } else {
+            wci = dir == 0 ? a.wc_text[row] : a.wc_video[row];
+        }
         const float* cvec = dir == 0 ? a.bank_c0 : a.bank_c1;
         const int n_cp = dir == 0 ? a.n_c0 : a.n_c1;
         const float* tgt = dir == 0 ? a.tgt_rows : a.tgt_cols;
@@ -275,7 +296,7 @@ extern "C" int nr_row_losses_fwd(const float* S, const float* G, const float* tg
     if (!S || !G || !tgt_rows || !tgt_cols || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale || !rowloss)
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;    // the reference raises IndexError for K > B
-    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f};
+    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, 0, 0.f};
     return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr, 0u}, (hipStream_t)stream);
 }
 
@@ -286,7 +307,7 @@ extern "C" int nr_row_losses_fwd_no_uniform(const float* S, const float* G, cons
                                             float temperature, float* rowloss, void* stream) {
     if (!S || !G || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale || !rowloss) return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;
-    NrRowArgs a{S, G, nullptr, nullptr, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f};
+    NrRowArgs a{S, G, nullptr, nullptr, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, 0, 0.f};
     return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr, 0u}, (hipStream_t)stream);
 }
 
@@ -304,7 +325,24 @@ extern "C" int nr_row_losses_fwd_no_uniform_final(const float* S, const float* G
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B || n_c0 <= 0 || n_c1 <= 0) return NR_EINVAL;
     NrRowArgs a{S, G, nullptr, nullptr, c0_parts, c1_parts, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0,
-                n_c0, n_c1, c_scale};
+                n_c0, n_c1, c_scale, nullptr, nullptr, nullptr, nullptr, 0, 0.f};
+    return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{counter, uniform_weight, neighbor_weight, kl_weight, losses,
+                                                           (unsigned)nr_split_tail_workgroups(B)}, (hipStream_t)stream);
+}
+
+// The same launch computing the centrality weights itself (see NrRowArgs::cw_*): g_text / g_video [B, d] the samples' ONE
+// global token, mean_text / mean_video [d] the means of the normalised batch tokens.
+extern "C" int nr_row_losses_fwd_no_uniform_final_cw(const float* S, const float* G, const float* c0_parts, int n_c0,
+                                                     const float* c1_parts, int n_c1, float c_scale, const float* g_text,
+                                                     const float* g_video, const float* mean_text, const float* mean_video, int d,
+                                                     float centrality_scale, const float* logit_scale, int B, int K,
+                                                     float temperature, float* rowloss, uint32_t* counter, float uniform_weight,
+                                                     float neighbor_weight, float kl_weight, float* losses, void* stream) {
+    if (!S || !G || !c0_parts || !c1_parts || !g_text || !g_video || !mean_text || !mean_video || !logit_scale || !rowloss || !counter || !losses)
+        return NR_EINVAL;
+    if (B <= 0 || K < 0 || K > B || n_c0 <= 0 || n_c1 <= 0 || d <= 0 || (d % 4) != 0) return NR_EINVAL;
+    NrRowArgs a{S, G, nullptr, nullptr, c0_parts, c1_parts, nullptr, nullptr, logit_scale, B, K, temperature, nullptr, 0, 0,
+                n_c0, n_c1, c_scale, g_text, g_video, mean_text, mean_video, d, centrality_scale};
     return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{counter, uniform_weight, neighbor_weight, kl_weight, losses,
                                                            (unsigned)nr_split_tail_workgroups(B)}, (hipStream_t)stream);
 }
@@ -316,7 +354,7 @@ extern "C" int nr_row_losses_fwd_slab(const float* S_rows, const float* S_cols, 
     if (!S_rows || !S_cols || !G || !tgt_rows || !tgt_cols || !bank_c0 || !bank_c1 || !wc_text || !wc_video || !logit_scale || !rowloss)
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B || row0 < 0 || n_rows <= 0 || row0 + n_rows > B) return NR_EINVAL;
-    NrRowArgs a{S_rows, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, S_cols, row0, n_rows, 0, 0, 0.f};
+    NrRowArgs a{S_rows, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, S_cols, row0, n_rows, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, 0, 0.f};
     return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{nullptr, 0.f, 0.f, 0.f, nullptr, 0u}, (hipStream_t)stream);
 }
 
@@ -329,7 +367,7 @@ extern "C" int nr_row_losses_fwd_final(const float* S, const float* G, const flo
         !counter || !losses)
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;
-    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f};
+    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, 0, 0.f};
     return nr_row_losses_fwd_launch(a, rowloss, NrRowFinal{counter, uniform_weight, neighbor_weight, kl_weight, losses, 0u},
                                     (hipStream_t)stream);
 }
@@ -495,7 +533,7 @@ extern "C" int nr_row_losses_bwd(const float* S, const float* G, const float* tg
         !dS_dir || !dG_dir || !d_c_rows || !d_wc || !d_ls_rows)
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B) return NR_EINVAL;
-    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f};
+    NrRowArgs a{S, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, nullptr, 0, 0, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, 0, 0.f};
     dim3 grid((B + 3) / 4, 2);
     hipStream_t st = (hipStream_t)stream;
 #define NR_BWD_CASE(N_) \
@@ -521,7 +559,7 @@ extern "C" int nr_row_losses_bwd_slab(const float* S_rows, const float* S_cols, 
         !g_rowloss || !dS_dir || !dG_dir || !d_c_rows || !d_wc || !d_ls_rows)
         return NR_EINVAL;
     if (B <= 0 || K < 0 || K > B || row0 < 0 || n_rows <= 0 || row0 + n_rows > B) return NR_EINVAL;
-    NrRowArgs a{S_rows, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, S_cols, row0, n_rows, 0, 0, 0.f};
+    NrRowArgs a{S_rows, G, tgt_rows, tgt_cols, bank_c0, bank_c1, wc_text, wc_video, logit_scale, B, K, temperature, S_cols, row0, n_rows, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, 0, 0.f};
     dim3 grid((n_rows + 3) / 4, 2);
     hipStream_t st = (hipStream_t)stream;
 #define NR_BWD_CASE(N_) \

@@ -137,6 +137,12 @@ TAIL_BEFORE_NEXT_PUSH = os.environ.get("NR_TAIL_EDGE", "1") == "2"
 # from --decouple_push: whenever a step's chip-filling launches are released ahead of the previous step's push, the replayed
 # graph runs slower, whatever the edges say.  NR_EARLY_FORK=1 turns it on (developer A/B switch).
 EARLY_LOCAL_FORK = os.environ.get("NR_EARLY_FORK", "0") == "1"
+# Loss-only split tail: the centrality weights computed inside the final row-loss launch (same arithmetic, same bits).
+# NR_FUSE_CW=0: their own launch in front of it (developer A/B switch).
+FUSE_CENTRALITY_WEIGHTS = os.environ.get("NR_FUSE_CW", "1") == "1"
+# The token means on the second bank stream instead of the local branch: measured SLOWER (3773-3789 vs 3844-3861 steps/s,
+# tools/ab_tail_fuse.sh; with the centrality weights fused: 3828-3839 vs 3873-3894) -- off; NR_COLSUM_OFF=1 turns it on (A/B switch)
+COLSUM_OFF_CHAIN = os.environ.get("NR_COLSUM_OFF", "0") == "1"
 # Loss-only step: the batch's text and video scorers as one launch (nr_token_weights_fwd_pair).  NR_PAIR_SCORERS=0: two launches (A/B).
 PAIR_BATCH_SCORERS = os.environ.get("NR_PAIR_SCORERS", "1") == "1"
 # ... from this many tokens in the smaller set on (a few workgroups per CU): configs[3] 517 -> 530 steps/s, configs[2] 424 -> 427;
@@ -234,9 +240,19 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         if not (bb_late and split_tail):
             L["S"], L["aux0"] = ops.local_level(pt_, pv_, L["w_t"], L["w_v"], B, Nt, B, Nv, p_bb, hip.OUT_FULL, keep)
             yield
-        # mean of the (unmasked) normalised tokens for the centrality weights -- still on the local branch, both in one launch
-        L["mean_t"], L["mean_v"] = ops.colsum_pair(pt_.colsum, 1.0 / pt_.n_tok, pv_.colsum, 1.0 / pv_.n_tok)
-        yield
+        # mean of the (unmasked) normalised tokens for the centrality weights, both in one launch.  Only the tail reads it: in the
+        # split tail it runs on the second bank stream (idle until then), off the chain prepare -> scorers -> products -> push
+        # that paces the pipelined steps; else here on the local branch
+        if COLSUM_OFF_CHAIN and split_tail and bank_early > 1:
+            side2_ = bank_streams[1]
+            wait_stream(side2_, torch.cuda.current_stream())
+            with torch.cuda.stream(side2_):
+                L["mean_t"], L["mean_v"] = ops.colsum_pair(pt_.colsum, 1.0 / pt_.n_tok, pv_.colsum, 1.0 / pv_.n_tok)
+            for t_ in (pt_.colsum, pv_.colsum):
+                t_.record_stream(side2_)
+        else:
+            L["mean_t"], L["mean_v"] = ops.colsum_pair(pt_.colsum, 1.0 / pt_.n_tok, pv_.colsum, 1.0 / pv_.n_tok)
+            yield
         # `bank_early` chains (0..2) run right behind the batch products, i.e. beside the clustering; the rest is
         # forked after the join (beside the Sinkhorn solve)
         if local_stream is not None and bank_early > 0:
@@ -437,9 +453,16 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
                         with torch.no_grad():
                             bank_push()
                 wait_event(side, g_ready)
-                wc_t, wc_v, cw_aux = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
-                ops.row_losses_no_uniform_final(S, G, c0, c1, 1.0 / M, wc_t, wc_v, ls, K, hp["temperature"], rowloss, counter,
-                                                *wts, losses)
+                if FUSE_CENTRALITY_WEIGHTS and gt2.shape[1] == 1 and gv2.shape[1] == 1 and gt2.shape[0] == B and gv2.shape[0] == B:
+                    # one global token per sample: the row-loss launch computes the centrality weights itself (one launch less
+                    # on the chain that the next step's bank reads wait for)
+                    wc_t = wc_v = cw_aux = None
+                    ops.row_losses_no_uniform_final_cw(S, G, c0, c1, 1.0 / M, gt2.view(B, -1), gv2.view(B, -1), mean_t, mean_v,
+                                                       hp["centrality_scale"], ls, K, hp["temperature"], rowloss, counter, *wts, losses)
+                else:
+                    wc_t, wc_v, cw_aux = ops.centrality_weights_pair(gt2, gv2, mean_t, mean_v, hp["centrality_scale"], keep)
+                    ops.row_losses_no_uniform_final(S, G, c0, c1, 1.0 / M, wc_t, wc_v, ls, K, hp["temperature"], rowloss, counter,
+                                                    *wts, losses)
                 if pipeline is not None:
                     pipeline.tail_done = record_event(side)
         except BaseException:
@@ -466,6 +489,8 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
             if push_stream is not None:
                 wait_stream(cur, push_stream)
         for t_ in (S, mean_t, mean_v, w_t, w_v, pt.hi, pv.hi, c0, c1, wc_t, wc_v, G, rowloss, losses):
+            if t_ is None:                   # (the centrality weights: computed inside the row-loss launch)
+                continue
             t_.record_stream(cur)
             t_.record_stream(side)
         if pt.lo is not None:

@@ -17,7 +17,7 @@ PREC_BF16 = 0
 PREC_BF16X3 = 1
 OUT_FULL, OUT_ROWSUM, OUT_COLSUM = 0, 1, 2
 NR_EINVAL, NR_EUNSUPPORTED = -1, -2          # status codes of include/nr_hip.h
-ABI_VERSION = 4                              # NR_ABI_VERSION this binding was written for (checked at load)
+ABI_VERSION = 5                              # NR_ABI_VERSION this binding was written for (checked at load)
 
 _lib = None
 
@@ -178,6 +178,7 @@ _SIGNATURES = {
     "nr_split_tail_workgroups": ([_I], _I),
     "nr_sinkhorn_uniform_rows_final": ([_P, _I, _F, _I, _F, _P, _P, _F, _F, _F, _P, _P, _P], _I),
     "nr_row_losses_fwd_no_uniform_final": ([_P, _P, _P, _I, _P, _I, _F, _P, _P, _P, _I, _I, _F, _P, _P, _F, _F, _F, _P, _P], _I),
+    "nr_row_losses_fwd_no_uniform_final_cw": ([_P, _P, _P, _I, _P, _I, _F, _P, _P, _P, _P, _I, _F, _P, _I, _I, _F, _P, _P, _F, _F, _F, _P, _P], _I),
     "nr_sinkhorn_targets": ([_P, _I, _F, _I, _P, _P, _P, _P], _I),
     "nr_row_losses_fwd": ([_P] * 9 + [_I, _I, _F, _P, _P], _I),
     "nr_row_losses_fwd_slab": ([_P, _P, _I, _I] + [_P] * 8 + [_I, _I, _F, _P, _P], _I),

@@ -372,6 +372,19 @@ def row_losses_no_uniform_final(S, G, c0_parts, c1_parts, c_scale, wc_text, wc_v
              hip.ptr(counter, torch.int32), float(wu), float(wn), float(wkl), hip.ptr(losses, torch.float32), hip.stream_ptr())
 
 
+def row_losses_no_uniform_final_cw(S, G, c0_parts, c1_parts, c_scale, g_text, g_video, mean_text, mean_video, centrality_scale,
+                                   logit_scale, K, T, rowloss, counter, wu, wn, wkl, losses):
+    """nr_row_losses_fwd_no_uniform_final_cw: row_losses_no_uniform_final with the centrality weights computed by the row's own
+    wave (one global token per sample: g_text / g_video [B, d], mean_text / mean_video [d])."""
+    B, d = S.shape[0], g_text.shape[-1]
+    hip.call("nr_row_losses_fwd_no_uniform_final_cw", hip.ptr(S, torch.float32), hip.ptr(G, torch.float32),
+             hip.ptr(c0_parts, torch.float32), c0_parts.shape[0], hip.ptr(c1_parts, torch.float32), c1_parts.shape[0],
+             float(c_scale), hip.ptr(g_text, torch.float32), hip.ptr(g_video, torch.float32), hip.ptr(mean_text, torch.float32),
+             hip.ptr(mean_video, torch.float32), int(d), float(centrality_scale), hip.ptr(logit_scale, torch.float32), B, int(K),
+             float(T), hip.ptr(rowloss, torch.float32), hip.ptr(counter, torch.int32), float(wu), float(wn), float(wkl),
+             hip.ptr(losses, torch.float32), hip.stream_ptr())
+
+
 def row_losses_no_uniform(S, G, bank_c0, bank_c1, wc_text, wc_video, logit_scale, K, T, rowloss):
     """Centrality / neighbour / KL row terms into rowloss[:, (0, 2, 3), :] (nr_row_losses_fwd_no_uniform)."""
     B = S.shape[0]

@@ -54,7 +54,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert declared == set(hip.exported_symbols()), declared ^ set(hip.exported_symbols())
-    assert lib.nr_version() == 4
+    assert lib.nr_version() == 5
     assert lib.nr_prepare_parts(10) == 1 and lib.nr_prepare_parts(3072) == 192 and lib.nr_prepare_parts(10 ** 6) == 256
 
 

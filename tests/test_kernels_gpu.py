@@ -24,7 +24,7 @@ def _tw(prep, mask, P, prefix, n, N, prec):
 
 
 def test_library_loads_and_version():
-    assert hip.version() == hip.ABI_VERSION == 4
+    assert hip.version() == hip.ABI_VERSION == 5
 
 
 @pytest.mark.parametrize("n,N,d", [(16, 24, 512), (5, 7, 256), (3, 64, 768)])
