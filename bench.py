@@ -1188,7 +1188,7 @@ def main():
         per_launch_s = e0.elapsed_time(e1) * 1e-3 / (n_launch * reps * inner)
         achieved = (f_sim / n_launch) / per_launch_s / 1e12
         traffic = mfma_busy = None
-        pmc = next((q_ for q_ in (os.path.join(ROOT, "profiles", f"r0{k_}_pmc_sim.json") for k_ in (4, 3, 2)) if os.path.exists(q_)),
+        pmc = next((q_ for q_ in (os.path.join(ROOT, "profiles", f"r0{k_}_pmc_sim.json") for k_ in (5, 4, 3, 2)) if os.path.exists(q_)),
                    os.path.join(ROOT, "profiles", "r03_pmc_sim.json"))
         pmc_name = "profiles/" + os.path.basename(pmc)
         if os.path.exists(pmc) and args.config == 1:     # PMC counters need rocprofv3 (separate passes): the committed passes are quoted here

@@ -130,6 +130,12 @@ typedef struct NrTokenWeightsProblem {
     int32_t n_samples, N, d, H, n_counters, reserved;
 } NrTokenWeightsProblem;
 int nr_token_weights_fwd_pair(const NrTokenWeightsProblem* a, const NrTokenWeightsProblem* b, int prec, void* stream);
+/* Up to four nr_token_weights_fwd calls -- the four token sets a step scores: batch text / video (modeling.py:485-492 inside
+ * local_level :283-287) and bank video / text (the two bank calls, until_module.py:170-185) -- each in its own precision
+ * (precs[i]: NR_PREC_*), in ONE launch of 192 x 256 blocks; split-bf16 sets as three accumulated passes.  NR_EUNSUPPORTED
+ * when a set does not fit that block (192 % N, H % 256): issue the sets one by one then.  One-pass sets: bit-identical to
+ * their single launch; split-bf16 sets: another summation order (~1e-7 relative).                                          */
+int nr_token_weights_fwd_group(const NrTokenWeightsProblem* probs, const int* precs, int n, void* stream);
 
 /* Fused local_level (modeling.py:499-512): token-token cosine products on MFMA, max-pool over
  * each token axis, weighted sums, (t2v+v2t)/2.  The [A,Bv,Nt,Nv] tensor is never materialised.

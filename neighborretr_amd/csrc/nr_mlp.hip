@@ -48,7 +48,10 @@ struct NrMlpProblem {
 
 // wg: the workgroup's index INSIDE this problem's (8-padded) grid -- blockIdx.x, or blockIdx.x minus the grids of the problems
 // in front of it in a paired launch (multiples of 8: the XCD a workgroup lands on is the same either way)
-template <int MI, int NI, int WC, bool X3, int STAGES>
+// ACC3 (one-pass ring only): the split-bf16 product as THREE accumulated passes over K through the ping-pong loop
+// (NrGemmTile::run_pp3: Ah Bh, then Ah Bl, then Al Bh) -- what lets split-bf16 token sets share a grid, a block shape and an
+// LDS footprint with one-pass sets (nr_mlp_group_kernel)
+template <int MI, int NI, int WC, bool X3, int STAGES, bool ACC3 = false>
 __device__ __forceinline__ void nr_mlp_body(const NrMlpProblem& q, const int wg, char* smem) {
     const uint16_t* __restrict__ tok_hi = q.tok_hi;
     const uint16_t* __restrict__ tok_lo = q.tok_lo;
@@ -79,7 +82,10 @@ __device__ __forceinline__ void nr_mlp_body(const NrMlpProblem& q, const int wg,
     tile.zero();
     // 8-wave blocks on a two-deep ring walk K with the ping-pong loop of the similarity kernel (the two wave rows alternate
     // between an MFMA phase and a memory phase: nr_gemm_tile.h); NR_MLP_PLAIN=1 (tuning builds): the plain loop
-    if constexpr (WC == 4 && STAGES == 2 && !X3) {
+    if constexpr (ACC3) {
+        static_assert(WC == 4 && STAGES == 2 && !X3, "three accumulated passes: 8 waves, two-deep one-pass ring");
+        tile.run_pp3(tok_hi, tok_lo, row0, n_tok, w1_hi, w1_lo, col0, H, d, smem);
+    } else if constexpr (WC == 4 && STAGES == 2 && !X3) {
         if (NR_MLP_PP) tile.run_pp(tok_hi, tok_lo, row0, n_tok, w1_hi, w1_lo, col0, H, d, smem);
         else tile.run(tok_hi, tok_lo, row0, n_tok, w1_hi, w1_lo, col0, H, d, smem);
     } else {
@@ -198,6 +204,31 @@ __global__ __launch_bounds__(128 * WC) void nr_mlp_pair_kernel(NrMlpProblem a, N
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < grid_a) nr_mlp_body<MI, NI, WC, X3, STAGES>(a, blockIdx.x, smem);
     else nr_mlp_body<MI, NI, WC, X3, STAGES>(b, (int)blockIdx.x - grid_a, smem);
+}
+
+// ---- ALL scorer calls of a step in one grid ---------------------------------------------------------------------------------
+// Up to NR_MLP_GROUP_MAX token sets, each in its own precision, on ONE block shape (192 x 256 hidden units on 8 waves, two-deep
+// one-pass ring); the split-bf16 sets run three accumulated passes.  Four launches of eight K slices each pay four starts and
+// four epilogues (about a third of a launch: nr_mlp.hip header of this round's notes) and leave CUs idle behind the small
+// sets; one grid pays them once and keeps every CU fed.  Workgroups of the split-bf16 sets come FIRST (three passes each).
+#define NR_MLP_GROUP_MAX 4
+struct NrMlpGroup {
+    NrMlpProblem p[NR_MLP_GROUP_MAX];
+    int x3[NR_MLP_GROUP_MAX];
+    int start[NR_MLP_GROUP_MAX + 1];       // first workgroup of every problem (multiples of 8: the XCD order of a problem's tiles)
+    int n;
+};
+
+template <int MI, int NI>
+__global__ __launch_bounds__(512) void nr_mlp_group_kernel(NrMlpGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < NR_MLP_GROUP_MAX; ++i)
+        if (i < g.n && (int)blockIdx.x >= g.start[i]) gi = i;
+    const int wg = (int)blockIdx.x - g.start[gi];
+    if (g.x3[gi]) nr_mlp_body<MI, NI, 4, false, 2, true>(g.p[gi], wg, smem);
+    else nr_mlp_body<MI, NI, 4, false, 2, false>(g.p[gi], wg, smem);
 }
 
 namespace {
@@ -364,6 +395,53 @@ extern "C" int nr_token_weights_fwd_pair(const NrTokenWeightsProblem* a, const N
     }
     if (a->counters == b->counters) return NR_EINVAL;               // (the two problems' row tiles count separately)
     return nr_mlp_go(q[0], &q[1], prec, stream);
+}
+
+// nr_token_weights_fwd for up to four token sets, each in its own precision, in ONE launch (192 x 256 blocks; see
+// nr_mlp_group_kernel).  NR_EUNSUPPORTED when a set does not fit that block (H % 256, 192 % N, missing lo halves): the caller
+// issues the sets one by one.  Split-bf16 sets come out of three accumulated passes (another summation order than the
+// single-launch split tile: equal to ~1e-7 relative, not bit for bit); one-pass sets are bit-identical to their single launch.
+extern "C" int nr_token_weights_fwd_group(const NrTokenWeightsProblem* probs, const int* precs, int n, void* stream) {
+    if (!probs || !precs || n <= 0 || n > NR_MLP_GROUP_MAX) return NR_EINVAL;
+    constexpr int MI = 6, NI = 4;
+    using Tile = NrGemmTile<MI, NI, false, 16, 16, 2, 4>;
+    NrMlpGroup g;
+    g.n = n;
+    int order[NR_MLP_GROUP_MAX], k = 0;
+    for (int pass = 0; pass < 2; ++pass)                       // split-bf16 sets first
+        for (int i = 0; i < n; ++i)
+            if ((precs[i] == NR_PREC_BF16X3) == (pass == 0)) order[k++] = i;
+    int total = 0;
+    for (int j = 0; j < n; ++j) {
+        const NrTokenWeightsProblem& t = probs[order[j]];
+        const int prec = precs[order[j]];
+        if (!t.counters || !t.b2 || !t.w || t.n_samples <= 0 || t.N <= 0) return NR_EINVAL;
+        if (t.N > 256 || (Tile::BM % t.N) != 0 || (t.H % Tile::BN) != 0) return NR_EUNSUPPORTED;
+        const long n_tok = (long)t.n_samples * t.N;
+        if (t.n_counters < (n_tok + 63) / 64) return NR_EINVAL;
+        NrMlpProblem q{t.tok_hi, t.tok_lo, t.norm, (int)n_tok, t.d, t.w1_hi, t.w1_lo, t.b1, t.w2, t.H, t.logit_part,
+                       NrMlpSoftmax{t.counters, t.b2, t.mask, t.N, t.w, t.logits}};
+        int rc = nr_mlp_check(q, prec);
+        if (rc != NR_OK) return rc;
+        for (int j2 = 0; j2 < j; ++j2)
+            if (g.p[j2].sm.counters == t.counters) return NR_EINVAL;      // (the problems' row tiles count separately)
+        g.p[j] = q;
+        g.x3[j] = prec == NR_PREC_BF16X3 ? 1 : 0;
+        g.start[j] = total;
+        total += nr_xcd_chunk_grid((t.H / Tile::BN) * (int)((n_tok + Tile::BM - 1) / Tile::BM));
+    }
+    for (int j = n; j <= NR_MLP_GROUP_MAX; ++j) g.start[j] = total;
+    size_t lds = Tile::RING_BYTES;
+    if (lds < 8192 + 16) lds = 8192 + 16;
+    static_assert((size_t)4 * Tile::BM * sizeof(float) <= 8192, "the flag sits behind sPart");
+    auto kern = nr_mlp_group_kernel<MI, NI>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(total), dim3(512), lds, (hipStream_t)stream, g);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
 }
 
 // ---- backward of the scorer MLP, hidden layer (no counterpart in the reference: autograd differentiates modeling.py:148-153) ----

@@ -143,6 +143,12 @@ FUSE_CENTRALITY_WEIGHTS = os.environ.get("NR_FUSE_CW", "1") == "1"
 # The token means on the second bank stream instead of the local branch: measured SLOWER (3773-3789 vs 3844-3861 steps/s,
 # tools/ab_tail_fuse.sh; with the centrality weights fused: 3828-3839 vs 3873-3894) -- off; NR_COLSUM_OFF=1 turns it on (A/B switch)
 COLSUM_OFF_CHAIN = os.environ.get("NR_COLSUM_OFF", "0") == "1"
+# Loss-only split tail: the step's four token sets scored by ONE launch (nr_token_weights_fwd_group).  Alone that launch takes
+# 51 us against 68 for the four (tools/microbench.py mlp) -- and the STEP is slower with it: 3773-3806 vs 3871-3888 steps/s at
+# configs[1], 521 vs 562 at configs[3] (tools/ab_group_scorers.sh, two A/B pairs each): its 8-wave 192 x 256 workgroups (165
+# registers a lane) leave no room on a CU for the clustering's workgroups, which then queue behind a 59 us launch (front kernel
+# 40 us instead of 13 in the trace).  OFF; NR_GROUP_SCORERS=1 turns it on (developer A/B switch)
+GROUP_SCORERS = os.environ.get("NR_GROUP_SCORERS", "0") == "1"
 # Loss-only step: the batch's text and video scorers as one launch (nr_token_weights_fwd_pair).  NR_PAIR_SCORERS=0: two launches (A/B).
 PAIR_BATCH_SCORERS = os.environ.get("NR_PAIR_SCORERS", "1") == "1"
 # ... from this many tokens in the smaller set on (a few workgroups per CU): configs[3] 517 -> 530 steps/s, configs[2] 424 -> 427;
@@ -226,7 +232,25 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
             L["masks"] = (tm_l, vm_l)
         L["pt"], L["pv"] = pt_, pv_ = ops.prepare_tokens_pair(text_feat, tm_l, video_feat, vm_l, want_lo=lo_b, want_colsum=True)
         yield
-        if PAIR_BATCH_SCORERS and not keep and B * min(Nt, Nv) >= PAIR_BATCH_SCORERS_FROM:
+        grouped = None
+        if (GROUP_SCORERS and split_tail and bank_prepared is not None and bank_early > 1 and local_stream is not None
+                and p_mlp == hip.PREC_BF16X3 and pt_.lo is not None):
+            # ALL four token sets of the step in one scorer launch (nr_token_weights_fwd_group): the bank's sets read its prepared
+            # shadow, so the launch waits for the previous step's push (as the step's prologue already did); the edge to the
+            # previous step's row losses moves to the first bank product (bank_video_steps / bank_text_steps)
+            if pipeline is not None and pipeline.prev_push_done is not None:
+                wait_event(torch.cuda.current_stream(), pipeline.prev_push_done)
+            pbt_, pbv_ = bank_prepared
+            grouped = ops.token_weights_group(
+                [(pt_, sw_t.w1_hi, sw_t.w1_lo, sw_t.b1, sw_t.w2, sw_t.b2, tm_l, B, Nt),
+                 (pv_, sw_v.w1_hi, sw_v.w1_lo, sw_v.b1, sw_v.w2, sw_v.b2, vm_l, B, Nv),
+                 (pbv_, sw_v.w1_hi, sw_v.w1_lo, sw_v.b1, sw_v.w2, sw_v.b2, mb_mask_v, M, Nv),
+                 (pbt_, sw_t.w1_hi, sw_t.w1_lo, sw_t.b1, sw_t.w2, sw_t.b2, mb_mask_t, M, Nt)],
+                [p_mlp, p_mlp, p_bank, p_bank])
+        if grouped is not None:
+            (L["w_t"], L["lg_t"]), (L["w_v"], L["lg_v"]), (L["w_bv"], _), (L["w_bt"], _) = grouped
+            yield
+        elif PAIR_BATCH_SCORERS and not keep and B * min(Nt, Nv) >= PAIR_BATCH_SCORERS_FROM:
             # the text and the video scorer in one grid; bit-identical to the two launches
             (L["w_t"], L["lg_t"]), (L["w_v"], L["lg_v"]) = ops.token_weights_pair(
                 [(pt_, sw_t.w1_hi, sw_t.w1_lo, sw_t.b1, sw_t.w2, sw_t.b2, tm_l, B, Nt),
@@ -288,8 +312,11 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         else:
             pbv = ops.prepare_tokens(mb_feat_v, mb_mask_v, want_lo=lo_k)
             yield
-        w_bv, lg_bv = token_weights(pbv, mb_mask_v, sw_v, M, Nv, p_bank, keep)
-        yield
+        if "w_bv" in L:                                   # (scored by the step's grouped scorer launch)
+            w_bv, lg_bv = L["w_bv"], None
+        else:
+            w_bv, lg_bv = token_weights(pbv, mb_mask_v, sw_v, M, Nv, p_bank, keep)
+            yield
         if pair_bank:
             return pbv, w_bv, lg_bv, None, None          # the product itself: one launch with the other chain's (below)
         p1, aux1 = ops.local_level(L["pt"], pbv, L["w_t"], w_bv, B, Nt, M, Nv, p_bank, hip.OUT_ROWSUM, keep)
@@ -308,8 +335,11 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         else:
             pbt = ops.prepare_tokens(mb_feat_t, mb_mask_t, want_lo=lo_k)
             yield
-        w_bt, lg_bt = token_weights(pbt, mb_mask_t, sw_t, M, Nt, p_bank, keep)
-        yield
+        if "w_bt" in L:
+            w_bt, lg_bt = L["w_bt"], None
+        else:
+            w_bt, lg_bt = token_weights(pbt, mb_mask_t, sw_t, M, Nt, p_bank, keep)
+            yield
         if pair_bank:
             return pbt, w_bt, lg_bt, None, None
         p0, aux2 = ops.local_level(pbt, L["pv"], w_bt, L["w_v"], M, Nt, B, Nv, p_bank, hip.OUT_COLSUM, keep)

@@ -140,6 +140,7 @@ _SIGNATURES = {
     "nr_token_mlp_bwd_part_rows": ([_I, _I, _I, _I], _I),
     "nr_token_mlp_bwd_hidden": ([_P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P], _I),
     "nr_token_weights_fwd_pair": ([ctypes.POINTER(TokenWeightsProblem), ctypes.POINTER(TokenWeightsProblem), _I, _P], _I),
+    "nr_token_weights_fwd_group": ([ctypes.POINTER(TokenWeightsProblem), ctypes.POINTER(ctypes.c_int), _I, _P], _I),
     "nr_token_weights_fwd": ([_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P], _I),
     "nr_local_level_tiles": ([_I, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)], _I),
     "nr_local_level_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),

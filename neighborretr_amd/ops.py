@@ -179,6 +179,44 @@ def token_weights_pair(calls, prec):
     return [token_weights(*c, prec) for c in calls]
 
 
+def token_weights_group(calls, precs):
+    """Up to four token_weights calls, each in its own precision, in ONE launch (nr_token_weights_fwd_group: 192 x 256 blocks,
+    split-bf16 sets as three accumulated passes).  calls: tuples (prep, w1_hi, w1_lo, b1, w2, b2, mask, n_samples, N); precs: one
+    hip.PREC_* per call.  -> [(w, None), ...], or None when a set does not fit the grouped form (nothing launched: the caller
+    issues the calls one by one)."""
+    import ctypes
+    if not FUSE_TOKEN_SOFTMAX or not 0 < len(calls) <= 4:
+        return None
+    dev = calls[0][0].hi.device
+    arr = (hip.TokenWeightsProblem * len(calls))()
+    outs, keep = [], []
+    for q, (prep, w1_hi, w1_lo, b1, w2, b2, mask, n_samples, N) in zip(arr, calls):
+        counters = _softmax_counters(dev, prep.n_tok)
+        if counters is None:
+            return None
+        H = w1_hi.shape[0]
+        parts = torch.empty((H // 128, prep.n_tok), dtype=torch.float32, device=dev)
+        w = torch.empty((n_samples, N), dtype=torch.float32, device=dev)
+        m = _f32(mask).contiguous() if mask is not None else None
+        q.tok_hi, q.tok_lo, q.norm = hip.ptr(prep.hi), hip.ptr(prep.lo, allow_none=True), hip.ptr(prep.norm)
+        q.w1_hi, q.w1_lo = hip.ptr(w1_hi), hip.ptr(w1_lo, allow_none=True)
+        q.b1, q.w2, q.b2 = hip.ptr(b1, torch.float32), hip.ptr(w2, torch.float32), hip.ptr(b2, torch.float32)
+        q.mask, q.logit_part, q.counters = hip.ptr(m, allow_none=True), hip.ptr(parts), hip.ptr(counters)
+        q.w, q.logits = hip.ptr(w), None
+        q.n_samples, q.N, q.d, q.H, q.n_counters = int(n_samples), int(N), int(prep.d), int(H), counters.numel()
+        outs.append((w, None))
+        keep += [parts, m]
+    pa = (ctypes.c_int * len(calls))(*[int(p) for p in precs])
+    hip.N_CALLS += 1
+    rc = hip.lib().nr_token_weights_fwd_group(arr, pa, len(calls), hip.stream_ptr())
+    if rc == 0:
+        return outs
+    hip.N_CALLS -= 1
+    if rc != hip.NR_EUNSUPPORTED:
+        hip._check("nr_token_weights_fwd_group", rc)
+    return None
+
+
 def local_level(prep_t, prep_v, w_t, w_v, A, Nt, Bv, Nv, prec=hip.PREC_BF16, out_mode=hip.OUT_FULL, want_arg=False):
     """Fused token-token similarity (nr_local_level_fwd).  Returns (out, aux); aux = None or
     (arg_v, arg_t, pmax, qmax) kept for the backward pass."""

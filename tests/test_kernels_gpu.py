@@ -783,6 +783,41 @@ def test_split_tail_matches_the_single_launch(B):
     assert maxdiff(got, ref) < 2e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("B", [16, 128])
+def test_split_tail_with_the_centrality_weights_inside_the_row_loss_launch(B):
+    """nr_row_losses_fwd_no_uniform_final_cw (the loss-only step's final launch computing compute_centrality_weights,
+    modeling.py:403-430, itself) == nr_centrality_weights_pair + nr_row_losses_fwd_no_uniform_final: the same five losses and
+    the same row terms, bit for bit; the weights against the oracle."""
+    g = torch.Generator().manual_seed(B + 11)
+    d, K, T, cs = 512, min(20, B), 3.0, 0.3
+    S = (torch.rand(B, B, generator=g) * 0.1).to(DEV)
+    G = (torch.randn(B, B, generator=g) * 6 + torch.eye(B) * 5).to(DEV)
+    parts = lambda n: (torch.rand(n, B, generator=g) * 0.1).to(DEV)
+    c0p, c1p = parts(16), parts(5)
+    gt, gv = torch.randn(B, 1, d, generator=g).to(DEV), torch.randn(B, 1, d, generator=g).to(DEV)
+    mean_t, mean_v = (torch.randn(d, generator=g) * 0.05).to(DEV), (torch.randn(d, generator=g) * 0.05).to(DEV)
+    ls = torch.tensor([100.0], device=DEV)
+    out = []
+    for fused in (False, True):
+        rl = torch.full((2, 4, B), float("nan"), device=DEV)
+        losses = torch.empty(5, device=DEV)
+        counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.sinkhorn_uniform_rows_final(G, 0.7, T, rl, counter, 1.0, 0.7, 1.3, losses, 50)
+        if fused:
+            ops.row_losses_no_uniform_final_cw(S, G, c0p, c1p, 1.0 / 512, gt.view(B, d), gv.view(B, d), mean_t, mean_v, cs, ls, K, T, rl,
+                                               counter, 1.0, 0.7, 1.3, losses)
+        else:
+            w_t, w_v, _ = ops.centrality_weights_pair(gt, gv, mean_t, mean_v, cs, False)
+            ops.row_losses_no_uniform_final(S, G, c0p, c1p, 1.0 / 512, w_t, w_v, ls, K, T, rl, counter, 1.0, 0.7, 1.3, losses)
+        torch.cuda.synchronize()
+        assert int(counter) == 0
+        out.append((rl.clone(), losses.clone()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert torch.isfinite(out[1][1]).all()
+    gn = torch.nn.functional.normalize(gt.view(B, d).cpu().double(), dim=-1)
+    assert maxdiff(w_t, torch.exp(cs * (gn @ mean_t.cpu().double()))) < 1e-6
+
+
 def test_bank_push_fifo():
     bank = torch.arange(10 * 6, dtype=torch.float32, device=DEV).reshape(10, 2, 3)
     ref = bank.clone()
@@ -808,3 +843,35 @@ def test_diag_ranks_match_reference_metrics():
     gr, eq = gr.cpu().numpy(), eq.cpu().numpy()
     cols = np.concatenate([np.arange(g, g + e) for g, e in zip(gr, eq)])
     assert np.array_equal(cols, golden("metrics256")["cols"])
+
+
+def test_grouped_scorer_launch_equals_the_four_single_launches():
+    """nr_token_weights_fwd_group: the step's four token sets (batch text / video in split-bf16, bank video / text in one bf16
+    pass) scored by ONE launch of 192 x 256 blocks.  One-pass sets: bit-identical to their single launch; split-bf16 sets (three
+    accumulated passes instead of the split tile): equal to 2e-6; sets that do not fit the block (192 % N != 0): None, nothing
+    launched."""
+    from neighborretr_amd import head
+    B, Nt, Nv, M = 128, 24, 12, 512
+    prob = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_problem(1002, B, Nt, Nv, M).items()}
+    P = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_params(7).items()}
+    sw = head.ScorerWeights(P["text_weight_fc.0.weight"], P["text_weight_fc.0.bias"], P["text_weight_fc.2.weight"], P["text_weight_fc.2.bias"])
+    pt = ops.prepare_tokens(prob["text_feat"], prob["text_mask"])
+    pv = ops.prepare_tokens(prob["video_feat"], prob["video_mask"])
+    pbt = ops.prepare_tokens(prob["mb_feat_t"], prob["mb_mask_t"])
+    pbv = ops.prepare_tokens(prob["mb_feat_v"], prob["mb_mask_v"])
+    sets = [(pt, prob["text_mask"], B, Nt, hip.PREC_BF16X3), (pv, prob["video_mask"], B, Nv, hip.PREC_BF16X3),
+            (pbv, prob["mb_mask_v"], M, Nv, hip.PREC_BF16), (pbt, prob["mb_mask_t"], M, Nt, hip.PREC_BF16)]
+    calls = [(p_, sw.w1_hi, sw.w1_lo, sw.b1, sw.w2, sw.b2, m_.float(), n_, N_) for p_, m_, n_, N_, _ in sets]
+    precs = [s_[-1] for s_ in sets]
+    one = [ops.token_weights(*c_, pr_)[0] for c_, pr_ in zip(calls, precs)]
+    grp = ops.token_weights_group(calls, precs)
+    assert grp is not None
+    for k, (a, (b, _)) in enumerate(zip(one, grp)):
+        assert maxdiff(a.sum(-1), torch.ones(a.shape[0])) < 1e-5
+        if precs[k] == hip.PREC_BF16:
+            assert torch.equal(a, b), k
+        else:
+            assert maxdiff(a, b) < 2e-6, (k, maxdiff(a, b))
+    # 20 tokens per sample: no whole samples in a 192-row block -> the grouped form declines
+    p20 = ops.prepare_tokens(prob["text_feat"][:, :20].contiguous(), prob["text_mask"][:, :20].contiguous())
+    assert ops.token_weights_group([(p20, sw.w1_hi, sw.w1_lo, sw.b1, sw.w2, sw.b2, None, B, 20)], [hip.PREC_BF16]) is None

@@ -83,6 +83,19 @@ def main():
             us = timeit(lambda: ops.token_logit_parts(prep, sw.w1_hi, sw.w1_lo, sw.b1, sw.w2, prec))
             fl = 2 * d * 1024 * prep.n_tok
             print(f"mlp {name} [{prep.n_tok} tok]: {us:8.1f} us  {fl / us / 1e6:8.1f} TFLOP/s")
+        # the four scorer calls of a step with their softmax, one by one and as ONE grouped launch (nr_token_weights_fwd_group)
+        fl_all = 2 * d * 1024 * (pt.n_tok + pv.n_tok + pbt.n_tok + pbv.n_tok)
+        sets = [(pt, B, Nt, hip.PREC_BF16X3), (pv, B, Nv, hip.PREC_BF16X3), (pbv, M, Nv, hip.PREC_BF16), (pbt, M, Nt, hip.PREC_BF16)]
+        calls = [(p_, sw.w1_hi, sw.w1_lo, sw.b1, sw.w2, sw.b2, None, n_, N_) for p_, n_, N_, _ in sets]
+
+        def singly():
+            return [ops.token_weights(*c_, pr_) for c_, (_, _, _, pr_) in zip(calls, sets)]
+        us1 = timeit(singly)
+        usg = timeit(lambda: ops.token_weights_group(calls, [pr_ for _, _, _, pr_ in sets]))
+        a_, b_ = singly(), ops.token_weights_group(calls, [pr_ for _, _, _, pr_ in sets])
+        dev_ = max(float((x[0] - y[0]).abs().max()) for x, y in zip(a_, b_))
+        print(f"mlp 4 sets + softmax, four launches : {us1:8.1f} us  {fl_all / us1 / 1e6:8.1f} TFLOP/s algorithmic")
+        print(f"mlp 4 sets + softmax, ONE launch    : {usg:8.1f} us  {fl_all / usg / 1e6:8.1f} TFLOP/s algorithmic   (max |dw| vs the four launches {dev_:.2e})")
     if "rowloss" in want:
         S = torch.rand(B, B, device=DEV) * 0.1
         tr, tc = ops.sinkhorn_targets(G, 0.7, 50)
