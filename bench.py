@@ -993,7 +993,10 @@ def main():
         print(json.dumps({"child": True, "steps": args.steps, "ms_per_step": round(dt / args.steps * 1e3, 4)}))
         return
     extra = {}
-    if world > 1 and interleaved and not args.no_sync_probe and not args.no_graph:
+    out_sync = {}
+
+    def sync_probe():
+        nonlocal interleaved, sharded, n_round, overlap_on, run, step_form, n_segments, graph
         # ---- second timed field: the SYNCHRONOUS sharded step (row slabs of S, 1/W of the bank and clustering work,
         # five collectives per step) -- the form a training step can use -- in the same job, same ranks, same K steps.  The
         # closures above read `interleaved` / `sharded` / `n_round` when they are called: flipped here, they build that form.
@@ -1035,7 +1038,7 @@ def main():
             ts_ = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
             dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
             dts = float(ts_.item())
-            extra["sync_step"] = {"what": "the synchronous sharded step (every rank takes part in every loss: row slabs of S, 1/W of the bank and "
+            out_sync["sync_step"] = {"what": "the synchronous sharded step (every rank takes part in every loss: row slabs of S, 1/W of the bank and "
                                           "clustering work, five collectives per step) timed in the same job over the same K steps",
                                   "value": round(args.steps / dts, 2), "unit": "steps/s", "ms_per_step": round(dts / args.steps * 1e3, 4),
                                   "step_form": form2_name, "graph_segments": nseg2,
@@ -1043,7 +1046,7 @@ def main():
         except Exception as e:               # the headline never depends on the second field
             import traceback
             traceback.print_exc()
-            extra["sync_step"] = {"error": f"{type(e).__name__}: {e}"}
+            out_sync["sync_step"] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.synchronize()
         finally:
             # back to the primary form for what follows (exchange timing, parity gate)
@@ -1052,6 +1055,7 @@ def main():
             model.interleave_overlap = primary["overlap"]
             model.use_side_streams = True
             step_form, n_segments, run, graph = primary["step_form"], primary["n_segments"], primary["run"], primary["graph"]
+
     if world > 1:
         # the exchange step alone (pack, packed all-gather, unpack; eager), so that a rehearsal on gloo ranks -- whose collectives
         # go through the host -- shows how much of a step is the collective's own data path
@@ -1313,6 +1317,24 @@ def main():
             model.config.world_size, model.shard_loss = ws_, sl_
         if world == 1 and not args.no_cpu_baseline and args.config == 1:
             line["cpu_baseline"] = cpu_baseline()
+    if world > 1 and interleaved and not args.no_sync_probe and not args.no_graph:
+        # The second field is built LAST, behind a timer of its own: should its collectives hang on some box, rank 0 still prints
+        # the line it has (with the reason in `sync_step`) and every rank leaves with status 0 -- the headline never depends on it.
+        import threading
+
+        def _sync_timeout():
+            if rank == 0:
+                line["sync_step"] = {"error": "no result after 240 s (the synchronous sharded step's probe was abandoned)"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        guard = threading.Timer(240.0, _sync_timeout)
+        guard.daemon = True
+        guard.start()
+        sync_probe()
+        guard.cancel()
+        if rank == 0:
+            line.update(out_sync)
+    if rank == 0:
         print(json.dumps(line))
     if watchdog is not None:
         watchdog.cancel()
