@@ -222,7 +222,13 @@ def test_bench_overlapped_owned_step_on_two_ranks():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["config"]["step_form"] == "segmented" and d["config"]["graph_segments"] == 2, d["config"]
-    assert d["config"]["owner_loss"].startswith("beside the following steps"), d["config"]
+    # the line times the MEDIAN of the validated draws (round 5: no best-of-N in the headline): that may be an overlapped draw or
+    # the serial form; what must hold is that overlapped draws were built, validated against the eager steps and probed
+    probes = d["config"]["form_probes"]
+    assert probes and any(p["owner_loss_beside"] for p in probes) and any(not p["owner_loss_beside"] for p in probes), probes
+    assert d["config"]["owner_loss"].startswith(("beside the following steps", "in front of the following steps")), d["config"]
+    us = sorted(p["us_per_step"] for p in probes)
+    assert len(us) >= 3
     assert "differs from the eager one" not in r.stderr, r.stderr[-2000:]
     assert d["parity"]["pass"] and all(x == x and abs(x) < 1e4 for x in d["losses"])
 
