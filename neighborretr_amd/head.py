@@ -149,6 +149,10 @@ COLSUM_OFF_CHAIN = os.environ.get("NR_COLSUM_OFF", "0") == "1"
 # registers a lane) leave no room on a CU for the clustering's workgroups, which then queue behind a 59 us launch (front kernel
 # 40 us instead of 13 in the trace).  OFF; NR_GROUP_SCORERS=1 turns it on (developer A/B switch)
 GROUP_SCORERS = os.environ.get("NR_GROUP_SCORERS", "0") == "1"
+# Pipelined steps: the global logits on the tail stream (in front of the Sinkhorn solve) instead of closing the origin's part of
+# the step.  OFF: bit-identical and 3.5 % SLOWER (3672-3689 vs 3807-3814 steps/s, three A/B pairs, tools/ab_logits_tail.sh) -- one
+# more case of a shorter chain and a slower graph.  NR_LOGITS_TAIL=1 turns it on (developer A/B switch)
+LOGITS_ON_TAIL = os.environ.get("NR_LOGITS_TAIL", "0") == "1"
 # Loss-only step: the batch's text and video scorers as one launch (nr_token_weights_fwd_pair).  NR_PAIR_SCORERS=0: two launches (A/B).
 PAIR_BATCH_SCORERS = os.environ.get("NR_PAIR_SCORERS", "1") == "1"
 # ... from this many tokens in the smaller set on (a few workgroups per CU): configs[3] 517 -> 530 steps/s, configs[2] 424 -> 427;
@@ -426,8 +430,19 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
     # themselves (whichever workgroup finishes last reduces the row terms to the five losses), so the critical path
     # is prologue -> clustering -> logits -> Sinkhorn, with neither a finalize launch nor the push behind it.
     if split_tail:
-        G = global_logits(gt, gv, sw_t1, sw_v1)
-        g_ready = record_event(cur)
+        tail = pipeline.tail_stream if pipeline is not None else None
+        if tail is not None and LOGITS_ON_TAIL:
+            # pipelined steps: the global logits (one small launch) open the TAIL stream instead of closing this one -- the next
+            # step's prologue follows the clustering's last launch directly
+            wait_stream(tail, cur)
+            with torch.cuda.stream(tail):
+                G = global_logits(gt, gv, sw_t1, sw_v1)
+                g_ready = record_event(tail)
+            for t_ in (gt, gv):
+                t_.record_stream(tail)
+        else:
+            G = global_logits(gt, gv, sw_t1, sw_v1)
+            g_ready = record_event(cur)
         rowloss = torch.empty((2, 4, B), dtype=torch.float32, device=G.device)
         losses = torch.empty((5,), dtype=torch.float32, device=G.device)
         counter = ops.split_tail_counter(G.device, slot)
@@ -435,7 +450,6 @@ def head_forward(text_feat, video_feat, text_mask, video_mask, mb_feat_t, mb_fea
         # The two self-finalizing launches share `counter`; only the one that finishes last resets it.  If anything raises
         # between them (the push callable, an NR_E* status), the word would stay non-zero and every later step would finalize
         # on incomplete row terms without an error: zero it before passing the exception on.
-        tail = pipeline.tail_stream if pipeline is not None else None
         try:
             if tail is not None:
                 wait_stream(tail, cur)
