@@ -26,6 +26,15 @@ __device__ __forceinline__ void nr_linear_tile(const NrLinearArgs& p, const int 
     Tile tile;
     tile.zero();
     if constexpr (CONV) tile.run_conv3(p.x_hi, p.x_lo, row0, p.M, p.w_hi, p.w_lo, col0, p.N, p.K, smem, p.conv_n);
+#ifdef NR_TUNE
+    else if constexpr (WC == 4 && STAGES == 2 && X3) {
+        // tuning builds: 8-wave split-bf16 blocks on a two-deep ring walk K with the ping-pong loop of the similarity kernel.
+        // Measured (tools/probe_linear_tiles.sh): the token convolution's shape on 128 x 128 blocks 38.5 us against 39.4 on the
+        // shipped 64 x 64 one-deep blocks (144 workgroups for 256 CUs), the kv shape 35.3 against 27.7 -- not shipped
+        if (p.ld == 0 || p.ld == p.K) tile.run_pp(p.x_hi, p.x_lo, row0, p.M, p.w_hi, p.w_lo, col0, p.N, p.K, smem);
+        else tile.run(p.x_hi, p.x_lo, row0, p.M, p.w_hi, p.w_lo, col0, p.N, p.K, smem, 0, false, p.ld);
+    }
+#endif
     else tile.run(p.x_hi, p.x_lo, row0, p.M, p.w_hi, p.w_lo, col0, p.N, p.K, smem, 0, false, p.ld);
 #pragma unroll
     for (int n = 0; n < NI; ++n) {

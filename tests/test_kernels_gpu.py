@@ -850,7 +850,7 @@ def test_grouped_scorer_launch_equals_the_four_single_launches():
     pass) scored by ONE launch of 192 x 256 blocks.  One-pass sets: bit-identical to their single launch; split-bf16 sets (three
     accumulated passes instead of the split tile): equal to 2e-6; sets that do not fit the block (192 % N != 0): None, nothing
     launched."""
-    from neighborretr_amd import head
+    from neighborretr_amd import head, synth
     B, Nt, Nv, M = 128, 24, 12, 512
     prob = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_problem(1002, B, Nt, Nv, M).items()}
     P = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_params(7).items()}
