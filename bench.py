@@ -1232,6 +1232,8 @@ def main():
                 calls = sum(v_[0] for _, v_ in hit)
                 return calls, (sum(v_[0] * v_[1] for _, v_ in hit) / calls if calls else None)
             ins = prof["in_step"]
+            # (whether the batch's two scorers really ran as ONE paired launch at this config -- read off the trace)
+            roofline["paired_batch_scorer_launch_taken"] = any("nr_mlp_pair_kernel" in n_ for n_ in ins)
             sim_calls, sim_us = pick(ins, "nr_sim_reg_kernel")
             pair_calls, pair_us = pick(ins, "nr_sim_pair_kernel")
             n_steps_traced = (sim_calls + pair_calls) / n_launch if (sim_calls + pair_calls) else 0
