@@ -292,6 +292,39 @@ def test_linear_x3_matches_fp64(M, N, K, bias, res):
     assert maxdiff(out, ref) < 3e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("sets", [[(128, 24), (128, 12)], [(128, 4), (128, 3)], [(5, 24), (7, 12)], [(32, 20), (32, 9)], [(3, 64)]])
+def test_token_convolution_launch_matches_fp64(sets):
+    """nr_linear_group with conv_n > 0 (the k=3, padding=1 token convolution read in place, cluster.py:664, residual and bias folded
+    in) against an fp64 convolution of the same split-bf16 operands: both modalities in one launch, ragged row counts, token
+    counts that do not divide the block height."""
+    from neighborretr_amd.cluster_backward_hip import _linear_group
+    C = 512
+    g = torch.Generator().manual_seed(5)
+
+    def split(t):
+        hi = t.to(torch.bfloat16)
+        lo = (t - hi.float()).to(torch.bfloat16)
+        return hi.view(torch.int16), lo.view(torch.int16), hi.double() + lo.double()
+
+    probs, refs = [], []
+    for B, n in sets:
+        x = torch.randn(B * n, C, generator=g).to(DEV)
+        w = (torch.randn(C, 3 * C, generator=g) * 0.03).to(DEV)
+        bias = torch.randn(C, generator=g).to(DEV)
+        xh, xl, xd = split(x)
+        wh, wl, wd = split(w)
+        out = torch.zeros(B * n, C, device=DEV)
+        probs.append((xh, xl, wh, wl, bias, x, out, B * n, C, 3 * C, 0, n))
+        xs = xd.view(B, n, C)
+        z = torch.zeros(B, 1, C, dtype=torch.float64, device=DEV)
+        cat = torch.cat([torch.cat([z, xs[:, :-1]], 1), xs, torch.cat([xs[:, 1:], z], 1)], 2).view(B * n, 3 * C)
+        refs.append(cat @ wd.t() + bias.double() + x.double())
+    _linear_group(probs)
+    torch.cuda.synchronize()
+    for p_, r in zip(probs, refs):
+        assert maxdiff(p_[6], r) < 3e-6 * float(r.abs().max())
+
+
 def test_ctm_front_back_equal_the_separate_kernels():
     """nr_ctm_front / nr_ctm_back (what the step runs) == nr_ctm_norm_score + nr_dpc_knn_assign + nr_merge_ln."""
     B, N, C, cnum = 16, 24, 512, 4

@@ -2,6 +2,7 @@
 //   mode 0: LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction)
 //   mode 1: global_load_dwordx4 -> VGPR -> ds_write_b128
 //   mode 2: half the pieces by DMA, half through registers
+//   mode 3: LDS-DMA of pieces of 16 rows x 64 B (a 32-element K slice: HALF of every 128-byte line per slice)
 // Access pattern of the GEMM tile engine: a piece = 8 rows x 128 B, rows 1 KiB apart in memory (K = 512 bf16).
 // Every workgroup re-reads its own 2 x 192 KiB region (L2-resident), `iters` slices of `PIECES` pieces each.
 #include <hip/hip_runtime.h>
@@ -21,18 +22,18 @@ __global__ __launch_bounds__(64 * NW) void fill_kernel(const char* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const char* base = g + (size_t)(blockIdx.x % regions) * (384 * 1024);
     // lane -> (row lane/8 of the piece, 16-byte chunk lane%8)
-    const size_t lane_off = (size_t)(lane >> 3) * 1024 + (lane & 7) * 16;
+    const size_t lane_off = MODE == 3 ? (size_t)(lane >> 2) * 1024 + (lane & 3) * 16 : (size_t)(lane >> 3) * 1024 + (lane & 7) * 16;
     float acc = 0.f;
     f32x4_t macc[8];
     for (int i = 0; i < 8; ++i) macc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
-        const int kb = (it & 7) * 128;                         // walk along K like the GEMM does
+        const int kb = MODE == 3 ? (it & 15) * 64 : (it & 7) * 128;      // walk along K like the GEMM does
         for (int i = 0; i < pieces_per_wave; ++i) {
             const int piece = wave + NW * i;                   // 8 rows each
-            const char* src = base + (size_t)piece * 8 * 1024 + lane_off + kb;
+            const char* src = base + (size_t)piece * (MODE == 3 ? 16 : 8) * 1024 + lane_off + kb;
             char* dst = smem + (it & 1) * (NW * pieces_per_wave * 1024) + piece * 1024;
-            bool dma = MODE == 0 || (MODE == 2 && (i & 1) == 0);
+            bool dma = MODE == 0 || MODE == 3 || (MODE == 2 && (i & 1) == 0);
             if (dma) {
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
             } else {
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(64 * NW) void fill_kernel(const char* __restrict__ 
             }
         }
         // the previous slice must have landed; this one stays in flight (counted wait needs a literal: 6 / 9 / 12)
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 3) {
             if (pieces_per_wave == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if (pieces_per_wave == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -111,6 +112,12 @@ int main() {
         }
         run<0, 8>("LDS-DMA (2-deep)", g, 9, regions, 24, 8, d_cycles, d_sink);
         run<0, 8>("LDS-DMA (2-deep)", g, 9, regions, 72, 8, d_cycles, d_sink);
+        // half-line pieces (K slices of 32): 36 KiB per slice on 4 waves as the tap-block convolution tried them, full-line pieces beside
+        for (int nm : {0, 72}) {
+            run<3, 4>("LDS-DMA 16 x 64 B pieces", g, 9, regions, nm, 24, d_cycles, d_sink);
+            run<0, 4>("LDS-DMA  8 x 128 B pieces", g, 9, regions, nm, 24, d_cycles, d_sink);
+            run<3, 8>("LDS-DMA 16 x 64 B pieces", g, 9, regions, nm, 24, d_cycles, d_sink);
+        }
     }
     return 0;
 }
