@@ -75,8 +75,8 @@ def parse():
                     help="consecutive steps captured per HIP graph, every dependency between them kept (the bank push of step k before "
                          "the bank products of step k+1): one replay then issues U steps and the ~10 us between two replays is paid "
                          "once per U steps (round 3: 312 / 306 / 304 us per step at U = 1 / 2 / 4).  A remainder of K mod U steps is "
-                         "replayed step by step.  0 (default) = --steps itself up to 40, else the U in 20..40 that leaves the fewest steps over (20 -> 20, 200 -> 40, 41 -> 40 "
-                         "+ 1): a graph's end costs ~90 us (the last step's tail runs alone), 3570 / 3640 / 3670 steps/s at U = 10 / 20 / 40.  "
+                         "replayed step by step.  0 (default) = 20, whatever --steps is (fewer only when fewer steps are timed): a graph's end costs ~90 us (the "
+                         "last step's tail runs alone), 3570 / 3640 / 3670 steps/s at U = 10 / 20 / 40.  "
                          "N > 1: one graph per step (see --round_graph).  1 = one step per graph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL; gloo only to rehearse ranks that share one GPU)")
@@ -131,9 +131,9 @@ def parse():
     args = ap.parse_args()
     CFG.update(CFGS[args.config])
     if args.unroll <= 0:
-        # K <= 40: one graph of K steps; else the U in 20..40 that leaves the fewest steps over (ties: the largest)
-        args.unroll = (max(args.steps, 1) if args.steps <= 40 else
-                       min(range(20, 41), key=lambda u: (args.steps % u, -u)))
+        # a FIXED 20 steps per graph whatever --steps asks for (fewer only when fewer are timed): K // 20 replays of it, the K % 20
+        # steps left over as single-step replays -- the graph is not sized to the caller's command line
+        args.unroll = min(max(args.steps, 1), 20)
     # (a batch as large as the bank -- configs[2] on one GPU -- replaces it IN PLACE, modeling.update_memory_bank: consecutive
     # steps of one graph see each other's bank there too; the unrolled graph is held against single-step replays like any other)
     return args
