@@ -161,25 +161,31 @@ struct NrRowState {
         min_c = nr_wave_min(mnc); max_c = nr_wave_max(mxc);
         // ---- positive weights: softmax over the neighbours of T*(ns - nc) ----
         const float rs = 1.0f / (max_s - min_s), rc = 1.0f / (max_c - min_c);
+        // K == B: the reference takes the first K of the descending sort, whose LAST entry is the diagonal (-9e15): the diagonal
+        // is a "neighbour" then and its adjusted similarity sits in the softmax's denominator (until_module.py:119-123, :147), before
+        // fill_diagonal_(1) overwrites its weight (:157).  The picks above never take it (-inf): counted here.
+        const bool diag_in = K >= B;
         float am = -INFINITY, em = -INFINITY;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            if (sel[e]) {
+            const bool diag = valid[e] && e * 64 + lane == i;
+            if (sel[e] || (diag && diag_in)) {
                 float adj = (s[e] - min_s) * rs - (c[e] - min_c) * rc;
                 am = fmaxf(am, adj * T);
             }
-            if (sel[e] || (valid[e] && e * 64 + lane == i)) em = fmaxf(em, s[e]);
+            if (sel[e] || diag) em = fmaxf(em, s[e]);
         }
         amax = nr_wave_max(am);
         em = nr_wave_max(em);
         float as = 0.f, es = 0.f;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            if (sel[e]) {
+            const bool diag = valid[e] && e * 64 + lane == i;
+            if (sel[e] || (diag && diag_in)) {
                 float adj = (s[e] - min_s) * rs - (c[e] - min_c) * rc;
                 as += expf(adj * T - amax);
             }
-            if (sel[e] || (valid[e] && e * 64 + lane == i)) es += expf(s[e] - em);
+            if (sel[e] || diag) es += expf(s[e] - em);
         }
         asum = nr_wave_sum(as);
         lse_e = em + logf(nr_wave_sum(es));

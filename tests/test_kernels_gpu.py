@@ -212,8 +212,10 @@ def test_sinkhorn_targets(B):
     assert maxdiff(Q.sum(0), torch.ones(B, dtype=torch.float64)) < 1e-4
 
 
-@pytest.mark.parametrize("B,K", [(16, 8), (32, 8), (128, 20), (200, 20), (16, 15)])
+@pytest.mark.parametrize("B,K", [(16, 8), (32, 8), (128, 20), (200, 20), (16, 15), (16, 16), (13, 13), (4, 4), (2, 2), (13, 5), (7, 1)])
 def test_row_losses(B, K):
+    # (K = B - 1: nothing is left outside the neighbour set, min / max fall back to +-9e15 and every adjusted similarity is 0;
+    #  K = B: the sort's last entry -- the diagonal -- is a "neighbour" too and sits in the softmax's denominator, until_module.py:119-123)
     g = torch.Generator().manual_seed(B + K)
     S = torch.rand(B, B, generator=g) * 0.12 + torch.eye(B) * 0.02
     G = torch.randn(B, B, generator=g) * 9
@@ -239,6 +241,47 @@ def test_row_losses(B, K):
     for k, r in enumerate(ref):
         assert abs(float(losses[k + 1]) - float(r)) < 1e-4 * max(1.0, abs(float(r))), (k, float(losses[k + 1]), float(r))
     assert abs(float(losses[0]) - float(sum(ref))) < 2e-4 * float(sum(ref))
+
+
+def test_row_losses_one_sample_outside_the_neighbour_set_is_nan_as_in_the_reference():
+    """K = B - 2: exactly ONE sample is left outside {diagonal, neighbours}; its min-max normalisation divides 0 by 0
+    (until_module.py:85) and the reference's neighbour loss is NaN.  Same here -- not a clamp, not a finite number."""
+    B, K = 13, 11
+    g = torch.Generator().manual_seed(1)
+    S = torch.rand(B, B, generator=g) * 0.12
+    G = torch.randn(B, B, generator=g)
+    v = lambda: torch.rand(B, generator=g) * 0.1
+    c0, c1 = v(), v()
+    assert torch.isnan(O.neighbor_loss(S, c1[:, None].expand(B, 4), c0[:, None].expand(B, 4), K, 3.0))
+    tr, tc = ops.sinkhorn_targets(G.to(DEV), 0.7, 50)
+    rl = ops.row_losses(S.to(DEV), G.to(DEV), tr, tc, c0.to(DEV), c1.to(DEV), (1 + v()).to(DEV), (1 + v()).to(DEV),
+                        torch.tensor([100.0], device=DEV), K, 3.0)
+    losses = ops.loss_finalize(rl, 1.0, 1.0, 1.0).cpu()
+    assert torch.isnan(losses[3]) and torch.isnan(losses[0]) and torch.isfinite(losses[[1, 2, 4]]).all()
+
+
+@pytest.mark.parametrize("B,K", [(16, 8), (16, 15), (16, 16), (13, 13), (9, 1), (130, 20)])
+def test_neighbour_term_gradient_matches_oracle_autograd(B, K):
+    """d (neighbour loss) / d S and d / d bank centralities through nr_row_losses_bwd against the oracle's autograd (fp64), at the
+    edges of K too: K = B - 1 (nothing outside the neighbour set), K = B (the diagonal inside the softmax, until_module.py:119-123)."""
+    from neighborretr_amd.backward import RowLossFn
+    g = torch.Generator().manual_seed(7 * B + K)
+    S0 = torch.rand(B, B, generator=g) * 0.12 + torch.eye(B) * 0.02
+    G = torch.randn(B, B, generator=g)
+    c0_0, c1_0 = torch.rand(B, generator=g) * 0.1, torch.rand(B, generator=g) * 0.1
+    T = 3.0
+    Sd, c0d, c1d = (t.double().requires_grad_() for t in (S0, c0_0, c1_0))
+    ref = O.neighbor_loss(Sd, c1d[:, None].expand(B, 4), c0d[:, None].expand(B, 4), K, T)
+    ref.backward()
+    S, c0, c1 = (t.to(DEV).requires_grad_() for t in (S0, c0_0, c1_0))
+    tr, tc = ops.sinkhorn_targets(G.to(DEV), 0.7, 50)
+    one = torch.ones(B, device=DEV)
+    rl = RowLossFn.apply(S, G.to(DEV), tr, tc, c0, c1, one, one, torch.tensor([100.0], device=DEV), K, T)
+    loss = rl[:, 2, :].mean()                       # (t2v rows + v2t rows) / 2B = the reference's neighbour loss
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach())))
+    loss.backward()
+    for got, want in ((S.grad, Sd.grad), (c0.grad, c0d.grad), (c1.grad, c1d.grad)):      # fp32 kernel against the fp64 oracle
+        assert maxdiff(got, want) < 1e-3 * float(want.abs().max()) + 1e-9
 
 
 def test_row_losses_rejects_bad_k():
