@@ -71,3 +71,148 @@ def test_too_few_tokens_for_the_second_stage_raises():
     nzg = {k: v.to(DEV) for k, v in nz.items()}
     with torch.no_grad(), pytest.raises((RuntimeError, ValueError)):
         m.merge_global_features(xg["text_feat"], xg["video_feat"], xg["text_mask"], xg["video_mask"], nzg)
+
+
+# ---- components, seeded random shapes ------------------------------------------------------------------------------------------
+def _m(precision="bf16x3"):
+    m = modeling.NeighborRetr(modeling.default_config(), precision=precision)
+    m.load_state_dict(params(), strict=False)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_rectangular_similarity_matches_the_oracle(seed):
+    """get_similarity_logits on A texts x Bv videos (evaluation's shape: the two counts differ), token counts up to 64 x 64, ragged
+    masks, one sample with a SINGLE valid token and one video with none at all."""
+    from neighborretr_amd import synth
+    r = np.random.RandomState(2000 + seed)
+    A, Bv = int(r.randint(1, 40)), int(r.randint(1, 40))
+    Nt, Nv = int(r.randint(1, 65)), int(r.randint(1, 65))
+    t, _, tm, _ = synth.make_samples(900 + seed, "batch", A, Nt, 1, 512, 6.0, True)
+    _, v, _, vm = synth.make_samples(950 + seed, "bank", Bv, 1, Nv, 512, 6.0, True)
+    tm[0] = 0
+    tm[0, 0] = 1
+    if Bv > 1:
+        vm[1] = 0                                   # a video without a valid frame: all scorer logits -9e15 -> uniform weights, products 0
+    t, v, tm, vm = (torch.from_numpy(x) for x in (t, v, tm, vm))
+    ref = O.local_level(t.double(), v.double(), tm, vm, {k: p.double() for k, p in params().items()})[0]
+    with torch.no_grad():
+        S, St = _m().get_similarity_logits(t.to(DEV), v.to(DEV), tm.to(DEV), vm.to(DEV))
+    assert S.shape == (A, Bv) and torch.equal(St, S.T)
+    d = float((S.cpu().double() - ref).abs().max())
+    print(f"\n[seed {seed}: {A} texts x {Bv} videos, {Nt} x {Nv} tokens] max|dS| = {d:.2e}")
+    assert d < 2e-6
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sinkhorn_sizes_match_the_oracle(seed):
+    """Every B, not only multiples of 4 / 64: the one-workgroup form, the cooperative form and the multi-launch fallback each get
+    sizes they do not own in the parametrised tests; logits up to |G| ~ 40 (exp(100 x cosine) territory)."""
+    from neighborretr_amd import ops
+    r = np.random.RandomState(3000 + seed)
+    B = int(r.choice([r.randint(2, 129), r.randint(129, 400), r.choice([192, 256, 320])]))
+    g = torch.Generator().manual_seed(seed)
+    G = torch.randn(B, B, generator=g) * float(r.choice([1.0, 9.0, 20.0]))
+    tr, tc = ops.sinkhorn_targets(G.to(DEV), 0.7, 50)
+    ref_r = O.sinkhorn_targets(G.double(), 0.7)
+    ref_c = O.sinkhorn_targets(G.double().t(), 0.7)
+    dr, dc = float((tr.cpu().double() - ref_r).abs().max()), float((tc.cpu().double() - ref_c).abs().max())
+    print(f"\n[seed {seed}: B={B}] max|d target| = {dr:.2e} / {dc:.2e}")
+    assert dr < 2e-5 and dc < 2e-5
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_dpc_knn_shapes_match_the_oracle(seed):
+    from neighborretr_amd import ops
+    r = np.random.RandomState(4000 + seed)
+    B, N = int(r.randint(1, 20)), int(r.randint(3, 65))
+    cnum = int(r.randint(1, min(N, 16) + 1))
+    g = torch.Generator().manual_seed(seed)
+    x = torch.nn.functional.layer_norm(torch.randn(B, N, 512, generator=g), (512,))
+    mask = None
+    if r.rand() < 0.7:
+        mask = (torch.arange(N)[None] < torch.randint(1, N + 1, (B, 1), generator=g)).long()
+    nz = torch.rand(B, N, generator=g)
+    ref = O.dpc_knn(x, cnum, 3, mask, nz)
+    got = ops.dpc_knn_assign(x.to(DEV), cnum, 3, None if mask is None else mask.to(DEV), nz.to(DEV)).cpu()
+    assert torch.equal(got, ref), (B, N, cnum)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_push_sequences_keep_the_bank_equal_to_the_oracle(seed):
+    """A run of pushes with varying batch sizes (smaller than, equal to, larger than the bank, not dividing it): the bank the
+    model holds -- read back through its public attributes, i.e. in the reference's newest-first order whatever the ring's head is --
+    equals the oracle's FIFO (modeling.py:222-249) after every push."""
+    r = np.random.RandomState(5000 + seed)
+    M = int(r.choice([8, 12, 20]))
+    Nt, Nv = 16, 9
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=2), precision="bf16")
+    m.load_state_dict(params(), strict=False)
+    m = m.to(DEV).train()
+    x0 = problem(6000 + seed, 2, Nt, Nv, M)
+    bank = (torch.arange(1000, 1000 + M), x0["mb_feat_t"], x0["mb_feat_v"], x0["mb_mask_t"].float(), x0["mb_mask_v"].float())
+    m.mb_feat_t, m.mb_feat_v = bank[1].to(DEV), bank[2].to(DEV)
+    m.mb_mask_t, m.mb_mask_v = bank[3].to(DEV), bank[4].to(DEV)
+    m.mb_ind = bank[0].to(DEV)
+    for step in range(7):
+        B = int(r.choice([1, 3, 4, M // 2, M - 1, M, M + 3]))
+        x = problem(6100 + 10 * seed + step, B, Nt, Nv, 1)
+        idx = torch.arange(B) + 100 * step
+        bank = O.update_memory_bank(bank, (idx, x["text_feat"], x["video_feat"], x["text_mask"].float(), x["video_mask"].float()))
+        with torch.no_grad():
+            m.update_memory_bank(idx.to(DEV), x["text_feat"].to(DEV), x["video_feat"].to(DEV), x["text_mask"].to(DEV), x["video_mask"].to(DEV))
+        for k, want in zip(("mb_ind", "mb_feat_t", "mb_feat_v", "mb_mask_t", "mb_mask_v"), bank):
+            got = getattr(m, k).cpu()
+            assert got.shape == want.shape and torch.equal(got.to(want.dtype), want), (seed, step, B, k)
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("fused", [True, False], ids=["fused-clustering", "traced-clustering"])
+def test_random_shapes_gradients_match_oracle_autograd(seed, fused):
+    """Backward of the whole head at random shapes (the reference-captured gradient fixtures are B = 16 / 128 at 24 x 12 tokens
+    only): d total / d features and per-parameter gradient norms against the CPU oracle's autograd, split-bf16 plan."""
+    r = np.random.RandomState(7000 + seed)
+    B = int(r.randint(5, 25))
+    Nt, Nv = int(r.randint(13, 25)), int(r.randint(9, 13))
+    M = int(r.choice([B, B + 3, 2 * B]))
+    K = int(r.randint(1, B - 2))                      # (K = B - 2 is NaN in the reference; K >= B - 1 has its own tests)
+    x = problem(7100 + seed, B, Nt, Nv, M)
+    nz = noise(7100 + seed, B, Nt, Nv)
+    P = {k: v.clone().requires_grad_(True) for k, v in params().items()}
+    tf, vf = x["text_feat"].clone().requires_grad_(True), x["video_feat"].clone().requires_grad_(True)
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K), precision="bf16x3")
+    m.load_state_dict(params(), strict=False)
+    m = m.to(DEV).train()
+    m.fused_training_clustering = fused
+    with torch.no_grad():
+        m.clip.logit_scale.fill_(float(np.log(100.0)))
+    c = m.config
+    hp = dict(centrality_scale=c.centrality_scale, beta=c.beta, num_neighbors=K, temperature=c.temperature,
+              uniform_weight=c.uniform_weight, neighbor_weight=c.neighbor_weight, kl_weight=c.kl_weight)
+    ref = O.compute_losses(tf, vf, x["text_mask"], x["video_mask"], x["mb_feat_t"], x["mb_feat_v"], x["mb_mask_t"], x["mb_mask_v"],
+                           P, hp, 100.0, nz)[0]
+    ref.backward()
+    xg = {k: v.to(DEV) for k, v in x.items()}
+    xg["text_feat"].requires_grad_(True)
+    xg["video_feat"].requires_grad_(True)
+    nzg = {k: v.to(DEV) for k, v in nz.items()}
+    got = m._compute_losses(xg["text_feat"], xg["video_feat"], xg["text_mask"], xg["video_mask"], xg["mb_feat_t"], xg["mb_feat_v"],
+                            xg["mb_mask_t"], xg["mb_mask_v"], c.centrality_scale, c.beta, K, c.temperature, m.clip.logit_scale.exp(),
+                            noise=nzg)[0]
+    assert abs(float(got.detach()) - float(ref.detach())) < 2e-4
+    got.backward()
+    dev = {}
+    for name, mine, want in (("text", xg["text_feat"].grad, tf.grad), ("video", xg["video_feat"].grad, vf.grad)):
+        dev[name] = float((mine.cpu() - want).abs().max()) / float(want.abs().max())
+    worst = ("", 0.0)
+    named = dict(m.named_parameters())
+    for n, p in P.items():
+        if p.grad is None or n not in named:
+            continue
+        mine = 0.0 if named[n].grad is None else float(named[n].grad.norm())
+        e = abs(mine - float(p.grad.norm())) / max(float(p.grad.norm()), 1e-3)
+        if e > worst[1]:
+            worst = (n, e)
+    print(f"\n[seed {seed} {'fused' if fused else 'traced'}: B={B} Nt={Nt} Nv={Nv} M={M} K={K}] feature-gradient max deviation / largest entry: "
+          f"text {dev['text']:.2e}, video {dev['video']:.2e}; worst parameter-gradient norm {worst[0]} {worst[1]:.2e}")
+    assert dev["text"] < 5e-3 and dev["video"] < 5e-3 and worst[1] < 5e-3, (dev, worst)
