@@ -216,3 +216,44 @@ def test_random_shapes_gradients_match_oracle_autograd(seed, fused):
     print(f"\n[seed {seed} {'fused' if fused else 'traced'}: B={B} Nt={Nt} Nv={Nv} M={M} K={K}] feature-gradient max deviation / largest entry: "
           f"text {dev['text']:.2e}, video {dev['video']:.2e}; worst parameter-gradient norm {worst[0]} {worst[1]:.2e}")
     assert dev["text"] < 5e-3 and dev["video"] < 5e-3 and worst[1] < 5e-3, (dev, worst)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_metrics_with_planted_ties_match_the_oracle(seed):
+    """compute_metrics on random sizes (1 .. 700 rows: one workgroup, many, not a multiple of anything) with exact ties planted on
+    and off the diagonal -- a tie with the diagonal is one extra hit per tied entry in the reference (utils/metrics.py:58-66)."""
+    from neighborretr_amd.metrics import RetrievalMetrics
+    r = np.random.RandomState(8000 + seed)
+    n = int(r.choice([1, 2, 3, r.randint(4, 130), r.randint(130, 700)]))
+    S = r.randn(n, n).astype(np.float32)
+    for _ in range(min(n, 12)):
+        i, j = r.randint(n), r.randint(n)
+        S[i, j] = S[i, i]                            # ties with the diagonal
+        S[r.randint(n), r.randint(n)] = S[r.randint(n), r.randint(n)]
+    if n > 3:
+        S[2, :] = 0.25                               # a whole row of equal scores
+    mine, ref = RetrievalMetrics.compute_metrics(S), O.compute_metrics(S)
+    assert mine["cols"] == ref["cols"]
+    for k in ("R1", "R5", "R10", "R50", "MR", "MedianR", "MeanR"):
+        assert mine[k] == ref[k], (k, mine[k], ref[k])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_multi_sentence_groups_match_the_oracle(seed):
+    """Multi-sentence retrieval (MSVD / ActivityNet style, evaluator.py:225-262) on random caption-group sizes, with exact ties."""
+    from neighborretr_amd.metrics import RetrievalMetrics
+    r = np.random.RandomState(9000 + seed)
+    n_video = int(r.randint(1, 60))
+    sizes = r.randint(1, 7, size=n_video)
+    cut = list(np.cumsum(sizes) - 1)
+    S = r.randn(int(sizes.sum()), n_video).astype(np.float32)
+    S[r.randint(S.shape[0], size=5), r.randint(n_video, size=5)] = 0.5
+    S[r.randint(S.shape[0], size=5), r.randint(n_video, size=5)] = 0.5
+    padded = O.pad_sentence_groups(S, cut)
+    ref_tv, ref_vt = O.multi_sentence_metrics(S, cut)
+    mine_tv = RetrievalMetrics.tensor_text_to_video_metrics(torch.from_numpy(padded).to(DEV))
+    for k, v in ref_tv.items():
+        assert abs(mine_tv[k] - v) < 1e-6 * max(1.0, abs(v)), (k, mine_tv[k], v)      # (the reference divides in fp32: metrics.py:113-126)
+    vt = RetrievalMetrics.tensor_video_to_text_sim(torch.from_numpy(padded).to(DEV))
+    mine_vt = RetrievalMetrics.compute_metrics(vt)
+    assert mine_vt["cols"] == ref_vt["cols"]
