@@ -257,3 +257,28 @@ def test_random_multi_sentence_groups_match_the_oracle(seed):
     vt = RetrievalMetrics.tensor_video_to_text_sim(torch.from_numpy(padded).to(DEV))
     mine_vt = RetrievalMetrics.compute_metrics(vt)
     assert mine_vt["cols"] == ref_vt["cols"]
+
+
+def test_strided_inputs_and_mask_dtypes_give_the_same_losses():
+    """What a caller may hand over: features as strided views (a slice of a wider buffer, an expanded batch), masks as int64 / int32 /
+    bool / fp32 -- the step's losses are those of the contiguous fp32 / int64 call, bit for bit."""
+    B, Nt, Nv, M, K = 12, 20, 11, 24, 4
+    x = problem(42, B, Nt, Nv, M, device=DEV)
+    nz = noise(42, B, Nt, Nv, device=DEV)
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K), precision="bf16")
+    m.load_state_dict(params(), strict=False)
+    m = m.to(DEV).train()
+    c = m.config
+
+    def losses(tf, vf, tm, vm):
+        with torch.no_grad():
+            return torch.stack(m._compute_losses(tf, vf, tm, vm, x["mb_feat_t"], x["mb_feat_v"], x["mb_mask_t"], x["mb_mask_v"],
+                                                 c.centrality_scale, c.beta, K, c.temperature, m.clip.logit_scale.exp(), noise=nz))
+    want = losses(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"])
+    wide_t = torch.zeros(B, Nt, 640, device=DEV)
+    wide_t[..., 64:576] = x["text_feat"]
+    wide_v = torch.zeros(2 * B, Nv, 512, device=DEV)
+    wide_v[::2] = x["video_feat"]
+    for cast in (lambda t: t, lambda t: t.int(), lambda t: t.bool(), lambda t: t.float()):
+        got = losses(wide_t[..., 64:576], wide_v[::2], cast(x["text_mask"]), cast(x["video_mask"]))
+        assert torch.equal(got, want)
