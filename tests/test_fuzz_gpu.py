@@ -282,3 +282,17 @@ def test_strided_inputs_and_mask_dtypes_give_the_same_losses():
     for cast in (lambda t: t, lambda t: t.int(), lambda t: t.bool(), lambda t: t.float()):
         got = losses(wide_t[..., 64:576], wide_v[::2], cast(x["text_mask"]), cast(x["video_mask"]))
         assert torch.equal(got, want)
+
+
+def test_random_sharded_steps_match_the_replicated_step():
+    """tools/sharded_sweep.py: the synchronous sharded step at random world sizes, per-rank batches of 1 .. 8 samples, odd
+    token counts and banks -- every emulated rank against the replicated step (<= 2e-5; the tool raises otherwise)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sharded_sweep.py"), "8"], capture_output=True, text=True, timeout=900,
+                       cwd=root, env=env)
+    print(r.stdout)
+    assert r.returncode == 0 and "sharded sweep: 8 cases passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
