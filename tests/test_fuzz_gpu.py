@@ -296,3 +296,37 @@ def test_random_sharded_steps_match_the_replicated_step():
                        cwd=root, env=env)
     print(r.stdout)
     assert r.returncode == 0 and "sharded sweep: 8 cases passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_long_token_counts_match_the_oracle(seed):
+    """Token counts above 24 / 12 (ActivityNet-like, BASELINE configs[3] is 64 x 64): several global tokens per sample survive the
+    clustering, the global logits take the multi-token form (modeling.py:516-539) and the centrality term the documented "mean"
+    reduction (the reference itself raises there, until_module.py:321) -- losses against the oracle run the same way."""
+    r = np.random.RandomState(12000 + seed)
+    B = int(r.randint(4, 20))
+    Nt, Nv = int(r.randint(25, 65)), int(r.randint(13, 65))
+    M = int(r.choice([B, B + 5, 2 * B]))
+    K = int(r.randint(1, B - 2))
+    x = problem(12100 + seed, B, Nt, Nv, M)
+    nz = noise(12100 + seed, B, Nt, Nv)
+    P = params()
+    m = modeling.NeighborRetr(modeling.default_config(num_neighbors=K, centrality_multi_token="mean"), precision="bf16x3")
+    m.load_state_dict(P, strict=False)
+    m = m.to(DEV).train()
+    with torch.no_grad():
+        m.clip.logit_scale.fill_(float(np.log(100.0)))
+    c = m.config
+    hp = dict(centrality_scale=c.centrality_scale, beta=c.beta, num_neighbors=K, temperature=c.temperature,
+              uniform_weight=c.uniform_weight, neighbor_weight=c.neighbor_weight, kl_weight=c.kl_weight)
+    ref = torch.stack(O.compute_losses(x["text_feat"], x["video_feat"], x["text_mask"], x["video_mask"], x["mb_feat_t"], x["mb_feat_v"],
+                                       x["mb_mask_t"], x["mb_mask_v"], P, hp, 100.0, nz, centrality_multi_token="mean")).numpy()
+    xg = {k: v.to(DEV) for k, v in x.items()}
+    nzg = {k: v.to(DEV) for k, v in nz.items()}
+    with torch.no_grad():
+        got = torch.stack(m._compute_losses(xg["text_feat"], xg["video_feat"], xg["text_mask"], xg["video_mask"], xg["mb_feat_t"],
+                                            xg["mb_feat_v"], xg["mb_mask_t"], xg["mb_mask_v"], c.centrality_scale, c.beta, K,
+                                            c.temperature, m.clip.logit_scale.exp(), noise=nzg)).cpu().numpy()
+    d = np.abs(got - ref)
+    print(f"\n[seed {seed}: B={B} Nt={Nt} Nv={Nv} M={M} K={K}] |dL| = {d.tolist()}")
+    assert np.isfinite(got).all() and d.max() < 2e-4, (got, ref)
