@@ -1276,6 +1276,38 @@ def main():
                     roofline["timing"] = ("frac / achieved / avg_launch_us: rocprofv3 per-kernel average of the step's three similarity launches "
                                           "ALONE (alone_source); frac_in_step: the same kernels inside the timed step loop (in_step_source); "
                                           "frac_hip_events_graph_of_30: HIP events around 50 replays of a graph of 10 x the three launches")
+                    # The three products one by one.  `frac` above averages them at their ALGORITHMIC flops; the batch x batch product of
+                    # the mixed plan runs split-bf16 (three MFMA passes for fp32-grade logits: a third of what it issues counts), the two
+                    # bank products one bf16 pass.  The kernel's template arguments tell them apart in the trace (5th: split-bf16 tile);
+                    # only reported when the trace shows exactly the expected split of launches.
+                    B_, Nt_, Nv_, M_, d_ = c["B"], c["Nt"], c["Nv"], c["M"], 512
+                    prods = [("batch text x batch video", 2.0 * d_ * (B_ * Nt_) * (B_ * Nv_), args.precision != "bf16_all"),
+                             ("batch text x bank video", 2.0 * d_ * (B_ * Nt_) * (M_ * Nv_), args.precision == "bf16x3"),
+                             ("bank text x batch video", 2.0 * d_ * (M_ * Nt_) * (B_ * Nv_), args.precision == "bf16x3")]
+
+                    def is_split(name):
+                        targs = name.split("<", 1)[1].split(">", 1)[0].split(",") if "<" in name else []
+                        return len(targs) > 4 and targs[4].strip() == "true"
+                    rows_ = [(n_, v_) for n_, v_ in prof["alone"].items() if "nr_sim_reg_kernel" in n_]
+                    by = []
+                    for split in (True, False):
+                        mine = [p_ for p_ in prods if p_[2] == split]
+                        hit = [(n_, v_) for n_, v_ in rows_ if is_split(n_) == split]
+                        calls = sum(v_[0] for _, v_ in hit)
+                        if not mine:
+                            continue
+                        if not calls or abs(calls / a_calls - len(mine) / 3.0) > 0.02:
+                            by = None                        # (another tile form took this product -- e.g. three passes on the one-pass tile)
+                            break
+                        us = sum(v_[0] * v_[1] for _, v_ in hit) / calls
+                        fl = sum(p_[1] for p_ in mine) / len(mine)
+                        by.append({"products": [p_[0] for p_ in mine], "arithmetic": "split-bf16 (3 MFMA passes)" if split else "one bf16 pass",
+                                   "launches_per_step": len(mine), "avg_launch_us": round(us, 2), "algorithmic_flops_per_launch": fl,
+                                   "frac": round(fl / (us * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                   "frac_of_issued_mfma_flops": round((3 if split else 1) * fl / (us * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                   "kernel_variants": [n_.split("(")[0].replace("void ", "") for n_, _ in hit]})
+                    if by:
+                        roofline["by_product"] = by
 
     if rank == 0:
         line = {
