@@ -35,6 +35,13 @@ for name, cs in sorted(acc.items()):
         for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
             if c in m:
                 k[c.lower() + "_frac_of_wave_cycles"] = round(m[c] / m["SQ_WAVE_CYCLES"], 4)
+    if m.get("SQ_INSTS_MFMA"):
+        # what a change to the kernels' fragment reads has to move: LDS instructions / LDS-active cycles per MFMA (wave-instruction
+        # counts summed over the launch)
+        for c, key in (("SQ_INSTS_LDS", "lds_insts_per_mfma"), ("SQ_LDS_IDX_ACTIVE", "lds_idx_active_cycles_per_mfma"),
+                       ("SQ_INSTS_VALU", "valu_insts_per_mfma")):
+            if c in m:
+                k[key] = round(m[c] / m["SQ_INSTS_MFMA"], 4)
     if "FETCH_SIZE" in m:
         k["fabric_read_bytes_per_launch"] = round(m["FETCH_SIZE"] * 1024 * 2)
     if "WRITE_SIZE" in m:
